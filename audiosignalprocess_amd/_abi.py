@@ -1,0 +1,82 @@
+"""ctypes mirror of include/asp_ns.h (plain data layouts only)."""
+import ctypes as C
+
+import numpy as np
+
+BLOCKL = 160
+ANAL = 256
+BINS = 129
+SIMULT = 3
+HIST = 1000
+
+MEM_HOST = 0
+MEM_DEVICE = 1
+
+
+class AspNsState(C.Structure):
+    """include/asp_ns.h: AspNsState (canonical per-stream snapshot)."""
+
+    _fields_ = [
+        ("fs", C.c_int32),
+        ("aggrMode", C.c_int32),
+        ("initFlag", C.c_int32),
+        ("gainmap", C.c_int32),
+        ("blockInd", C.c_int32),
+        ("updates", C.c_int32),
+        ("counter", C.c_int32 * SIMULT),
+        ("modelUpdatePars", C.c_int32 * 4),
+        ("overdrive", C.c_float),
+        ("denoiseBound", C.c_float),
+        ("priorSpeechProb", C.c_float),
+        ("signalEnergy", C.c_float),
+        ("sumMagn", C.c_float),
+        ("whiteNoiseLevel", C.c_float),
+        ("pinkNoiseNumerator", C.c_float),
+        ("pinkNoiseExp", C.c_float),
+        ("priorModelPars", C.c_float * 7),
+        ("featureData", C.c_float * 7),
+        ("analyzeBuf", C.c_float * ANAL),
+        ("dataBuf", C.c_float * ANAL),
+        ("syntBuf", C.c_float * ANAL),
+        ("density", C.c_float * (SIMULT * BINS)),
+        ("lquantile", C.c_float * (SIMULT * BINS)),
+        ("quantile", C.c_float * BINS),
+        ("smooth", C.c_float * BINS),
+        ("noise", C.c_float * BINS),
+        ("noisePrev", C.c_float * BINS),
+        ("magnPrevAnalyze", C.c_float * BINS),
+        ("magnPrevProcess", C.c_float * BINS),
+        ("logLrtTimeAvg", C.c_float * BINS),
+        ("magnAvgPause", C.c_float * BINS),
+        ("initMagnEst", C.c_float * BINS),
+        ("parametricNoise", C.c_float * BINS),
+        ("speechProb", C.c_float * BINS),
+        ("histLrt", C.c_int32 * HIST),
+        ("histSpecFlat", C.c_int32 * HIST),
+        ("histSpecDiff", C.c_int32 * HIST),
+    ]
+
+    def field_array(self, name):
+        """numpy copy of one field (scalars become 0-d arrays)."""
+        v = getattr(self, name)
+        if isinstance(v, (int, float)):
+            return np.asarray(v)
+        return np.ctypeslib.as_array(v).copy()
+
+    def to_dict(self):
+        return {n: self.field_array(n) for n, _ in self._fields_}
+
+    @classmethod
+    def from_dict(cls, d):
+        s = cls()
+        for n, t in cls._fields_:
+            v = d[n]
+            if hasattr(t, "_length_"):
+                arr = np.ctypeslib.as_array(getattr(s, n))
+                arr[...] = np.asarray(v).reshape(arr.shape)
+            else:
+                setattr(s, n, np.asarray(v).item())
+        return s
+
+
+STATE_FIELDS = [n for n, _ in AspNsState._fields_]

@@ -1,0 +1,47 @@
+"""Deterministic synthetic inputs; numpy only.
+
+These are the generators the bench and the parity tests feed to every engine
+(HIP path, CPU restatement, compiled reference) so all of them see identical
+float32 frames.
+"""
+import numpy as np
+
+_A = np.uint32(1664525)
+_C = np.uint32(1013904223)
+
+
+def _lcg_uniform(seeds, t0, count):
+    """n[s, k] for absolute sample indices t0 .. t0+count-1 of each stream.
+
+    u <- u*1664525 + 1013904223 (mod 2**32) once per sample, seeded per
+    stream; n = ((u >> 16) - 32768) / 32768 in [-1, 1).
+    """
+    seeds = np.asarray(seeds, dtype=np.uint32)
+    total = t0 + count
+    with np.errstate(over="ignore"):
+        a_pow = np.cumprod(np.full(total, _A, dtype=np.uint32), dtype=np.uint32)  # a^(t+1)
+        geo = np.cumsum(np.concatenate(([np.uint32(1)], a_pow[:-1])), dtype=np.uint32)
+        c_t = (_C * geo).astype(np.uint32)  # c * (a^t + ... + 1)
+        u = seeds[:, None] * a_pow[None, t0:] + c_t[None, t0:]
+    u = u.astype(np.uint32)
+    return ((u >> np.uint32(16)).astype(np.float64) - 32768.0) / 32768.0
+
+
+def ns_frames(num_streams, num_frames, stream0=0, frame0=0):
+    """NS input, float-S16 units, shape [num_frames][num_streams][160] float32.
+
+    x = 600 n + g(f) 3000 sin(2 pi (300 + 5 (s mod 64)) t / 16000) (0.5 + 0.5 sin(0.01 f)),
+    g(f) = 1 when floor(f/100) is odd else 0; never all-zero.
+    """
+    s = np.arange(stream0, stream0 + num_streams, dtype=np.int64)
+    seeds = (12345 + 7919 * s) & 0xFFFFFFFF
+    n = _lcg_uniform(seeds, 160 * frame0, 160 * num_frames)  # [S][T]
+    t = np.arange(160 * frame0, 160 * (frame0 + num_frames), dtype=np.float64)
+    f = np.floor(t / 160.0)
+    g = ((np.floor(f / 100.0).astype(np.int64) & 1) == 1).astype(np.float64)
+    freq = 300.0 + 5.0 * (s % 64).astype(np.float64)
+    tone = np.sin(2.0 * np.pi * freq[:, None] * t[None, :] / 16000.0)
+    env = g * 3000.0 * (0.5 + 0.5 * np.sin(0.01 * f))
+    x = 600.0 * n + tone * env[None, :]
+    x = x.astype(np.float32).reshape(num_streams, num_frames, 160)
+    return np.ascontiguousarray(x.transpose(1, 0, 2))

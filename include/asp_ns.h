@@ -1,0 +1,174 @@
+/*
+ * asp_ns.h -- C-ABI of the MI355X batched noise-suppression engine.
+ *
+ * Two layers, both plain C (no C++/torch types cross this boundary):
+ *
+ *  1. The reference's own per-stream "process-frame" API, signature-identical,
+ *     so the unmodified driver logic of WebRtc_AMP_Port/test_ns_module.cpp:59-113
+ *     links against this library instead of the reference's C objects:
+ *       WebRtcNs_Create / _Free / _Init / _set_policy / _Analyze / _Process /
+ *       _prior_speech_probability
+ *     (replaces webrtc/modules/audio_processing/ns/include/noise_suppression.h:16-122,
+ *      implemented in the reference by ns/noise_suppression.c:20-66 over ns/ns_core.c).
+ *     Each handle is a batch of one stream on the GPU.
+ *
+ *  2. The batched extension AspNsBatch_*: the same verbs with N independent
+ *     streams per call, frames laid out [stream][160] float (float-S16 range,
+ *     webrtc/modules/audio_processing/audio_buffer.h:71-72), caller-owned,
+ *     host or device pointers.  One opaque handle owns all device state.
+ *
+ * Only fs = 16000 (blockLen 160, anaLen 256, magnLen 129; ns_core.c:93-98) and
+ * num_bands = 1 are implemented; other rates return -1 from Init.
+ */
+#ifndef ASP_NS_H_
+#define ASP_NS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASP_NS_BLOCKL 160   /* ns/defines.h:14 */
+#define ASP_NS_ANAL 256     /* ns/defines.h:15 */
+#define ASP_NS_BINS 129     /* ns/defines.h:16 */
+#define ASP_NS_SIMULT 3     /* ns/defines.h:21 */
+#define ASP_NS_HIST 1000    /* ns/defines.h:45 */
+
+/* ---------------------------------------------------------------- layer 1 */
+
+typedef struct NsHandleT NsHandle; /* noise_suppression.h:16 */
+
+int WebRtcNs_Create(NsHandle** NS_inst);               /* noise_suppression.h:26  */
+int WebRtcNs_Free(NsHandle* NS_inst);                  /* noise_suppression.h:38  */
+int WebRtcNs_Init(NsHandle* NS_inst, uint32_t fs);     /* noise_suppression.h:54  */
+int WebRtcNs_set_policy(NsHandle* NS_inst, int mode);  /* noise_suppression.h:69  */
+void WebRtcNs_Analyze(NsHandle* NS_inst, const float* spframe); /* :84 */
+void WebRtcNs_Process(NsHandle* NS_inst,               /* noise_suppression.h:104 */
+                      const float* const* spframe,
+                      int num_bands,
+                      float* const* outframe);
+float WebRtcNs_prior_speech_probability(NsHandle* handle); /* :117 */
+
+/* ---------------------------------------------------------------- layer 2 */
+
+/* Canonical, natural-bin-order snapshot of one stream's state.  Field names
+ * and meanings follow NoiseSuppressionC (ns/ns_core.h:52-114); it is the
+ * checkpoint/restore blob and the teacher-forcing device of the parity tests.
+ * speechProb[] is transient on the device (only the >16 kHz high-band branch
+ * ns_core.c:1362-1414 reads it across calls) and is exported as zeros. */
+typedef struct AspNsState {
+  int32_t fs;
+  int32_t aggrMode;
+  int32_t initFlag;
+  int32_t gainmap;
+  int32_t blockInd;
+  int32_t updates;
+  int32_t counter[ASP_NS_SIMULT];
+  int32_t modelUpdatePars[4];
+  float overdrive;
+  float denoiseBound;
+  float priorSpeechProb;
+  float signalEnergy;
+  float sumMagn;
+  float whiteNoiseLevel;
+  float pinkNoiseNumerator;
+  float pinkNoiseExp;
+  float priorModelPars[7];
+  float featureData[7];
+  float analyzeBuf[ASP_NS_ANAL];
+  float dataBuf[ASP_NS_ANAL];
+  float syntBuf[ASP_NS_ANAL];
+  float density[ASP_NS_SIMULT * ASP_NS_BINS];
+  float lquantile[ASP_NS_SIMULT * ASP_NS_BINS];
+  float quantile[ASP_NS_BINS];
+  float smooth[ASP_NS_BINS];
+  float noise[ASP_NS_BINS];
+  float noisePrev[ASP_NS_BINS];
+  float magnPrevAnalyze[ASP_NS_BINS];
+  float magnPrevProcess[ASP_NS_BINS];
+  float logLrtTimeAvg[ASP_NS_BINS];
+  float magnAvgPause[ASP_NS_BINS];
+  float initMagnEst[ASP_NS_BINS];
+  float parametricNoise[ASP_NS_BINS];
+  float speechProb[ASP_NS_BINS];
+  int32_t histLrt[ASP_NS_HIST];
+  int32_t histSpecFlat[ASP_NS_HIST];
+  int32_t histSpecDiff[ASP_NS_HIST];
+} AspNsState;
+
+typedef struct AspNsBatch AspNsBatch;
+
+/* Where the caller's frame buffers live. */
+enum { ASP_MEM_HOST = 0, ASP_MEM_DEVICE = 1 };
+
+/* Error codes (layer 2 returns 0 on success, a negative code otherwise). */
+enum {
+  ASP_OK = 0,
+  ASP_ERR_PARAM = -1,    /* bad argument (same value the reference returns)   */
+  ASP_ERR_NO_DEVICE = -2,/* no usable HIP device / kernel image not loadable  */
+  ASP_ERR_HIP = -3,      /* a HIP call failed (see AspNs_last_error)          */
+  ASP_ERR_STATE = -4     /* handle not initialised                            */
+};
+
+/* Creates a batch of `num_streams` independent streams on HIP device `device`
+ * (sharding hint: one batch per GPU, streams are never exchanged). */
+int AspNsBatch_Create(AspNsBatch** out, int num_streams, int device);
+int AspNsBatch_Free(AspNsBatch* b);
+/* WebRtcNs_Init for every stream (ns_core.c:74-214). */
+int AspNsBatch_Init(AspNsBatch* b, uint32_t fs);
+/* WebRtcNs_set_policy for every stream (ns_core.c:1013-1041). */
+int AspNsBatch_set_policy(AspNsBatch* b, int mode);
+int AspNsBatch_num_streams(const AspNsBatch* b);
+
+/* frames: [num_streams][160] float.  Asynchronous on the batch's HIP stream
+ * for ASP_MEM_DEVICE; ASP_MEM_HOST copies in/out and returns when done. */
+int AspNsBatch_Analyze(AspNsBatch* b, const float* frames, int mem);
+int AspNsBatch_Process(AspNsBatch* b, const float* in, float* out, int mem);
+/* Analyze(frame) immediately followed by Process(frame) on the same frame for
+ * every stream -- the loop body of test_ns_module.cpp:97-99 -- as one fused
+ * launch per frame.  in/out: [num_frames][num_streams][160]; in == out is
+ * allowed (the driver aliases them, test_ns_module.cpp:98-99). */
+int AspNsBatch_AnalyzeProcess(AspNsBatch* b, const float* in, float* out,
+                              int num_frames, int mem);
+
+int AspNsBatch_ExportState(AspNsBatch* b, int stream, AspNsState* out);
+int AspNsBatch_ImportState(AspNsBatch* b, int stream, const AspNsState* in);
+/* priorSpeechProb of every stream (noise_suppression.c:57-66), out[num_streams]. */
+int AspNsBatch_prior_speech_probability(AspNsBatch* b, float* out);
+
+/* Launch stream control: by default the batch owns a private HIP stream.
+ * SetStream adopts a caller-owned hipStream_t (passed as void*). */
+int AspNsBatch_SetStream(AspNsBatch* b, void* hip_stream);
+void* AspNsBatch_GetStream(AspNsBatch* b);
+int AspNsBatch_Synchronize(AspNsBatch* b);
+
+/* Device scratch for callers without their own allocator (C drivers, bench). */
+int AspNs_DeviceAlloc(void** ptr, size_t bytes, int device);
+int AspNs_DeviceFree(void* ptr);
+int AspNs_MemcpyH2D(void* dst, const void* src, size_t bytes);
+int AspNs_MemcpyD2H(void* dst, const void* src, size_t bytes);
+
+/* Timed replay for bench.py: runs `steps` fused frame-steps on device buffers
+ * in/out ([frames_in_ring][num_streams][160], step k uses ring slot k %
+ * frames_in_ring) on the batch's stream, bracketed by hipEvents recorded on
+ * that stream.  *elapsed_ms receives the event time for all steps. */
+int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out,
+                          int frames_in_ring, int steps, float* elapsed_ms);
+
+/* Number of HIP devices visible, or a negative error code. */
+int AspNs_device_count(void);
+/* Text of the most recent error on this thread ("" if none). */
+const char* AspNs_last_error(void);
+
+/* FFT seam used by the parity tests: batched 256-point real FFT in Ooura
+ * packing (a[0]=R0, a[1]=R128, a[2k]=Rk, a[2k+1]=Ik; fft4g.c:90-118), i.e.
+ * what WebRtc_rdft(256, isgn, a, ip, w) (fft4g.c:324-362) does to each row.
+ * data: [count][256] float, in place; isgn = +1 forward, -1 inverse (unscaled). */
+int AspNs_rdft256_batch(float* data, int count, int isgn, int mem, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASP_NS_H_ */

@@ -1,0 +1,62 @@
+/*
+ * ns_oracle.h -- CPU restatement of the reference's float noise suppressor.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * build, load or call it, and only as the checker / the timed CPU baseline.
+ *
+ * Parity status: PINNED.  The restatement is checked bit-for-bit against the
+ * reference C (ns_core.c + noise_suppression.c + fft4g.c compiled in place
+ * from /root/reference into oracle/_ref/libns_ref.so by oracle/Makefile) in
+ * tests/test_ns_oracle_vs_ref.py, and against the committed golden vectors
+ * tests/golden/ns_*.npz that the same reference build produced
+ * (tests/golden/make_ns_golden.py).
+ *
+ * State is the canonical AspNsState of include/asp_ns.h.
+ */
+#ifndef ASP_NS_ORACLE_H_
+#define ASP_NS_ORACLE_H_
+
+#include "asp_ns.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* How cross-bin sums are associated.
+ *   SEQ : left-to-right in bin order, exactly as the reference's loops do
+ *         (ns_core.c:951-960, 1088-1101, 538-545, 605-621, 676-683).
+ *   TREE: the fixed wave64 butterfly order of the HIP kernels
+ *         (slot-local sum, then xor 32,16,8,4,2,1), so the device path can be
+ *         checked bit-for-bit against this restatement. */
+enum { ASP_NS_REDUCE_SEQ = 0, ASP_NS_REDUCE_TREE = 1 };
+
+int asp_ns_oracle_init(AspNsState* s, uint32_t fs);           /* ns_core.c:74-214   */
+int asp_ns_oracle_set_policy(AspNsState* s, int mode);        /* ns_core.c:1013-1041 */
+void asp_ns_oracle_analyze(AspNsState* s, const float* frame, /* ns_core.c:1043-1181 */
+                           int reduce_mode);
+void asp_ns_oracle_process(AspNsState* s, const float* in,    /* ns_core.c:1183-1359 */
+                           float* out, int reduce_mode);
+
+/* Batch helper: frames [num_frames][num_streams][160]; Analyze then Process on
+ * the same frame per stream (test_ns_module.cpp:97-99). */
+void asp_ns_oracle_run(AspNsState* states, int num_streams, const float* in,
+                       float* out, int num_frames, int reduce_mode);
+/* Same, with `threads` pthreads each owning a contiguous shard of streams. */
+void asp_ns_oracle_run_mt(AspNsState* states, int num_streams, const float* in,
+                          float* out, int num_frames, int reduce_mode,
+                          int threads);
+
+/* 256-point real FFT in Ooura packing, in place; WebRtc_rdft(256, isgn, ...)
+ * (fft4g.c:324-362).  isgn=+1 forward, -1 inverse (unscaled). */
+void asp_ns_oracle_rdft256(float* a, int isgn);
+
+/* Tables shared with the device path (so tests can compare them). */
+const float* asp_ns_oracle_window(void);      /* kBlocks160w256, windows_private.h:94-147 */
+const float* asp_ns_oracle_fft_w(void);       /* makewt(64) table, fft4g.c:642-669        */
+const float* asp_ns_oracle_fft_c(void);       /* makect(64) table, fft4g.c:671-690        */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
