@@ -1,0 +1,785 @@
+// ns_api.hip -- host side of include/asp_ns.h: table construction, the batch
+// handle that owns the device state, state import/export, and the reference's
+// per-stream WebRtcNs_* entry points implemented as a batch of one.
+//
+// There is NO CPU fallback: every entry point that computes needs a HIP device
+// and fails with ASP_ERR_NO_DEVICE / -1 otherwise.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "asp_ns.h"
+#include "ns_layout.h"
+
+using namespace aspns;
+
+namespace aspns {
+hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables* T,
+                           const float* in, float* out, int num_streams, hipStream_t s);
+hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
+hipError_t launch_ns_set_policy(float* state, int num_streams, int mode, float overdrive,
+                                float denoiseBound, int gainmap, hipStream_t s);
+hipError_t launch_rdft256(float* data, int count, int isgn, const NsTables* T, hipStream_t s);
+}  // namespace aspns
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  if (e != hipSuccess)
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(g_err, sizeof g_err, "%s", what);
+  return code;
+}
+
+#define HIP_TRY(expr)                                         \
+  do {                                                        \
+    hipError_t e_ = (expr);                                   \
+    if (e_ != hipSuccess) return fail(ASP_ERR_HIP, #expr, e_); \
+  } while (0)
+
+// ------------------------------------------------------------------ tables
+
+unsigned bitrev(unsigned x, int bits) {
+  unsigned r = 0;
+  for (int b = 0; b < bits; ++b) r |= ((x >> b) & 1u) << (bits - 1 - b);
+  return r;
+}
+
+// kBlocks160w256 (ns/windows_private.h:94-147): sin(pi*i/192) ramps printed
+// with 8 decimals and read back as (float)<double literal>.
+float window_entry(int i) {
+  if (i >= 96 && i <= 160) return 1.0f;
+  char buf[32];
+  double s = sin(M_PI * (double)(i < 96 ? i : 256 - i) / 192.0);
+  snprintf(buf, sizeof buf, "%.8f", s);
+  return (float)strtod(buf, NULL);
+}
+
+// NOTE: this file is C++, where cos(float) would resolve to the float overload;
+// the reference is C, where cos() is the double function.  Every libm call
+// below therefore casts its argument to double explicitly.
+void build_tables(NsTables* T) {
+  memset(T, 0, sizeof *T);
+  float w[64], c[64], tmp[64];
+  {  // makewt(64), utility/fft4g.c:642-669; bitrv2 == bit reversal of 32 complex entries
+    const int nw = 64, nwh = 32;
+    float delta = (float)atan((double)1.0f) / nwh;  // C semantics: double atan
+    tmp[0] = 1;
+    tmp[1] = 0;
+    tmp[nwh] = (float)cos((double)(delta * nwh));
+    tmp[nwh + 1] = tmp[nwh];
+    for (int j = 2; j < nwh; j += 2) {
+      float x = (float)cos((double)(delta * j));
+      float y = (float)sin((double)(delta * j));
+      tmp[j] = x;
+      tmp[j + 1] = y;
+      tmp[nw - j] = y;
+      tmp[nw - j + 1] = x;
+    }
+    for (int j = 0; j < 32; ++j) {
+      unsigned r = bitrev((unsigned)j, 5);
+      w[2 * j] = tmp[2 * r];
+      w[2 * j + 1] = tmp[2 * r + 1];
+    }
+  }
+  {  // makect(64), utility/fft4g.c:671-690
+    const int nc = 64, nch = 32;
+    float delta = (float)atan((double)1.0f) / nch;
+    c[0] = (float)cos((double)(delta * nch));
+    c[nch] = 0.5f * c[0];
+    for (int j = 1; j < nch; j++) {
+      c[j] = 0.5f * (float)cos((double)(delta * j));
+      c[nc - j] = 0.5f * (float)sin((double)(delta * j));
+    }
+  }
+  for (int i = 0; i < kAnal; ++i) T->window[i] = window_entry(i);
+  // Per-lane twiddles of the three radix-4 passes.  Lane = 2*b + h handles half
+  // h of butterfly b; the block index B selects the reference's twiddle case
+  // (fft4g.c:1008-1102 / 1114-1229): 0 none, 1 the w[2] block, 2u / 2u+1 general.
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int lane = 0; lane < 64; ++lane) {
+      const int b = lane >> 1, h = lane & 1;
+      const int B = pass == 0 ? b : (pass == 1 ? b >> 2 : b >> 4);
+      float tAr = 1.f, tAi = 0.f, tBr = 1.f, tBi = 0.f;
+      bool diag = false;
+      if (B == 1) {
+        if (h == 0) {
+          tBr = 0.f;
+          tBi = 1.f;
+        } else {
+          diag = true;
+          tAr = w[2];
+        }
+      } else if (B >= 2) {
+        const int u = B >> 1;
+        const float wk2r = w[2 * u], wk2i = w[2 * u + 1];
+        float w1r, w1i, w3r, w3i, w2r, w2i;
+        if ((B & 1) == 0) {
+          w1r = w[4 * u];
+          w1i = w[4 * u + 1];
+          w3r = w1r - 2 * wk2i * w1i;
+          w3i = 2 * wk2i * w1r - w1i;
+          w2r = wk2r;
+          w2i = wk2i;
+        } else {
+          w1r = w[4 * u + 2];
+          w1i = w[4 * u + 3];
+          w3r = w1r - 2 * wk2r * w1i;
+          w3i = 2 * wk2r * w1r - w1i;
+          w2r = -wk2i;
+          w2i = wk2r;
+        }
+        if (h == 0) {
+          tBr = w2r;
+          tBi = w2i;
+        } else {
+          tAr = w1r;
+          tAi = w1i;
+          tBr = w3r;
+          tBi = w3i;
+        }
+      }
+      T->tw[pass][lane][0] = tAr;
+      T->tw[pass][lane][1] = tAi;
+      T->tw[pass][lane][2] = tBr;
+      T->tw[pass][lane][3] = tBi;
+      if (diag) T->diag[lane] |= 1 << pass;
+    }
+  }
+  for (int q = 0; q < 64; ++q) {
+    T->cq[q] = c[q];
+    T->cr[q] = q == 0 ? 0.f : c[64 - q];
+  }
+  T->logi[0] = 0.f;
+  for (int i = 1; i < kBins; ++i) T->logi[i] = (float)log((double)(float)i);
+  float sli = 0.f, slis = 0.f;  // ns_core.c:1094-1095, sequential over i = 5..128
+  for (int i = 5; i < kBins; ++i) {
+    sli += T->logi[i];
+    slis += T->logi[i] * T->logi[i];
+  }
+  T->sum_log_i = sli;
+  T->sum_log_i_square = slis;
+}
+
+constexpr int kMaxDevices = 64;
+std::mutex g_tab_mu;
+NsTables* g_dev_tables[kMaxDevices] = {nullptr};
+
+int device_tables(int device, NsTables** out) {
+  if (device < 0 || device >= kMaxDevices) return fail(ASP_ERR_PARAM, "device ordinal out of range");
+  std::lock_guard<std::mutex> lk(g_tab_mu);
+  if (!g_dev_tables[device]) {
+    NsTables* host = (NsTables*)malloc(sizeof(NsTables));
+    build_tables(host);
+    NsTables* dev = nullptr;
+    hipError_t e = hipMalloc((void**)&dev, sizeof(NsTables));
+    if (e == hipSuccess) e = hipMemcpy(dev, host, sizeof(NsTables), hipMemcpyHostToDevice);
+    free(host);
+    if (e != hipSuccess) return fail(ASP_ERR_HIP, "uploading constant tables", e);
+    g_dev_tables[device] = dev;
+  }
+  *out = g_dev_tables[device];
+  return ASP_OK;
+}
+
+int select_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(ASP_ERR_NO_DEVICE, "no HIP device available (the NS engine has no CPU fallback)", e);
+  if (device < 0 || device >= n) return fail(ASP_ERR_PARAM, "device ordinal out of range");
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "hipSetDevice", e);
+  return ASP_OK;
+}
+
+// --------------------------------------------------- canonical <-> device image
+
+inline float i2f(int32_t v) {
+  float f;
+  memcpy(&f, &v, 4);
+  return f;
+}
+inline int32_t f2i(float f) {
+  int32_t v;
+  memcpy(&v, &f, 4);
+  return v;
+}
+
+void vec_put(float* blk, int f, const float* src) {
+  float* d = blk + kOffVec + f * kVecStride;
+  memcpy(d, src, sizeof(float) * kBins);
+  for (int i = kBins; i < kVecStride; ++i) d[i] = 0.f;
+}
+void vec_get(const float* blk, int f, float* dst) {
+  memcpy(dst, blk + kOffVec + f * kVecStride, sizeof(float) * kBins);
+}
+
+void pack_stream(const AspNsState* s, float* blk, int32_t* hist) {
+  memset(blk, 0, sizeof(float) * kStreamDwords);
+  float* sc = blk + kOffScalars;
+  sc[S_BLOCKIND] = i2f(s->blockInd);
+  sc[S_UPDATES] = i2f(s->updates);
+  sc[S_COUNTER0] = i2f(s->counter[0]);
+  sc[S_COUNTER1] = i2f(s->counter[1]);
+  sc[S_COUNTER2] = i2f(s->counter[2]);
+  for (int i = 0; i < 4; ++i) sc[S_MUP0 + i] = i2f(s->modelUpdatePars[i]);
+  sc[S_GAINMAP] = i2f(s->gainmap);
+  sc[S_AGGRMODE] = i2f(s->aggrMode);
+  sc[S_INITFLAG] = i2f(s->initFlag);
+  sc[S_OVERDRIVE] = s->overdrive;
+  sc[S_DENOISEBOUND] = s->denoiseBound;
+  sc[S_PRIORSPEECHPROB] = s->priorSpeechProb;
+  sc[S_SIGNALENERGY] = s->signalEnergy;
+  sc[S_SUMMAGN] = s->sumMagn;
+  sc[S_WHITE] = s->whiteNoiseLevel;
+  sc[S_PINKNUM] = s->pinkNoiseNumerator;
+  sc[S_PINKEXP] = s->pinkNoiseExp;
+  for (int i = 0; i < 7; ++i) sc[S_PMP0 + i] = s->priorModelPars[i];
+  for (int i = 0; i < 7; ++i) sc[S_FD0 + i] = s->featureData[i];
+  sc[S_FS] = i2f(s->fs);
+  memcpy(blk + kOffAnaHist, s->analyzeBuf + kBlockL, sizeof(float) * kCarry);
+  memcpy(blk + kOffDataHist, s->dataBuf + kBlockL, sizeof(float) * kCarry);
+  memcpy(blk + kOffSynt, s->syntBuf, sizeof(float) * kCarry);
+  for (int k = 0; k < 3; ++k) {
+    vec_put(blk, V_LQ0 + k, s->lquantile + k * kBins);
+    vec_put(blk, V_DEN0 + k, s->density + k * kBins);
+  }
+  vec_put(blk, V_QUANT, s->quantile);
+  vec_put(blk, V_SMOOTH, s->smooth);
+  vec_put(blk, V_NOISEPREV, s->noisePrev);
+  vec_put(blk, V_MAGNPREV_A, s->magnPrevAnalyze);
+  vec_put(blk, V_LOGLRT, s->logLrtTimeAvg);
+  vec_put(blk, V_AVGPAUSE, s->magnAvgPause);
+  vec_put(blk, V_NOISE, s->noise);
+  vec_put(blk, V_MAGNPREV_P, s->magnPrevProcess);
+  vec_put(blk, V_INITMAGN, s->initMagnEst);
+  vec_put(blk, V_PARAMNOISE, s->parametricNoise);
+  memset(hist, 0, sizeof(int32_t) * kHistDwords);
+  memcpy(hist, s->histLrt, sizeof(int32_t) * kHist);
+  memcpy(hist + kHistStride, s->histSpecFlat, sizeof(int32_t) * kHist);
+  memcpy(hist + 2 * kHistStride, s->histSpecDiff, sizeof(int32_t) * kHist);
+}
+
+void unpack_stream(const float* blk, const int32_t* hist, bool paired, AspNsState* s) {
+  memset(s, 0, sizeof *s);
+  const float* sc = blk + kOffScalars;
+  s->blockInd = f2i(sc[S_BLOCKIND]);
+  s->updates = f2i(sc[S_UPDATES]);
+  s->counter[0] = f2i(sc[S_COUNTER0]);
+  s->counter[1] = f2i(sc[S_COUNTER1]);
+  s->counter[2] = f2i(sc[S_COUNTER2]);
+  for (int i = 0; i < 4; ++i) s->modelUpdatePars[i] = f2i(sc[S_MUP0 + i]);
+  s->gainmap = f2i(sc[S_GAINMAP]);
+  s->aggrMode = f2i(sc[S_AGGRMODE]);
+  s->initFlag = f2i(sc[S_INITFLAG]);
+  s->overdrive = sc[S_OVERDRIVE];
+  s->denoiseBound = sc[S_DENOISEBOUND];
+  s->priorSpeechProb = sc[S_PRIORSPEECHPROB];
+  s->signalEnergy = sc[S_SIGNALENERGY];
+  s->sumMagn = sc[S_SUMMAGN];
+  s->whiteNoiseLevel = sc[S_WHITE];
+  s->pinkNoiseNumerator = sc[S_PINKNUM];
+  s->pinkNoiseExp = sc[S_PINKEXP];
+  for (int i = 0; i < 7; ++i) s->priorModelPars[i] = sc[S_PMP0 + i];
+  for (int i = 0; i < 7; ++i) s->featureData[i] = sc[S_FD0 + i];
+  s->fs = f2i(sc[S_FS]);
+  // only the live 96 samples of each sliding buffer exist on the device
+  memcpy(s->analyzeBuf + kBlockL, blk + kOffAnaHist, sizeof(float) * kCarry);
+  memcpy(s->dataBuf + kBlockL, blk + (paired ? kOffAnaHist : kOffDataHist),
+         sizeof(float) * kCarry);
+  memcpy(s->syntBuf, blk + kOffSynt, sizeof(float) * kCarry);
+  for (int k = 0; k < 3; ++k) {
+    vec_get(blk, V_LQ0 + k, s->lquantile + k * kBins);
+    vec_get(blk, V_DEN0 + k, s->density + k * kBins);
+  }
+  vec_get(blk, V_QUANT, s->quantile);
+  vec_get(blk, V_SMOOTH, s->smooth);
+  vec_get(blk, V_NOISEPREV, s->noisePrev);
+  vec_get(blk, V_MAGNPREV_A, s->magnPrevAnalyze);
+  vec_get(blk, V_LOGLRT, s->logLrtTimeAvg);
+  vec_get(blk, V_AVGPAUSE, s->magnAvgPause);
+  vec_get(blk, paired ? V_NOISEPREV : V_NOISE, s->noise);
+  vec_get(blk, paired ? V_MAGNPREV_A : V_MAGNPREV_P, s->magnPrevProcess);
+  vec_get(blk, V_INITMAGN, s->initMagnEst);
+  vec_get(blk, V_PARAMNOISE, s->parametricNoise);
+  memcpy(s->histLrt, hist, sizeof(int32_t) * kHist);
+  memcpy(s->histSpecFlat, hist + kHistStride, sizeof(int32_t) * kHist);
+  memcpy(s->histSpecDiff, hist + 2 * kHistStride, sizeof(int32_t) * kHist);
+}
+
+// WebRtcNs_InitCore (ns_core.c:74-214) as a canonical state.
+void init_state(AspNsState* s, uint32_t fs) {
+  memset(s, 0, sizeof *s);
+  s->fs = (int32_t)fs;
+  for (int i = 0; i < ASP_NS_SIMULT * kBins; i++) {
+    s->lquantile[i] = 8.f;
+    s->density[i] = 0.3f;
+  }
+  for (int i = 0; i < ASP_NS_SIMULT; i++)
+    s->counter[i] = (int)floor((float)(200 * (i + 1)) / (float)ASP_NS_SIMULT);
+  for (int i = 0; i < kBins; i++) s->smooth[i] = 1.f;
+  s->priorSpeechProb = 0.5f;
+  for (int i = 0; i < kBins; i++) s->logLrtTimeAvg[i] = (float)0.5;
+  s->featureData[0] = (float)0.5;
+  s->featureData[3] = (float)0.5;
+  s->featureData[4] = (float)0.5;
+  s->blockInd = -1;
+  s->priorModelPars[0] = (float)0.5;
+  s->priorModelPars[1] = 0.5f;
+  s->priorModelPars[2] = 1.f;
+  s->priorModelPars[3] = 0.5f;
+  s->priorModelPars[4] = 1.f;
+  s->modelUpdatePars[0] = 2;
+  s->modelUpdatePars[1] = 500;
+  s->modelUpdatePars[2] = 0;
+  s->modelUpdatePars[3] = 500;
+  s->overdrive = 1.f;  // WebRtcNs_set_policy_core(self, 0), ns_core.c:1020-1023
+  s->denoiseBound = 0.5f;
+  s->gainmap = 0;
+  s->aggrMode = 0;
+  s->initFlag = 1;
+}
+
+bool state_is_paired(const AspNsState* s) {
+  return memcmp(s->analyzeBuf + kBlockL, s->dataBuf + kBlockL, sizeof(float) * kCarry) == 0 &&
+         memcmp(s->magnPrevAnalyze, s->magnPrevProcess, sizeof s->magnPrevAnalyze) == 0 &&
+         memcmp(s->noise, s->noisePrev, sizeof s->noise) == 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------- handle
+
+struct AspNsBatch {
+  int S = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  float* state = nullptr;
+  int32_t* hist = nullptr;
+  NsTables* tables = nullptr;
+  float* stage_in = nullptr;   // device staging for ASP_MEM_HOST callers
+  float* stage_out = nullptr;
+  size_t stage_frames = 0;
+  bool inited = false;
+  bool paired = true;  // see ns_kernels.hip: fused step representation
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int ensure_stage(AspNsBatch* b, size_t frames) {
+  if (b->stage_frames >= frames) return ASP_OK;
+  if (b->stage_in) (void)hipFree(b->stage_in);
+  if (b->stage_out) (void)hipFree(b->stage_out);
+  b->stage_in = b->stage_out = nullptr;
+  b->stage_frames = 0;
+  const size_t bytes = frames * (size_t)b->S * kBlockL * sizeof(float);
+  HIP_TRY(hipMalloc((void**)&b->stage_in, bytes));
+  HIP_TRY(hipMalloc((void**)&b->stage_out, bytes));
+  b->stage_frames = frames;
+  return ASP_OK;
+}
+
+int ensure_unpaired(AspNsBatch* b) {
+  if (!b->paired) return ASP_OK;
+  HIP_TRY(launch_ns_unpair(b->state, b->S, b->stream));
+  b->paired = false;
+  return ASP_OK;
+}
+
+int check(AspNsBatch* b) {
+  if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
+  if (!b->inited) return fail(ASP_ERR_STATE, "batch not initialised (call AspNsBatch_Init)");
+  hipError_t e = hipSetDevice(b->device);
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "hipSetDevice", e);
+  return ASP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* AspNs_last_error(void) { return g_err; }
+
+// Host-side copy of the constant tables (window, per-lane twiddles, ...): no
+// device needed, so the CPU test-suite can pin them against the oracle.
+int AspNs_host_tables(void* out, size_t bytes) {
+  if (!out || bytes != sizeof(NsTables)) return fail(ASP_ERR_PARAM, "AspNs_host_tables: size mismatch");
+  build_tables((NsTables*)out);
+  return ASP_OK;
+}
+size_t AspNs_host_tables_size(void) { return sizeof(NsTables); }
+
+int AspNs_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(ASP_ERR_NO_DEVICE, "hipGetDeviceCount", e);
+  return n;
+}
+
+int AspNsBatch_Create(AspNsBatch** out, int num_streams, int device) {
+  if (!out || num_streams <= 0) return fail(ASP_ERR_PARAM, "AspNsBatch_Create: bad argument");
+  *out = nullptr;
+  int rc = select_device(device);
+  if (rc) return rc;
+  AspNsBatch* b = new AspNsBatch();
+  b->S = num_streams;
+  b->device = device;
+  rc = device_tables(device, &b->tables);
+  if (rc) {
+    delete b;
+    return rc;
+  }
+  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) b->own_stream = true;
+  if (e == hipSuccess) e = hipMalloc((void**)&b->state, (size_t)num_streams * kStreamDwords * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->hist, (size_t)num_streams * kHistDwords * 4);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+  if (e != hipSuccess) {
+    AspNsBatch_Free(b);
+    return fail(ASP_ERR_HIP, "AspNsBatch_Create: device allocation", e);
+  }
+  *out = b;
+  return ASP_OK;
+}
+
+int AspNsBatch_Free(AspNsBatch* b) {
+  if (!b) return ASP_OK;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->state) (void)hipFree(b->state);
+  if (b->hist) (void)hipFree(b->hist);
+  if (b->stage_in) (void)hipFree(b->stage_in);
+  if (b->stage_out) (void)hipFree(b->stage_out);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return ASP_OK;
+}
+
+int AspNsBatch_num_streams(const AspNsBatch* b) { return b ? b->S : ASP_ERR_PARAM; }
+
+int AspNsBatch_Init(AspNsBatch* b, uint32_t fs) {
+  if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
+  if (fs != 16000)  // ns_core.c:82-86 accepts 8/16/32/48 kHz; only 16 kHz is built
+    return fail(ASP_ERR_PARAM, "AspNsBatch_Init: only fs = 16000 is implemented");
+  HIP_TRY(hipSetDevice(b->device));
+  AspNsState* s0 = (AspNsState*)malloc(sizeof(AspNsState));
+  init_state(s0, fs);
+  const int chunk = b->S < 256 ? b->S : 256;
+  std::vector<float> blk((size_t)chunk * kStreamDwords);
+  std::vector<int32_t> hh(kHistDwords);
+  pack_stream(s0, blk.data(), hh.data());
+  free(s0);
+  for (int i = 1; i < chunk; ++i)
+    memcpy(blk.data() + (size_t)i * kStreamDwords, blk.data(), sizeof(float) * kStreamDwords);
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  for (int s = 0; s < b->S; s += chunk) {
+    const int n = (b->S - s) < chunk ? (b->S - s) : chunk;
+    HIP_TRY(hipMemcpy(b->state + (size_t)s * kStreamDwords, blk.data(),
+                      (size_t)n * kStreamDwords * 4, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemset(b->hist, 0, (size_t)b->S * kHistDwords * 4));
+  b->inited = true;
+  b->paired = true;
+  return ASP_OK;
+}
+
+int AspNsBatch_set_policy(AspNsBatch* b, int mode) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (mode < 0 || mode > 3) return fail(ASP_ERR_PARAM, "set_policy: mode must be 0..3");
+  // ns_core.c:1020-1039
+  static const float kOver[4] = {1.f, 1.f, 1.1f, 1.25f};
+  static const float kBound[4] = {0.5f, 0.25f, 0.125f, 0.09f};
+  static const int kMap[4] = {0, 1, 1, 1};
+  HIP_TRY(launch_ns_set_policy(b->state, b->S, mode, kOver[mode], kBound[mode], kMap[mode],
+                               b->stream));
+  return ASP_OK;
+}
+
+static int run_frames(AspNsBatch* b, int kmode, const float* in, float* out, int num_frames,
+                      int mem) {
+  const size_t per = (size_t)b->S * kBlockL;
+  const float* din = in;
+  float* dout = out;
+  if (mem == ASP_MEM_HOST) {
+    int rc = ensure_stage(b, (size_t)num_frames);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->stage_in, in, per * num_frames * 4, hipMemcpyHostToDevice,
+                           b->stream));
+    din = b->stage_in;
+    dout = b->stage_out;
+  } else if (mem != ASP_MEM_DEVICE) {
+    return fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  }
+  for (int f = 0; f < num_frames; ++f) {
+    const float* fi = din + per * f;
+    float* fo = dout ? dout + per * f : nullptr;
+    if (kmode == 2 && !b->paired) {
+      HIP_TRY(launch_ns_frame(0, b->state, b->hist, b->tables, fi, fo, b->S, b->stream));
+      HIP_TRY(launch_ns_frame(1, b->state, b->hist, b->tables, fi, fo, b->S, b->stream));
+    } else {
+      HIP_TRY(launch_ns_frame(kmode, b->state, b->hist, b->tables, fi, fo, b->S, b->stream));
+    }
+  }
+  if (mem == ASP_MEM_HOST) {
+    if (out && kmode != 0)
+      HIP_TRY(hipMemcpyAsync(out, b->stage_out, per * num_frames * 4, hipMemcpyDeviceToHost,
+                             b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return ASP_OK;
+}
+
+int AspNsBatch_Analyze(AspNsBatch* b, const float* frames, int mem) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!frames) return fail(ASP_ERR_PARAM, "Analyze: null frames");
+  rc = ensure_unpaired(b);
+  if (rc) return rc;
+  return run_frames(b, 0, frames, nullptr, 1, mem);
+}
+
+int AspNsBatch_Process(AspNsBatch* b, const float* in, float* out, int mem) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!in || !out) return fail(ASP_ERR_PARAM, "Process: null frames");
+  rc = ensure_unpaired(b);
+  if (rc) return rc;
+  return run_frames(b, 1, in, out, 1, mem);
+}
+
+int AspNsBatch_AnalyzeProcess(AspNsBatch* b, const float* in, float* out, int num_frames,
+                              int mem) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!in || !out || num_frames < 0) return fail(ASP_ERR_PARAM, "AnalyzeProcess: bad argument");
+  return run_frames(b, 2, in, out, num_frames, mem);
+}
+
+int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames_in_ring,
+                          int steps, float* elapsed_ms) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!in || !out || frames_in_ring <= 0 || steps < 0 || !elapsed_ms)
+    return fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
+  if (!b->paired) return fail(ASP_ERR_STATE, "TimedSteps needs the fused (paired) representation");
+  const size_t per = (size_t)b->S * kBlockL;
+  HIP_TRY(hipEventRecord(b->ev0, b->stream));
+  for (int k = 0; k < steps; ++k) {
+    const size_t off = per * (size_t)(k % frames_in_ring);
+    HIP_TRY(launch_ns_frame(2, b->state, b->hist, b->tables, in + off, out + off, b->S,
+                            b->stream));
+  }
+  HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  HIP_TRY(hipEventSynchronize(b->ev1));
+  HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+  return ASP_OK;
+}
+
+int AspNsBatch_ExportState(AspNsBatch* b, int stream, AspNsState* out) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!out || stream < 0 || stream >= b->S) return fail(ASP_ERR_PARAM, "ExportState: bad argument");
+  std::vector<float> blk(kStreamDwords);
+  std::vector<int32_t> hh(kHistDwords);
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(blk.data(), b->state + (size_t)stream * kStreamDwords, kStreamDwords * 4,
+                    hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hh.data(), b->hist + (size_t)stream * kHistDwords, kHistDwords * 4,
+                    hipMemcpyDeviceToHost));
+  unpack_stream(blk.data(), hh.data(), b->paired, out);
+  return ASP_OK;
+}
+
+int AspNsBatch_ImportState(AspNsBatch* b, int stream, const AspNsState* in) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!in || stream < 0 || stream >= b->S) return fail(ASP_ERR_PARAM, "ImportState: bad argument");
+  if (in->fs != 16000) return fail(ASP_ERR_PARAM, "ImportState: only fs = 16000 is implemented");
+  for (int i = kCarry; i < kAnal; ++i)
+    if (in->syntBuf[i] != 0.f)
+      return fail(ASP_ERR_PARAM, "ImportState: syntBuf[96..255] must be zero (between frames)");
+  if (!state_is_paired(in)) {
+    rc = ensure_unpaired(b);
+    if (rc) return rc;
+  }
+  std::vector<float> blk(kStreamDwords);
+  std::vector<int32_t> hh(kHistDwords);
+  pack_stream(in, blk.data(), hh.data());
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(b->state + (size_t)stream * kStreamDwords, blk.data(), kStreamDwords * 4,
+                    hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->hist + (size_t)stream * kHistDwords, hh.data(), kHistDwords * 4,
+                    hipMemcpyHostToDevice));
+  return ASP_OK;
+}
+
+int AspNsBatch_prior_speech_probability(AspNsBatch* b, float* out) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!out) return fail(ASP_ERR_PARAM, "null output");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy2D(out, sizeof(float), b->state + kOffScalars + S_PRIORSPEECHPROB,
+                      (size_t)kStreamDwords * 4, sizeof(float), (size_t)b->S,
+                      hipMemcpyDeviceToHost));
+  return ASP_OK;
+}
+
+int AspNsBatch_SetStream(AspNsBatch* b, void* hip_stream) {
+  if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  b->stream = (hipStream_t)hip_stream;
+  b->own_stream = false;
+  return ASP_OK;
+}
+
+void* AspNsBatch_GetStream(AspNsBatch* b) { return b ? (void*)b->stream : nullptr; }
+
+int AspNsBatch_Synchronize(AspNsBatch* b) {
+  if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return ASP_OK;
+}
+
+int AspNs_DeviceAlloc(void** ptr, size_t bytes, int device) {
+  if (!ptr) return fail(ASP_ERR_PARAM, "null pointer");
+  int rc = select_device(device);
+  if (rc) return rc;
+  HIP_TRY(hipMalloc(ptr, bytes));
+  return ASP_OK;
+}
+int AspNs_DeviceFree(void* ptr) {
+  HIP_TRY(hipFree(ptr));
+  return ASP_OK;
+}
+int AspNs_MemcpyH2D(void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return ASP_OK;
+}
+int AspNs_MemcpyD2H(void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return ASP_OK;
+}
+
+int AspNs_rdft256_batch(float* data, int count, int isgn, int mem, int device) {
+  if (!data || count <= 0) return fail(ASP_ERR_PARAM, "rdft256_batch: bad argument");
+  int rc = select_device(device);
+  if (rc) return rc;
+  NsTables* T = nullptr;
+  rc = device_tables(device, &T);
+  if (rc) return rc;
+  float* d = data;
+  const size_t bytes = (size_t)count * kAnal * sizeof(float);
+  if (mem == ASP_MEM_HOST) {
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    HIP_TRY(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice));
+  }
+  hipError_t e = launch_rdft256(d, count, isgn, T, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (mem == ASP_MEM_HOST) {
+    if (e == hipSuccess) e = hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+  }
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "rdft256_batch", e);
+  return ASP_OK;
+}
+
+// ----------------------------------------------------------------- layer 1
+// The reference's per-stream API (ns/noise_suppression.c:20-66) over a batch of
+// one stream on device 0.  Frames are host pointers, as in the reference.
+
+struct NsHandleT {
+  AspNsBatch* batch;
+  int initFlag;
+};
+
+int WebRtcNs_Create(NsHandle** NS_inst) {
+  if (!NS_inst) return -1;
+  NsHandleT* h = (NsHandleT*)malloc(sizeof(NsHandleT));
+  if (!h) return -1;
+  h->batch = nullptr;
+  h->initFlag = 0;
+  if (AspNsBatch_Create(&h->batch, 1, 0) != ASP_OK) {
+    fprintf(stderr, "WebRtcNs_Create: %s\n", g_err);
+    free(h);
+    *NS_inst = NULL;
+    return -1;
+  }
+  *NS_inst = h;
+  return 0;
+}
+
+int WebRtcNs_Free(NsHandle* NS_inst) {
+  if (NS_inst) {
+    AspNsBatch_Free(NS_inst->batch);
+    free(NS_inst);
+  }
+  return 0;
+}
+
+int WebRtcNs_Init(NsHandle* NS_inst, uint32_t fs) {
+  if (!NS_inst) return -1;
+  if (AspNsBatch_Init(NS_inst->batch, fs) != ASP_OK) return -1;
+  NS_inst->initFlag = 1;
+  return 0;
+}
+
+int WebRtcNs_set_policy(NsHandle* NS_inst, int mode) {
+  if (!NS_inst || !NS_inst->initFlag) return -1;
+  return AspNsBatch_set_policy(NS_inst->batch, mode) == ASP_OK ? 0 : -1;
+}
+
+void WebRtcNs_Analyze(NsHandle* NS_inst, const float* spframe) {
+  if (!NS_inst || !NS_inst->initFlag) {  // reference: assert(initFlag == 1), ns_core.c:1064
+    fprintf(stderr, "WebRtcNs_Analyze: handle not initialised\n");
+    abort();
+  }
+  if (AspNsBatch_Analyze(NS_inst->batch, spframe, ASP_MEM_HOST) != ASP_OK) {
+    fprintf(stderr, "WebRtcNs_Analyze: %s\n", g_err);
+    abort();
+  }
+}
+
+void WebRtcNs_Process(NsHandle* NS_inst, const float* const* spframe, int num_bands,
+                      float* const* outframe) {
+  if (!NS_inst || !NS_inst->initFlag) {  // ns_core.c:1208
+    fprintf(stderr, "WebRtcNs_Process: handle not initialised\n");
+    abort();
+  }
+  if (num_bands != 1) {
+    fprintf(stderr, "WebRtcNs_Process: only num_bands = 1 (<= 16 kHz) is implemented\n");
+    abort();
+  }
+  if (AspNsBatch_Process(NS_inst->batch, spframe[0], outframe[0], ASP_MEM_HOST) != ASP_OK) {
+    fprintf(stderr, "WebRtcNs_Process: %s\n", g_err);
+    abort();
+  }
+}
+
+float WebRtcNs_prior_speech_probability(NsHandle* handle) {
+  if (handle == NULL) return -1;
+  if (handle->initFlag == 0) return -1;
+  float p = -1.f;
+  if (AspNsBatch_prior_speech_probability(handle->batch, &p) != ASP_OK) return -1;
+  return p;
+}
+
+}  // extern "C"

@@ -1,0 +1,977 @@
+// ns_kernels.hip -- hand-written gfx950 kernels of the batched noise suppressor.
+//
+// Replaces, for N independent 16 kHz streams per launch, the reference's
+//   WebRtcNs_AnalyzeCore  (ns/ns_core.c:1043-1181)
+//   WebRtcNs_ProcessCore  (ns/ns_core.c:1183-1359)
+//   WebRtc_rdft(256, +-1) (utility/fft4g.c:324-362)
+// (paths relative to WebRtc_AMP_Port/webrtc/modules/audio_processing/).
+//
+// Mapping: one wave64 per stream, four streams per 256-thread workgroup, no
+// workgroup barrier anywhere.  Lane q owns bins q and q+64; bin 128 is computed
+// redundantly on every lane.  Per-stream scalars are wave-uniform, so every
+// data-independent branch of the reference (startup phases, tracker publish,
+// histogram window) is a scalar branch.
+//
+// FFT: the 256-point real transform runs as a 128-point complex transform whose
+// three radix-4 passes are staged through a 1 KB LDS tile private to the wave;
+// each radix-4 butterfly is split over a lane pair (one lane produces outputs
+// 0/2, the other 1/3) so all 64 lanes work; the radix-2 tail and the real
+// split use registers plus one wavefront shuffle (lane q <-> lane 64-q).  The
+// butterflies perform the float operations of the reference's Ooura code in
+// the same order, so spectra are bit-identical to WebRtc_rdft.
+//
+// Cross-bin sums use a fixed association (slot-local, then xor 32,16,8,4,2,1)
+// that oracle/ns_oracle.c reproduces in ASP_NS_REDUCE_TREE mode.
+//
+// Compile with -ffp-contract=off: parity depends on unfused mul/add.
+#include <hip/hip_runtime.h>
+
+#include "ns_layout.h"
+
+using namespace aspns;
+
+namespace {
+
+// ns/defines.h:19-48, same (float)<double literal> spelling as the reference
+#define NS_QUANTILE (float)0.25
+#define NS_END_STARTUP_LONG 200
+#define NS_END_STARTUP_SHORT 50
+#define NS_FACTOR (float)40.0
+#define NS_WIDTH (float)0.01
+#define NS_DD_PR_SNR (float)0.98
+#define NS_LRT_TAVG (float)0.50
+#define NS_SPECT_FL_TAVG (float)0.30
+#define NS_SPECT_DIFF_TAVG (float)0.30
+#define NS_PRIOR_UPDATE (float)0.10
+#define NS_NOISE_UPDATE (float)0.90
+#define NS_SPEECH_UPDATE (float)0.99
+#define NS_WIDTH_PR_MAP (float)4.0
+#define NS_PROB_RANGE (float)0.20
+#define NS_GAMMA_PAUSE (float)0.05
+#define NS_B_LIM (float)0.5
+#define NS_START_BAND 5
+
+__device__ __forceinline__ float xorf(float x, uint32_t m) {
+  return __uint_as_float(__float_as_uint(x) ^ m);
+}
+
+// Orders the wave's own LDS traffic for the compiler; the hardware executes
+// one wave's DS instructions in order, so no s_barrier is needed.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, 64);
+  return v;
+}
+
+struct FftLane {
+  float4 tw0, tw1, tw2;  // (tAr, tAi, tBr, tBi) for passes 1..3
+  int diag;
+  float cq, cr;
+};
+
+__device__ __forceinline__ FftLane load_fft_lane(const NsTables* __restrict__ T, int lane) {
+  FftLane L;
+  L.tw0 = *reinterpret_cast<const float4*>(T->tw[0][lane]);
+  L.tw1 = *reinterpret_cast<const float4*>(T->tw[1][lane]);
+  L.tw2 = *reinterpret_cast<const float4*>(T->tw[2][lane]);
+  L.diag = T->diag[lane];
+  L.cq = T->cq[lane];
+  L.cr = T->cr[lane];
+  return L;
+}
+
+// Half of one radix-4 butterfly of cft1st / cftmdl (fft4g.c:1002-1231).
+// Lane parity h = 0 produces outputs 0 and 2 of the butterfly, h = 1 outputs
+// 1 and 3.  With s = (h ? -1 : +1):
+//   u = c0 + s*c1, v = c2 + s*c3, h: v <- i*v, p = u + v, m = u - v
+//   out_first = tA * p, out_second = tB * m
+// where tA/tB come from the per-lane table (identity for twiddle-free blocks)
+// and `diag` selects the reference's factored form for the w[2] block.
+__device__ __forceinline__ void cft_half_pass(float2* buf, int r0, int r1, int r2, int r3,
+                                              int w0, int w1, bool h, float4 tw, bool diag) {
+  const float2 c0 = buf[r0], c1 = buf[r1], c2 = buf[r2], c3 = buf[r3];
+  const uint32_t sm = h ? 0x80000000u : 0u;
+  const float ur = c0.x + xorf(c1.x, sm), ui = c0.y + xorf(c1.y, sm);
+  const float vr = c2.x + xorf(c3.x, sm), vi = c2.y + xorf(c3.y, sm);
+  const float vr2 = h ? -vi : vr;
+  const float vi2 = h ? vr : vi;
+  const float pr = ur + vr2, pi = ui + vi2;
+  const float mr = ur - vr2, mi = ui - vi2;
+  const float g1r = tw.x * pr - tw.y * pi, g1i = tw.x * pi + tw.y * pr;
+  const float g2r = tw.z * mr - tw.w * mi, g2i = tw.z * mi + tw.w * mr;
+  const float d1r = tw.x * (pr - pi), d1i = tw.x * (pr + pi);
+  const float d2r = -(tw.x * (mr + mi)), d2i = tw.x * (mr - mi);
+  buf[w0] = diag ? make_float2(d1r, d1i) : make_float2(g1r, g1i);
+  buf[w1] = diag ? make_float2(d2r, d2i) : make_float2(g2r, g2i);
+}
+
+// The three radix-4 passes of cftfsub/cftbsub for 128 complex points; input in
+// natural order in buf (the first pass reads bit-reversed = bitrv2).
+__device__ __forceinline__ void cft128_passes(float2* buf, const FftLane& L, int lane) {
+  const int b = lane >> 1;
+  const bool h = (lane & 1) != 0;
+  {
+    const int rb = (int)(__brev((unsigned)b) >> 27);
+    cft_half_pass(buf, rb, rb + 64, rb + 32, rb + 96, 4 * b + (h ? 1 : 0), 4 * b + (h ? 3 : 2), h,
+                  L.tw0, (L.diag & 1) != 0);
+  }
+  wave_lds_fence();
+  {
+    const int base = 16 * (b >> 2) + (b & 3);
+    cft_half_pass(buf, base, base + 4, base + 8, base + 12, base + (h ? 4 : 0),
+                  base + (h ? 12 : 8), h, L.tw1, (L.diag & 2) != 0);
+  }
+  wave_lds_fence();
+  {
+    const int base = 64 * (b >> 4) + (b & 15);
+    cft_half_pass(buf, base, base + 16, base + 32, base + 48, base + (h ? 16 : 0),
+                  base + (h ? 48 : 32), h, L.tw2, (L.diag & 4) != 0);
+  }
+  wave_lds_fence();
+}
+
+// WebRtc_rdft(256, +1): buf holds the 128 complex inputs (x[2n], x[2n+1]) in
+// natural order.  Returns complex elements q (lo) and q+64 (hi) of the Ooura
+// packed spectrum; lane 0: lo = (R0, R128).
+__device__ __forceinline__ void rdft256_fwd(float2* buf, const FftLane& L, int lane, float2& lo,
+                                            float2& hi) {
+  cft128_passes(buf, L, lane);
+  const float2 a = buf[lane], c = buf[lane + 64];
+  const float lor = a.x + c.x, loi = a.y + c.y;  // fft4g.c:939-947
+  const float hir = a.x - c.x, hii = a.y - c.y;
+  const int src = (64 - lane) & 63;
+  const float plor = __shfl(lor, src, 64), ploi = __shfl(loi, src, 64);
+  const float phir = __shfl(hir, src, 64), phii = __shfl(hii, src, 64);
+  // rftfsub (fft4g.c:1234-1256): pair (j = q, k = 128 - q) updates lo ...
+  const float wkr1 = 0.5f - L.cr, wki1 = L.cq;
+  float xr = lor - phir, xi = loi + phii;
+  float yr = wkr1 * xr - wki1 * xi, yi = wkr1 * xi + wki1 * xr;
+  float nlor = lor - yr, nloi = loi - yi;
+  // ... and pair (j = 64 - q, k = 64 + q) updates hi.
+  const float wkr2 = 0.5f - L.cq, wki2 = L.cr;
+  xr = plor - hir;
+  xi = ploi + hii;
+  yr = wkr2 * xr - wki2 * xi;
+  yi = wkr2 * xi + wki2 * xr;
+  float nhir = hir + yr, nhii = hii - yi;
+  if (lane == 0) {  // fft4g.c:347-349, element 64 untouched
+    nlor = lor + loi;
+    nloi = lor - loi;
+    nhir = hir;
+    nhii = hii;
+  }
+  lo = make_float2(nlor, nloi);
+  hi = make_float2(nhir, nhii);
+}
+
+// WebRtc_rdft(256, -1), unscaled.  In: packed spectrum elements q / q+64.
+// Out: lo = (x[2q], x[2q+1]), hi = (x[2q+128], x[2q+129]).
+__device__ __forceinline__ void rdft256_inv(float2* buf, const FftLane& L, int lane, float2& lo,
+                                            float2& hi) {
+  const float lor = lo.x, loi = lo.y, hir = hi.x, hii = hi.y;
+  const int src = (64 - lane) & 63;
+  const float plor = __shfl(lor, src, 64), ploi = __shfl(loi, src, 64);
+  const float phir = __shfl(hir, src, 64), phii = __shfl(hii, src, 64);
+  // rftbsub (fft4g.c:1259-1283)
+  const float wkr1 = 0.5f - L.cr, wki1 = L.cq;
+  float xr = lor - phir, xi = loi + phii;
+  float yr = wkr1 * xr + wki1 * xi, yi = wkr1 * xi - wki1 * xr;
+  float nlor = lor - yr, nloi = yi - loi;
+  const float wkr2 = 0.5f - L.cq, wki2 = L.cr;
+  xr = plor - hir;
+  xi = ploi + hii;
+  yr = wkr2 * xr + wki2 * xi;
+  yi = wkr2 * xi - wki2 * xr;
+  float nhir = hir + yr, nhii = yi - hii;
+  if (lane == 0) {  // fft4g.c:351-352, :1264, :1282
+    const float t = 0.5f * (lor - loi);
+    nlor = lor - t;
+    nloi = -t;
+    nhir = hir;
+    nhii = -hii;
+  }
+  buf[lane] = make_float2(nlor, nloi);
+  buf[lane + 64] = make_float2(nhir, nhii);
+  wave_lds_fence();
+  cft128_passes(buf, L, lane);
+  const float2 a = buf[lane], c = buf[lane + 64];
+  lo = make_float2(a.x + c.x, -a.y - c.y);  // fft4g.c:989-997
+  hi = make_float2(a.x - c.x, -a.y + c.y);
+}
+
+// --------------------------------------------------------------------------
+// Histogram window close: FeatureParameterExtraction(self, 1), ns_core.c:337-517.
+// Runs once per 500 frames per stream.  Zero bins cannot change any of the
+// running sums / peaks, so only non-empty bins are visited, in bin order, which
+// keeps the reference's sequential float sums and tie-breaking exactly.
+struct PriorModel {
+  float p0, p1, p3, p4, p5, p6;
+};
+
+__device__ __noinline__ PriorModel close_histogram_window(int32_t* __restrict__ hist, int lane,
+                                                          int updateWindow, bool zero_after,
+                                                          PriorModel pm) {
+  // ---- LRT histogram, :340-373
+  float avgHistLrt = 0.f, avgHistLrtCompl = 0.f, avgSquareHistLrt = 0.f;
+  int numHistLrt = 0;
+  for (int r = 0; r < 16; ++r) {
+    const int i = r * 64 + lane;
+    const int v = i < kHist ? hist[i] : 0;
+    unsigned long long m = __ballot(v != 0);
+    while (m) {
+      const int p = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int hv = __shfl(v, p, 64);
+      const float binMid = ((float)(r * 64 + p) + 0.5f) * 0.1f;
+      if (binMid <= 1.f) {
+        avgHistLrt += hv * binMid;
+        numHistLrt += hv;
+      }
+      avgSquareHistLrt += hv * binMid * binMid;
+      avgHistLrtCompl += hv * binMid;
+    }
+  }
+  if (numHistLrt > 0) avgHistLrt = avgHistLrt / ((float)numHistLrt);
+  avgHistLrtCompl = avgHistLrtCompl / ((float)updateWindow);
+  avgSquareHistLrt = avgSquareHistLrt / ((float)updateWindow);
+  const float fluctLrt = avgSquareHistLrt - avgHistLrt * avgHistLrtCompl;
+  if (fluctLrt < 0.05f) {
+    pm.p0 = 1.f;
+  } else {
+    pm.p0 = 1.2f * avgHistLrt;
+    if (pm.p0 < 0.2f) pm.p0 = 0.2f;
+    if (pm.p0 > 1.f) pm.p0 = 1.f;
+  }
+  // ---- two dominant peaks of the flatness and difference histograms, :378-432
+  float pos1[2], pos2[2];
+  int wt1[2], wt2[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int32_t* hh = hist + (k + 1) * kHistStride;
+    const float binSize = k == 0 ? 0.05f : 0.1f;
+    int maxPeak1 = 0, maxPeak2 = 0;
+    pos1[k] = 0.f;
+    pos2[k] = 0.f;
+    wt1[k] = 0;
+    wt2[k] = 0;
+    for (int r = 0; r < 16; ++r) {
+      const int i = r * 64 + lane;
+      const int v = i < kHist ? hh[i] : 0;
+      unsigned long long m = __ballot(v != 0);
+      while (m) {
+        const int p = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int hv = __shfl(v, p, 64);
+        const float binMid = ((float)(r * 64 + p) + 0.5f) * binSize;
+        if (hv > maxPeak1) {
+          maxPeak2 = maxPeak1;
+          wt2[k] = wt1[k];
+          pos2[k] = pos1[k];
+          maxPeak1 = hv;
+          wt1[k] = hv;
+          pos1[k] = binMid;
+        } else if (hv > maxPeak2) {
+          maxPeak2 = hv;
+          wt2[k] = hv;
+          pos2[k] = binMid;
+        }
+      }
+    }
+  }
+  const int thresWeight = (int)(0.3 * updateWindow);  // :67-70
+  // ---- flatness, :435-463
+  int useFlat = 1;
+  if ((fabsf(pos2[0] - pos1[0]) < 2 * 0.05f) && (wt2[0] > 0.5f * wt1[0])) {
+    wt1[0] += wt2[0];
+    pos1[0] = 0.5f * (pos1[0] + pos2[0]);
+  }
+  if (wt1[0] < thresWeight || pos1[0] < 0.6f) useFlat = 0;
+  if (useFlat == 1) {
+    pm.p1 = 0.9f * pos1[0];
+    if (pm.p1 < 0.1f) pm.p1 = 0.1f;
+    if (pm.p1 > 0.95f) pm.p1 = 0.95f;
+  }
+  // ---- template difference, :467-498
+  int useDiff = 1;
+  if ((fabsf(pos2[1] - pos1[1]) < 2 * 0.1f) && (wt2[1] > 0.5f * wt1[1])) {
+    wt1[1] += wt2[1];
+    pos1[1] = 0.5f * (pos1[1] + pos2[1]);
+  }
+  pm.p3 = 1.2f * pos1[1];
+  if (wt1[1] < thresWeight) useDiff = 0;
+  if (pm.p3 < 0.16f) pm.p3 = 0.16f;
+  if (pm.p3 > 1.f) pm.p3 = 1.f;
+  if (fluctLrt < 0.05f) useDiff = 0;
+  const float featureSum = (float)(1 + useFlat + useDiff);  // :504-507
+  pm.p4 = 1.f / featureSum;
+  pm.p5 = ((float)useFlat) / featureSum;
+  pm.p6 = ((float)useDiff) / featureSum;
+  if (zero_after) {  // :510-516
+    for (int k = 0; k < 3; ++k)
+      for (int r = 0; r < 16; ++r) hist[k * kHistStride + r * 64 + lane] = 0;
+  }
+  return pm;
+}
+
+// --------------------------------------------------------------------------
+// One 10 ms frame of one stream per wave.
+//   DO_A && DO_P : Analyze(frame) then Process(frame) on the same frame with
+//                  the streams' state "paired" (analyzeBuf == dataBuf,
+//                  magnPrevAnalyze == magnPrevProcess, noise == noisePrev at
+//                  rest), which holds as long as a stream has only ever been
+//                  driven through this fused step -- the loop body of
+//                  test_ns_module.cpp:97-99.  One forward FFT serves both.
+//   DO_A only    : WebRtcNs_AnalyzeCore.
+//   DO_P only    : WebRtcNs_ProcessCore (one band).
+template <bool DO_A, bool DO_P>
+__global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state,
+                                                       int32_t* __restrict__ hist_all,
+                                                       const NsTables* __restrict__ T,
+                                                       const float* __restrict__ in,
+                                                       float* __restrict__ out, int num_streams) {
+  __shared__ float2 lds[4][128];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = blockIdx.x * 4 + wv;
+  if (stream >= num_streams) return;
+  float* __restrict__ st = state + (size_t)stream * kStreamDwords;
+  float* __restrict__ vec = st + kOffVec;
+  int32_t* __restrict__ hist = hist_all + (size_t)stream * kHistDwords;
+  float2* buf = lds[wv];
+
+  // ---- per-stream scalars: lane k holds scalar k
+  float sv = st[kOffScalars + lane];
+#define SC_I(k) __builtin_amdgcn_readlane(__float_as_int(sv), (k))
+#define SC_F(k) __int_as_float(SC_I(k))
+#define SC_SET_I(k, val) sv = (lane == (k)) ? __int_as_float(val) : sv
+#define SC_SET_F(k, val) sv = (lane == (k)) ? (val) : sv
+
+  // ---- sliding analysis buffer: [96 carried samples | 160 new], lane l owns 4l..4l+3
+  float* hbuf = st + ((DO_A) ? kOffAnaHist : kOffDataHist);
+  const float* src =
+      lane < 24 ? hbuf + 4 * lane : in + (size_t)stream * kBlockL + 4 * (lane - 24);
+  const float4 s4 = *reinterpret_cast<const float4*>(src);
+  const float4 w4 = *reinterpret_cast<const float4*>(T->window + 4 * lane);
+
+  // ---- state rows (issued early; consumed after the FFT)
+  float LQ[3][3], DEN[3][3], quant[3], smooth[3], noisePrev[3], magnPrevA[3], logLrt[3],
+      avgPause[3], noiseSt[3], magnPrevP[3];
+#define LOAD_ROW(dst, f)                          \
+  {                                               \
+    dst[0] = vec[(f)*kVecStride + lane];          \
+    dst[1] = vec[(f)*kVecStride + 64 + lane];     \
+    dst[2] = vec[(f)*kVecStride + 128];           \
+  }
+#define STORE_ROW(f, srcv)                                  \
+  {                                                         \
+    vec[(f)*kVecStride + lane] = srcv[0];                   \
+    vec[(f)*kVecStride + 64 + lane] = srcv[1];              \
+    if (lane == 0) vec[(f)*kVecStride + 128] = srcv[2];     \
+  }
+  if (DO_A) {
+    LOAD_ROW(LQ[0], V_LQ0) LOAD_ROW(LQ[1], V_LQ1) LOAD_ROW(LQ[2], V_LQ2)
+    LOAD_ROW(DEN[0], V_DEN0) LOAD_ROW(DEN[1], V_DEN1) LOAD_ROW(DEN[2], V_DEN2)
+    LOAD_ROW(quant, V_QUANT) LOAD_ROW(magnPrevA, V_MAGNPREV_A)
+    LOAD_ROW(logLrt, V_LOGLRT) LOAD_ROW(avgPause, V_AVGPAUSE)
+  }
+  LOAD_ROW(smooth, V_SMOOTH) LOAD_ROW(noisePrev, V_NOISEPREV)
+  if (DO_P && !DO_A) {
+    LOAD_ROW(noiseSt, V_NOISE) LOAD_ROW(magnPrevP, V_MAGNPREV_P)
+  }
+  float2 carry = make_float2(0.f, 0.f);  // syntBuf[0..95], lane l owns 2l, 2l+1
+  if (DO_P && lane < 48) carry = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * lane);
+  const FftLane L = load_fft_lane(T, lane);
+
+  // Windowing + Energy (ns_core.c:969-978, 951-960)
+  const float wx0 = w4.x * s4.x, wx1 = w4.y * s4.y, wx2 = w4.z * s4.z, wx3 = w4.w * s4.w;
+  float epart = wx0 * wx0;
+  epart += wx1 * wx1;
+  epart += wx2 * wx2;
+  epart += wx3 * wx3;
+  const float energy1 = wave_sum(epart);
+
+  int blockInd = SC_I(S_BLOCKIND);
+  const float overdrive = SC_F(S_OVERDRIVE);
+  const float denoiseBound = SC_F(S_DENOISEBOUND);
+  float priorSpeechProb = SC_F(S_PRIORSPEECHPROB);
+
+  // the carried 96 samples for the next frame are this frame's last 96
+  if (lane >= 40) *reinterpret_cast<float4*>(hbuf + 4 * (lane - 40)) = s4;
+
+  if (energy1 == 0.0f) {
+    // Analyze: nothing but the buffer slide (ns_core.c:1072-1082).
+    // Process: emit the synthesis tail (ns_core.c:1239-1264).
+    if (DO_P) {
+      float* sy = st + kOffSynt;
+      float* y = out + (size_t)stream * kBlockL;
+      float2 o01 = carry;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      o01.x = o01.x > 32767 ? 32767 : (o01.x < -32768 ? -32768 : o01.x);
+      o01.y = o01.y > 32767 ? 32767 : (o01.y < -32768 ? -32768 : o01.y);
+      *reinterpret_cast<float2*>(y + 2 * lane) = o01;
+      if (lane < 16) *reinterpret_cast<float2*>(y + 128 + 2 * lane) = make_float2(0.f, 0.f);
+      if (lane < 48) *reinterpret_cast<float2*>(sy + 2 * lane) = make_float2(0.f, 0.f);
+    }
+    return;
+  }
+
+  // ---- forward FFT (ns_core.c:886-911)
+  *reinterpret_cast<float4*>(&buf[2 * lane]) = make_float4(wx0, wx1, wx2, wx3);
+  wave_lds_fence();
+  float2 lo, hi;
+  rdft256_fwd(buf, L, lane, lo, hi);
+  const float re128 = __shfl(lo.y, 0, 64);
+  float re[3], im[3], magn[3];
+  re[0] = lo.x;
+  im[0] = lane == 0 ? 0.f : lo.y;
+  re[1] = hi.x;
+  im[1] = hi.y;
+  re[2] = re128;
+  im[2] = 0.f;
+  {
+    const float m0 = sqrtf(re[0] * re[0] + im[0] * im[0]) + 1.f;
+    magn[0] = lane == 0 ? fabsf(re[0]) + 1.f : m0;
+    magn[1] = sqrtf(re[1] * re[1] + im[1] * im[1]) + 1.f;
+    magn[2] = fabsf(re[2]) + 1.f;
+  }
+
+  float noise[3];  // noise estimate handed from Analyze to Process
+
+  if (DO_A) {
+    blockInd++;  // ns_core.c:1084
+    const int updateParsFlag = SC_I(S_MUP0);
+    int updates = SC_I(S_UPDATES);
+    int counter[3] = {SC_I(S_COUNTER0), SC_I(S_COUNTER1), SC_I(S_COUNTER2)};
+
+    float lmagn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lmagn[k] = (float)log((double)magn[k]);
+
+    // signalEnergy, sumMagn (ns_core.c:1088-1104)
+    float t_se = (re[0] * re[0] + im[0] * im[0]) + (re[1] * re[1] + im[1] * im[1]);
+    float t_sm = magn[0] + magn[1];
+    if (lane == 0) {
+      t_se = t_se + (re[2] * re[2] + im[2] * im[2]);
+      t_sm = t_sm + magn[2];
+    }
+    float signalEnergy = wave_sum(t_se);
+    const float sumMagn = wave_sum(t_sm);
+    signalEnergy = signalEnergy / ((float)kBins);
+
+    // ---- NoiseEstimation (ns_core.c:217-285)
+    if (updates < NS_END_STARTUP_LONG) updates++;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const float cnt = (float)counter[s];
+      const float cnt1 = (float)(counter[s] + 1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float den = DEN[s][k], lq = LQ[s][k];
+        const float delta = den > 1.0f ? NS_FACTOR * 1.f / den : NS_FACTOR;
+        const bool up = lmagn[k] > lq;
+        const float step = (up ? NS_QUANTILE * delta : (1.f - NS_QUANTILE) * delta) / cnt1;
+        lq = up ? lq + step : lq - step;
+        const float nd = (cnt * den + 1.f / (2.f * NS_WIDTH)) / cnt1;
+        den = fabsf(lmagn[k] - lq) < NS_WIDTH ? nd : den;
+        DEN[s][k] = den;
+        LQ[s][k] = lq;
+      }
+      if (counter[s] >= NS_END_STARTUP_LONG) {
+        counter[s] = 0;
+        if (updates >= NS_END_STARTUP_LONG) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) quant[k] = (float)exp((double)LQ[s][k]);
+        }
+      }
+      counter[s]++;
+    }
+    if (updates < NS_END_STARTUP_LONG) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) quant[k] = (float)exp((double)LQ[2][k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) noise[k] = quant[k];
+
+    // ---- startup noise model (ns_core.c:1091-1100, 1109-1162)
+    float whiteNoiseLevel = SC_F(S_WHITE);
+    float pinkNoiseNumerator = SC_F(S_PINKNUM);
+    float pinkNoiseExp = SC_F(S_PINKEXP);
+    float fd5 = SC_F(S_FD5);
+    if (blockInd < NS_END_STARTUP_SHORT) {
+      float logi[3];
+      logi[0] = T->logi[lane];
+      logi[1] = T->logi[64 + lane];
+      logi[2] = T->logi[128];
+      float t_lm = (lane >= NS_START_BAND ? lmagn[0] : 0.f) + lmagn[1];
+      float t_lilm = (lane >= NS_START_BAND ? logi[0] * lmagn[0] : 0.f) + logi[1] * lmagn[1];
+      if (lane == 0) {
+        t_lm = t_lm + lmagn[2];
+        t_lilm = t_lilm + logi[2] * lmagn[2];
+      }
+      const float sum_log_magn = wave_sum(t_lm);
+      const float sum_log_i_log_magn = wave_sum(t_lilm);
+      const float sum_log_i = T->sum_log_i, sum_log_i_square = T->sum_log_i_square;
+      whiteNoiseLevel += sumMagn / ((float)kBins) * overdrive;
+      float tmpFloat1 = sum_log_i_square * ((float)(kBins - NS_START_BAND));
+      tmpFloat1 -= (sum_log_i * sum_log_i);
+      float tmpFloat2 = (sum_log_i_square * sum_log_magn - sum_log_i * sum_log_i_log_magn);
+      float tmpFloat3 = tmpFloat2 / tmpFloat1;
+      if (tmpFloat3 < 0.f) tmpFloat3 = 0.f;
+      pinkNoiseNumerator += tmpFloat3;
+      tmpFloat2 = (sum_log_i * sum_log_magn);
+      tmpFloat2 -= ((float)(kBins - NS_START_BAND)) * sum_log_i_log_magn;
+      tmpFloat3 = tmpFloat2 / tmpFloat1;
+      if (tmpFloat3 < 0.f) tmpFloat3 = 0.f;
+      if (tmpFloat3 > 1.f) tmpFloat3 = 1.f;
+      pinkNoiseExp += tmpFloat3;
+      float parametric_num = 0.f, parametric_exp = 0.f;
+      if (pinkNoiseExp > 0.f) {
+        parametric_num = (float)exp((double)(pinkNoiseNumerator / (float)(blockInd + 1)));
+        parametric_num *= (float)(blockInd + 1);
+        parametric_exp = pinkNoiseExp / (float)(blockInd + 1);
+      }
+      float pn[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int bin = k == 0 ? lane : (k == 1 ? 64 + lane : 128);
+        if (pinkNoiseExp == 0.f) {
+          pn[k] = whiteNoiseLevel;
+        } else {
+          const float use_band = (float)(bin < NS_START_BAND ? NS_START_BAND : bin);
+          pn[k] = (float)((double)parametric_num / pow((double)use_band, (double)parametric_exp));
+        }
+        noise[k] *= (blockInd);
+        const float t2 = pn[k] * (NS_END_STARTUP_SHORT - blockInd);
+        noise[k] += (t2 / (float)(blockInd + 1));
+        noise[k] /= NS_END_STARTUP_SHORT;
+      }
+      STORE_ROW(V_PARAMNOISE, pn)
+    }
+    if (blockInd < NS_END_STARTUP_LONG) {  // ns_core.c:1165-1169
+      fd5 *= blockInd;
+      fd5 += signalEnergy;
+      fd5 /= (blockInd + 1);
+    }
+
+    // ---- ComputeSnr (ns_core.c:566-588)
+    float snrLocPost[3], snrLocPrior[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float previousEstimateStsa = magnPrevA[k] / (noisePrev[k] + 0.0001f) * smooth[k];
+      snrLocPost[k] = 0.f;
+      if (magn[k] > noise[k]) snrLocPost[k] = magn[k] / (noise[k] + 0.0001f) - 1.f;
+      snrLocPrior[k] =
+          NS_DD_PR_SNR * previousEstimateStsa + (1.f - NS_DD_PR_SNR) * snrLocPost[k];
+    }
+
+    // ---- ComputeSpectralFlatness (ns_core.c:523-556)
+    float fd0 = SC_F(S_FD0), fd4 = SC_F(S_FD4), fd6 = SC_F(S_FD6);
+    float t_fl = (lane >= 1 ? lmagn[0] : 0.f) + lmagn[1];
+    float t_ap = avgPause[0] + avgPause[1];
+    if (lane == 0) {
+      t_fl = t_fl + lmagn[2];
+      t_ap = t_ap + avgPause[2];
+    }
+    {
+      float num = wave_sum(t_fl);
+      float den = sumMagn - __shfl(magn[0], 0, 64);
+      den = den / kBins;
+      num = num / kBins;
+      const float spectralTmp = (float)exp((double)num) / den;
+      fd0 += NS_SPECT_FL_TAVG * (spectralTmp - fd0);
+    }
+    // ---- ComputeSpectralDifference (ns_core.c:595-634)
+    {
+      float avgPauseMean = wave_sum(t_ap);
+      float avgMagn = sumMagn;
+      avgPauseMean = avgPauseMean / ((float)kBins);
+      avgMagn = avgMagn / ((float)kBins);
+      float dm[3], dp[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dm[k] = magn[k] - avgMagn;
+        dp[k] = avgPause[k] - avgPauseMean;
+      }
+      float t_cov = dm[0] * dp[0] + dm[1] * dp[1];
+      float t_vp = dp[0] * dp[0] + dp[1] * dp[1];
+      float t_vm = dm[0] * dm[0] + dm[1] * dm[1];
+      if (lane == 0) {
+        t_cov = t_cov + dm[2] * dp[2];
+        t_vp = t_vp + dp[2] * dp[2];
+        t_vm = t_vm + dm[2] * dm[2];
+      }
+      float covMagnPause = wave_sum(t_cov);
+      float varPause = wave_sum(t_vp);
+      float varMagn = wave_sum(t_vm);
+      covMagnPause = covMagnPause / ((float)kBins);
+      varPause = varPause / ((float)kBins);
+      varMagn = varMagn / ((float)kBins);
+      fd6 += signalEnergy;
+      float avgDiffNormMagn = varMagn - (covMagnPause * covMagnPause) / (varPause + 0.0001f);
+      avgDiffNormMagn = (float)(avgDiffNormMagn / (fd5 + 0.0001f));
+      fd4 += NS_SPECT_DIFF_TAVG * (avgDiffNormMagn - fd4);
+    }
+
+    // ---- histograms / prior model (FeatureUpdate, ns_core.c:766-790)
+    float fd3 = SC_F(S_FD3);  // previous frame's average LRT feeds the histogram
+    PriorModel pm;
+    pm.p0 = SC_F(S_PMP0);
+    pm.p1 = SC_F(S_PMP1);
+    pm.p3 = SC_F(S_PMP3);
+    pm.p4 = SC_F(S_PMP4);
+    pm.p5 = SC_F(S_PMP5);
+    pm.p6 = SC_F(S_PMP6);
+    const float pmp2 = SC_F(S_PMP2);
+    int mup0 = updateParsFlag, mup3 = SC_I(S_MUP3);
+    const int mup1 = SC_I(S_MUP1);
+    if (updateParsFlag >= 1) {
+      mup3--;
+      if (mup3 > 0) {  // FeatureParameterExtraction(self, 0), ns_core.c:309-334
+        if (lane == 0) {
+          if ((fd3 < kHist * 0.1f) && (fd3 >= 0.0f)) hist[(int)(fd3 / 0.1f)]++;
+          if ((fd0 < kHist * 0.05f) && (fd0 >= 0.0f)) hist[kHistStride + (int)(fd0 / 0.05f)]++;
+          if ((fd4 < kHist * 0.1f) && (fd4 >= 0.0f))
+            hist[2 * kHistStride + (int)(fd4 / 0.1f)]++;
+        }
+      }
+      if (mup3 == 0) {
+        pm = close_histogram_window(hist, lane, mup1, mup0 >= 1, pm);
+        mup3 = mup1;
+        if (updateParsFlag == 1) {
+          mup0 = 0;
+        } else {
+          fd6 = fd6 / ((float)mup1);
+          fd5 = 0.5f * (fd6 + fd5);
+          fd6 = 0.f;
+        }
+      }
+    }
+
+    // ---- SpeechNoiseProb (ns_core.c:642-749)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float t1 = 1.f + 2.f * snrLocPrior[k];
+      const float t2 = 2.f * snrLocPrior[k] / (t1 + 0.0001f);
+      const float besselTmp = (snrLocPost[k] + 1.f) * t2;
+      logLrt[k] += NS_LRT_TAVG * (besselTmp - (float)log((double)t1) - logLrt[k]);
+    }
+    float t_ll = logLrt[0] + logLrt[1];
+    if (lane == 0) t_ll = t_ll + logLrt[2];
+    float logLrtTimeAvgKsum = wave_sum(t_ll);
+    logLrtTimeAvgKsum = (float)logLrtTimeAvgKsum / (kBins);
+    fd3 = logLrtTimeAvgKsum;
+    {
+      const float widthPrior0 = NS_WIDTH_PR_MAP, widthPrior1 = 2.f * NS_WIDTH_PR_MAP,
+                  widthPrior2 = 2.f * NS_WIDTH_PR_MAP;
+      const int sgnMap = (int)pmp2;
+      float widthPrior = widthPrior0;
+      if (logLrtTimeAvgKsum < pm.p0) widthPrior = widthPrior1;
+      const float arg0 = widthPrior * (logLrtTimeAvgKsum - pm.p0);
+      widthPrior = widthPrior0;
+      if (sgnMap == 1 && (fd0 > pm.p1)) widthPrior = widthPrior1;
+      if (sgnMap == -1 && (fd0 < pm.p1)) widthPrior = widthPrior1;
+      const float arg1 = (float)sgnMap * widthPrior * (pm.p1 - fd0);
+      widthPrior = widthPrior0;
+      if (fd4 < pm.p3) widthPrior = widthPrior2;
+      const float arg2 = widthPrior * (fd4 - pm.p3);
+      // the three tanh() of :696-725 evaluated on lanes 0..2 of one call
+      const float arg = lane == 0 ? arg0 : (lane == 1 ? arg1 : arg2);
+      const float th = (float)tanh((double)arg);
+      const float indicator0 = 0.5f * (__shfl(th, 0, 64) + 1.f);
+      const float indicator1 = 0.5f * (__shfl(th, 1, 64) + 1.f);
+      const float indicator2 = 0.5f * (__shfl(th, 2, 64) + 1.f);
+      const float indPrior = pm.p4 * indicator0 + pm.p5 * indicator1 + pm.p6 * indicator2;
+      priorSpeechProb += NS_PRIOR_UPDATE * (indPrior - priorSpeechProb);
+      if (priorSpeechProb > 1.f) priorSpeechProb = 1.f;
+      if (priorSpeechProb < 0.01f) priorSpeechProb = 0.01f;
+    }
+    float probSpeech[3];
+    {
+      const float gainPrior = (1.f - priorSpeechProb) / (priorSpeechProb + 0.0001f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float invLrt = (float)exp((double)(-logLrt[k]));
+        invLrt = (float)gainPrior * invLrt;
+        probSpeech[k] = 1.f / (1.f + invLrt);
+      }
+    }
+
+    // ---- UpdateNoiseEstimate (ns_core.c:800-846).  The time constant carried
+    // into bin i is the one bin i-1 selected from its speech probability.
+    {
+      const float upA = __shfl_up(probSpeech[0], 1, 64);
+      float upB = __shfl_up(probSpeech[1], 1, 64);
+      const float a63 = __shfl(probSpeech[0], 63, 64);
+      const float b63 = __shfl(probSpeech[1], 63, 64);
+      if (lane == 0) upB = a63;
+      float prevProb[3] = {upA, upB, b63};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float gammaOld = prevProb[k] > NS_PROB_RANGE ? NS_SPEECH_UPDATE : NS_NOISE_UPDATE;
+        if (k == 0 && lane == 0) gammaOld = NS_NOISE_UPDATE;
+        const float ps = probSpeech[k], pns = 1.f - probSpeech[k];
+        const float noiseUpdateTmp =
+            gammaOld * noisePrev[k] +
+            (1.f - gammaOld) * (pns * magn[k] + ps * noisePrev[k]);
+        float gammaNew = NS_NOISE_UPDATE;
+        if (ps > NS_PROB_RANGE) gammaNew = NS_SPEECH_UPDATE;
+        if (ps < NS_PROB_RANGE) avgPause[k] += NS_GAMMA_PAUSE * (magn[k] - avgPause[k]);
+        float nz;
+        if (gammaNew == gammaOld) {
+          nz = noiseUpdateTmp;
+        } else {
+          nz = gammaNew * noisePrev[k] +
+               (1.f - gammaNew) * (pns * magn[k] + ps * noisePrev[k]);
+          if (noiseUpdateTmp < nz) nz = noiseUpdateTmp;
+        }
+        noise[k] = nz;
+      }
+    }
+
+    // ---- commit Analyze state
+    STORE_ROW(V_LQ0, LQ[0]) STORE_ROW(V_LQ1, LQ[1]) STORE_ROW(V_LQ2, LQ[2])
+    STORE_ROW(V_DEN0, DEN[0]) STORE_ROW(V_DEN1, DEN[1]) STORE_ROW(V_DEN2, DEN[2])
+    STORE_ROW(V_QUANT, quant)
+    STORE_ROW(V_LOGLRT, logLrt) STORE_ROW(V_AVGPAUSE, avgPause)
+    STORE_ROW(V_MAGNPREV_A, magn)  // ns_core.c:1180
+    if (!DO_P) STORE_ROW(V_NOISE, noise)  // ns_core.c:1179
+    SC_SET_I(S_UPDATES, updates);
+    SC_SET_I(S_COUNTER0, counter[0]);
+    SC_SET_I(S_COUNTER1, counter[1]);
+    SC_SET_I(S_COUNTER2, counter[2]);
+    SC_SET_I(S_MUP0, mup0);
+    SC_SET_I(S_MUP3, mup3);
+    SC_SET_F(S_SIGNALENERGY, signalEnergy);
+    SC_SET_F(S_SUMMAGN, sumMagn);
+    SC_SET_F(S_WHITE, whiteNoiseLevel);
+    SC_SET_F(S_PINKNUM, pinkNoiseNumerator);
+    SC_SET_F(S_PINKEXP, pinkNoiseExp);
+    SC_SET_F(S_PMP0, pm.p0);
+    SC_SET_F(S_PMP1, pm.p1);
+    SC_SET_F(S_PMP3, pm.p3);
+    SC_SET_F(S_PMP4, pm.p4);
+    SC_SET_F(S_PMP5, pm.p5);
+    SC_SET_F(S_PMP6, pm.p6);
+    SC_SET_F(S_FD0, fd0);
+    SC_SET_F(S_FD3, fd3);
+    SC_SET_F(S_FD4, fd4);
+    SC_SET_F(S_FD5, fd5);
+    SC_SET_F(S_FD6, fd6);
+    SC_SET_I(S_BLOCKIND, blockInd);
+    SC_SET_F(S_PRIORSPEECHPROB, priorSpeechProb);
+  }
+
+  if (DO_P) {
+    if (!DO_A) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) noise[k] = noiseSt[k];
+    }
+    float mprev[3];  // paired: magnPrevProcess == magnPrevAnalyze (previous frame's magn)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mprev[k] = DO_A ? magnPrevA[k] : magnPrevP[k];
+    const int gainmap = SC_I(S_GAINMAP);
+
+    float initMagn[3], pnoise[3];
+    if (blockInd < NS_END_STARTUP_SHORT) {  // ns_core.c:1268-1272
+      LOAD_ROW(initMagn, V_INITMAGN)
+      LOAD_ROW(pnoise, V_PARAMNOISE)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) initMagn[k] += magn[k];
+      STORE_ROW(V_INITMAGN, initMagn)
+    }
+    float gainv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      // ComputeDdBasedWienerFilter (ns_core.c:985-1007)
+      const float previousEstimateStsa = mprev[k] / (noisePrev[k] + 0.0001f) * smooth[k];
+      float currentEstimateStsa = 0.f;
+      if (magn[k] > noise[k]) currentEstimateStsa = magn[k] / (noise[k] + 0.0001f) - 1.f;
+      const float snrPrior =
+          NS_DD_PR_SNR * previousEstimateStsa + (1.f - NS_DD_PR_SNR) * currentEstimateStsa;
+      float g = snrPrior / (overdrive + snrPrior);
+      // floors and startup blend (ns_core.c:1276-1307)
+      if (g < denoiseBound) g = denoiseBound;
+      if (g > 1.f) g = 1.f;
+      if (blockInd < NS_END_STARTUP_SHORT) {
+        float tmp = (initMagn[k] - overdrive * pnoise[k]);
+        tmp /= (initMagn[k] + 0.0001f);
+        if (tmp < denoiseBound) tmp = denoiseBound;
+        if (tmp > 1.f) tmp = 1.f;
+        g *= (blockInd);
+        tmp *= (NS_END_STARTUP_SHORT - blockInd);
+        g += tmp;
+        g /= (NS_END_STARTUP_SHORT);
+      }
+      gainv[k] = g;
+      re[k] *= g;
+      im[k] *= g;
+    }
+    STORE_ROW(V_SMOOTH, gainv)           // ns_core.c:1304
+    STORE_ROW(V_NOISEPREV, noise)        // ns_core.c:1310
+    if (!DO_A) STORE_ROW(V_MAGNPREV_P, magn)  // ns_core.c:1309 (paired: V_MAGNPREV_A holds it)
+
+    // ---- IFFT (ns_core.c:923-944)
+    float2 tlo = make_float2(re[0], lane == 0 ? re[2] : im[0]);
+    float2 thi = make_float2(re[1], im[1]);
+    rdft256_inv(buf, L, lane, tlo, thi);
+    float td0 = tlo.x * (2.f / kAnal), td1 = tlo.y * (2.f / kAnal);
+    float td2 = thi.x * (2.f / kAnal), td3 = thi.y * (2.f / kAnal);
+
+    // ---- energy-based gain compensation (ns_core.c:1315-1342)
+    float factor = 1.f;
+    if (gainmap == 1 && blockInd > NS_END_STARTUP_LONG) {
+      float factor1 = 1.f, factor2 = 1.f;
+      float e2 = td0 * td0;
+      e2 += td1 * td1;
+      e2 += td2 * td2;
+      e2 += td3 * td3;
+      const float energy2 = wave_sum(e2);
+      float gain = sqrtf(energy2 / (energy1 + 1.f));
+      if (gain > NS_B_LIM) {
+        factor1 = 1.f + 1.3f * (gain - NS_B_LIM);
+        if (gain * factor1 > 1.f) factor1 = 1.f / gain;
+      }
+      if (gain < NS_B_LIM) {
+        if (gain <= denoiseBound) gain = denoiseBound;
+        factor2 = 1.f - 0.3f * (NS_B_LIM - gain);
+      }
+      factor = priorSpeechProb * factor1 + (1.f - priorSpeechProb) * factor2;
+    }
+
+    // ---- synthesis window, overlap-add, emit 160, carry 96 (ns_core.c:1344-1359)
+    const float2 wlo = *reinterpret_cast<const float2*>(T->window + 2 * lane);
+    const float2 whi = *reinterpret_cast<const float2*>(T->window + 128 + 2 * lane);
+    float* sy = st + kOffSynt;
+    float* y = out + (size_t)stream * kBlockL;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // carry was read long ago; keep it so
+    float o0 = carry.x + factor * (wlo.x * td0);
+    float o1 = carry.y + factor * (wlo.y * td1);
+    float o2 = 0.f + factor * (whi.x * td2);
+    float o3 = 0.f + factor * (whi.y * td3);
+    if (lane >= 16) {  // samples 160..255 become the next carry
+      *reinterpret_cast<float2*>(sy + 2 * lane - 32) = make_float2(o2, o3);
+    }
+    o0 = o0 > 32767 ? 32767 : (o0 < -32768 ? -32768 : o0);
+    o1 = o1 > 32767 ? 32767 : (o1 < -32768 ? -32768 : o1);
+    *reinterpret_cast<float2*>(y + 2 * lane) = make_float2(o0, o1);
+    if (lane < 16) {
+      o2 = o2 > 32767 ? 32767 : (o2 < -32768 ? -32768 : o2);
+      o3 = o3 > 32767 ? 32767 : (o3 < -32768 ? -32768 : o3);
+      *reinterpret_cast<float2*>(y + 128 + 2 * lane) = make_float2(o2, o3);
+    }
+  }
+
+  if (DO_A) st[kOffScalars + lane] = sv;
+#undef SC_I
+#undef SC_F
+#undef SC_SET_I
+#undef SC_SET_F
+#undef LOAD_ROW
+#undef STORE_ROW
+}
+
+// Leaves the paired representation: materialises dataBuf / magnPrevProcess /
+// noise copies so Analyze and Process can be called separately afterwards.
+__global__ __launch_bounds__(256) void ns_unpair_kernel(float* __restrict__ state,
+                                                        int num_streams) {
+  const int lane = threadIdx.x & 63;
+  const int stream = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (stream >= num_streams) return;
+  float* st = state + (size_t)stream * kStreamDwords;
+  float* vec = st + kOffVec;
+  for (int i = lane; i < kCarry; i += 64) st[kOffDataHist + i] = st[kOffAnaHist + i];
+  for (int i = lane; i < kVecStride; i += 64) {
+    vec[V_MAGNPREV_P * kVecStride + i] = vec[V_MAGNPREV_A * kVecStride + i];
+    vec[V_NOISE * kVecStride + i] = vec[V_NOISEPREV * kVecStride + i];
+  }
+}
+
+// WebRtcNs_set_policy_core (ns_core.c:1013-1041) for every stream.
+__global__ void ns_set_policy_kernel(float* __restrict__ state, int num_streams, int mode,
+                                     float overdrive, float denoiseBound, int gainmap) {
+  const int stream = blockIdx.x * blockDim.x + threadIdx.x;
+  if (stream >= num_streams) return;
+  float* sc = state + (size_t)stream * kStreamDwords + kOffScalars;
+  sc[S_AGGRMODE] = __int_as_float(mode);
+  sc[S_OVERDRIVE] = overdrive;
+  sc[S_DENOISEBOUND] = denoiseBound;
+  sc[S_GAINMAP] = __int_as_float(gainmap);
+}
+
+// FFT seam for the parity tests: WebRtc_rdft(256, isgn) on each 256-float row.
+__global__ __launch_bounds__(256) void rdft256_kernel(float* __restrict__ data, int count,
+                                                      int isgn,
+                                                      const NsTables* __restrict__ T) {
+  __shared__ float2 lds[4][128];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= count) return;
+  float* a = data + (size_t)row * kAnal;
+  float2* buf = lds[wv];
+  const FftLane L = load_fft_lane(T, lane);
+  float2 lo, hi;
+  if (isgn >= 0) {
+    *reinterpret_cast<float4*>(&buf[2 * lane]) = *reinterpret_cast<const float4*>(a + 4 * lane);
+    wave_lds_fence();
+    rdft256_fwd(buf, L, lane, lo, hi);
+  } else {
+    lo = *reinterpret_cast<const float2*>(a + 2 * lane);
+    hi = *reinterpret_cast<const float2*>(a + 128 + 2 * lane);
+    rdft256_inv(buf, L, lane, lo, hi);
+  }
+  *reinterpret_cast<float2*>(a + 2 * lane) = lo;
+  *reinterpret_cast<float2*>(a + 128 + 2 * lane) = hi;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------ launch wrappers
+namespace aspns {
+
+hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables* T,
+                           const float* in, float* out, int num_streams, hipStream_t s) {
+  const dim3 grid((num_streams + 3) / 4), block(256);
+  switch (mode) {
+    case 0:
+      hipLaunchKernelGGL((ns_frame_kernel<true, false>), grid, block, 0, s, state, hist, T, in,
+                         out, num_streams);
+      break;
+    case 1:
+      hipLaunchKernelGGL((ns_frame_kernel<false, true>), grid, block, 0, s, state, hist, T, in,
+                         out, num_streams);
+      break;
+    default:
+      hipLaunchKernelGGL((ns_frame_kernel<true, true>), grid, block, 0, s, state, hist, T, in,
+                         out, num_streams);
+      break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s) {
+  hipLaunchKernelGGL(ns_unpair_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
+                     num_streams);
+  return hipGetLastError();
+}
+
+hipError_t launch_ns_set_policy(float* state, int num_streams, int mode, float overdrive,
+                                float denoiseBound, int gainmap, hipStream_t s) {
+  hipLaunchKernelGGL(ns_set_policy_kernel, dim3((num_streams + 255) / 256), dim3(256), 0, s,
+                     state, num_streams, mode, overdrive, denoiseBound, gainmap);
+  return hipGetLastError();
+}
+
+hipError_t launch_rdft256(float* data, int count, int isgn, const NsTables* T, hipStream_t s) {
+  hipLaunchKernelGGL(rdft256_kernel, dim3((count + 3) / 4), dim3(256), 0, s, data, count, isgn,
+                     T);
+  return hipGetLastError();
+}
+
+}  // namespace aspns

@@ -1,0 +1,79 @@
+// ns_layout.h -- HBM layout of the per-stream noise-suppressor state and of the
+// constant tables, shared by the kernels (ns_kernels.hip) and the host side of
+// the C-ABI (ns_api.hip).
+//
+// One stream = one wave64.  Lane q owns spectrum bins q ("slot A") and q+64
+// ("slot B"); bin 128 ("slot C") is replicated on every lane and committed by
+// lane 0.  Every 129-bin array is stored in natural bin order padded to 132
+// floats, so a wave reads it as two fully coalesced 256-byte rows plus one
+// broadcast dword.  All arrays of one stream are contiguous (one ~10 KB block
+// per stream, 256-byte aligned), fields the fused frame step touches first.
+#pragma once
+#include <stdint.h>
+
+namespace aspns {
+
+constexpr int kBlockL = 160;   // ns/defines.h:14
+constexpr int kAnal = 256;     // ns/defines.h:15
+constexpr int kBins = 129;     // ns/defines.h:16
+constexpr int kHist = 1000;    // ns/defines.h:45
+constexpr int kVecStride = 132;
+constexpr int kCarry = kAnal - kBlockL;  // 96 live samples of each sliding buffer
+
+// 129-bin arrays, in block order.  "hot" = touched by the fused lock-step step.
+enum Vec : int {
+  V_LQ0 = 0, V_LQ1, V_LQ2,     // lquantile[3][129]   (ns_core.h:67)
+  V_DEN0, V_DEN1, V_DEN2,      // density[3][129]     (ns_core.h:66)
+  V_QUANT,                     // quantile            (ns_core.h:68)
+  V_SMOOTH,                    // smooth              (ns_core.h:72)
+  V_NOISEPREV,                 // noisePrev           (ns_core.h:86)
+  V_MAGNPREV_A,                // magnPrevAnalyze     (ns_core.h:88)
+  V_LOGLRT,                    // logLrtTimeAvg       (ns_core.h:91)
+  V_AVGPAUSE,                  // magnAvgPause        (ns_core.h:95)
+  V_HOT_COUNT,
+  V_NOISE = V_HOT_COUNT,       // noise               (ns_core.h:85)  cold: == noisePrev while paired
+  V_MAGNPREV_P,                // magnPrevProcess     (ns_core.h:90)  cold: == magnPrevAnalyze while paired
+  V_INITMAGN,                  // initMagnEst         (ns_core.h:99)  startup only
+  V_PARAMNOISE,                // parametricNoise     (ns_core.h:102) startup only
+  V_COUNT
+};
+
+// per-stream scalars, one dword each (lane k of the wave holds scalar k)
+enum Scalar : int {
+  S_BLOCKIND = 0, S_UPDATES, S_COUNTER0, S_COUNTER1, S_COUNTER2,
+  S_MUP0, S_MUP1, S_MUP2, S_MUP3, S_GAINMAP, S_AGGRMODE, S_INITFLAG,
+  S_OVERDRIVE, S_DENOISEBOUND, S_PRIORSPEECHPROB, S_SIGNALENERGY, S_SUMMAGN,
+  S_WHITE, S_PINKNUM, S_PINKEXP,
+  S_PMP0, S_PMP1, S_PMP2, S_PMP3, S_PMP4, S_PMP5, S_PMP6,
+  S_FD0, S_FD1, S_FD2, S_FD3, S_FD4, S_FD5, S_FD6,
+  S_FS,
+  S_COUNT
+};
+
+// dword offsets inside one stream block
+constexpr int kOffScalars = 0;                               // 64 dwords
+constexpr int kOffAnaHist = 64;                              // analyzeBuf[160..255]
+constexpr int kOffSynt = kOffAnaHist + kCarry;               // syntBuf[0..95]
+constexpr int kOffVec = kOffSynt + kCarry;                   // 256
+constexpr int kOffDataHist = kOffVec + V_COUNT * kVecStride; // dataBuf[160..255] (cold)
+constexpr int kStreamDwordsRaw = kOffDataHist + kCarry;
+constexpr int kStreamDwords = (kStreamDwordsRaw + 63) / 64 * 64;  // 256-byte multiple
+
+// histograms: [stream][3][kHistStride] int32 (histLrt, histSpecFlat, histSpecDiff)
+constexpr int kHistStride = 1024;
+constexpr int kHistDwords = 3 * kHistStride;
+
+// Constant tables (one copy per device).
+struct NsTables {
+  float window[kAnal];        // kBlocks160w256 (ns/windows_private.h:94-147)
+  float tw[3][64][4];         // per pass, per lane: (tAr, tAi, tBr, tBi) -- see ns_kernels.hip
+  int32_t diag[64];           // bit s set: pass s uses the w[2] "diagonal" form on this lane
+  float cq[64];               // makect table c[q]      (fft4g.c:671-690)
+  float cr[64];               // makect table c[64 - q] (lane 0: unused)
+  float logi[kVecStride];     // (float)log((float)i), ns_core.c:1093
+  float sum_log_i;            // sequential sums over i = 5..128, ns_core.c:1094-1095
+  float sum_log_i_square;
+  float pad[2];
+};
+
+}  // namespace aspns

@@ -1,0 +1,214 @@
+"""Python mirror of the batched NS C-ABI (include/asp_ns.h) over ctypes.
+
+This is plumbing only: every call goes straight into libasp_amd.so (the
+hand-written HIP path).  There is no CPU fallback -- if the library is missing
+or no HIP device is present the constructor raises.
+
+Method names mirror the reference's verbs (WebRtcNs_Init / _set_policy /
+_Analyze / _Process, noise_suppression.h:16-122) with a leading stream count.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import BLOCKL, MEM_DEVICE, MEM_HOST, AspNsState
+from .build import LIB
+
+_lib = None
+
+
+class AspError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen lib/libasp_amd.so (built by build.py / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise AspError(
+            "HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (there is no CPU fallback)" % LIB)
+    lib = C.CDLL(LIB)
+    vp, ip, fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    sig = {
+        "AspNsBatch_Create": [C.POINTER(vp), ip, ip],
+        "AspNsBatch_Free": [vp],
+        "AspNsBatch_Init": [vp, C.c_uint32],
+        "AspNsBatch_set_policy": [vp, ip],
+        "AspNsBatch_num_streams": [vp],
+        "AspNsBatch_Analyze": [vp, vp, ip],
+        "AspNsBatch_Process": [vp, vp, vp, ip],
+        "AspNsBatch_AnalyzeProcess": [vp, vp, vp, ip, ip],
+        "AspNsBatch_ExportState": [vp, ip, C.POINTER(AspNsState)],
+        "AspNsBatch_ImportState": [vp, ip, C.POINTER(AspNsState)],
+        "AspNsBatch_prior_speech_probability": [vp, vp],
+        "AspNsBatch_SetStream": [vp, vp],
+        "AspNsBatch_Synchronize": [vp],
+        "AspNsBatch_TimedSteps": [vp, vp, vp, ip, ip, fp],
+        "AspNs_DeviceAlloc": [C.POINTER(vp), C.c_size_t, ip],
+        "AspNs_DeviceFree": [vp],
+        "AspNs_MemcpyH2D": [vp, vp, C.c_size_t],
+        "AspNs_MemcpyD2H": [vp, vp, C.c_size_t],
+        "AspNs_rdft256_batch": [vp, ip, ip, ip, ip],
+        "AspNs_device_count": [],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.AspNsBatch_GetStream.argtypes = [vp]
+    lib.AspNsBatch_GetStream.restype = vp
+    lib.AspNs_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise AspError("%s failed (%d): %s" % (what, rc, load_library().AspNs_last_error().decode()))
+
+
+def device_count():
+    n = load_library().AspNs_device_count()
+    return max(n, 0)
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class DeviceBuffer:
+    """Raw device allocation owned by the library (for callers without torch)."""
+
+    def __init__(self, nbytes, device=0):
+        self.lib = load_library()
+        p = C.c_void_p()
+        _check(self.lib.AspNs_DeviceAlloc(C.byref(p), nbytes, device), "AspNs_DeviceAlloc")
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _check(self.lib.AspNs_MemcpyH2D(self.ptr, _ptr(arr), arr.nbytes), "AspNs_MemcpyH2D")
+
+    def download(self, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        _check(self.lib.AspNs_MemcpyD2H(_ptr(out), self.ptr, out.nbytes), "AspNs_MemcpyD2H")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.lib.AspNs_DeviceFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class NsBatch:
+    """N independent 16 kHz noise-suppressor streams on one GPU."""
+
+    def __init__(self, num_streams, device=0, fs=16000, policy=None):
+        self.lib = load_library()
+        self.S = int(num_streams)
+        self.device = device
+        h = C.c_void_p()
+        _check(self.lib.AspNsBatch_Create(C.byref(h), self.S, device), "AspNsBatch_Create")
+        self.h = h
+        self.init(fs)
+        if policy is not None:
+            self.set_policy(policy)
+
+    def init(self, fs=16000):
+        _check(self.lib.AspNsBatch_Init(self.h, fs), "AspNsBatch_Init")
+
+    def set_policy(self, mode):
+        _check(self.lib.AspNsBatch_set_policy(self.h, mode), "AspNsBatch_set_policy")
+
+    # -- host-array convenience (copies in/out, synchronous)
+    def analyze(self, frames):
+        frames = np.ascontiguousarray(frames, np.float32)
+        assert frames.shape == (self.S, BLOCKL)
+        _check(self.lib.AspNsBatch_Analyze(self.h, _ptr(frames), MEM_HOST), "AspNsBatch_Analyze")
+
+    def process(self, frames):
+        frames = np.ascontiguousarray(frames, np.float32)
+        assert frames.shape == (self.S, BLOCKL)
+        out = np.empty_like(frames)
+        _check(self.lib.AspNsBatch_Process(self.h, _ptr(frames), _ptr(out), MEM_HOST),
+               "AspNsBatch_Process")
+        return out
+
+    def analyze_process(self, frames):
+        """frames [F][S][160] -> denoised [F][S][160] (fused step per frame)."""
+        frames = np.ascontiguousarray(frames, np.float32)
+        F = frames.shape[0]
+        assert frames.shape == (F, self.S, BLOCKL)
+        out = np.empty_like(frames)
+        _check(self.lib.AspNsBatch_AnalyzeProcess(self.h, _ptr(frames), _ptr(out), F, MEM_HOST),
+               "AspNsBatch_AnalyzeProcess")
+        return out
+
+    # -- device-pointer path (asynchronous on the batch's stream)
+    def analyze_process_device(self, in_ptr, out_ptr, num_frames):
+        _check(self.lib.AspNsBatch_AnalyzeProcess(self.h, C.c_void_p(in_ptr), C.c_void_p(out_ptr),
+                                                  num_frames, MEM_DEVICE),
+               "AspNsBatch_AnalyzeProcess")
+
+    def timed_steps(self, in_ptr, out_ptr, frames_in_ring, steps):
+        """K fused frame steps bracketed by hipEvents on the launch stream -> ms."""
+        ms = C.c_float()
+        _check(self.lib.AspNsBatch_TimedSteps(self.h, C.c_void_p(in_ptr), C.c_void_p(out_ptr),
+                                              frames_in_ring, steps, C.byref(ms)),
+               "AspNsBatch_TimedSteps")
+        return ms.value
+
+    def set_stream(self, hip_stream):
+        _check(self.lib.AspNsBatch_SetStream(self.h, C.c_void_p(hip_stream)), "AspNsBatch_SetStream")
+
+    def synchronize(self):
+        _check(self.lib.AspNsBatch_Synchronize(self.h), "AspNsBatch_Synchronize")
+
+    def export_state(self, stream):
+        s = AspNsState()
+        _check(self.lib.AspNsBatch_ExportState(self.h, stream, C.byref(s)), "AspNsBatch_ExportState")
+        return s
+
+    def import_state(self, stream, state):
+        _check(self.lib.AspNsBatch_ImportState(self.h, stream, C.byref(state)),
+               "AspNsBatch_ImportState")
+
+    def prior_speech_probability(self):
+        out = np.empty(self.S, np.float32)
+        _check(self.lib.AspNsBatch_prior_speech_probability(self.h, _ptr(out)),
+               "AspNsBatch_prior_speech_probability")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.AspNsBatch_Free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rdft256(rows, isgn, device=0):
+    """WebRtc_rdft(256, isgn) on every row of `rows` ([count][256] float32)."""
+    lib = load_library()
+    rows = np.ascontiguousarray(rows, np.float32).copy()
+    flat = rows.reshape(-1, 256)
+    _check(lib.AspNs_rdft256_batch(_ptr(flat), flat.shape[0], isgn, MEM_HOST, device),
+           "AspNs_rdft256_batch")
+    return rows

@@ -162,6 +162,11 @@ int AspNs_device_count(void);
 /* Text of the most recent error on this thread ("" if none). */
 const char* AspNs_last_error(void);
 
+/* Host copy of the constant tables the kernels use (layout: struct NsTables in
+ * audiosignalprocess_amd/csrc/ns_layout.h); needs no device. */
+int AspNs_host_tables(void* out, size_t bytes);
+size_t AspNs_host_tables_size(void);
+
 /* FFT seam used by the parity tests: batched 256-point real FFT in Ooura
  * packing (a[0]=R0, a[1]=R128, a[2k]=Rk, a[2k+1]=Ik; fft4g.c:90-118), i.e.
  * what WebRtc_rdft(256, isgn, a, ip, w) (fft4g.c:324-362) does to each row.
