@@ -10,6 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libasp_amd.so")
 SOURCES = ["ns_kernels.hip", "ns_api.hip"]
+C_SOURCES = ["wav_io.c"]  # host-only C (kept C, as in the reference)
 # -ffp-contract=off: parity with the reference depends on unfused mul/add.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
@@ -44,6 +45,15 @@ def build_library(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
         objs.append(o)
+    for s in C_SOURCES:
+        src = os.path.join(CSRC, s)
+        o = os.path.join(LIBDIR, s + ".o")
+        if force or _stale(o, [src, os.path.join(ROOT, "include", "wav_io.h")]):
+            cmd = ["gcc", "-O2", "-std=gnu99", "-fPIC", "-Wall"] + inc + ["-c", src, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        objs.append(o)
     if force or _stale(LIB, objs):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
         if verbose:
@@ -52,5 +62,25 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+def build_drivers(verbose=False):
+    """The C WAV drivers (drivers/*.c) linked against the in-tree library."""
+    out_dir = os.path.join(ROOT, "drivers", "bin")
+    os.makedirs(out_dir, exist_ok=True)
+    built = []
+    for name in ["test_ns_module"]:
+        src = os.path.join(ROOT, "drivers", name + ".c")
+        exe = os.path.join(out_dir, name)
+        if _stale(exe, [src, LIB]):
+            cmd = ["gcc", "-O2", "-std=gnu99", "-Wall", "-I" + os.path.join(ROOT, "include"), src,
+                   "-L" + LIBDIR, "-lasp_amd", "-Wl,-rpath,$ORIGIN/../../audiosignalprocess_amd/lib",
+                   "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        built.append(exe)
+    return built
+
+
 if __name__ == "__main__":
     print(build_library(verbose=True))
+    print(build_drivers(verbose=True))

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the batched Wiener noise suppressor on MI355X.
+
+Metric (BASELINE.json): 10 ms @16 kHz audio frames per second through the NS
+hot path (Analyze + Process, policy 1), whole job over N GPUs, plus the
+achieved fraction of the HBM roofline for the fused frame-step kernel.
+
+One "step" = one 10 ms frame of every stream = ONE launch of the fused kernel
+(frame-synchronous model: all per-stream state round-trips HBM every step).
+Workload at N = 1: BASELINE config[1], 4096 concurrent mono 16 kHz streams on
+one MI355X.  N > 1: the same 4096 streams on every GPU (weak scaling; streams
+are independent, no collective on the data path -- torch.distributed/RCCL is
+used only for the timing barrier and the max-over-ranks).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_FRAME = 15716  # frame-synchronous NS model
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return int(os.environ.get("ASP_BENCH_CPU_THREADS", n))
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU path timed on this box's host cores (rank 0, N = 1 only).
+
+    kind "reference": oracle/_ref/libns_ref.so = the reference's own ns_core.c /
+    fft4g.c compiled in the build container; kind "port": this repo's C
+    restatement (oracle/ns_oracle.c) when the reference build is absent.
+    """
+    from audiosignalprocess_amd.synth import ns_frames
+    from tests import oracle_lib
+
+    threads = host_cores()
+    warm, timed = 250, 500
+    # ~90 k frames/s/core measured for the reference
+    streams = int(max(threads, min(64 * threads, seconds_budget * 90e3 / (warm + timed))))
+    x = ns_frames(streams, 50, frame0=50)
+    reps_w, reps_t = warm // 50, timed // 50
+    if oracle_lib.have_ref():
+        eng, kind = oracle_lib.RefNs(streams, policy=1), "reference"
+    else:
+        eng, kind = oracle_lib.OracleNs(streams, policy=1), "port"
+    for _ in range(reps_w):
+        eng.run(x, threads=threads)
+    t0 = time.perf_counter()
+    for _ in range(reps_t):
+        eng.run(x, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": streams * timed / dt,
+        "unit": "frames/s",
+        "cores": threads,
+        "kind": kind,
+        "sample": "%d streams x %d frames after %d warm-up frames, %d pthreads over streams, "
+                  "gcc -O2 -ffp-contract=off" % (streams, timed, warm, threads),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=250)
+    ap.add_argument("--streams-per-gpu", type=int, default=4096)
+    ap.add_argument("--ring", type=int, default=100, help="distinct input frames resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from audiosignalprocess_amd.ns import NsBatch
+    from audiosignalprocess_amd.shard import max_over_ranks, shard_streams
+    from audiosignalprocess_amd.synth import ns_frames
+
+    ring = args.ring
+    # every rank owns a disjoint contiguous shard of stream ids (no data-path collective)
+    stream0, S = shard_streams(rank, world, args.streams_per_gpu)
+    x = ns_frames(S, ring, stream0=stream0, frame0=50)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    del x
+    ns = NsBatch(S, device=local_rank, policy=1)
+    ns.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: past END_STARTUP_LONG = 200 so the steady-state branches are timed
+    done = 0
+    while done < args.warmup:
+        n = min(ring, args.warmup - done)
+        ns.analyze_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
+        done += n
+    barrier()
+    t0 = time.perf_counter()
+    ev_ms = ns.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, args.steps)
+    barrier()
+    wall = time.perf_counter() - t0
+    if not torch.isfinite(d_out).all():
+        raise SystemExit("non-finite output")
+
+    wall_max, ev_max = max_over_ranks(dist, [wall, ev_ms / 1e3], device="cuda")
+
+    if rank == 0:
+        frames = S * world * args.steps
+        launch_s = ev_max / max(args.steps, 1)  # average duration of one fused launch
+        achieved = ALGO_BYTES_PER_FRAME * S / launch_s / 1e9
+        line = {
+            "metric": "audio frames/sec (10 ms @16 kHz) Wiener NS",
+            "value": frames / wall_max,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall_max / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "WebRTC NS (test_ns_module): 10 ms/16 kHz frames, %d concurrent mono "
+                            "streams per MI355X, policy 1, Analyze+Process fused, "
+                            "frame-synchronous (1 launch per frame)" % S,
+                "streams_per_gpu": S,
+                "total_streams": S * world,
+                "input_ring_frames": ring,
+                "parallelism": "stream-sharded x%d, no collectives" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "ns_frame_kernel<true,true>",
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * S,
+                "avg_launch_us": launch_s * 1e6,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

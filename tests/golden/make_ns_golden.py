@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ns_golden.npz from the REFERENCE build.
+
+Run in the build container only (needs oracle/_ref/libns_ref.so, i.e. the
+reference's ns_core.c / noise_suppression.c / fft4g.c compiled in place from
+/root/reference by oracle/Makefile).  The reference publishes no golden
+vectors for this path, so these are outputs of the
+reference itself run here:
+
+  in_i16      [F][S][160] int16   synthetic NS input rounded to PCM
+  out_f32     [F][S][160] float32 WebRtcNs_Analyze + WebRtcNs_Process output, policy 1
+  snap_frames [K]                 number of frames processed at each snapshot
+  snap_state  [K][S][sizeof(AspNsState)] uint8, full reference state
+  wav_in_i16 / wav_out_i16        stream 0 as the WAV driver sees it, including the
+                                  extra stale frame of `while(!feof)` (test_ns_module.cpp:83-86)
+                                  and FloatS16ToS16 rounding (audio_util.h:41-49)
+  fft_in / fft_fwd / fft_inv      WebRtc_rdft(256, +1 / -1) known answers
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from audiosignalprocess_amd._abi import AspNsState  # noqa: E402
+from audiosignalprocess_amd.synth import ns_frames  # noqa: E402
+from tests.oracle_lib import RefNs, have_ref  # noqa: E402
+
+S, F = 2, 1100
+SNAPS = [1, 49, 50, 51, 199, 200, 201, 202, 499, 500, 501, 999, 1000, 1100]
+
+
+def float_s16_to_s16(v):
+    v = np.asarray(v, np.float32)
+    pos = np.where(v >= np.float32(32766.5), 32767, (v + np.float32(0.5)).astype(np.int32))
+    neg = np.where(v <= np.float32(-32767.5), -32768, (v - np.float32(0.5)).astype(np.int32))
+    return np.where(v > 0, pos, neg).astype(np.int16)
+
+
+def main():
+    assert have_ref(), "build oracle/_ref first (make -C oracle)"
+    x = np.clip(np.rint(ns_frames(S, F)), -32768, 32767).astype(np.int16)
+    xf = x.astype(np.float32)
+    ref = RefNs(S, policy=1)
+    out = np.empty_like(xf)
+    snaps = []
+    done = 0
+    for k in SNAPS:
+        out[done:k] = ref.run(xf[done:k])
+        done = k
+        row = []
+        for s in range(S):
+            st = ref.export_state(s)
+            row.append(np.frombuffer(bytes(st), dtype=np.uint8).copy())
+        snaps.append(np.stack(row))
+    assert done == F
+    # WAV-driver view of stream 0: one extra pass over the stale last frame
+    wav_in = x[:, 0, :].reshape(-1)
+    ref1 = RefNs(1, policy=1)
+    xin = np.concatenate([xf[:, 0:1, :], xf[-1:, 0:1, :]], axis=0)
+    wav_out = float_s16_to_s16(ref1.run(xin)[:, 0, :]).reshape(-1)
+    # FFT known answers
+    rng = np.random.default_rng(1234)
+    i = np.arange(256)
+    fft_in = np.stack([
+        np.sin(i).astype(np.float32),              # the input of unittest_real_fft.cpp:29-31
+        (i == 0).astype(np.float32),               # impulse
+        (i == 3).astype(np.float32) * 1000,        # shifted impulse
+        np.ones(256, np.float32) * 7,              # DC
+        np.where(i % 2 == 0, 1, -1).astype(np.float32) * 5,  # Nyquist
+        (rng.standard_normal(256) * 3000).astype(np.float32),
+        (rng.standard_normal(256) * 1e-3).astype(np.float32),
+    ])
+    fft_fwd = ref.rdft256(fft_in, 1)
+    fft_inv = ref.rdft256(fft_fwd, -1)
+    path = os.path.join(ROOT, "tests", "golden", "ns_golden.npz")
+    np.savez_compressed(path, in_i16=x, out_f32=out, snap_frames=np.array(SNAPS),
+                        snap_state=np.stack(snaps), wav_in_i16=wav_in, wav_out_i16=wav_out,
+                        fft_in=fft_in, fft_fwd=fft_fwd, fft_inv=fft_inv,
+                        state_sizeof=np.array(C.sizeof(AspNsState)))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""CPU suite: the C-ABI library loads, exports every declared symbol, and refuses to compute
+without a device (no silent CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", txt)))
+
+
+@pytest.mark.parametrize("header", ["asp_ns.h", "wav_io.h"])
+def test_every_declared_symbol_is_exported(built_lib, header):
+    lib = C.CDLL(built_lib)
+    names = declared_functions(header)
+    assert len(names) >= 6
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert missing == []
+
+
+def test_reference_symbol_names_present(built_lib):
+    lib = C.CDLL(built_lib)
+    for n in ["WebRtcNs_Create", "WebRtcNs_Free", "WebRtcNs_Init", "WebRtcNs_set_policy",
+              "WebRtcNs_Analyze", "WebRtcNs_Process", "WebRtcNs_prior_speech_probability",
+              "search_ID", "read_header", "write_header", "read_samples", "write_samples",
+              "print_header"]:
+        assert hasattr(lib, n), n
+
+
+def test_host_tables_match_oracle(built_lib):
+    """Window / twiddle / log tables the kernels consume == the oracle's (pinned to the reference)."""
+    lib = C.CDLL(built_lib)
+    lib.AspNs_host_tables_size.restype = C.c_size_t
+    lib.AspNs_host_tables.argtypes = [C.c_void_p, C.c_size_t]
+    n = lib.AspNs_host_tables_size()
+    buf = np.zeros(n // 4, np.float32)
+    assert lib.AspNs_host_tables(buf.ctypes.data, n) == 0
+    win, cq, cr = buf[:256], buf[1088:1152], buf[1152:1216]
+    logi = buf[1216:1216 + 129]
+    c = oracle_lib.oracle_table("fft_c", 64)
+    assert np.array_equal(win, oracle_lib.oracle_table("window", 256))
+    assert np.array_equal(cq, c)
+    assert np.array_equal(cr[1:], c[63:0:-1])
+    assert np.array_equal(logi[1:], np.log(np.arange(1, 129, dtype=np.float32).astype(np.float64)).astype(np.float32))
+    # general twiddles of pass 1: lane 2b+1 carries (w[4u], w[4u+1]) for even blocks b = 2u
+    w = oracle_lib.oracle_table("fft_w", 64)
+    tw = buf[256:256 + 768].reshape(3, 64, 4)
+    for u in range(1, 16):
+        assert tuple(tw[0, 2 * (2 * u) + 1, :2]) == (w[4 * u], w[4 * u + 1])
+        assert tuple(tw[0, 2 * (2 * u + 1) + 1, :2]) == (w[4 * u + 2], w[4 * u + 3])
+        assert tuple(tw[0, 2 * (2 * u), 2:]) == (w[2 * u], w[2 * u + 1])
+
+
+def test_no_device_fails_loudly(built_lib):
+    """Without a GPU the product path must error out, never fall back to CPU code."""
+    from audiosignalprocess_amd import ns
+
+    lib = ns.load_library()
+    if lib.AspNs_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(ns.AspError):
+        ns.NsBatch(4)
+    h = C.c_void_p()
+    assert lib.WebRtcNs_Create(C.byref(h)) == -1
+
+
+def test_wav_io_roundtrip(built_lib, tmp_path):
+    """Header parse by chunk search, verbatim header copy with fmt.size forced to 16 (wav_io.c:87-93)."""
+    import struct
+
+    lib = C.CDLL(built_lib)
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    libc.ftell.argtypes = [C.c_void_p]
+    libc.ftell.restype = C.c_long
+    samples = np.arange(-300, 300, dtype=np.int16)
+    # a LIST chunk between fmt and data, fmt size 18 with 2 extra bytes: the parser searches IDs
+    fmt = struct.pack("<4sihhiihh", b"fmt ", 18, 1, 1, 16000, 32000, 2, 16) + b"\0\0"
+    lst = b"LIST" + struct.pack("<i", 4) + b"abcd"
+    data = b"data" + struct.pack("<i", samples.nbytes)
+    body = b"WAVE" + fmt + lst + data + samples.tobytes()
+    src = tmp_path / "in.wav"
+    src.write_bytes(b"RIFF" + struct.pack("<i", len(body)) + body)
+    hdr = (C.c_char * 44)()
+    for f in (lib.read_header, lib.write_header):
+        f.argtypes = [C.c_void_p, C.c_void_p]
+    lib.read_samples.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    fp = libc.fopen(str(src).encode(), b"rb")
+    assert lib.read_header(hdr, fp) == 0
+    riff_id, riff_size, wave, fmt_id, fmt_size, tag, ch, rate, bps, align, bits, data_id, data_size = \
+        struct.unpack("<4si4s4sihhiihh4si", bytes(hdr))
+    assert (riff_id, wave, fmt_id, data_id) == (b"RIFF", b"WAVE", b"fmt ", b"data")
+    assert (fmt_size, ch, rate, bits, data_size) == (18, 1, 16000, 16, samples.nbytes)
+    assert libc.ftell(fp) == len(b"RIFF....WAVE") + len(fmt) + len(lst) + 8
+    got = np.zeros(600, np.int16)
+    assert lib.read_samples(got.ctypes.data, 600, hdr, fp) == 600
+    assert np.array_equal(got, samples)
+    libc.fclose(fp)
+    dst = tmp_path / "out.wav"
+    fo = libc.fopen(str(dst).encode(), b"wb")
+    lib.write_header(hdr, fo)
+    libc.fclose(fo)
+    out = dst.read_bytes()
+    assert len(out) == 44 and struct.unpack("<i", out[16:20])[0] == 16 and out[36:40] == b"data"
+    # not a WAVE file
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"RIFF" + struct.pack("<i", 4) + b"AVI " + b"\0" * 64)
+    fp = libc.fopen(str(bad).encode(), b"rb")
+    assert lib.read_header(hdr, fp) == -1
+    libc.fclose(fp)

@@ -1,0 +1,297 @@
+"""GPU parity suite (-m gpu): the hand-written HIP path, called through the C-ABI
+(libasp_amd.so), against the oracle and the reference's golden vectors.
+
+Bars:
+  * bit-exact vs the oracle in ASP_NS_REDUCE_TREE mode (same float operations in the same
+    order, including the wave64 reduction association);
+  * <= 1e-4 relative (per-stream L2) vs the reference's outputs (golden vectors; the only
+    difference is the association of the ~10 cross-bin sums per frame), BASELINE.json tolerance.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from audiosignalprocess_amd.synth import ns_frames
+from tests.conftest import rel_l2_per_stream, state_diff, state_from_bytes
+from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, OracleNs
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REL_TOL = 1e-4  # BASELINE.json north_star: <= 1e-4 relative vs the CPU reference
+
+
+@pytest.fixture(scope="module")
+def ns():
+    from audiosignalprocess_amd import ns as mod
+
+    assert mod.device_count() >= 1, "GPU tests need a HIP device"
+    return mod
+
+
+def test_fft_bit_exact(ns, golden):
+    assert np.array_equal(ns.rdft256(golden["fft_in"], 1), golden["fft_fwd"])
+    assert np.array_equal(ns.rdft256(golden["fft_fwd"], -1), golden["fft_inv"])
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((1000, 256)) * rng.choice([1e-3, 1.0, 3e3, 1e6], size=(1000, 1))).astype(np.float32)
+    o = OracleNs(1)
+    f = ns.rdft256(x, 1)
+    assert np.array_equal(f, o.rdft256(x, 1))
+    assert np.array_equal(ns.rdft256(f, -1), o.rdft256(f, -1))
+
+
+def test_fft_linearity_and_roundtrip_large(ns):
+    """Size-independent properties at a batch far beyond what the CPU checker covers."""
+    rng = np.random.default_rng(5)
+    n = 65536
+    a = rng.standard_normal((n, 256)).astype(np.float32)
+    fa = ns.rdft256(a, 1)
+    back = ns.rdft256(fa, -1) * np.float32(2.0 / 256)
+    assert np.abs(back - a).max() <= 2e-6 * np.abs(a).max() * 8
+    # Parseval: sum x^2 == (R0^2 + R128^2 + 2 sum |X_k|^2) / 256
+    e_t = (a.astype(np.float64) ** 2).sum(axis=1)
+    e_f = (fa[:, 0].astype(np.float64) ** 2 + fa[:, 1].astype(np.float64) ** 2
+           + 2 * (fa[:, 2:].astype(np.float64) ** 2).sum(axis=1)) / 256
+    assert np.abs(e_f / e_t - 1).max() < 1e-5
+
+
+def test_fused_free_running_bit_exact_vs_tree_oracle(ns):
+    S, F = 24, 1100  # crosses blockInd 50 / 200 and two 500-frame histogram windows
+    x = ns_frames(S, F)
+    g = ns.NsBatch(S, policy=1)
+    y = g.analyze_process(x)
+    o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE)
+    yo = o.run(x, threads=8)
+    assert np.isfinite(y).all()
+    assert np.array_equal(y, yo)
+    for s in range(0, S, 5):
+        assert state_diff(g.export_state(s), o.export_state(s)) == {}
+    assert np.array_equal(g.prior_speech_probability(),
+                          np.array([o.export_state(s).priorSpeechProb for s in range(S)], np.float32))
+    g.close()
+
+
+def test_golden_reference_outputs_within_tolerance(ns, golden):
+    x = golden["in_i16"].astype(np.float32)
+    F, S, _ = x.shape
+    g = ns.NsBatch(S, policy=1)
+    y = g.analyze_process(x)
+    rel = rel_l2_per_stream(y, golden["out_f32"])
+    assert rel.max() <= REL_TOL, rel
+    # robust frame-level statistic
+    num = np.sqrt(((y - golden["out_f32"]).astype(np.float64) ** 2).sum(axis=2))
+    den = np.sqrt((golden["out_f32"].astype(np.float64) ** 2).sum(axis=2)) + 1e-9
+    assert np.percentile(num / den, 95) <= REL_TOL
+    g.close()
+
+
+def test_golden_teacher_forced_single_step(ns, golden):
+    """Inject each reference snapshot, advance one frame, compare output and every state array
+    with the reference one frame later (snapshots k, k+1 exist for 49/50/51, 199..202, 499..501)."""
+    x = golden["in_i16"].astype(np.float32)
+    S = x.shape[1]
+    frames = [int(f) for f in golden["snap_frames"]]
+    checked = 0
+    for k, f0 in enumerate(frames):
+        if f0 >= x.shape[0]:
+            continue
+        g = ns.NsBatch(S, policy=1)
+        for s in range(S):
+            g.import_state(s, state_from_bytes(golden["snap_state"][k, s]))
+        y = g.analyze_process(x[f0:f0 + 1])
+        ref_y = golden["out_f32"][f0:f0 + 1]
+        scale = np.abs(ref_y).max()
+        # the start-up pink-noise fit (ns_core.c:1113-1133) subtracts nearly equal sums, so the
+        # first 50 frames amplify the reduction-order difference (measured 3.5e-5 at frame 1,
+        # <= 1.2e-7 after start-up); the bar stays inside BASELINE's 1e-4.
+        tol = REL_TOL if f0 < 50 else 1e-5
+        assert np.abs(y - ref_y).max() <= tol * scale, f0
+        if f0 + 1 in frames:
+            k1 = frames.index(f0 + 1)
+            for s in range(S):
+                bad = state_diff(g.export_state(s), state_from_bytes(golden["snap_state"][k1, s]))
+                ref_d = state_from_bytes(golden["snap_state"][k1, s]).to_dict()
+                for name, (_, maxabs) in bad.items():
+                    assert maxabs <= tol * max(1.0, float(np.abs(ref_d[name]).max())), (f0, s, name, bad)
+            checked += 1
+        g.close()
+    assert checked >= 6
+
+
+def test_unfused_analyze_process_equals_fused(ns):
+    """Separate Analyze / Process launches (general state representation) == fused launch,
+    including the paired -> unpaired transition mid-stream."""
+    S, F = 7, 260  # ragged: not a multiple of the 4 streams per workgroup
+    x = ns_frames(S, F, stream0=11)
+    g1 = ns.NsBatch(S, policy=2)
+    y1 = g1.analyze_process(x)
+    g2 = ns.NsBatch(S, policy=2)
+    y2 = np.empty_like(x)
+    y2[:100] = g2.analyze_process(x[:100])  # fused / paired
+    for f in range(100, F):                  # then the reference's two-call protocol
+        g2.analyze(x[f])
+        y2[f] = g2.process(x[f])
+    assert np.array_equal(y1, y2)
+    y3 = g2.analyze_process(x[:5])           # fused entry point after un-pairing still works
+    y4 = g1.analyze_process(x[:5])
+    assert np.array_equal(y3, y4)
+    for s in range(S):
+        assert state_diff(g1.export_state(s), g2.export_state(s)) == {}
+    g1.close()
+    g2.close()
+
+
+def test_analyze_and_process_on_different_frames(ns):
+    """Analyze(a) / Process(b) with a != b (legal in the reference API) vs the oracle."""
+    S, F = 3, 120
+    a = ns_frames(S, F, stream0=40)
+    b = ns_frames(S, F, stream0=50)
+    g = ns.NsBatch(S, policy=1)
+    o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE)
+    for f in range(F):
+        g.analyze(a[f])
+        o.analyze(a[f])
+        assert np.array_equal(g.process(b[f]), o.process(b[f])), f
+    for s in range(S):
+        assert state_diff(g.export_state(s), o.export_state(s)) == {}
+    g.close()
+
+
+def test_zero_and_silence_edge_cases(ns):
+    S, F = 5, 60
+    x = ns_frames(S, F, stream0=3)
+    x[10:16, 1] = 0.0      # stream 1: silence long enough for energy == 0 frames
+    x[:, 2] = 0.0          # stream 2: digital silence from the start
+    x[30:, 3] = 32767.0    # stream 3: full-scale DC (saturation path)
+    g = ns.NsBatch(S, policy=3)
+    o = OracleNs(S, policy=3, reduce_mode=REDUCE_TREE)
+    y, yo = g.analyze_process(x), o.run(x)
+    assert np.isfinite(y).all()
+    assert np.array_equal(y, yo)
+    assert (y[:, 2] == 0).all()
+    assert np.abs(y).max() <= 32768.0
+    for s in range(S):
+        assert state_diff(g.export_state(s), o.export_state(s)) == {}
+    assert g.export_state(2).blockInd == -1
+    g.close()
+
+
+def test_all_policies_bit_exact(ns):
+    for policy in range(4):
+        S, F = 4, 230
+        x = ns_frames(S, F, stream0=20 * policy)
+        g = ns.NsBatch(S, policy=policy)
+        o = OracleNs(S, policy=policy, reduce_mode=REDUCE_TREE)
+        assert np.array_equal(g.analyze_process(x), o.run(x)), policy
+        g.close()
+
+
+def test_state_export_import_roundtrip(ns):
+    """Checkpoint / restore: a restored batch continues bit-identically."""
+    S, F = 4, 300
+    x = ns_frames(S, F + 50, stream0=77)
+    g = ns.NsBatch(S, policy=1)
+    g.analyze_process(x[:F])
+    saved = [g.export_state(s) for s in range(S)]
+    y_a = g.analyze_process(x[F:])
+    g2 = ns.NsBatch(S, policy=0)
+    for s in range(S):
+        g2.import_state(s, saved[s])
+    y_b = g2.analyze_process(x[F:])
+    assert np.array_equal(y_a, y_b)
+    g.close()
+    g2.close()
+
+
+def test_config2_scale_4096_streams(ns):
+    """BASELINE config[1] size: 4096 streams.  Spot-check streams against the oracle and check
+    size-independent properties on all of them."""
+    S, F = 4096, 60
+    x = ns_frames(S, F)
+    g = ns.NsBatch(S, policy=1)
+    y = g.analyze_process(x)
+    assert np.isfinite(y).all() and np.abs(y).max() <= 32768.0
+    pick = [0, 1, 2, 3, 63, 64, 1023, 2048, 4093, 4094, 4095]
+    o = OracleNs(len(pick), policy=1, reduce_mode=REDUCE_TREE)
+    yo = o.run(np.ascontiguousarray(x[:, pick]))
+    assert np.array_equal(y[:, pick], yo)
+    # streams are independent: permuting the batch permutes the outputs
+    perm = np.random.default_rng(0).permutation(S)
+    g2 = ns.NsBatch(S, policy=1)
+    y2 = g2.analyze_process(np.ascontiguousarray(x[:, perm]))
+    assert np.array_equal(y2, y[:, perm])
+    # a noise suppressor never amplifies the frame energy by much after start-up
+    e_in = (x[50:].astype(np.float64) ** 2).sum(axis=(0, 2))
+    e_out = (y[50:].astype(np.float64) ** 2).sum(axis=(0, 2))
+    assert (e_out <= 1.05 * e_in).all()
+    g.close()
+    g2.close()
+
+
+def test_device_pointer_path_in_place(ns):
+    """ASP_MEM_DEVICE with in == out (the driver aliases them, test_ns_module.cpp:98-99)."""
+    S, F = 16, 40
+    x = ns_frames(S, F, stream0=5)
+    buf = ns.DeviceBuffer(x.nbytes)
+    buf.upload(x)
+    g = ns.NsBatch(S, policy=1)
+    g.analyze_process_device(buf.ptr, buf.ptr, F)
+    g.synchronize()
+    y = buf.download(x.shape)
+    assert np.array_equal(y, OracleNs(S, policy=1, reduce_mode=REDUCE_TREE).run(x))
+    g.close()
+    buf.free()
+
+
+def test_layer1_reference_api(ns, built_lib):
+    """The reference's own per-stream symbols (noise_suppression.h:16-122) over ctypes."""
+    lib = C.CDLL(built_lib)
+    lib.WebRtcNs_prior_speech_probability.restype = C.c_float
+    h = C.c_void_p()
+    assert lib.WebRtcNs_prior_speech_probability(None) == -1.0
+    assert lib.WebRtcNs_Create(C.byref(h)) == 0
+    assert lib.WebRtcNs_prior_speech_probability(h) == -1.0  # not initialised yet
+    assert lib.WebRtcNs_Init(h, 44100) == -1
+    assert lib.WebRtcNs_Init(h, 16000) == 0
+    assert lib.WebRtcNs_set_policy(h, 7) == -1
+    assert lib.WebRtcNs_set_policy(h, 1) == 0
+    x = ns_frames(1, 80, stream0=9)
+    o = OracleNs(1, policy=1, reduce_mode=REDUCE_TREE)
+    yo = o.run(x)
+    fp = C.POINTER(C.c_float)
+    for f in range(80):
+        frame = np.ascontiguousarray(x[f, 0])
+        ptr = frame.ctypes.data_as(fp)
+        lib.WebRtcNs_Analyze(h, ptr)
+        bands = (fp * 1)(ptr)
+        lib.WebRtcNs_Process(h, bands, 1, bands)  # in place
+        assert np.array_equal(frame, yo[f, 0]), f
+    assert lib.WebRtcNs_prior_speech_probability(h) == np.float32(o.export_state(0).priorSpeechProb)
+    assert lib.WebRtcNs_Free(h) == 0
+
+
+def test_wav_driver_end_to_end(ns, golden, tmp_path):
+    """drivers/test_ns_module (C host code over the GPU library) vs the reference driver semantics:
+    int16 diff <= 1 LSB, almost all samples identical, extra stale frame reproduced."""
+    from audiosignalprocess_amd.build import build_drivers
+
+    exe = build_drivers()[0]
+    pcm = golden["wav_in_i16"]
+    hdr = b"RIFF" + struct.pack("<i", 36 + pcm.nbytes) + b"WAVE" + \
+        struct.pack("<4sihhiihh", b"fmt ", 16, 1, 1, 16000, 32000, 2, 16) + \
+        b"data" + struct.pack("<i", pcm.nbytes)
+    src, dst = tmp_path / "in.wav", tmp_path / "out.wav"
+    src.write_bytes(hdr + pcm.tobytes())
+    subprocess.run([exe, str(src), str(dst), "-q"], check=True, stdout=subprocess.DEVNULL)
+    raw = dst.read_bytes()
+    assert raw[:44] == hdr  # header copied verbatim
+    out = np.frombuffer(raw[44:], dtype=np.int16)
+    ref = golden["wav_out_i16"]
+    assert out.shape == ref.shape == (pcm.size + 160,)
+    d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1
+    assert (d == 0).mean() >= 0.999
