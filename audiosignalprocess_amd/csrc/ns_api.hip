@@ -26,6 +26,9 @@ hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_set_policy(float* state, int num_streams, int mode, float overdrive,
                                 float denoiseBound, int gainmap, hipStream_t s);
 hipError_t launch_rdft256(float* data, int count, int isgn, const NsTables* T, hipStream_t s);
+hipError_t launch_debug_eval(int fn, float* data, size_t n, hipStream_t s);
+hipError_t launch_debug_compare(int fn_a, int fn_b, unsigned start, unsigned count,
+                                unsigned* n_bad, unsigned* bad_bits, hipStream_t s);
 }  // namespace aspns
 
 namespace {
@@ -699,6 +702,39 @@ int AspNs_rdft256_batch(float* data, int count, int isgn, int mem, int device) {
     (void)hipFree(d);
   }
   if (e != hipSuccess) return fail(ASP_ERR_HIP, "rdft256_batch", e);
+  return ASP_OK;
+}
+
+// Test seams for the device math (see debug_fn in ns_kernels.hip).
+int AspNs_debug_eval(int fn, float* data, size_t n, int device) {
+  if (!data || n == 0) return fail(ASP_ERR_PARAM, "debug_eval: bad argument");
+  int rc = select_device(device);
+  if (rc) return rc;
+  float* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, n * sizeof(float)));
+  hipError_t e = hipMemcpy(d, data, n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_debug_eval(fn, d, n, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(data, d, n * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "debug_eval", e);
+  return ASP_OK;
+}
+
+int AspNs_debug_compare(int fn_a, int fn_b, uint32_t start, uint32_t count, uint32_t* n_bad,
+                        uint32_t* bad_bits64, int device) {
+  if (!n_bad || !bad_bits64) return fail(ASP_ERR_PARAM, "debug_compare: bad argument");
+  int rc = select_device(device);
+  if (rc) return rc;
+  unsigned* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 65 * sizeof(unsigned)));
+  hipError_t e = hipMemset(d, 0, 65 * sizeof(unsigned));
+  if (e == hipSuccess) e = launch_debug_compare(fn_a, fn_b, start, count, d, d + 1, nullptr);
+  unsigned h[65];
+  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "debug_compare", e);
+  *n_bad = h[0];
+  memcpy(bad_bits64, h + 1, 64 * sizeof(unsigned));
   return ASP_OK;
 }
 

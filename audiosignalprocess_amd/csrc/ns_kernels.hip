@@ -20,7 +20,7 @@
 // butterflies perform the float operations of the reference's Ooura code in
 // the same order, so spectra are bit-identical to WebRtc_rdft.
 //
-// Cross-bin sums use a fixed association (slot-local, then xor 32,16,8,4,2,1)
+// Cross-bin sums use a fixed association (slot-local, then xor 1,2,4,8,16,32)
 // that oracle/ns_oracle.c reproduces in ASP_NS_REDUCE_TREE mode.
 //
 // Compile with -ffp-contract=off: parity depends on unfused mul/add.
@@ -63,10 +63,98 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {  // lane: compile-time constant
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Wave64 all-reduce with the association of an ascending xor-butterfly
+// (xor 1, 2, 4, 8, 16, 32; every lane ends with the same value), which
+// oracle/ns_oracle.c reproduces in ASP_NS_REDUCE_TREE mode.  Steps 1 and 2 are
+// DPP quad permutes; after them a quad is uniform, so the half-row and row
+// mirrors deliver exactly the xor-4 / xor-8 partners' values; the four uniform
+// row sums are then combined through scalar broadcasts as (r0+r1)+(r2+r3).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, 64);
-  return v;
+  v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]  == xor 1
+  v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]  == xor 2
+  v = v + dpp_move<0x141>(v);  // row_half_mirror      == xor 4 (quads uniform)
+  v = v + dpp_move<0x140>(v);  // row_mirror           == xor 8 (octets uniform)
+  const float r0 = lane_bcast(v, 0), r1 = lane_bcast(v, 16);
+  const float r2 = lane_bcast(v, 32), r3 = lane_bcast(v, 48);
+  return (r0 + r1) + (r2 + r3);
+}
+
+// Correctly rounded a / d for a divisor shared by the whole wave: `rd` is the
+// correctly rounded reciprocal of d (one exact division per wave), then
+// Markstein's q0 = a*rd, r = a - d*q0, q = q0 + r*rd is the rounded quotient
+// (needs no range scaling here: |a/d| and d stay far from the float limits).
+__device__ __forceinline__ float div_by_uniform(float a, float d, float rd) {
+  const float q0 = a * rd;
+  const float r = __builtin_fmaf(-d, q0, a);
+  return __builtin_fmaf(r, rd, q0);
+}
+
+// (float)log((double)x), the reference's idiom (ns_core.c:228,540,681,1096), for
+// positive finite normal x.  Lean fp64 evaluation:
+//   x = 2^e m, m in [sqrt(1/2), sqrt(2)); s = (m-1)/(m+1) (quotient from a float
+//   reciprocal plus an exact fp64 residual); log m = 2s + s z P(z), z = s^2.
+// Its error is a few 2^-52, so the float rounding is decided unless the fp64
+// value sits within 2^-44 (relative) of a rounding boundary; those cases
+// (about 3e-6 of inputs) and non-normal inputs are redone with the fp64 libm log,
+// which makes the result identical to (float)log((double)x) from ocml for every
+// float (checked exhaustively in tests/test_ns_gpu.py).
+__device__ __forceinline__ double log_lean_f64(float x) {
+  const int xb = __float_as_int(x);
+  int e = ((xb >> 23) & 0xff) - 127;
+  float mf = __int_as_float((xb & 0x007fffff) | 0x3f800000);  // [1, 2)
+  const bool big = mf > 1.41421356f;
+  mf = big ? mf * 0.5f : mf;  // exact
+  e += big ? 1 : 0;
+  const float ff = mf - 1.0f;  // exact (Sterbenz)
+  const float gf = mf + 1.0f;  // rounded to float; the residual below uses g exactly in fp64
+  const double g = (double)mf + 1.0;
+  const double c = (double)__builtin_amdgcn_rcpf(gf);
+  const double f = (double)ff;
+  const double s0 = f * c;                        // exact: 24 x 24 bits
+  const double d = __builtin_fma(g, c, -1.0);     // exact: g c - 1, |d| < 2^-22
+  double s = __builtin_fma(-s0, d, s0);           // s0 (1 - d + d^2)
+  s = __builtin_fma(s0 * d, d, s);
+  const double z = s * s;
+  double p = 2.0 / 21.0;
+  p = __builtin_fma(p, z, 2.0 / 19.0);
+  p = __builtin_fma(p, z, 2.0 / 17.0);
+  p = __builtin_fma(p, z, 2.0 / 15.0);
+  p = __builtin_fma(p, z, 2.0 / 13.0);
+  p = __builtin_fma(p, z, 2.0 / 11.0);
+  p = __builtin_fma(p, z, 2.0 / 9.0);
+  p = __builtin_fma(p, z, 2.0 / 7.0);
+  p = __builtin_fma(p, z, 2.0 / 5.0);
+  p = __builtin_fma(p, z, 2.0 / 3.0);
+  const double lm = __builtin_fma(s * z, p, s + s);
+  const double ed = (double)e;
+  const double ln2_hi = 0x1.62e42fefa38p-1;   // 41 significant bits: e * ln2_hi is exact
+  const double ln2_lo = 0x1.ef35793c7673p-45;
+  return __builtin_fma(ed, ln2_hi, __builtin_fma(ed, ln2_lo, lm));
+}
+
+__device__ __forceinline__ bool f64_rounds_safely_to_f32(double y) {
+  // the 29 bits dropped by the conversion; unsafe when they are within 2^9
+  // (= 2^-44 relative) of the half-way pattern 0x10000000
+  const unsigned lo = (unsigned)__double2loint(y) & 0x1fffffffu;
+  return ((lo - 0x0ffffe00u) > 0x400u);
+}
+
+__device__ __forceinline__ float log_f32_via_f64(float x) {
+  const unsigned ax = __float_as_uint(x);
+  const bool normal_pos = (ax - 0x00800000u) < 0x7f000000u;  // [2^-126, inf)
+  const double y = log_lean_f64(x);
+  const bool ok = normal_pos && f64_rounds_safely_to_f32(y);
+  float r = (float)y;
+  if (__builtin_expect(!ok, 0)) r = (float)log((double)x);
+  return r;
 }
 
 struct FftLane {
@@ -426,7 +514,7 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
   wave_lds_fence();
   float2 lo, hi;
   rdft256_fwd(buf, L, lane, lo, hi);
-  const float re128 = __shfl(lo.y, 0, 64);
+  const float re128 = lane_bcast(lo.y, 0);
   float re[3], im[3], magn[3];
   re[0] = lo.x;
   im[0] = lane == 0 ? 0.f : lo.y;
@@ -451,7 +539,7 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
 
     float lmagn[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) lmagn[k] = (float)log((double)magn[k]);
+    for (int k = 0; k < 3; ++k) lmagn[k] = log_f32_via_f64(magn[k]);
 
     // signalEnergy, sumMagn (ns_core.c:1088-1104)
     float t_se = (re[0] * re[0] + im[0] * im[0]) + (re[1] * re[1] + im[1] * im[1]);
@@ -470,14 +558,16 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     for (int s = 0; s < 3; ++s) {
       const float cnt = (float)counter[s];
       const float cnt1 = (float)(counter[s] + 1);
+      const float rcnt1 = 1.f / cnt1;  // correctly rounded, once per wave
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         float den = DEN[s][k], lq = LQ[s][k];
         const float delta = den > 1.0f ? NS_FACTOR * 1.f / den : NS_FACTOR;
         const bool up = lmagn[k] > lq;
-        const float step = (up ? NS_QUANTILE * delta : (1.f - NS_QUANTILE) * delta) / cnt1;
+        const float step =
+            div_by_uniform(up ? NS_QUANTILE * delta : (1.f - NS_QUANTILE) * delta, cnt1, rcnt1);
         lq = up ? lq + step : lq - step;
-        const float nd = (cnt * den + 1.f / (2.f * NS_WIDTH)) / cnt1;
+        const float nd = div_by_uniform(cnt * den + 1.f / (2.f * NS_WIDTH), cnt1, rcnt1);
         den = fabsf(lmagn[k] - lq) < NS_WIDTH ? nd : den;
         DEN[s][k] = den;
         LQ[s][k] = lq;
@@ -580,7 +670,7 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     }
     {
       float num = wave_sum(t_fl);
-      float den = sumMagn - __shfl(magn[0], 0, 64);
+      float den = sumMagn - lane_bcast(magn[0], 0);
       den = den / kBins;
       num = num / kBins;
       const float spectralTmp = (float)exp((double)num) / den;
@@ -659,7 +749,7 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
       const float t1 = 1.f + 2.f * snrLocPrior[k];
       const float t2 = 2.f * snrLocPrior[k] / (t1 + 0.0001f);
       const float besselTmp = (snrLocPost[k] + 1.f) * t2;
-      logLrt[k] += NS_LRT_TAVG * (besselTmp - (float)log((double)t1) - logLrt[k]);
+      logLrt[k] += NS_LRT_TAVG * (besselTmp - log_f32_via_f64(t1) - logLrt[k]);
     }
     float t_ll = logLrt[0] + logLrt[1];
     if (lane == 0) t_ll = t_ll + logLrt[2];
@@ -683,9 +773,9 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
       // the three tanh() of :696-725 evaluated on lanes 0..2 of one call
       const float arg = lane == 0 ? arg0 : (lane == 1 ? arg1 : arg2);
       const float th = (float)tanh((double)arg);
-      const float indicator0 = 0.5f * (__shfl(th, 0, 64) + 1.f);
-      const float indicator1 = 0.5f * (__shfl(th, 1, 64) + 1.f);
-      const float indicator2 = 0.5f * (__shfl(th, 2, 64) + 1.f);
+      const float indicator0 = 0.5f * (lane_bcast(th, 0) + 1.f);
+      const float indicator1 = 0.5f * (lane_bcast(th, 1) + 1.f);
+      const float indicator2 = 0.5f * (lane_bcast(th, 2) + 1.f);
       const float indPrior = pm.p4 * indicator0 + pm.p5 * indicator1 + pm.p6 * indicator2;
       priorSpeechProb += NS_PRIOR_UPDATE * (indPrior - priorSpeechProb);
       if (priorSpeechProb > 1.f) priorSpeechProb = 1.f;
@@ -705,10 +795,10 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     // ---- UpdateNoiseEstimate (ns_core.c:800-846).  The time constant carried
     // into bin i is the one bin i-1 selected from its speech probability.
     {
-      const float upA = __shfl_up(probSpeech[0], 1, 64);
-      float upB = __shfl_up(probSpeech[1], 1, 64);
-      const float a63 = __shfl(probSpeech[0], 63, 64);
-      const float b63 = __shfl(probSpeech[1], 63, 64);
+      const float upA = dpp_move<0x138>(probSpeech[0]);  // wave_shr:1 : lane q <- lane q-1
+      float upB = dpp_move<0x138>(probSpeech[1]);
+      const float a63 = lane_bcast(probSpeech[0], 63);
+      const float b63 = lane_bcast(probSpeech[1], 63);
       if (lane == 0) upB = a63;
       float prevProb[3] = {upA, upB, b63};
 #pragma unroll
@@ -904,6 +994,34 @@ __global__ void ns_set_policy_kernel(float* __restrict__ state, int num_streams,
   sc[S_GAINMAP] = __int_as_float(gainmap);
 }
 
+// Test seams for the device math: fn 0 = log_f32_via_f64 (lean path + fallback),
+// 1 = (float)log((double)x), 2 = (float)exp((double)x), 3 = (float)tanh((double)x).
+__device__ __forceinline__ float debug_fn(int fn, float x) {
+  switch (fn) {
+    case 0: return log_f32_via_f64(x);
+    case 1: return (float)log((double)x);
+    case 2: return (float)exp((double)x);
+    default: return (float)tanh((double)x);
+  }
+}
+__global__ void debug_eval_kernel(int fn, float* data, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) data[i] = debug_fn(fn, data[i]);
+}
+// Compares fn_a and fn_b on every float whose bit pattern is in [start, start+count).
+__global__ void debug_compare_kernel(int fn_a, int fn_b, unsigned start, unsigned count,
+                                     unsigned* n_bad, unsigned* bad_bits) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float x = __uint_as_float(start + i);
+  const float a = debug_fn(fn_a, x), b = debug_fn(fn_b, x);
+  const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
+  if (!same) {
+    const unsigned k = atomicAdd(n_bad, 1u);
+    if (k < 64) bad_bits[k] = start + i;
+  }
+}
+
 // FFT seam for the parity tests: WebRtc_rdft(256, isgn) on each 256-float row.
 __global__ __launch_bounds__(256) void rdft256_kernel(float* __restrict__ data, int count,
                                                       int isgn,
@@ -965,6 +1083,18 @@ hipError_t launch_ns_set_policy(float* state, int num_streams, int mode, float o
                                 float denoiseBound, int gainmap, hipStream_t s) {
   hipLaunchKernelGGL(ns_set_policy_kernel, dim3((num_streams + 255) / 256), dim3(256), 0, s,
                      state, num_streams, mode, overdrive, denoiseBound, gainmap);
+  return hipGetLastError();
+}
+
+hipError_t launch_debug_eval(int fn, float* data, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn,
+                     data, n);
+  return hipGetLastError();
+}
+hipError_t launch_debug_compare(int fn_a, int fn_b, unsigned start, unsigned count,
+                                unsigned* n_bad, unsigned* bad_bits, hipStream_t s) {
+  hipLaunchKernelGGL(debug_compare_kernel, dim3((count + 255) / 256), dim3(256), 0, s, fn_a, fn_b,
+                     start, count, n_bad, bad_bits);
   return hipGetLastError();
 }
 

@@ -299,9 +299,9 @@ void asp_ns_oracle_rdft256(float* a, int isgn) {
 /* -------------------------------------------------------------- reductions */
 
 /* The wave64 association used by the HIP kernels: 64 partials, butterfly
- * xor 32,16,8,4,2,1 (every lane ends with the same value). */
+ * xor 1,2,4,8,16,32 (every lane ends with the same value). */
 static float butterfly64(float* t) {
-  for (int m = 32; m >= 1; m >>= 1) {
+  for (int m = 1; m <= 32; m <<= 1) {
     float u[64];
     for (int l = 0; l < 64; ++l) u[l] = t[l] + t[l ^ m];
     memcpy(t, u, sizeof u);
@@ -953,4 +953,13 @@ void asp_ns_oracle_run_mt(AspNsState* states, int num_streams, const float* in,
   for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
   free(th);
   free(sh);
+}
+
+/* The host libm idioms of the reference, (float)fn((double)x), applied in place:
+ * fn 1 = log, 2 = exp, 3 = tanh.  Used to check the device math against glibc. */
+void asp_oracle_libm_f32(int fn, float* data, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const double x = (double)data[i];
+    data[i] = (float)(fn == 1 ? log(x) : (fn == 2 ? exp(x) : tanh(x)));
+  }
 }

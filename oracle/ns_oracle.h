@@ -27,7 +27,7 @@ extern "C" {
  *   SEQ : left-to-right in bin order, exactly as the reference's loops do
  *         (ns_core.c:951-960, 1088-1101, 538-545, 605-621, 676-683).
  *   TREE: the fixed wave64 butterfly order of the HIP kernels
- *         (slot-local sum, then xor 32,16,8,4,2,1), so the device path can be
+ *         (slot-local sum, then xor 1,2,4,8,16,32), so the device path can be
  *         checked bit-for-bit against this restatement. */
 enum { ASP_NS_REDUCE_SEQ = 0, ASP_NS_REDUCE_TREE = 1 };
 
@@ -50,6 +50,9 @@ void asp_ns_oracle_run_mt(AspNsState* states, int num_streams, const float* in,
 /* 256-point real FFT in Ooura packing, in place; WebRtc_rdft(256, isgn, ...)
  * (fft4g.c:324-362).  isgn=+1 forward, -1 inverse (unscaled). */
 void asp_ns_oracle_rdft256(float* a, int isgn);
+
+/* (float)fn((double)x) with the host libm, in place: fn 1 = log, 2 = exp, 3 = tanh. */
+void asp_oracle_libm_f32(int fn, float* data, size_t n);
 
 /* Tables shared with the device path (so tests can compare them). */
 const float* asp_ns_oracle_window(void);      /* kBlocks160w256, windows_private.h:94-147 */

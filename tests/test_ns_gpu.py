@@ -295,3 +295,58 @@ def test_wav_driver_end_to_end(ns, golden, tmp_path):
     d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
     assert d.max() <= 1
     assert (d == 0).mean() >= 0.999
+
+
+def _debug_compare(lib, fn_a, fn_b, start, count):
+    n_bad = C.c_uint32()
+    bad = (C.c_uint32 * 64)()
+    lib.AspNs_debug_compare.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]
+    assert lib.AspNs_debug_compare(fn_a, fn_b, start, count, C.byref(n_bad), bad, 0) == 0
+    return n_bad.value, [bad[i] for i in range(min(n_bad.value, 64))]
+
+
+def test_device_log_exhaustive_vs_libm_form(ns):
+    """The kernels' lean (float)log((double)x) equals the libm-based form for EVERY positive
+    float bit pattern (normal, denormal, inf) -- 2^31 inputs, checked on the device."""
+    lib = ns.load_library()
+    total_bad, examples = 0, []
+    step = 1 << 28
+    for start in range(0x00000000, 0x7f800001, step):
+        count = min(step, 0x7f800001 - start)
+        n, ex = _debug_compare(lib, 0, 1, start, count)
+        total_bad += n
+        examples += ex
+    assert total_bad == 0, [hex(b) for b in examples[:8]]
+
+
+def test_device_libm_matches_host_libm(ns):
+    """(float)log/exp/tanh((double)x) on the device == glibc on this host, over dense samples of
+    the ranges the NS path feeds them (magn, 1+2 snr in [1, 2^31); -logLrt, lquantile in
+    [-88, 88]; tanh arguments in [-40, 40])."""
+    from tests.oracle_lib import oracle_lib
+
+    lib, olib = ns.load_library(), oracle_lib()
+    lib.AspNs_debug_eval.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+    olib.asp_oracle_libm_f32.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(11)
+    n = 1 << 22
+    cases = {
+        1: np.concatenate([rng.integers(0x3f800000, 0x4f000000, n, dtype=np.uint32).view(np.float32),
+                           (1.0 + rng.random(n // 4) * 1e-3).astype(np.float32)]),
+        2: ((rng.random(n) - 0.5) * 176).astype(np.float32),
+        3: ((rng.random(n) - 0.5) * 80).astype(np.float32),
+    }
+    for fn, x in cases.items():
+        dev = np.ascontiguousarray(x.copy())
+        host = np.ascontiguousarray(x.copy())
+        assert lib.AspNs_debug_eval(fn, dev.ctypes.data, dev.size, 0) == 0
+        olib.asp_oracle_libm_f32(fn, host.ctypes.data, host.size)
+        bad = np.nonzero(dev.view(np.uint32) != host.view(np.uint32))[0]
+        assert bad.size == 0, (fn, bad.size, x[bad[:4]], dev[bad[:4]], host[bad[:4]])
+    # and the lean log against glibc on the same sample
+    dev = np.ascontiguousarray(cases[1].copy())
+    host = np.ascontiguousarray(cases[1].copy())
+    assert lib.AspNs_debug_eval(0, dev.ctypes.data, dev.size, 0) == 0
+    olib.asp_oracle_libm_f32(1, host.ctypes.data, host.size)
+    assert np.array_equal(dev.view(np.uint32), host.view(np.uint32))
