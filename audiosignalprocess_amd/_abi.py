@@ -80,3 +80,9 @@ class AspNsState(C.Structure):
 
 
 STATE_FIELDS = [n for n, _ in AspNsState._fields_]
+
+
+class AspBtState(C.Structure):
+    """include/asp_bt.h: AspBtState (carried state between macroblocks)."""
+
+    _fields_ = [("win_size", C.c_int32), ("inbuf_tail", C.c_float * 512), ("out_tail", C.c_float * 512)]

@@ -26,9 +26,10 @@ hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_set_policy(float* state, int num_streams, int mode, float overdrive,
                                 float denoiseBound, int gainmap, hipStream_t s);
 hipError_t launch_rdft256(float* data, int count, int isgn, const NsTables* T, hipStream_t s);
-hipError_t launch_debug_eval(int fn, float* data, size_t n, hipStream_t s);
+hipError_t launch_debug_eval(int fn, float* data, size_t n, const NsTables* T, hipStream_t s);
 hipError_t launch_debug_compare(int fn_a, int fn_b, unsigned start, unsigned count,
-                                unsigned* n_bad, unsigned* bad_bits, hipStream_t s);
+                                unsigned* n_bad, unsigned* bad_bits, float param,
+                                const NsTables* T, hipStream_t s);
 }  // namespace aspns
 
 namespace {
@@ -171,6 +172,7 @@ void build_tables(NsTables* T) {
   }
   T->sum_log_i = sli;
   T->sum_log_i_square = slis;
+  for (int j = 0; j < 64; ++j) T->exp2_64[j] = exp2((double)j / 64.0);
 }
 
 constexpr int kMaxDevices = 64;
@@ -710,10 +712,13 @@ int AspNs_debug_eval(int fn, float* data, size_t n, int device) {
   if (!data || n == 0) return fail(ASP_ERR_PARAM, "debug_eval: bad argument");
   int rc = select_device(device);
   if (rc) return rc;
+  NsTables* T = nullptr;
+  rc = device_tables(device, &T);
+  if (rc) return rc;
   float* d = nullptr;
   HIP_TRY(hipMalloc((void**)&d, n * sizeof(float)));
   hipError_t e = hipMemcpy(d, data, n * sizeof(float), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = launch_debug_eval(fn, d, n, nullptr);
+  if (e == hipSuccess) e = launch_debug_eval(fn, d, n, T, nullptr);
   if (e == hipSuccess) e = hipMemcpy(data, d, n * sizeof(float), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(ASP_ERR_HIP, "debug_eval", e);
@@ -721,14 +726,17 @@ int AspNs_debug_eval(int fn, float* data, size_t n, int device) {
 }
 
 int AspNs_debug_compare(int fn_a, int fn_b, uint32_t start, uint32_t count, uint32_t* n_bad,
-                        uint32_t* bad_bits64, int device) {
+                        uint32_t* bad_bits64, float param, int device) {
   if (!n_bad || !bad_bits64) return fail(ASP_ERR_PARAM, "debug_compare: bad argument");
   int rc = select_device(device);
+  if (rc) return rc;
+  NsTables* T = nullptr;
+  rc = device_tables(device, &T);
   if (rc) return rc;
   unsigned* d = nullptr;
   HIP_TRY(hipMalloc((void**)&d, 65 * sizeof(unsigned)));
   hipError_t e = hipMemset(d, 0, 65 * sizeof(unsigned));
-  if (e == hipSuccess) e = launch_debug_compare(fn_a, fn_b, start, count, d, d + 1, nullptr);
+  if (e == hipSuccess) e = launch_debug_compare(fn_a, fn_b, start, count, d, d + 1, param, T, nullptr);
   unsigned h[65];
   if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
   (void)hipFree(d);

@@ -97,6 +97,25 @@ __device__ __forceinline__ float div_by_uniform(float a, float d, float rd) {
   return __builtin_fmaf(r, rd, q0);
 }
 
+// Correctly rounded n / d without the range scaling / special-case fix-up of
+// the generic expansion: the same Newton + residual arithmetic hipcc emits for
+// `/` (v_rcp, two reciprocal refinements, two quotient corrections), valid
+// while d and n/d are normal floats away from the range limits -- true for
+// every use below (denominators are x + 1e-4, 1 + x, overdrive + x or a
+// density > 0 with int16-range audio).  Checked against `/` on the device over
+// full mantissa sweeps (tests/test_ns_gpu.py).
+__device__ __forceinline__ float fdiv(float n, float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  const float r1 = __builtin_fmaf(e0, r0, r0);
+  const float q0 = n * r1;
+  const float e1 = __builtin_fmaf(-d, q0, n);
+  const float q1 = __builtin_fmaf(e1, r1, q0);
+  const float e2 = __builtin_fmaf(-d, q1, n);
+  return __builtin_fmaf(e2, r1, q1);
+}
+#define DIV129(a) div_by_uniform((a), 129.0f, 1.0f / 129.0f)
+
 // (float)log((double)x), the reference's idiom (ns_core.c:228,540,681,1096), for
 // positive finite normal x.  Lean fp64 evaluation:
 //   x = 2^e m, m in [sqrt(1/2), sqrt(2)); s = (m-1)/(m+1) (quotient from a float
@@ -145,6 +164,80 @@ __device__ __forceinline__ bool f64_rounds_safely_to_f32(double y) {
   // (= 2^-44 relative) of the half-way pattern 0x10000000
   const unsigned lo = (unsigned)__double2loint(y) & 0x1fffffffu;
   return ((lo - 0x0ffffe00u) > 0x400u);
+}
+
+// exp((double)x) for a float x with |x| <= 87 (float result normal), lean fp64:
+// k = rint(64 x / ln 2), r = x - k ln2/64 (|r| <= 0.0055), e^r by a degree-5
+// polynomial, 2^(k/64) from a 64-entry table.  Relative error < 2^-51.
+__device__ __forceinline__ double exp_lean_f64(float xf, const double* __restrict__ t64) {
+  const double x = (double)xf;
+  const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);
+  const int k = (int)kd;
+  double r = __builtin_fma(-kd, 0x1.62e42ff000000p-7, x);  // exact: 32-bit constant
+  r = __builtin_fma(-kd, -0x1.718432a1b0e26p-41, r);
+  double q = 1.0 / 120.0;
+  q = __builtin_fma(q, r, 1.0 / 24.0);
+  q = __builtin_fma(q, r, 1.0 / 6.0);
+  q = __builtin_fma(q, r, 0.5);
+  const double p = __builtin_fma(q, r * r, r);
+  const double T = t64[k & 63];
+  return __builtin_amdgcn_ldexp(__builtin_fma(T, p, T), k >> 6);
+}
+
+// (float)exp((double)x), the reference's idiom (ns_core.c:266,278,551,745).
+__device__ __forceinline__ float exp_f32_via_f64(float x, const double* __restrict__ t64) {
+  const bool in_range = fabsf(x) <= 87.0f;  // false for NaN too
+  const double y = exp_lean_f64(in_range ? x : 0.0f, t64);
+  const bool ok = in_range && f64_rounds_safely_to_f32(y);
+  float r = (float)y;
+  if (__builtin_expect(!ok, 0)) r = (float)exp((double)x);
+  return r;
+}
+
+// (float)tanh((double)a), the reference's idiom (ns_core.c:698,713,725).
+//   |a| < 2^-5 : odd series through a^9 (next term < 2^-57 relative)
+//   else       : u = exp(-2|a|), tanh = (1 - u) / (1 + u), quotient by a float
+//                reciprocal refined twice in fp64 plus one residual correction.
+__device__ __forceinline__ float tanh_f32_via_f64(float a, const double* __restrict__ t64) {
+  const float ax = fabsf(a);
+  const bool finite_ok = ax <= 40.0f;  // beyond: |tanh| rounds to 1, left to libm; NaN too
+  const double ad = (double)ax;
+  const double a2 = ad * ad;
+  double sr = 0x1.664f4882c10fap-6;                 // 62/2835
+  sr = __builtin_fma(sr, a2, -0x1.ba1ba1ba1ba1cp-5);  // -17/315
+  sr = __builtin_fma(sr, a2, 0x1.1111111111111p-3);   // 2/15
+  sr = __builtin_fma(sr, a2, -0x1.5555555555555p-2);  // -1/3
+  const double t_small = __builtin_fma(ad * a2, sr, ad);
+  const double u = exp_lean_f64(finite_ok ? -2.0f * ax : 0.0f, t64);
+  const double num = 1.0 - u, den = 1.0 + u;
+  double rc = (double)__builtin_amdgcn_rcpf((float)den);
+  rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+  rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+  double qv = num * rc;
+  qv = __builtin_fma(__builtin_fma(-qv, den, num), rc, qv);
+  const double t = ax < 0.03125f ? t_small : qv;
+  const bool ok = finite_ok && f64_rounds_safely_to_f32(t);
+  float r = __builtin_copysignf((float)t, a);
+  if (__builtin_expect(!ok, 0)) r = (float)tanh((double)a);
+  return r;
+}
+
+// Correctly rounded sqrtf for x >= 0 (Newton on v_rsq with exact residuals).
+// The residual arithmetic underflows below about 2^-102, so inputs under
+// 2^-100 (never produced by int16-range audio) take the generic sqrtf; with
+// that, equal to sqrtf for every non-negative float (checked exhaustively).
+__device__ __forceinline__ float fsqrt(float x) {
+  const float r = __builtin_amdgcn_rsqf(x);
+  float g = x * r;
+  float h = 0.5f * r;
+  const float e = __builtin_fmaf(-h, g, 0.5f);
+  g = __builtin_fmaf(g, e, g);
+  h = __builtin_fmaf(h, e, h);
+  const float d = __builtin_fmaf(-g, g, x);
+  g = __builtin_fmaf(d, h, g);
+  float res = (x == 0.0f || x == __builtin_inff()) ? x : g;
+  if (__builtin_expect(x < 0x1p-100f && x > 0.0f, 0)) res = sqrtf(x);
+  return res;
 }
 
 __device__ __forceinline__ float log_f32_via_f64(float x) {
@@ -418,7 +511,7 @@ __device__ __noinline__ PriorModel close_histogram_window(int32_t* __restrict__ 
 //   DO_A only    : WebRtcNs_AnalyzeCore.
 //   DO_P only    : WebRtcNs_ProcessCore (one band).
 template <bool DO_A, bool DO_P>
-__global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state,
+__global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ state,
                                                        int32_t* __restrict__ hist_all,
                                                        const NsTables* __restrict__ T,
                                                        const float* __restrict__ in,
@@ -465,12 +558,7 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
   if (DO_A) {
     LOAD_ROW(LQ[0], V_LQ0) LOAD_ROW(LQ[1], V_LQ1) LOAD_ROW(LQ[2], V_LQ2)
     LOAD_ROW(DEN[0], V_DEN0) LOAD_ROW(DEN[1], V_DEN1) LOAD_ROW(DEN[2], V_DEN2)
-    LOAD_ROW(quant, V_QUANT) LOAD_ROW(magnPrevA, V_MAGNPREV_A)
-    LOAD_ROW(logLrt, V_LOGLRT) LOAD_ROW(avgPause, V_AVGPAUSE)
-  }
-  LOAD_ROW(smooth, V_SMOOTH) LOAD_ROW(noisePrev, V_NOISEPREV)
-  if (DO_P && !DO_A) {
-    LOAD_ROW(noiseSt, V_NOISE) LOAD_ROW(magnPrevP, V_MAGNPREV_P)
+    LOAD_ROW(quant, V_QUANT)
   }
   float2 carry = make_float2(0.f, 0.f);  // syntBuf[0..95], lane l owns 2l, 2l+1
   if (DO_P && lane < 48) carry = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * lane);
@@ -514,6 +602,16 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
   wave_lds_fence();
   float2 lo, hi;
   rdft256_fwd(buf, L, lane, lo, hi);
+  // second group of state rows: issued after the FFT so they do not hold
+  // registers across it; their latency hides under the magnitude / log / trackers
+  asm volatile("" ::: "memory");
+  if (DO_A) {
+    LOAD_ROW(magnPrevA, V_MAGNPREV_A) LOAD_ROW(logLrt, V_LOGLRT) LOAD_ROW(avgPause, V_AVGPAUSE)
+  }
+  LOAD_ROW(smooth, V_SMOOTH) LOAD_ROW(noisePrev, V_NOISEPREV)
+  if (DO_P && !DO_A) {
+    LOAD_ROW(noiseSt, V_NOISE) LOAD_ROW(magnPrevP, V_MAGNPREV_P)
+  }
   const float re128 = lane_bcast(lo.y, 0);
   float re[3], im[3], magn[3];
   re[0] = lo.x;
@@ -523,13 +621,14 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
   re[2] = re128;
   im[2] = 0.f;
   {
-    const float m0 = sqrtf(re[0] * re[0] + im[0] * im[0]) + 1.f;
+    const float m0 = fsqrt(re[0] * re[0] + im[0] * im[0]) + 1.f;
     magn[0] = lane == 0 ? fabsf(re[0]) + 1.f : m0;
-    magn[1] = sqrtf(re[1] * re[1] + im[1] * im[1]) + 1.f;
+    magn[1] = fsqrt(re[1] * re[1] + im[1] * im[1]) + 1.f;
     magn[2] = fabsf(re[2]) + 1.f;
   }
 
-  float noise[3];  // noise estimate handed from Analyze to Process
+  float noise[3];      // noise estimate handed from Analyze to Process
+  float prevStsaA[3];  // magnPrev / (noisePrev + 1e-4) * smooth, identical in both halves when paired
 
   if (DO_A) {
     blockInd++;  // ns_core.c:1084
@@ -550,7 +649,7 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     }
     float signalEnergy = wave_sum(t_se);
     const float sumMagn = wave_sum(t_sm);
-    signalEnergy = signalEnergy / ((float)kBins);
+    signalEnergy = DIV129(signalEnergy);
 
     // ---- NoiseEstimation (ns_core.c:217-285)
     if (updates < NS_END_STARTUP_LONG) updates++;
@@ -562,7 +661,7 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         float den = DEN[s][k], lq = LQ[s][k];
-        const float delta = den > 1.0f ? NS_FACTOR * 1.f / den : NS_FACTOR;
+        const float delta = den > 1.0f ? fdiv(NS_FACTOR * 1.f, den) : NS_FACTOR;
         const bool up = lmagn[k] > lq;
         const float step =
             div_by_uniform(up ? NS_QUANTILE * delta : (1.f - NS_QUANTILE) * delta, cnt1, rcnt1);
@@ -576,14 +675,14 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
         counter[s] = 0;
         if (updates >= NS_END_STARTUP_LONG) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) quant[k] = (float)exp((double)LQ[s][k]);
+          for (int k = 0; k < 3; ++k) quant[k] = exp_f32_via_f64(LQ[s][k], T->exp2_64);
         }
       }
       counter[s]++;
     }
     if (updates < NS_END_STARTUP_LONG) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) quant[k] = (float)exp((double)LQ[2][k]);
+      for (int k = 0; k < 3; ++k) quant[k] = exp_f32_via_f64(LQ[2][k], T->exp2_64);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) noise[k] = quant[k];
@@ -607,7 +706,7 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
       const float sum_log_magn = wave_sum(t_lm);
       const float sum_log_i_log_magn = wave_sum(t_lilm);
       const float sum_log_i = T->sum_log_i, sum_log_i_square = T->sum_log_i_square;
-      whiteNoiseLevel += sumMagn / ((float)kBins) * overdrive;
+      whiteNoiseLevel += DIV129(sumMagn) * overdrive;
       float tmpFloat1 = sum_log_i_square * ((float)(kBins - NS_START_BAND));
       tmpFloat1 -= (sum_log_i * sum_log_i);
       float tmpFloat2 = (sum_log_i_square * sum_log_magn - sum_log_i * sum_log_i_log_magn);
@@ -653,9 +752,10 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     float snrLocPost[3], snrLocPrior[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float previousEstimateStsa = magnPrevA[k] / (noisePrev[k] + 0.0001f) * smooth[k];
+      const float previousEstimateStsa = fdiv(magnPrevA[k], noisePrev[k] + 0.0001f) * smooth[k];
+      prevStsaA[k] = previousEstimateStsa;
       snrLocPost[k] = 0.f;
-      if (magn[k] > noise[k]) snrLocPost[k] = magn[k] / (noise[k] + 0.0001f) - 1.f;
+      if (magn[k] > noise[k]) snrLocPost[k] = fdiv(magn[k], noise[k] + 0.0001f) - 1.f;
       snrLocPrior[k] =
           NS_DD_PR_SNR * previousEstimateStsa + (1.f - NS_DD_PR_SNR) * snrLocPost[k];
     }
@@ -671,17 +771,17 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     {
       float num = wave_sum(t_fl);
       float den = sumMagn - lane_bcast(magn[0], 0);
-      den = den / kBins;
-      num = num / kBins;
-      const float spectralTmp = (float)exp((double)num) / den;
+      den = DIV129(den);
+      num = DIV129(num);
+      const float spectralTmp = fdiv(exp_f32_via_f64(num, T->exp2_64), den);
       fd0 += NS_SPECT_FL_TAVG * (spectralTmp - fd0);
     }
     // ---- ComputeSpectralDifference (ns_core.c:595-634)
     {
       float avgPauseMean = wave_sum(t_ap);
       float avgMagn = sumMagn;
-      avgPauseMean = avgPauseMean / ((float)kBins);
-      avgMagn = avgMagn / ((float)kBins);
+      avgPauseMean = DIV129(avgPauseMean);
+      avgMagn = DIV129(avgMagn);
       float dm[3], dp[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -699,12 +799,12 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
       float covMagnPause = wave_sum(t_cov);
       float varPause = wave_sum(t_vp);
       float varMagn = wave_sum(t_vm);
-      covMagnPause = covMagnPause / ((float)kBins);
-      varPause = varPause / ((float)kBins);
-      varMagn = varMagn / ((float)kBins);
+      covMagnPause = DIV129(covMagnPause);
+      varPause = DIV129(varPause);
+      varMagn = DIV129(varMagn);
       fd6 += signalEnergy;
-      float avgDiffNormMagn = varMagn - (covMagnPause * covMagnPause) / (varPause + 0.0001f);
-      avgDiffNormMagn = (float)(avgDiffNormMagn / (fd5 + 0.0001f));
+      float avgDiffNormMagn = varMagn - fdiv(covMagnPause * covMagnPause, varPause + 0.0001f);
+      avgDiffNormMagn = fdiv(avgDiffNormMagn, fd5 + 0.0001f);
       fd4 += NS_SPECT_DIFF_TAVG * (avgDiffNormMagn - fd4);
     }
 
@@ -719,19 +819,21 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     pm.p6 = SC_F(S_PMP6);
     const float pmp2 = SC_F(S_PMP2);
     int mup0 = updateParsFlag, mup3 = SC_I(S_MUP3);
+    bool window_closed = false;
     const int mup1 = SC_I(S_MUP1);
     if (updateParsFlag >= 1) {
       mup3--;
       if (mup3 > 0) {  // FeatureParameterExtraction(self, 0), ns_core.c:309-334
         if (lane == 0) {
-          if ((fd3 < kHist * 0.1f) && (fd3 >= 0.0f)) hist[(int)(fd3 / 0.1f)]++;
-          if ((fd0 < kHist * 0.05f) && (fd0 >= 0.0f)) hist[kHistStride + (int)(fd0 / 0.05f)]++;
+          if ((fd3 < kHist * 0.1f) && (fd3 >= 0.0f)) hist[(int)div_by_uniform(fd3, 0.1f, 1.0f / 0.1f)]++;
+          if ((fd0 < kHist * 0.05f) && (fd0 >= 0.0f)) hist[kHistStride + (int)div_by_uniform(fd0, 0.05f, 1.0f / 0.05f)]++;
           if ((fd4 < kHist * 0.1f) && (fd4 >= 0.0f))
-            hist[2 * kHistStride + (int)(fd4 / 0.1f)]++;
+            hist[2 * kHistStride + (int)div_by_uniform(fd4, 0.1f, 1.0f / 0.1f)]++;
         }
       }
       if (mup3 == 0) {
         pm = close_histogram_window(hist, lane, mup1, mup0 >= 1, pm);
+        window_closed = true;
         mup3 = mup1;
         if (updateParsFlag == 1) {
           mup0 = 0;
@@ -747,14 +849,14 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const float t1 = 1.f + 2.f * snrLocPrior[k];
-      const float t2 = 2.f * snrLocPrior[k] / (t1 + 0.0001f);
+      const float t2 = fdiv(2.f * snrLocPrior[k], t1 + 0.0001f);
       const float besselTmp = (snrLocPost[k] + 1.f) * t2;
       logLrt[k] += NS_LRT_TAVG * (besselTmp - log_f32_via_f64(t1) - logLrt[k]);
     }
     float t_ll = logLrt[0] + logLrt[1];
     if (lane == 0) t_ll = t_ll + logLrt[2];
     float logLrtTimeAvgKsum = wave_sum(t_ll);
-    logLrtTimeAvgKsum = (float)logLrtTimeAvgKsum / (kBins);
+    logLrtTimeAvgKsum = DIV129(logLrtTimeAvgKsum);
     fd3 = logLrtTimeAvgKsum;
     {
       const float widthPrior0 = NS_WIDTH_PR_MAP, widthPrior1 = 2.f * NS_WIDTH_PR_MAP,
@@ -772,7 +874,7 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
       const float arg2 = widthPrior * (fd4 - pm.p3);
       // the three tanh() of :696-725 evaluated on lanes 0..2 of one call
       const float arg = lane == 0 ? arg0 : (lane == 1 ? arg1 : arg2);
-      const float th = (float)tanh((double)arg);
+      const float th = tanh_f32_via_f64(arg, T->exp2_64);
       const float indicator0 = 0.5f * (lane_bcast(th, 0) + 1.f);
       const float indicator1 = 0.5f * (lane_bcast(th, 1) + 1.f);
       const float indicator2 = 0.5f * (lane_bcast(th, 2) + 1.f);
@@ -783,12 +885,12 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     }
     float probSpeech[3];
     {
-      const float gainPrior = (1.f - priorSpeechProb) / (priorSpeechProb + 0.0001f);
+      const float gainPrior = fdiv(1.f - priorSpeechProb, priorSpeechProb + 0.0001f);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        float invLrt = (float)exp((double)(-logLrt[k]));
+        float invLrt = exp_f32_via_f64(-logLrt[k], T->exp2_64);
         invLrt = (float)gainPrior * invLrt;
-        probSpeech[k] = 1.f / (1.f + invLrt);
+        probSpeech[k] = fdiv(1.f, 1.f + invLrt);
       }
     }
 
@@ -839,15 +941,19 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     SC_SET_I(S_MUP3, mup3);
     SC_SET_F(S_SIGNALENERGY, signalEnergy);
     SC_SET_F(S_SUMMAGN, sumMagn);
-    SC_SET_F(S_WHITE, whiteNoiseLevel);
-    SC_SET_F(S_PINKNUM, pinkNoiseNumerator);
-    SC_SET_F(S_PINKEXP, pinkNoiseExp);
-    SC_SET_F(S_PMP0, pm.p0);
-    SC_SET_F(S_PMP1, pm.p1);
-    SC_SET_F(S_PMP3, pm.p3);
-    SC_SET_F(S_PMP4, pm.p4);
-    SC_SET_F(S_PMP5, pm.p5);
-    SC_SET_F(S_PMP6, pm.p6);
+    if (blockInd < NS_END_STARTUP_SHORT) {  // only the start-up model moves these
+      SC_SET_F(S_WHITE, whiteNoiseLevel);
+      SC_SET_F(S_PINKNUM, pinkNoiseNumerator);
+      SC_SET_F(S_PINKEXP, pinkNoiseExp);
+    }
+    if (window_closed) {  // only FeatureParameterExtraction(self, 1) moves these
+      SC_SET_F(S_PMP0, pm.p0);
+      SC_SET_F(S_PMP1, pm.p1);
+      SC_SET_F(S_PMP3, pm.p3);
+      SC_SET_F(S_PMP4, pm.p4);
+      SC_SET_F(S_PMP5, pm.p5);
+      SC_SET_F(S_PMP6, pm.p6);
+    }
     SC_SET_F(S_FD0, fd0);
     SC_SET_F(S_FD3, fd3);
     SC_SET_F(S_FD4, fd4);
@@ -879,12 +985,13 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       // ComputeDdBasedWienerFilter (ns_core.c:985-1007)
-      const float previousEstimateStsa = mprev[k] / (noisePrev[k] + 0.0001f) * smooth[k];
+      const float previousEstimateStsa =
+          DO_A ? prevStsaA[k] : fdiv(mprev[k], noisePrev[k] + 0.0001f) * smooth[k];
       float currentEstimateStsa = 0.f;
-      if (magn[k] > noise[k]) currentEstimateStsa = magn[k] / (noise[k] + 0.0001f) - 1.f;
+      if (magn[k] > noise[k]) currentEstimateStsa = fdiv(magn[k], noise[k] + 0.0001f) - 1.f;
       const float snrPrior =
           NS_DD_PR_SNR * previousEstimateStsa + (1.f - NS_DD_PR_SNR) * currentEstimateStsa;
-      float g = snrPrior / (overdrive + snrPrior);
+      float g = fdiv(snrPrior, overdrive + snrPrior);
       // floors and startup blend (ns_core.c:1276-1307)
       if (g < denoiseBound) g = denoiseBound;
       if (g > 1.f) g = 1.f;
@@ -909,7 +1016,12 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
     // ---- IFFT (ns_core.c:923-944)
     float2 tlo = make_float2(re[0], lane == 0 ? re[2] : im[0]);
     float2 thi = make_float2(re[1], im[1]);
-    rdft256_inv(buf, L, lane, tlo, thi);
+    {
+      int lane_o = lane;  // opaque copy: keeps the compiler from holding the forward tables live
+      asm volatile("" : "+v"(lane_o));
+      const FftLane Li = load_fft_lane(T, lane_o);
+      rdft256_inv(buf, Li, lane, tlo, thi);
+    }
     float td0 = tlo.x * (2.f / kAnal), td1 = tlo.y * (2.f / kAnal);
     float td2 = thi.x * (2.f / kAnal), td3 = thi.y * (2.f / kAnal);
 
@@ -922,10 +1034,10 @@ __global__ __launch_bounds__(256) void ns_frame_kernel(float* __restrict__ state
       e2 += td2 * td2;
       e2 += td3 * td3;
       const float energy2 = wave_sum(e2);
-      float gain = sqrtf(energy2 / (energy1 + 1.f));
+      float gain = fsqrt(fdiv(energy2, energy1 + 1.f));
       if (gain > NS_B_LIM) {
         factor1 = 1.f + 1.3f * (gain - NS_B_LIM);
-        if (gain * factor1 > 1.f) factor1 = 1.f / gain;
+        if (gain * factor1 > 1.f) factor1 = fdiv(1.f, gain);
       }
       if (gain < NS_B_LIM) {
         if (gain <= denoiseBound) gain = denoiseBound;
@@ -995,26 +1107,40 @@ __global__ void ns_set_policy_kernel(float* __restrict__ state, int num_streams,
 }
 
 // Test seams for the device math: fn 0 = log_f32_via_f64 (lean path + fallback),
-// 1 = (float)log((double)x), 2 = (float)exp((double)x), 3 = (float)tanh((double)x).
-__device__ __forceinline__ float debug_fn(int fn, float x) {
+// 1 = (float)log((double)x), 2 = (float)exp((double)x), 3 = (float)tanh((double)x),
+// 4..8 division forms, 9/10 sqrtf / fsqrt, 11/12 the kernels' exp / tanh.
+__device__ __forceinline__ float debug_fn(int fn, float x, float param,
+                                          const double* __restrict__ t64) {
   switch (fn) {
+    case 9: return sqrtf(x);
+    case 10: return fsqrt(x);
+    case 11: return exp_f32_via_f64(x, t64);
+    case 12: return tanh_f32_via_f64(x, t64);
+    case 4: return x / param;
+    case 5: return div_by_uniform(x, param, 1.0f / param);
+    case 6: return fdiv(x, param);
+    case 7: return param / x;
+    case 8: return fdiv(param, x);
     case 0: return log_f32_via_f64(x);
     case 1: return (float)log((double)x);
     case 2: return (float)exp((double)x);
-    default: return (float)tanh((double)x);
+    case 3: return (float)tanh((double)x);
+    default: return x;
   }
 }
-__global__ void debug_eval_kernel(int fn, float* data, size_t n) {
+__global__ void debug_eval_kernel(int fn, float* data, size_t n,
+                                  const NsTables* __restrict__ T) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) data[i] = debug_fn(fn, data[i]);
+  if (i < n) data[i] = debug_fn(fn, data[i], 1.0f, T->exp2_64);
 }
 // Compares fn_a and fn_b on every float whose bit pattern is in [start, start+count).
 __global__ void debug_compare_kernel(int fn_a, int fn_b, unsigned start, unsigned count,
-                                     unsigned* n_bad, unsigned* bad_bits) {
+                                     unsigned* n_bad, unsigned* bad_bits, float param,
+                                     const NsTables* __restrict__ T) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const float x = __uint_as_float(start + i);
-  const float a = debug_fn(fn_a, x), b = debug_fn(fn_b, x);
+  const float a = debug_fn(fn_a, x, param, T->exp2_64), b = debug_fn(fn_b, x, param, T->exp2_64);
   const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
   if (!same) {
     const unsigned k = atomicAdd(n_bad, 1u);
@@ -1086,15 +1212,16 @@ hipError_t launch_ns_set_policy(float* state, int num_streams, int mode, float o
   return hipGetLastError();
 }
 
-hipError_t launch_debug_eval(int fn, float* data, size_t n, hipStream_t s) {
+hipError_t launch_debug_eval(int fn, float* data, size_t n, const NsTables* T, hipStream_t s) {
   hipLaunchKernelGGL(debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn,
-                     data, n);
+                     data, n, T);
   return hipGetLastError();
 }
 hipError_t launch_debug_compare(int fn_a, int fn_b, unsigned start, unsigned count,
-                                unsigned* n_bad, unsigned* bad_bits, hipStream_t s) {
+                                unsigned* n_bad, unsigned* bad_bits, float param,
+                                const NsTables* T, hipStream_t s) {
   hipLaunchKernelGGL(debug_compare_kernel, dim3((count + 255) / 256), dim3(256), 0, s, fn_a, fn_b,
-                     start, count, n_bad, bad_bits);
+                     start, count, n_bad, bad_bits, param, T);
   return hipGetLastError();
 }
 

@@ -74,6 +74,7 @@ struct NsTables {
   float sum_log_i;            // sequential sums over i = 5..128, ns_core.c:1094-1095
   float sum_log_i_square;
   float pad[2];
+  double exp2_64[64];         // 2^(j/64), range-reduction table of the lean exp
 };
 
 }  // namespace aspns

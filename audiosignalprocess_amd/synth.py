@@ -45,3 +45,20 @@ def ns_frames(num_streams, num_frames, stream0=0, frame0=0):
     x = 600.0 * n + tone * env[None, :]
     x = x.astype(np.float32).reshape(num_streams, num_frames, 160)
     return np.ascontiguousarray(x.transpose(1, 0, 2))
+
+
+def bt_samples(num_streams, num_samples, stream0=0, t0=0):
+    """BlockThresholding input, float in [-1, 1], shape [num_streams][num_samples] float32.
+
+    0.2 sin(0.02 t (1 + 0.1 (s mod 16))) (1 if floor(t/20000) odd else 0.1) + 0.08 n
+    (SURVEY.md section 8(d)); never an all-zero macroblock (the reference divides by the
+    block energy, audioDenoiseBlockTreshold.c:397-398).
+    """
+    s = np.arange(stream0, stream0 + num_streams, dtype=np.int64)
+    seeds = (12345 + 7919 * s) & 0xFFFFFFFF
+    n = _lcg_uniform(seeds, t0, num_samples)
+    t = np.arange(t0, t0 + num_samples, dtype=np.float64)
+    gate = np.where((np.floor(t / 20000.0).astype(np.int64) & 1) == 1, 1.0, 0.1)
+    w = 0.02 * (1.0 + 0.1 * (s % 16).astype(np.float64))
+    x = 0.2 * np.sin(w[:, None] * t[None, :]) * gate[None, :] + 0.08 * n
+    return np.ascontiguousarray(x.astype(np.float32))

@@ -169,12 +169,15 @@ size_t AspNs_host_tables_size(void);
 
 /* Test seams for the device math.  fn: 0 = the kernels' (float)log((double)x)
  * (lean fp64 path with libm fallback), 1/2/3 = libm-based (float)log / exp /
- * tanh of (double)x.  debug_eval maps a host array in place; debug_compare
+ * tanh of (double)x; 4 = x / param, 5 = the kernels' division by a wave-uniform
+ * divisor, 6 = the kernels' lean division x / param, 7 = param / x, 8 = lean
+ * param / x, 9 = sqrtf, 10 = the kernels' sqrt, 11 / 12 = the kernels' exp / tanh.
+ * debug_eval maps a host array in place; debug_compare
  * evaluates fn_a and fn_b on every float with bit pattern in
  * [start, start+count) and reports how many differ (first 64 patterns). */
 int AspNs_debug_eval(int fn, float* data, size_t n, int device);
 int AspNs_debug_compare(int fn_a, int fn_b, uint32_t start, uint32_t count,
-                        uint32_t* n_bad, uint32_t* bad_bits64, int device);
+                        uint32_t* n_bad, uint32_t* bad_bits64, float param, int device);
 
 /* FFT seam used by the parity tests: batched 256-point real FFT in Ooura
  * packing (a[0]=R0, a[1]=R128, a[2k]=Rk, a[2k+1]=Ik; fft4g.c:90-118), i.e.

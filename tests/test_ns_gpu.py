@@ -297,12 +297,12 @@ def test_wav_driver_end_to_end(ns, golden, tmp_path):
     assert (d == 0).mean() >= 0.999
 
 
-def _debug_compare(lib, fn_a, fn_b, start, count):
+def _debug_compare(lib, fn_a, fn_b, start, count, param=1.0):
     n_bad = C.c_uint32()
     bad = (C.c_uint32 * 64)()
     lib.AspNs_debug_compare.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32,
-                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]
-    assert lib.AspNs_debug_compare(fn_a, fn_b, start, count, C.byref(n_bad), bad, 0) == 0
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_float, C.c_int]
+    assert lib.AspNs_debug_compare(fn_a, fn_b, start, count, C.byref(n_bad), bad, param, 0) == 0
     return n_bad.value, [bad[i] for i in range(min(n_bad.value, 64))]
 
 
@@ -350,3 +350,48 @@ def test_device_libm_matches_host_libm(ns):
     assert lib.AspNs_debug_eval(0, dev.ctypes.data, dev.size, 0) == 0
     olib.asp_oracle_libm_f32(1, host.ctypes.data, host.size)
     assert np.array_equal(dev.view(np.uint32), host.view(np.uint32))
+
+
+def test_device_division_forms_exact(ns):
+    """The kernels' two cheaper division forms give the IEEE quotient: division by a wave-uniform
+    divisor for every divisor the path uses (129, 50, counters 1..201, 500) and the lean Newton
+    form, over full 2^23-mantissa sweeps of the other operand at several exponents."""
+    lib = ns.load_library()
+
+    def f32bits(v):
+        return int(np.float32(v).view(np.uint32))
+
+    sweeps = [f32bits(1.0), f32bits(2.0 ** 20), f32bits(2.0 ** -10)]
+    divisors = [129.0, 50.0, 500.0, float(np.float32(0.1)), float(np.float32(0.05))] + [float(c) for c in range(1, 202)]
+    for d in divisors:
+        for start in sweeps[:2] if d not in (129.0, 50.0) else sweeps:
+            n, ex = _debug_compare(lib, 4, 5, start, 1 << 23, d)
+            assert n == 0, (d, [hex(b) for b in ex[:4]])
+    rng = np.random.default_rng(2)
+    params = list(np.exp(rng.uniform(np.log(1e-4), np.log(1e9), 40)).astype(np.float32)) + [1.0, 40.0, 1.0001]
+    for prm in params:
+        for start in sweeps:
+            n, ex = _debug_compare(lib, 4, 6, start, 1 << 23, float(prm))   # x / param
+            assert n == 0, ("x/p", prm, [hex(b) for b in ex[:4]])
+            n, ex = _debug_compare(lib, 7, 8, start, 1 << 23, float(prm))   # param / x
+            assert n == 0, ("p/x", prm, [hex(b) for b in ex[:4]])
+
+
+def _sweep_all_floats(lib, fn_a, fn_b, lo=0x00000000, hi=0x100000000):
+    total, examples = 0, []
+    step = 1 << 28
+    for start in range(lo, hi, step):
+        n, ex = _debug_compare(lib, fn_a, fn_b, start, min(step, hi - start))
+        total += n
+        examples += ex
+    return total, examples
+
+
+def test_device_exp_tanh_sqrt_exhaustive(ns):
+    """The kernels' lean exp / tanh equal the libm-based (float)f((double)x) forms, and the lean
+    sqrt equals sqrtf, for EVERY float bit pattern (2^32 inputs each; sqrt: non-negative)."""
+    lib = ns.load_library()
+    for fa, fb, lo, hi, name in [(11, 2, 0, 1 << 32, "exp"), (12, 3, 0, 1 << 32, "tanh"),
+                                 (10, 9, 0, 0x7f800001, "sqrt")]:
+        bad, ex = _sweep_all_floats(lib, fa, fb, lo, hi)
+        assert bad == 0, (name, bad, [hex(b) for b in ex[:8]])
