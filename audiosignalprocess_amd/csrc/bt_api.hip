@@ -1,0 +1,432 @@
+// bt_api.hip -- host side of include/asp_bt.h: constant tables, the batch handle, and the
+// reference's per-stream blockThreshold_* protocol (audioDenoiseBlockTreshold.h:46-74)
+// implemented as a batch of one with host-side hop buffering.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "asp_bt.h"
+#include "asp_ns.h"
+#include "bt_layout.h"
+
+using namespace aspbt;
+
+namespace aspbt {
+size_t macroblock_lds_bytes(int n);
+hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const float* in,
+                                float* out, int num_streams, int frames, int threshold,
+                                int in_stride, int out_stride, hipStream_t s);
+hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int inverse,
+                          const BtTables* T, hipStream_t s);
+}  // namespace aspbt
+
+namespace {
+
+thread_local char g_bt_err[512] = "";
+int bt_fail(int code, const char* what, hipError_t e = hipSuccess) {
+  if (e != hipSuccess)
+    snprintf(g_bt_err, sizeof g_bt_err, "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(g_bt_err, sizeof g_bt_err, "%s", what);
+  fprintf(stderr, "asp_bt: %s\n", g_bt_err);
+  return code;
+}
+#define BT_TRY(expr)                                            \
+  do {                                                          \
+    hipError_t e_ = (expr);                                     \
+    if (e_ != hipSuccess) return bt_fail(ASP_ERR_HIP, #expr, e_); \
+  } while (0)
+
+// NOTE: C++ translation unit; every libm call casts to double explicitly so the
+// arithmetic is that of the reference's C (see ns_api.hip).
+void fill_size(BtSize* S, int n, float* hann, float* tw_f, float* tw_i, float* sup_f, float* sup_i) {
+  const int half = n / 2, nc = n / 2;
+  for (int i = 0; i < half; i++) {  // make_hanning_window, .c:70-77
+    hann[i] = (float)(0.5 - 0.5 * cos(2 * M_PI * i / (double)(n - 1)));
+    hann[n - 1 - i] = hann[i];
+  }
+  for (int i = 0; i < nc; ++i) {  // kiss_fft_alloc, kiss_fft.c:357-363
+    const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+    double phase = -2 * pi * i / nc;
+    tw_f[2 * i] = (float)cos(phase);
+    tw_f[2 * i + 1] = (float)sin(phase);
+    phase *= -1;
+    tw_i[2 * i] = (float)cos(phase);
+    tw_i[2 * i + 1] = (float)sin(phase);
+  }
+  for (int i = 0; i < nc / 2; ++i) {  // kiss_fftr_alloc, kiss_fftr.c:57-63
+    double phase = -3.14159265358979323846264338327 * ((double)(i + 1) / nc + .5);
+    sup_f[2 * i] = (float)cos(phase);
+    sup_f[2 * i + 1] = (float)sin(phase);
+    phase *= -1;
+    sup_i[2 * i] = (float)cos(phase);
+    sup_i[2 * i + 1] = (float)sin(phase);
+  }
+  const float sigma_noise = (float)0.047;                              // .c:111
+  const float sigma_h = (float)((double)sigma_noise * sqrt(0.375));    // .c:112
+  static const float m_lambda[3][5] = {{1.5, 1.8, 2, 2.5, 2.5},        // .c:11-13
+                                       {1.8, 2, 2.5, 3.5, 3.5},
+                                       {2, 2.5, 3.5, 4.7, 4.7}};
+  S->norm = (float)(sqrt(2.0) / (sqrt((double)n) * (double)sigma_h));  // .c:365
+  const float L_pi = 8.0, Lambda_pi = 2.5;
+  S->dc_const = Lambda_pi * L_pi * (sigma_h * sigma_h) * (float)n;     // .c:503
+  S->wiener_c = (float)n * (sigma_h * sigma_h);                        // .c:481
+  S->pad = 0.f;
+  for (int T = 0; T < 3; ++T)
+    for (int F = 0; F < 5; ++F) {
+      const int TT = 8 >> T, FF = 16 >> F;
+      const float lambda = m_lambda[T][F];
+      const float size_blk = (float)(TT * FF);
+      BtSeg& g = S->seg[T][F];
+      g.size_blk = size_blk;
+      g.temp = (lambda * lambda) * (size_blk * size_blk) - 2 * lambda * size_blk * (size_blk - 2);
+      g.thr = lambda * size_blk;
+      g.two_size = 2 * size_blk;
+      g.a_const = (float)((double)(lambda * TT * FF) * pow((double)sigma_h, 2.0) * (double)n);
+    }
+}
+
+void build_bt_tables(BtTables* T) {
+  memset(T, 0, sizeof *T);
+  fill_size(&T->s256, 256, T->hann256, T->tw256_f, T->tw256_i, T->sup256_f, T->sup256_i);
+  fill_size(&T->s1024, 1024, T->hann1024, T->tw1024_f, T->tw1024_i, T->sup1024_f, T->sup1024_i);
+}
+
+std::mutex g_bt_mu;
+BtTables* g_bt_dev[64] = {nullptr};
+
+int bt_tables(int device, BtTables** out) {
+  if (device < 0 || device >= 64) return bt_fail(ASP_ERR_PARAM, "device ordinal out of range");
+  std::lock_guard<std::mutex> lk(g_bt_mu);
+  if (!g_bt_dev[device]) {
+    BtTables* host = (BtTables*)malloc(sizeof(BtTables));
+    build_bt_tables(host);
+    BtTables* dev = nullptr;
+    hipError_t e = hipMalloc((void**)&dev, sizeof(BtTables));
+    if (e == hipSuccess) e = hipMemcpy(dev, host, sizeof(BtTables), hipMemcpyHostToDevice);
+    free(host);
+    if (e != hipSuccess) return bt_fail(ASP_ERR_HIP, "uploading BT tables", e);
+    g_bt_dev[device] = dev;
+  }
+  *out = g_bt_dev[device];
+  return ASP_OK;
+}
+
+int bt_select_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return bt_fail(ASP_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)", e);
+  if (device < 0 || device >= n) return bt_fail(ASP_ERR_PARAM, "device ordinal out of range");
+  BT_TRY(hipSetDevice(device));
+  return ASP_OK;
+}
+
+}  // namespace
+
+struct AspBtBatch {
+  int S = 0, win = 0, half = 0, macro = 0, device = 0;
+  hipStream_t stream = nullptr;
+  float* state = nullptr;
+  BtTables* tables = nullptr;
+  float *stage_in = nullptr, *stage_out = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int device) {
+  if (!out || num_streams <= 0) return bt_fail(ASP_ERR_PARAM, "AspBtBatch_Create: bad argument");
+  *out = nullptr;
+  if (win_size != 256 && win_size != 1024)
+    return bt_fail(ASP_ERR_PARAM, "AspBtBatch_Create: win_size must be 256 or 1024");
+  int rc = bt_select_device(device);
+  if (rc) return rc;
+  AspBtBatch* b = new AspBtBatch();
+  b->S = num_streams;
+  b->win = win_size;
+  b->half = win_size / 2;
+  b->macro = 8 * b->half;
+  b->device = device;
+  rc = bt_tables(device, &b->tables);
+  if (rc) {
+    delete b;
+    return rc;
+  }
+  const size_t frame_bytes = (size_t)num_streams * b->macro * sizeof(float);
+  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->state, (size_t)num_streams * kStateFloats * 4);
+  if (e == hipSuccess) e = hipMemset(b->state, 0, (size_t)num_streams * kStateFloats * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->stage_in, frame_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out, frame_bytes);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+  if (e != hipSuccess) {
+    AspBtBatch_Free(b);
+    return bt_fail(ASP_ERR_HIP, "AspBtBatch_Create: device allocation", e);
+  }
+  *out = b;
+  return ASP_OK;
+}
+
+int AspBtBatch_Free(AspBtBatch* b) {
+  if (!b) return ASP_OK;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->state) (void)hipFree(b->state);
+  if (b->stage_in) (void)hipFree(b->stage_in);
+  if (b->stage_out) (void)hipFree(b->stage_out);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return ASP_OK;
+}
+
+int AspBtBatch_Reset(AspBtBatch* b) {
+  if (!b) return bt_fail(ASP_ERR_PARAM, "null batch handle");
+  BT_TRY(hipSetDevice(b->device));
+  BT_TRY(hipMemsetAsync(b->state, 0, (size_t)b->S * kStateFloats * 4, b->stream));
+  return ASP_OK;
+}
+
+int AspBtBatch_num_streams(const AspBtBatch* b) { return b ? b->S : ASP_ERR_PARAM; }
+int AspBtBatch_macro_size(const AspBtBatch* b) { return b ? b->macro : ASP_ERR_PARAM; }
+
+static int bt_run(AspBtBatch* b, const float* in, float* out, int frames, int threshold, int mem) {
+  if (!b || !out || (!in && frames > 0)) return bt_fail(ASP_ERR_PARAM, "null argument");
+  if (frames < 0 || frames > 8) return bt_fail(ASP_ERR_PARAM, "frames must be 0..8");
+  BT_TRY(hipSetDevice(b->device));
+  const int n = frames * b->half;
+  const float* din = in;
+  float* dout = out;
+  if (frames == 0) return ASP_OK;
+  if (mem == ASP_MEM_HOST) {
+    BT_TRY(hipMemcpyAsync(b->stage_in, in, (size_t)b->S * n * 4, hipMemcpyHostToDevice, b->stream));
+    din = b->stage_in;
+    dout = b->stage_out;
+  } else if (mem != ASP_MEM_DEVICE) {
+    return bt_fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  }
+  BT_TRY(launch_bt_macroblock(b->win, b->state, b->tables, din, dout, b->S, frames, threshold, n,
+                              n, b->stream));
+  if (mem == ASP_MEM_HOST) {
+    BT_TRY(hipMemcpyAsync(out, b->stage_out, (size_t)b->S * n * 4, hipMemcpyDeviceToHost,
+                          b->stream));
+    BT_TRY(hipStreamSynchronize(b->stream));
+  }
+  return ASP_OK;
+}
+
+int AspBtBatch_Denoise(AspBtBatch* b, const float* in, float* out, int mem) {
+  return bt_run(b, in, out, 8, 1, mem);
+}
+
+int AspBtBatch_Flush(AspBtBatch* b, const float* in, int hops, float* out, int mem) {
+  if (hops < 0 || hops > 7) return bt_fail(ASP_ERR_PARAM, "Flush: hops must be 0..7");
+  return bt_run(b, in, out, hops, 0, mem);
+}
+
+int AspBtBatch_Synchronize(AspBtBatch* b) {
+  if (!b) return bt_fail(ASP_ERR_PARAM, "null batch handle");
+  BT_TRY(hipSetDevice(b->device));
+  BT_TRY(hipStreamSynchronize(b->stream));
+  return ASP_OK;
+}
+
+int AspBtBatch_TimedSteps(AspBtBatch* b, const float* in, float* out, int blocks_in_ring,
+                          int steps, float* elapsed_ms) {
+  if (!b || !in || !out || blocks_in_ring <= 0 || steps < 0 || !elapsed_ms)
+    return bt_fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
+  BT_TRY(hipSetDevice(b->device));
+  const size_t per = (size_t)b->S * b->macro;
+  BT_TRY(hipEventRecord(b->ev0, b->stream));
+  for (int k = 0; k < steps; ++k) {
+    const size_t off = per * (size_t)(k % blocks_in_ring);
+    BT_TRY(launch_bt_macroblock(b->win, b->state, b->tables, in + off, out + off, b->S, 8, 1,
+                                b->macro, b->macro, b->stream));
+  }
+  BT_TRY(hipEventRecord(b->ev1, b->stream));
+  BT_TRY(hipEventSynchronize(b->ev1));
+  BT_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+  return ASP_OK;
+}
+
+int AspBtBatch_ExportState(AspBtBatch* b, int stream, AspBtState* out) {
+  if (!b || !out || stream < 0 || stream >= b->S) return bt_fail(ASP_ERR_PARAM, "ExportState: bad argument");
+  BT_TRY(hipSetDevice(b->device));
+  BT_TRY(hipStreamSynchronize(b->stream));
+  float blk[kStateFloats];
+  BT_TRY(hipMemcpy(blk, b->state + (size_t)stream * kStateFloats, sizeof blk, hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof *out);
+  out->win_size = b->win;
+  memcpy(out->inbuf_tail, blk + kOffInTail, sizeof(float) * b->half);
+  memcpy(out->out_tail, blk + kOffOutTail, sizeof(float) * b->half);
+  return ASP_OK;
+}
+
+int AspBtBatch_ImportState(AspBtBatch* b, int stream, const AspBtState* in) {
+  if (!b || !in || stream < 0 || stream >= b->S) return bt_fail(ASP_ERR_PARAM, "ImportState: bad argument");
+  if (in->win_size != b->win) return bt_fail(ASP_ERR_PARAM, "ImportState: win_size mismatch");
+  BT_TRY(hipSetDevice(b->device));
+  BT_TRY(hipStreamSynchronize(b->stream));
+  float blk[kStateFloats];
+  memset(blk, 0, sizeof blk);
+  memcpy(blk + kOffInTail, in->inbuf_tail, sizeof(float) * b->half);
+  memcpy(blk + kOffOutTail, in->out_tail, sizeof(float) * b->half);
+  BT_TRY(hipMemcpy(b->state + (size_t)stream * kStateFloats, blk, sizeof blk, hipMemcpyHostToDevice));
+  return ASP_OK;
+}
+
+static int bt_fft_seam(const float* src, float* dst, int n, int count, int inverse, int device) {
+  if (!src || !dst || count <= 0 || (n != 256 && n != 1024))
+    return bt_fail(ASP_ERR_PARAM, "kiss_fftr seam: bad argument");
+  int rc = bt_select_device(device);
+  if (rc) return rc;
+  BtTables* T = nullptr;
+  rc = bt_tables(device, &T);
+  if (rc) return rc;
+  const size_t tb = (size_t)count * n * 4, fb = (size_t)count * (n + 2) * 4;
+  float *ds = nullptr, *dd = nullptr;
+  BT_TRY(hipMalloc((void**)&ds, inverse ? fb : tb));
+  BT_TRY(hipMalloc((void**)&dd, inverse ? tb : fb));
+  hipError_t e = hipMemcpy(ds, src, inverse ? fb : tb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_bt_fftr(n, ds, dd, count, inverse, T, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(dst, dd, inverse ? tb : fb, hipMemcpyDeviceToHost);
+  (void)hipFree(ds);
+  (void)hipFree(dd);
+  if (e != hipSuccess) return bt_fail(ASP_ERR_HIP, "kiss_fftr seam", e);
+  return ASP_OK;
+}
+
+int AspBt_kiss_fftr_batch(const float* timedata, float* freqdata, int n, int count, int device) {
+  return bt_fft_seam(timedata, freqdata, n, count, 0, device);
+}
+int AspBt_kiss_fftri_batch(const float* freqdata, float* timedata, int n, int count, int device) {
+  return bt_fft_seam(freqdata, timedata, n, count, 1, device);
+}
+
+// ----------------------------------------------------------------- layer 1
+// audioDenoiseBlockTreshold.h:46-74 over a batch of one; hops are buffered on the host
+// until a macroblock (8 hops) is complete (.c:541-575).
+
+struct MarsBlockThreshold {
+  AspBtBatch* batch;
+  int32_t win_size, half_win_size, macro_size, have_nblk_time;
+  float* pending;  // [macro]
+  float* outbuf;   // [macro]
+};
+
+static int16_t bt_float_to_s16(float v) {  // .c:259-265
+  if (v > 0) return v >= 1 ? 32767 : (int16_t)(v * 32767 + 0.5f);
+  return v <= -1 ? (int16_t)(-32768) : (int16_t)(-v * (-32768) - 0.5);
+}
+static float bt_s16_to_float(int16_t v) {  // .c:267-271
+  static const float kMaxInt16Inverse = 1.f / 32767;
+  static const float kMinInt16Inverse = 1.f / (-32768);
+  return v * (v > 0 ? kMaxInt16Inverse : -kMinInt16Inverse);
+}
+
+MarsBlockThreshold_t* blockThreshold_init(int32_t time_win, int32_t fs, int32_t* err) {
+  int32_t dummy;
+  if (!err) err = &dummy;
+  if (time_win <= 0 || fs <= 0) {
+    *err = MARS_ERROR_PARAMS;
+    return NULL;
+  }
+  int32_t win = fs / 1000 * time_win;  // .c:91-94
+  if (win & 0x01) win += 1;
+  if (win != 256 && win != 1024) {
+    fprintf(stderr, "blockThreshold_init: window of %d samples is not built (256 / 1024 only)\n", win);
+    *err = MARS_ERROR_PARAMS;
+    return NULL;
+  }
+  MarsBlockThreshold* h = (MarsBlockThreshold*)calloc(1, sizeof *h);
+  if (!h || AspBtBatch_Create(&h->batch, 1, win, 0) != ASP_OK) {
+    free(h);
+    *err = MARS_ERROR_MEMORY;
+    return NULL;
+  }
+  h->win_size = win;
+  h->half_win_size = win / 2;
+  h->macro_size = h->half_win_size * 8;
+  h->pending = (float*)calloc((size_t)h->macro_size, sizeof(float));
+  h->outbuf = (float*)calloc((size_t)h->macro_size, sizeof(float));
+  *err = MARS_OK;
+  return h;
+}
+
+int32_t blockThreshold_reset(MarsBlockThreshold_t* h) {
+  if (!h) return MARS_ERROR_PARAMS;
+  h->have_nblk_time = 0;
+  memset(h->outbuf, 0, sizeof(float) * (size_t)h->macro_size);
+  return AspBtBatch_Reset(h->batch) == ASP_OK ? MARS_OK : MARS_ERROR_MEMORY;
+}
+
+int32_t blockThreshold_denoise_float(MarsBlockThreshold_t* h, float* in, int32_t in_len) {
+  if (!h || (in_len != h->half_win_size) || (!in)) return MARS_ERROR_PARAMS;
+  memcpy(h->pending + (size_t)h->have_nblk_time * h->half_win_size, in,
+         sizeof(float) * (size_t)h->half_win_size);
+  h->have_nblk_time++;
+  if (h->have_nblk_time != 8) return MARS_NEED_MORE_SAMPLES;
+  if (AspBtBatch_Denoise(h->batch, h->pending, h->outbuf, ASP_MEM_HOST) != ASP_OK) abort();
+  h->have_nblk_time = 0;
+  return MARS_CAN_OUTPUT;
+}
+
+int32_t blockThreshold_denoise_int16(MarsBlockThreshold_t* h, int16_t* in, int32_t in_len) {
+  if (!h || (in_len != h->half_win_size) || (!in)) return MARS_ERROR_PARAMS;
+  std::vector<float> tmp((size_t)in_len);
+  for (int32_t i = 0; i < in_len; i++) tmp[i] = bt_s16_to_float(in[i]);
+  return blockThreshold_denoise_float(h, tmp.data(), in_len);
+}
+
+int32_t blockThreshold_output_float(MarsBlockThreshold_t* h, float* out, int32_t out_len) {
+  if (out_len < h->macro_size) return 0;
+  memcpy(out, h->outbuf, sizeof(float) * (size_t)h->macro_size);
+  return h->macro_size;
+}
+
+int32_t blockThreshold_output_int16(MarsBlockThreshold_t* h, int16_t* out, int32_t out_len) {
+  if (out_len < h->macro_size) return 0;
+  for (int32_t i = 0; i < h->macro_size; i++) out[i] = bt_float_to_s16(h->outbuf[i]);
+  return h->macro_size;
+}
+
+int32_t blockThreshold_flush_float(MarsBlockThreshold_t* h, float* out, int32_t out_len) {
+  const int32_t out_size = h->have_nblk_time * h->half_win_size;
+  if (out_len < out_size) return -1;
+  if (out_size == 0) return 0;
+  if (AspBtBatch_Flush(h->batch, h->pending, h->have_nblk_time, out, ASP_MEM_HOST) != ASP_OK) abort();
+  return out_size;
+}
+
+int32_t blockThreshold_flush_int16(MarsBlockThreshold_t* h, int16_t* out, int32_t out_len) {
+  const int32_t out_size = h->have_nblk_time * h->half_win_size;
+  if (out_len < out_size) return -1;
+  if (out_size == 0) return 0;
+  std::vector<float> tmp((size_t)out_size);
+  if (AspBtBatch_Flush(h->batch, h->pending, h->have_nblk_time, tmp.data(), ASP_MEM_HOST) != ASP_OK)
+    abort();
+  for (int32_t i = 0; i < out_size; i++) out[i] = bt_float_to_s16(tmp[i]);
+  return out_size;
+}
+
+void blockThreshold_free(MarsBlockThreshold_t* h) {
+  if (!h) return;
+  AspBtBatch_Free(h->batch);
+  free(h->pending);
+  free(h->outbuf);
+  free(h);
+}
+
+int32_t blockThreshold_max_output(const MarsBlockThreshold_t* h) { return h->macro_size; }
+int32_t blockThreshold_samples_per_time(const MarsBlockThreshold_t* h) { return h->half_win_size; }
+
+}  // extern "C"

@@ -1,0 +1,416 @@
+// bt_kernels.hip -- gfx950 kernels of the batched time-frequency block-thresholding
+// denoiser.  Replaces, for many independent stream-channels per launch,
+//   blockThreshold_STFT / _core / _adaptive_block / blockTreshold_compute_thre /
+//   blockThreshold_wiener / blockThreshold_inverse_STFT
+//   (Denoise/BlockThresholding/src/audioDenoiseBlockTreshold.c:273-539) and
+//   kiss_fftr / kiss_fftri (common/kiss_fft/kiss_fftr.c:67-159, kiss_fft.c:21-302).
+//
+// Mapping: one workgroup (N/2 threads) per stream-channel macroblock (8 hops of N/2
+// samples).  The eight N/2-point complex FFTs of a macroblock advance together, one
+// radix stage per barrier, in a 32 KB LDS tile; inputs are scattered into kiss_fft's
+// decimation order while loading, so every stage is in place.  The butterflies and the
+// real-FFT split perform kiss_fft's float operations in kiss_fft's order, and every
+// block sum of the SURE search / Stein attenuation runs rows-outer / columns-inner in
+// one thread as the reference does, so results are bit-identical to oracle/bt_oracle.c.
+// The 8 x (N/2+1) coefficient and attenuated tiles live in LDS (65.7 KB at N = 1024, two
+// workgroups per CU); HBM sees only samples in, samples out and the two N/2-sample tails.
+//
+// Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "bt_layout.h"
+
+using namespace aspbt;
+
+namespace {
+
+struct cpx {
+  float r, i;
+};
+
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) {  // C_MUL
+  cpx m;
+  m.r = a.r * b.r - a.i * b.i;
+  m.i = a.r * b.i + a.i * b.r;
+  return m;
+}
+
+// position of input index n after kiss_fft's recursive decimation (kf_work,
+// kiss_fft.c:237-302) for factors 4,4,..,4,2: n = k0 + 4 k1 + 16 k2 + ... ,
+// position = k0 * (NC/4) + k1 * (NC/16) + ... + k_last.
+template <int NC>
+__device__ __forceinline__ int kiss_position(int n) {
+  int pos = 0, m = NC;
+#pragma unroll
+  for (int rem = NC; rem > 2; rem >>= 2) {
+    m >>= 2;
+    pos += (n & 3) * m;
+    n >>= 2;
+  }
+  return pos + n;  // the radix-2 leaf digit
+}
+
+// All radix stages of `frames` NC-point FFTs held in work[frame][NC] (kiss order input).
+template <int NC>
+__device__ __forceinline__ void kiss_stages(cpx* work, const cpx* __restrict__ tw, int frames,
+                                            bool inverse, int tid) {
+  // radix-2 leaves, m = 1, twiddle index 0 (kf_bfly2, kiss_fft.c:21-42)
+  for (int w = tid; w < frames * (NC / 2); w += NC) {
+    const int fr = w / (NC / 2), b = w % (NC / 2);
+    cpx* F = work + fr * NC + 2 * b;
+    const cpx t = cmul(F[1], tw[0]);
+    const cpx a = F[0];
+    F[1].r = a.r - t.r;
+    F[1].i = a.i - t.i;
+    F[0].r = a.r + t.r;
+    F[0].i = a.i + t.i;
+  }
+  __syncthreads();
+  // radix-4 stages, m = 2, 8, 32, ... (kf_bfly4, kiss_fft.c:44-90)
+  for (int m = 2; m < NC; m <<= 2) {
+    const int fstride = NC / (4 * m);
+    for (int w = tid; w < frames * (NC / 4); w += NC) {
+      const int fr = w / (NC / 4), b = w % (NC / 4);
+      const int g = b / m, k = b % m;
+      cpx* F = work + fr * NC + g * 4 * m + k;
+      const cpx s0 = cmul(F[m], tw[k * fstride]);
+      const cpx s1 = cmul(F[2 * m], tw[k * fstride * 2]);
+      const cpx s2 = cmul(F[3 * m], tw[k * fstride * 3]);
+      cpx f0 = F[0], s3, s4, s5;
+      s5.r = f0.r - s1.r;
+      s5.i = f0.i - s1.i;
+      f0.r += s1.r;
+      f0.i += s1.i;
+      s3.r = s0.r + s2.r;
+      s3.i = s0.i + s2.i;
+      s4.r = s0.r - s2.r;
+      s4.i = s0.i - s2.i;
+      F[2 * m].r = f0.r - s3.r;
+      F[2 * m].i = f0.i - s3.i;
+      f0.r += s3.r;
+      f0.i += s3.i;
+      F[0] = f0;
+      if (inverse) {
+        F[m].r = s5.r - s4.i;
+        F[m].i = s5.i + s4.r;
+        F[3 * m].r = s5.r + s4.i;
+        F[3 * m].i = s5.i - s4.r;
+      } else {
+        F[m].r = s5.r + s4.i;
+        F[m].i = s5.i - s4.r;
+        F[3 * m].r = s5.r - s4.i;
+        F[3 * m].i = s5.i + s4.r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// kiss_fftr post-pass (kiss_fftr.c:92-120): work[fr][NC] -> freq[fr][NC+1]
+template <int NC>
+__device__ __forceinline__ void real_split_forward(const cpx* work, cpx* freq,
+                                                   const cpx* __restrict__ sup, int frames,
+                                                   int tid) {
+  for (int w = tid; w < frames * (NC / 2 + 1); w += NC) {
+    const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
+    const cpx* T = work + fr * NC;
+    cpx* Fq = freq + fr * (NC + 1);
+    if (k == 0) {
+      const float tdr = T[0].r, tdi = T[0].i;
+      Fq[0].r = tdr + tdi;
+      Fq[0].i = 0.f;
+      Fq[NC].r = tdr - tdi;
+      Fq[NC].i = 0.f;
+    } else {
+      const cpx fpk = T[k];
+      cpx fpnk, f1k, f2k;
+      fpnk.r = T[NC - k].r;
+      fpnk.i = -T[NC - k].i;
+      f1k.r = fpk.r + fpnk.r;
+      f1k.i = fpk.i + fpnk.i;
+      f2k.r = fpk.r - fpnk.r;
+      f2k.i = fpk.i - fpnk.i;
+      const cpx twv = cmul(f2k, sup[k - 1]);
+      const float a_r = (f1k.r + twv.r) * 0.5f, a_i = (f1k.i + twv.i) * 0.5f;
+      const float b_r = (f1k.r - twv.r) * 0.5f, b_i = (twv.i - f1k.i) * 0.5f;
+      if (k != NC - k) {
+        Fq[k].r = a_r;
+        Fq[k].i = a_i;
+      }
+      Fq[NC - k].r = b_r;  // for k = NC/2 the second assignment is the one that stays
+      Fq[NC - k].i = b_i;
+    }
+  }
+}
+
+// kiss_fftri pre-pass (kiss_fftr.c:137-157): freq[fr][NC+1] -> work[fr][kiss order]
+template <int NC>
+__device__ __forceinline__ void real_merge_inverse(const cpx* freq, cpx* work,
+                                                   const cpx* __restrict__ sup, int frames,
+                                                   int tid) {
+  for (int w = tid; w < frames * (NC / 2 + 1); w += NC) {
+    const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
+    const cpx* Fq = freq + fr * (NC + 1);
+    cpx* T = work + fr * NC;
+    if (k == 0) {
+      cpx v;
+      v.r = Fq[0].r + Fq[NC].r;
+      v.i = Fq[0].r - Fq[NC].r;
+      T[kiss_position<NC>(0)] = v;
+    } else {
+      const cpx fk = Fq[k];
+      cpx fnkc, fek, tmp;
+      fnkc.r = Fq[NC - k].r;
+      fnkc.i = -Fq[NC - k].i;
+      fek.r = fk.r + fnkc.r;
+      fek.i = fk.i + fnkc.i;
+      tmp.r = fk.r - fnkc.r;
+      tmp.i = fk.i - fnkc.i;
+      const cpx fok = cmul(tmp, sup[k - 1]);
+      cpx a, b;
+      a.r = fek.r + fok.r;
+      a.i = fek.i + fok.i;
+      b.r = fek.r - fok.r;
+      b.i = (fek.i - fok.i) * -1;
+      if (k != NC - k) T[kiss_position<NC>(k)] = a;
+      T[kiss_position<NC>(NC - k)] = b;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// One macroblock (frames = 8, threshold = 1) or one flush (frames < 8, threshold = 0)
+// of every stream.
+template <int N>
+__global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
+    float* __restrict__ state, const BtTables* __restrict__ Tb, const float* __restrict__ in,
+    float* __restrict__ out, int frames, int threshold, int in_stride, int out_stride) {
+  constexpr int NC = N / 2, HALF = N / 2, NB = N / 2 + 1;
+  constexpr int NCOL = (N - 1) / 2 / 16;  // macro-columns of 16 bins (.c:493)
+  extern __shared__ __align__(16) unsigned char smem[];
+  cpx* coef = reinterpret_cast<cpx*>(smem);  // [8][NB]
+  cpx* thre = coef + 8 * NB;                 // [8][NB]; FFT work tile aliases it
+  cpx* work = thre;                          // [8][NC]
+  float* sure = reinterpret_cast<float*>(thre + 8 * NB);  // [NCOL][15]
+
+  const int tid = threadIdx.x;
+  const int stream = blockIdx.x;
+  float* st = state + (size_t)stream * kStateFloats;
+  const float* x = in + (size_t)stream * in_stride;
+  float* y = out + (size_t)stream * out_stride;
+  const BtSize& P = N == 1024 ? Tb->s1024 : Tb->s256;
+  const float* hann = N == 1024 ? Tb->hann1024 : Tb->hann256;
+  const cpx* tw_f = reinterpret_cast<const cpx*>(N == 1024 ? Tb->tw1024_f : Tb->tw256_f);
+  const cpx* tw_i = reinterpret_cast<const cpx*>(N == 1024 ? Tb->tw1024_i : Tb->tw256_i);
+  const cpx* sup_f = reinterpret_cast<const cpx*>(N == 1024 ? Tb->sup1024_f : Tb->sup256_f);
+  const cpx* sup_i = reinterpret_cast<const cpx*>(N == 1024 ? Tb->sup1024_i : Tb->sup256_i);
+
+  // ---- STFT (blockThreshold_STFT, .c:273-282): frame t sees B[HALF t .. HALF t + N) of
+  // B = [inbuf tail | new samples]; windowed pairs go straight to kiss order.
+  const int total = frames * HALF;  // new samples this call
+  for (int w = tid; w < frames * NC; w += NC) {
+    const int fr = w / NC, n = w % NC;
+    const int p0 = HALF * fr + 2 * n;  // position in B
+    const float b0 = p0 < HALF ? st[kOffInTail + p0] : x[p0 - HALF];
+    const float b1 = p0 + 1 < HALF ? st[kOffInTail + p0 + 1] : x[p0 + 1 - HALF];
+    cpx z;
+    z.r = b0 * hann[2 * n];
+    z.i = b1 * hann[2 * n + 1];
+    work[fr * NC + kiss_position<NC>(n)] = z;
+  }
+  __syncthreads();
+  // carry the last HALF input samples (after every thread has read the old tail)
+  for (int i = tid; i < HALF; i += NC) {
+    const int p = total + i;  // position in B of the new tail
+    st[kOffInTail + i] = p < HALF ? st[kOffInTail + p] : x[p - HALF];
+  }
+  kiss_stages<NC>(work, tw_f, frames, false, tid);
+  real_split_forward<NC>(work, coef, sup_f, frames, tid);
+  __syncthreads();
+
+  if (threshold) {
+    // ---- DC column and the bins past the last whole macro-column (.c:501-506, 518-532)
+    for (int w = tid; w < 1 + (NB - (1 + NCOL * 16)); w += NC) {
+      const int col = w == 0 ? 0 : (1 + NCOL * 16) + (w - 1);
+      float sum = 0.0f;
+      for (int t = 0; t < 8; ++t) {
+        const float r = coef[t * NB + col].r, i = coef[t * NB + col].i;
+        sum += r * r + i * i;
+      }
+      float a = 1 - P.dc_const / sum;
+      if (a < 0) a = 0;
+      for (int t = 0; t < 8; ++t) {
+        thre[t * NB + col].r = coef[t * NB + col].r * a;
+        thre[t * NB + col].i = coef[t * NB + col].i * a;
+      }
+    }
+    // ---- SURE of the 15 dyadic segmentations of every macro-column (.c:354-401)
+    for (int w = tid; w < NCOL * 15; w += NC) {
+      const int m = w / 15, c = w % 15, T = c / 5, F = c % 5;
+      const int TT = 8 >> T, FF = 16 >> F;
+      const int base = 1 + m * 16;
+      const BtSeg& sg = P.seg[T][F];
+      float SURE_real = 0.0f;
+      for (int ii = 0; ii < (1 << T); ii++)
+        for (int jj = 0; jj < (1 << F); jj++) {
+          float energy_real = 0.0f;
+          for (int r = TT * ii; r < TT * (ii + 1); r++)
+            for (int cc = FF * jj; cc < FF * (jj + 1); cc++) {
+              const float v = coef[r * NB + base + cc].r * P.norm;
+              energy_real += v * v;
+            }
+          SURE_real += sg.size_blk + sg.temp / energy_real * (float)(energy_real > sg.thr) +
+                       (energy_real - sg.two_size) * (float)(energy_real <= sg.thr);
+        }
+      sure[w] = SURE_real;
+    }
+    __syncthreads();
+    // ---- argmin (first wins, .c:404-416) + Stein attenuation of the chosen blocks (.c:421-454)
+    for (int w = tid; w < NCOL * 64; w += NC) {
+      const int m = w / 64, sb = w % 64;
+      float best = sure[m * 15];
+      int bc = 0;
+      for (int c = 1; c < 15; ++c)
+        if (sure[m * 15 + c] < best) {
+          best = sure[m * 15 + c];
+          bc = c;
+        }
+      const int T = bc / 5, F = bc % 5;
+      if (sb < (1 << (T + F))) {
+        const int TT = 8 >> T, FF = 16 >> F;
+        const int ii = sb >> F, jj = sb & ((1 << F) - 1);
+        const int base = 1 + m * 16;
+        float power = 0.0f;
+        for (int r = TT * ii; r < TT * (ii + 1); r++)
+          for (int cc = FF * jj; cc < FF * (jj + 1); cc++) {
+            const float re = coef[r * NB + base + cc].r, im = coef[r * NB + base + cc].i;
+            power += re * re + im * im;
+          }
+        float a = (float)(1.0 - (double)(P.seg[T][F].a_const / power));
+        a = a * (float)(a > 0);
+        for (int r = TT * ii; r < TT * (ii + 1); r++)
+          for (int cc = FF * jj; cc < FF * (jj + 1); cc++) {
+            thre[r * NB + base + cc].r = coef[r * NB + base + cc].r * a;
+            thre[r * NB + base + cc].i = coef[r * NB + base + cc].i * a;
+          }
+      }
+    }
+    __syncthreads();
+    // ---- empirical Wiener on bins 0 .. N/2-1, Nyquist untouched (.c:469-486)
+    for (int w = tid; w < 8 * NC; w += NC) {
+      const int t = w / NC, f = w % NC;
+      const float r = thre[t * NB + f].r, i = thre[t * NB + f].i;
+      float wiener = r * r + i * i;
+      wiener = wiener / (wiener + P.wiener_c);
+      coef[t * NB + f].r *= wiener;
+      coef[t * NB + f].i *= wiener;
+    }
+    __syncthreads();
+  }
+
+  // ---- inverse STFT + overlap-add (blockThreshold_inverse_STFT, .c:284-300)
+  real_merge_inverse<NC>(coef, work, sup_i, frames, tid);
+  __syncthreads();
+  kiss_stages<NC>(work, tw_i, frames, true, tid);
+  const float* td = reinterpret_cast<const float*>(work);  // frame fr sample j at fr*N + j
+  const float fn = (float)N;
+  for (int q = tid; q < total + HALF; q += NC) {
+    const int t2 = q / HALF, t1 = t2 - 1;
+    float v = q < HALF ? st[kOffOutTail + q] : 0.0f;
+    if (t1 >= 0 && t1 < frames) v += td[t1 * N + (q - HALF * t1)] / fn;
+    if (t2 < frames) v += td[t2 * N + (q - HALF * t2)] / fn;
+    if (q < total)
+      y[q] = v;
+    else
+      sure[q - total] = v;  // stage the new tail: other threads still read the old one
+  }
+  __syncthreads();
+  for (int i = tid; i < HALF; i += NC)
+    st[kOffOutTail + i] = threshold ? sure[i] : 0.0f;  // a flush leaves the tail cleared (.c:656-672)
+}
+
+// kiss_fftr / kiss_fftri seam: one workgroup per row.
+template <int N>
+__global__ __launch_bounds__(N / 2) void bt_fftr_kernel(const float* __restrict__ src,
+                                                        float* __restrict__ dst, int inverse,
+                                                        const BtTables* __restrict__ Tb) {
+  constexpr int NC = N / 2, NB = N / 2 + 1;
+  __shared__ cpx work[NC];
+  __shared__ cpx freq[NB];
+  const int tid = threadIdx.x, row = blockIdx.x;
+  const cpx* tw_f = reinterpret_cast<const cpx*>(N == 1024 ? Tb->tw1024_f : Tb->tw256_f);
+  const cpx* tw_i = reinterpret_cast<const cpx*>(N == 1024 ? Tb->tw1024_i : Tb->tw256_i);
+  const cpx* sup_f = reinterpret_cast<const cpx*>(N == 1024 ? Tb->sup1024_f : Tb->sup256_f);
+  const cpx* sup_i = reinterpret_cast<const cpx*>(N == 1024 ? Tb->sup1024_i : Tb->sup256_i);
+  if (!inverse) {
+    const float* x = src + (size_t)row * N;
+    cpx z;
+    z.r = x[2 * tid];
+    z.i = x[2 * tid + 1];
+    work[kiss_position<NC>(tid)] = z;
+    __syncthreads();
+    kiss_stages<NC>(work, tw_f, 1, false, tid);
+    real_split_forward<NC>(work, freq, sup_f, 1, tid);
+    __syncthreads();
+    float* o = dst + (size_t)row * 2 * NB;
+    for (int k = tid; k < NB; k += NC) {
+      o[2 * k] = freq[k].r;
+      o[2 * k + 1] = freq[k].i;
+    }
+  } else {
+    const float* f = src + (size_t)row * 2 * NB;
+    for (int k = tid; k < NB; k += NC) {
+      freq[k].r = f[2 * k];
+      freq[k].i = f[2 * k + 1];
+    }
+    __syncthreads();
+    real_merge_inverse<NC>(freq, work, sup_i, 1, tid);
+    __syncthreads();
+    kiss_stages<NC>(work, tw_i, 1, true, tid);
+    float* o = dst + (size_t)row * N;
+    o[2 * tid] = work[tid].r;
+    o[2 * tid + 1] = work[tid].i;
+  }
+}
+
+}  // namespace
+
+namespace aspbt {
+
+size_t macroblock_lds_bytes(int n) {
+  const int nb = n / 2 + 1, ncol = (n - 1) / 2 / 16;
+  size_t sure = (size_t)(ncol * 15 > n / 2 ? ncol * 15 : n / 2) * sizeof(float);
+  return (size_t)2 * 8 * nb * 8 + sure;
+}
+
+hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const float* in,
+                                float* out, int num_streams, int frames, int threshold,
+                                int in_stride, int out_stride, hipStream_t s) {
+  const size_t lds = macroblock_lds_bytes(n);
+  if (n == 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bt_macroblock_kernel<1024>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(bt_macroblock_kernel<1024>, dim3(num_streams), dim3(512), lds, s, state, T,
+                       in, out, frames, threshold, in_stride, out_stride);
+  } else {
+    hipLaunchKernelGGL(bt_macroblock_kernel<256>, dim3(num_streams), dim3(128), lds, s, state, T,
+                       in, out, frames, threshold, in_stride, out_stride);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int inverse,
+                          const BtTables* T, hipStream_t s) {
+  if (n == 1024)
+    hipLaunchKernelGGL(bt_fftr_kernel<1024>, dim3(count), dim3(512), 0, s, src, dst, inverse, T);
+  else
+    hipLaunchKernelGGL(bt_fftr_kernel<256>, dim3(count), dim3(128), 0, s, src, dst, inverse, T);
+  return hipGetLastError();
+}
+
+}  // namespace aspbt

@@ -1,0 +1,167 @@
+"""GPU parity suite for BlockThresholding (-m gpu): HIP kernels through the C-ABI vs the oracle.
+Bar: bit-exact (same float operations in the same order; PARITY UNPINNED vs the reference itself,
+which cannot be built -- see oracle/bt_oracle.c)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from audiosignalprocess_amd.synth import bt_samples
+from tests.oracle_lib import OracleBt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bt():
+    from audiosignalprocess_amd import bt as mod
+    from audiosignalprocess_amd import ns
+
+    assert ns.device_count() >= 1
+    return mod
+
+
+@pytest.mark.parametrize("n", [256, 1024])
+def test_kiss_fftr_bit_exact(bt, n):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal((300, n)) * rng.choice([1e-3, 1.0, 100.0], size=(300, 1))).astype(np.float32)
+    x[0] = np.sin(np.arange(n))
+    o = OracleBt(n)
+    f = bt.kiss_fftr(x, n)
+    fo = np.stack([o.kiss_fftr(r) for r in x])
+    assert np.array_equal(f, fo)
+    t = bt.kiss_fftri(f, n)
+    to = np.stack([o.kiss_fftri(r) for r in fo])
+    assert np.array_equal(t, to)
+    X = np.fft.rfft(x.astype(np.float64), axis=1)
+    assert np.abs((f[:, 0::2] + 1j * f[:, 1::2]) - X).max() <= 1e-6 * np.abs(X).max()
+
+
+@pytest.mark.parametrize("n", [256, 1024])
+def test_macroblocks_bit_exact_vs_oracle(bt, n):
+    S, K = 6, 5
+    g = bt.BtBatch(S, n)
+    x = bt_samples(S, K * g.macro)
+    y = g.run(x)
+    assert np.isfinite(y).all()
+    for s in range(S):
+        o = OracleBt(n)
+        assert np.array_equal(y[s], o.run(x[s])), s
+        so, sg = o.export_state(), g.export_state(s)
+        assert np.array_equal(np.ctypeslib.as_array(so.inbuf_tail), np.ctypeslib.as_array(sg.inbuf_tail))
+        assert np.array_equal(np.ctypeslib.as_array(so.out_tail), np.ctypeslib.as_array(sg.out_tail))
+    g.close()
+
+
+def test_stereo_48k_config3_shape(bt):
+    """BASELINE config 3: stereo = two independent stream-channels, 1024-point STFT."""
+    g = bt.BtBatch(2, 1024)
+    x = bt_samples(2, 3 * g.macro, stream0=100)
+    y = g.run(x)
+    for ch in range(2):
+        assert np.array_equal(y[ch], OracleBt(1024).run(x[ch]))
+    # denoising: quiet passages (sine at 0.02 amplitude + noise 0.046 rms) come out quieter
+    assert np.sqrt((y[:, 3000:12000] ** 2).mean()) < 0.6 * np.sqrt((x[:, 3000:12000] ** 2).mean())
+    g.close()
+
+
+def test_state_roundtrip_and_reset(bt):
+    g = bt.BtBatch(3, 256)
+    x = bt_samples(3, 4 * g.macro, stream0=7)
+    y_all = g.run(x)
+    g2 = bt.BtBatch(3, 256)
+    g2.run(x[:, :2 * g.macro])
+    saved = [g2.export_state(s) for s in range(3)]
+    g3 = bt.BtBatch(3, 256)
+    for s in range(3):
+        g3.import_state(s, saved[s])
+    assert np.array_equal(g3.run(x[:, 2 * g.macro:]), y_all[:, 2 * g.macro:])
+    g3.reset()
+    assert np.array_equal(g3.run(x[:, :g.macro]), y_all[:, :g.macro])
+    for h in (g, g2, g3):
+        h.close()
+
+
+def test_flush_partial_macroblock(bt):
+    for n in (256, 1024):
+        g = bt.BtBatch(2, n)
+        x = bt_samples(2, g.macro + 5 * g.half, stream0=31)
+        g.denoise(x[:, :g.macro])
+        y = g.flush(x[:, g.macro:], 5)
+        for s in range(2):
+            o = OracleBt(n)
+            o.macroblock(x[s, :g.macro])
+            for hop in x[s, g.macro:].reshape(5, g.half):
+                o.denoise_float(hop)
+            got, yo = o.flush_float(5 * g.half)
+            assert got == 5 * g.half and np.array_equal(y[s], yo)
+        g.close()
+
+
+def test_scale_2048_streams(bt):
+    S = 2048
+    g = bt.BtBatch(S, 1024)
+    x = bt_samples(S, g.macro)
+    y = g.denoise(x)
+    assert np.isfinite(y).all()
+    for s in (0, 1, 17, 1023, 2047):
+        assert np.array_equal(y[s], OracleBt(1024).macroblock(x[s]))
+    perm = np.random.default_rng(1).permutation(S)
+    g2 = bt.BtBatch(S, 1024)
+    assert np.array_equal(g2.denoise(np.ascontiguousarray(x[perm])), y[perm])
+    g.close()
+    g2.close()
+
+
+def test_layer1_reference_protocol(bt, built_lib):
+    """blockThreshold_* (audioDenoiseBlockTreshold.h:46-74) over ctypes, float and int16 paths."""
+    lib = C.CDLL(built_lib)
+    lib.blockThreshold_init.restype = C.c_void_p
+    lib.blockThreshold_init.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    for name in ("denoise_float", "output_float", "flush_float", "denoise_int16", "output_int16"):
+        getattr(lib, "blockThreshold_" + name).argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.blockThreshold_free.argtypes = [C.c_void_p]
+    lib.blockThreshold_max_output.argtypes = [C.c_void_p]
+    lib.blockThreshold_samples_per_time.argtypes = [C.c_void_p]
+    err = C.c_int32(-1)
+    assert lib.blockThreshold_init(0, 16000, C.byref(err)) is None and err.value == 0x02
+    assert lib.blockThreshold_init(20, 16000, C.byref(err)) is None and err.value == 0x02  # 320: not built
+    h = lib.blockThreshold_init(16, 16000, C.byref(err))  # win 256
+    assert h and err.value == 0
+    assert lib.blockThreshold_max_output(h) == 1024 and lib.blockThreshold_samples_per_time(h) == 128
+    o = OracleBt(256)
+    x = bt_samples(1, 2 * 1024 + 3 * 128, stream0=5)[0]
+    out = np.zeros(1024, np.float32)
+    for k, hop in enumerate(np.ascontiguousarray(x[:2048]).reshape(16, 128)):
+        hop = np.ascontiguousarray(hop)
+        rc = lib.blockThreshold_denoise_float(h, hop.ctypes.data, 128)
+        assert rc == (0x20 if k % 8 == 7 else 0x10)
+        assert rc == o.denoise_float(hop)
+        if rc == 0x20:
+            assert lib.blockThreshold_output_float(h, out.ctypes.data, 1000) == 0
+            assert lib.blockThreshold_output_float(h, out.ctypes.data, 1024) == 1024
+            assert np.array_equal(out, o.output_float()[1])
+    assert lib.blockThreshold_denoise_float(h, out.ctypes.data, 127) == 0x02
+    for hop in np.ascontiguousarray(x[2048:]).reshape(3, 128):
+        hop = np.ascontiguousarray(hop)
+        lib.blockThreshold_denoise_float(h, hop.ctypes.data, 128)
+        o.denoise_float(hop)
+    fl = np.zeros(384, np.float32)
+    assert lib.blockThreshold_flush_float(h, fl.ctypes.data, 383) == -1
+    assert lib.blockThreshold_flush_float(h, fl.ctypes.data, 384) == 384
+    assert np.array_equal(fl, o.flush_float(384)[1])
+    lib.blockThreshold_free(h)
+    # int16 path: S16ToFloat in, FloatToS16 out (.c:259-271)
+    h = lib.blockThreshold_init(16, 16000, C.byref(err))
+    o = OracleBt(256)
+    pcm = np.clip(np.rint(bt_samples(1, 1024, stream0=8)[0] * 32767), -32768, 32767).astype(np.int16)
+    for hop in pcm.reshape(8, 128):
+        hop = np.ascontiguousarray(hop)
+        rc = lib.blockThreshold_denoise_int16(h, hop.ctypes.data, 128)
+        o.denoise_float(np.array([o.lib.bt_oracle_s16_to_float(int(v)) for v in hop], np.float32))
+    assert rc == 0x20
+    out16 = np.zeros(1024, np.int16)
+    assert lib.blockThreshold_output_int16(h, out16.ctypes.data, 1024) == 1024
+    ref16 = np.array([o.lib.bt_oracle_float_to_s16(float(v)) for v in o.output_float()[1]], np.int16)
+    assert np.array_equal(out16, ref16)
+    lib.blockThreshold_free(h)
