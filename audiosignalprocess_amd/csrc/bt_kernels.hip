@@ -50,6 +50,47 @@ __device__ __forceinline__ int kiss_position(int n) {
   return pos + n;  // the radix-2 leaf digit
 }
 
+template <int NC, int M>
+__device__ __forceinline__ void radix4_stage(cpx* work, const cpx* __restrict__ tw, int frames,
+                                             bool inverse, int tid) {
+  if (M >= NC) return;
+  constexpr int fstride = (4 * M <= NC) ? NC / (4 * M) : 1;
+  for (int w = tid; w < frames * (NC / 4); w += NC) {
+    const int fr = w / (NC / 4), b = w % (NC / 4);
+    const int g = b / M, k = b % M;
+    cpx* F = work + fr * NC + g * 4 * M + k;
+    const cpx s0 = cmul(F[M], tw[k * fstride]);
+    const cpx s1 = cmul(F[2 * M], tw[k * fstride * 2]);
+    const cpx s2 = cmul(F[3 * M], tw[k * fstride * 3]);
+    cpx f0 = F[0], s3, s4, s5;
+    s5.r = f0.r - s1.r;
+    s5.i = f0.i - s1.i;
+    f0.r += s1.r;
+    f0.i += s1.i;
+    s3.r = s0.r + s2.r;
+    s3.i = s0.i + s2.i;
+    s4.r = s0.r - s2.r;
+    s4.i = s0.i - s2.i;
+    F[2 * M].r = f0.r - s3.r;
+    F[2 * M].i = f0.i - s3.i;
+    f0.r += s3.r;
+    f0.i += s3.i;
+    F[0] = f0;
+    if (inverse) {
+      F[M].r = s5.r - s4.i;
+      F[M].i = s5.i + s4.r;
+      F[3 * M].r = s5.r + s4.i;
+      F[3 * M].i = s5.i - s4.r;
+    } else {
+      F[M].r = s5.r + s4.i;
+      F[M].i = s5.i - s4.r;
+      F[3 * M].r = s5.r - s4.i;
+      F[3 * M].i = s5.i + s4.r;
+    }
+  }
+  __syncthreads();
+}
+
 // All radix stages of `frames` NC-point FFTs held in work[frame][NC] (kiss order input).
 template <int NC>
 __device__ __forceinline__ void kiss_stages(cpx* work, const cpx* __restrict__ tw, int frames,
@@ -66,44 +107,11 @@ __device__ __forceinline__ void kiss_stages(cpx* work, const cpx* __restrict__ t
     F[0].i = a.i + t.i;
   }
   __syncthreads();
-  // radix-4 stages, m = 2, 8, 32, ... (kf_bfly4, kiss_fft.c:44-90)
-  for (int m = 2; m < NC; m <<= 2) {
-    const int fstride = NC / (4 * m);
-    for (int w = tid; w < frames * (NC / 4); w += NC) {
-      const int fr = w / (NC / 4), b = w % (NC / 4);
-      const int g = b / m, k = b % m;
-      cpx* F = work + fr * NC + g * 4 * m + k;
-      const cpx s0 = cmul(F[m], tw[k * fstride]);
-      const cpx s1 = cmul(F[2 * m], tw[k * fstride * 2]);
-      const cpx s2 = cmul(F[3 * m], tw[k * fstride * 3]);
-      cpx f0 = F[0], s3, s4, s5;
-      s5.r = f0.r - s1.r;
-      s5.i = f0.i - s1.i;
-      f0.r += s1.r;
-      f0.i += s1.i;
-      s3.r = s0.r + s2.r;
-      s3.i = s0.i + s2.i;
-      s4.r = s0.r - s2.r;
-      s4.i = s0.i - s2.i;
-      F[2 * m].r = f0.r - s3.r;
-      F[2 * m].i = f0.i - s3.i;
-      f0.r += s3.r;
-      f0.i += s3.i;
-      F[0] = f0;
-      if (inverse) {
-        F[m].r = s5.r - s4.i;
-        F[m].i = s5.i + s4.r;
-        F[3 * m].r = s5.r + s4.i;
-        F[3 * m].i = s5.i - s4.r;
-      } else {
-        F[m].r = s5.r + s4.i;
-        F[m].i = s5.i - s4.r;
-        F[3 * m].r = s5.r - s4.i;
-        F[3 * m].i = s5.i + s4.r;
-      }
-    }
-    __syncthreads();
-  }
+  // radix-4 stages, m = 2, 8, 32, ... (kf_bfly4, kiss_fft.c:44-90); strides are compile-time
+  radix4_stage<NC, 2>(work, tw, frames, inverse, tid);
+  if (NC > 8) radix4_stage<NC, 8>(work, tw, frames, inverse, tid);
+  if (NC > 32) radix4_stage<NC, 32>(work, tw, frames, inverse, tid);
+  if (NC > 128) radix4_stage<NC, 128>(work, tw, frames, inverse, tid);
 }
 
 // kiss_fftr post-pass (kiss_fftr.c:92-120): work[fr][NC] -> freq[fr][NC+1]
@@ -229,6 +237,44 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
   __syncthreads();
 
   if (threshold) {
+    // ---- squared normalised real parts, laid out [row * 16 + bin][column] so that the
+    // SURE pass (lanes = macro-columns) reads consecutive LDS words (.c:365-375, 322-338)
+    constexpr int SQW = NCOL <= 8 ? 8 : 32;      // columns per table row (7 or 31 used)
+    static_assert(128 * SQW * 4 <= 8 * NB * 8, "squared-real table must fit the thre tile");
+    float* sq = reinterpret_cast<float*>(thre);  // 128 x SQW floats, dead before thre is written
+    for (int w = tid; w < 128 * SQW; w += NC) {
+      const int m = w % SQW, e = w / SQW;  // e = r * 16 + cc
+      float v2 = 0.0f;
+      if (m < NCOL) {
+        const float v = coef[(e >> 4) * NB + 1 + m * 16 + (e & 15)].r * P.norm;
+        v2 = v * v;
+      }
+      sq[w] = v2;
+    }
+    __syncthreads();
+    // ---- SURE of the 15 dyadic segmentations of every macro-column (.c:354-401).  A wave
+    // takes whole segmentations (wave-uniform loop bounds), lane = macro-column; every sum
+    // runs in the reference's order: blocks ii-major / jj-minor, rows outer, columns inner.
+    {
+      const int wave = tid >> 6, lane = tid & 63, nwaves = NC / 64;
+      for (int c = wave; c < 15; c += nwaves) {
+        const int T = c / 5, F = c % 5;
+        const int TT = 8 >> T, FF = 16 >> F;
+        const BtSeg sg = P.seg[T][F];
+        const int m = lane % SQW;
+        float SURE_real = 0.0f;
+        for (int ii = 0; ii < (1 << T); ii++)
+          for (int jj = 0; jj < (1 << F); jj++) {
+            float energy_real = 0.0f;
+            for (int r = TT * ii; r < TT * (ii + 1); r++)
+              for (int cc = FF * jj; cc < FF * (jj + 1); cc++) energy_real += sq[(r * 16 + cc) * SQW + m];
+            SURE_real += sg.size_blk + sg.temp / energy_real * (float)(energy_real > sg.thr) +
+                         (energy_real - sg.two_size) * (float)(energy_real <= sg.thr);
+          }
+        if (lane < NCOL) sure[lane * 15 + c] = SURE_real;
+      }
+    }
+    __syncthreads();
     // ---- DC column and the bins past the last whole macro-column (.c:501-506, 518-532)
     for (int w = tid; w < 1 + (NB - (1 + NCOL * 16)); w += NC) {
       const int col = w == 0 ? 0 : (1 + NCOL * 16) + (w - 1);
@@ -244,27 +290,6 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
         thre[t * NB + col].i = coef[t * NB + col].i * a;
       }
     }
-    // ---- SURE of the 15 dyadic segmentations of every macro-column (.c:354-401)
-    for (int w = tid; w < NCOL * 15; w += NC) {
-      const int m = w / 15, c = w % 15, T = c / 5, F = c % 5;
-      const int TT = 8 >> T, FF = 16 >> F;
-      const int base = 1 + m * 16;
-      const BtSeg& sg = P.seg[T][F];
-      float SURE_real = 0.0f;
-      for (int ii = 0; ii < (1 << T); ii++)
-        for (int jj = 0; jj < (1 << F); jj++) {
-          float energy_real = 0.0f;
-          for (int r = TT * ii; r < TT * (ii + 1); r++)
-            for (int cc = FF * jj; cc < FF * (jj + 1); cc++) {
-              const float v = coef[r * NB + base + cc].r * P.norm;
-              energy_real += v * v;
-            }
-          SURE_real += sg.size_blk + sg.temp / energy_real * (float)(energy_real > sg.thr) +
-                       (energy_real - sg.two_size) * (float)(energy_real <= sg.thr);
-        }
-      sure[w] = SURE_real;
-    }
-    __syncthreads();
     // ---- argmin (first wins, .c:404-416) + Stein attenuation of the chosen blocks (.c:421-454)
     for (int w = tid; w < NCOL * 64; w += NC) {
       const int m = w / 64, sb = w % 64;
@@ -313,12 +338,12 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
   __syncthreads();
   kiss_stages<NC>(work, tw_i, frames, true, tid);
   const float* td = reinterpret_cast<const float*>(work);  // frame fr sample j at fr*N + j
-  const float fn = (float)N;
+  const float inv_n = 1.0f / (float)N;  // N is a power of two: x * (1/N) == x / N exactly
   for (int q = tid; q < total + HALF; q += NC) {
     const int t2 = q / HALF, t1 = t2 - 1;
     float v = q < HALF ? st[kOffOutTail + q] : 0.0f;
-    if (t1 >= 0 && t1 < frames) v += td[t1 * N + (q - HALF * t1)] / fn;
-    if (t2 < frames) v += td[t2 * N + (q - HALF * t2)] / fn;
+    if (t1 >= 0 && t1 < frames) v += td[t1 * N + (q - HALF * t1)] * inv_n;
+    if (t2 < frames) v += td[t2 * N + (q - HALF * t2)] * inv_n;
     if (q < total)
       y[q] = v;
     else

@@ -90,6 +90,47 @@ def cpu_baseline(seconds_budget=20.0):
     }
 
 
+def bench_bt(args):
+    """Secondary line (BASELINE config 3 / 1): BlockThresholding macroblocks per second, 1 GPU."""
+    import torch
+
+    from audiosignalprocess_amd.bt import BtBatch
+    from audiosignalprocess_amd.synth import bt_samples
+
+    n = 1024 if args.workload == "bt1024" else 256
+    S = args.streams_per_gpu
+    ring = 4
+    g = BtBatch(S, n)
+    x = bt_samples(S, ring * g.macro).reshape(S, ring, g.macro).transpose(1, 0, 2)
+    d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    d_out = torch.empty_like(d_in)
+    steps, warm = max(args.steps // 10, 10), max(args.warmup // 10, 4)
+    g.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev_ms = g.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    algo = 40 * (n // 2) * 2 * 1  # 10 B per sample: in + out + both tails read and written
+    algo = 10 * g.macro
+    launch_s = ev_ms / 1e3 / steps
+    achieved = algo * S / launch_s / 1e9
+    line = {
+        "metric": "BlockThresholding macroblocks/sec (secondary)", "value": S * steps / wall,
+        "unit": "macroblocks/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": 1e3 * wall / steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Denoise/BlockThresholding: %d-pt STFT, Stein block threshold, %d "
+                               "stream-channels on 1 MI355X, one 8-hop macroblock per launch" % (n, S),
+                   "samples_per_s": S * steps * g.macro / wall},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "bt_macroblock_kernel<%d>" % n,
+                     "algorithmic_bytes_per_launch": algo * S, "avg_launch_us": launch_s * 1e6},
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +139,11 @@ def main():
     ap.add_argument("--streams-per-gpu", type=int, default=4096)
     ap.add_argument("--ring", type=int, default=100, help="distinct input frames resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256"],
+                    help="ns = the headline metric (default); bt* = secondary BlockThresholding line")
     args = ap.parse_args()
+    if args.workload != "ns":
+        return bench_bt(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
