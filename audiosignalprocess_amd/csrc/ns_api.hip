@@ -379,6 +379,12 @@ struct AspNsBatch {
   bool inited = false;
   bool paired = true;  // see ns_kernels.hip: fused step representation
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // Optional: the fused step of a large batch issued as `split` independent
+  // sub-launches on separate HIP streams, so one part's load/store phases
+  // overlap another part's arithmetic (streams never interact).
+  int split = 1;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -470,6 +476,11 @@ int AspNsBatch_Free(AspNsBatch* b) {
   if (b->stage_out) (void)hipFree(b->stage_out);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
+  for (int i = 0; i < 3; ++i) {
+    if (b->join_ev[i]) (void)hipEventDestroy(b->join_ev[i]);
+    if (b->side[i]) (void)hipStreamDestroy(b->side[i]);
+  }
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return ASP_OK;
@@ -516,6 +527,42 @@ int AspNsBatch_set_policy(AspNsBatch* b, int mode) {
   return ASP_OK;
 }
 
+// `steps` fused frame steps on device buffers; step k reads/writes ring slot k % ring.
+static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, int steps) {
+  const size_t per = (size_t)b->S * kBlockL;
+  const int parts = (b->split > 1 && b->S >= 8 * b->split) ? b->split : 1;
+  if (parts == 1) {
+    for (int k = 0; k < steps; ++k) {
+      const size_t off = per * (size_t)(k % ring);
+      HIP_TRY(launch_ns_frame(2, b->state, b->hist, b->tables, din + off, dout + off, b->S,
+                              b->stream));
+    }
+    return ASP_OK;
+  }
+  // parts are multiples of 4 streams (one workgroup = 4 streams)
+  int base[5];
+  for (int p = 0; p <= parts; ++p) base[p] = (int)(((long long)b->S * p / parts) / 4 * 4);
+  base[parts] = b->S;
+  HIP_TRY(hipEventRecord(b->fork_ev, b->stream));
+  for (int p = 1; p < parts; ++p) HIP_TRY(hipStreamWaitEvent(b->side[p - 1], b->fork_ev, 0));
+  for (int k = 0; k < steps; ++k) {
+    const size_t off = per * (size_t)(k % ring);
+    for (int p = 0; p < parts; ++p) {
+      hipStream_t st = p == 0 ? b->stream : b->side[p - 1];
+      const int s0 = base[p], n = base[p + 1] - base[p];
+      HIP_TRY(launch_ns_frame(2, b->state + (size_t)s0 * kStreamDwords,
+                              b->hist + (size_t)s0 * kHistDwords, b->tables,
+                              din + off + (size_t)s0 * kBlockL, dout + off + (size_t)s0 * kBlockL,
+                              n, st));
+    }
+  }
+  for (int p = 1; p < parts; ++p) {
+    HIP_TRY(hipEventRecord(b->join_ev[p - 1], b->side[p - 1]));
+    HIP_TRY(hipStreamWaitEvent(b->stream, b->join_ev[p - 1], 0));
+  }
+  return ASP_OK;
+}
+
 static int run_frames(AspNsBatch* b, int kmode, const float* in, float* out, int num_frames,
                       int mem) {
   const size_t per = (size_t)b->S * kBlockL;
@@ -531,6 +578,10 @@ static int run_frames(AspNsBatch* b, int kmode, const float* in, float* out, int
   } else if (mem != ASP_MEM_DEVICE) {
     return fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
   }
+  if (kmode == 2 && b->paired && num_frames > 0) {
+    int rc = fused_steps(b, din, dout, num_frames, num_frames);
+    if (rc) return rc;
+  } else
   for (int f = 0; f < num_frames; ++f) {
     const float* fi = din + per * f;
     float* fo = dout ? dout + per * f : nullptr;
@@ -583,13 +634,9 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
   if (!in || !out || frames_in_ring <= 0 || steps < 0 || !elapsed_ms)
     return fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
   if (!b->paired) return fail(ASP_ERR_STATE, "TimedSteps needs the fused (paired) representation");
-  const size_t per = (size_t)b->S * kBlockL;
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
-  for (int k = 0; k < steps; ++k) {
-    const size_t off = per * (size_t)(k % frames_in_ring);
-    HIP_TRY(launch_ns_frame(2, b->state, b->hist, b->tables, in + off, out + off, b->S,
-                            b->stream));
-  }
+  rc = fused_steps(b, in, out, frames_in_ring, steps);
+  if (rc) return rc;
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
   HIP_TRY(hipEventSynchronize(b->ev1));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
@@ -642,6 +689,18 @@ int AspNsBatch_prior_speech_probability(AspNsBatch* b, float* out) {
   HIP_TRY(hipMemcpy2D(out, sizeof(float), b->state + kOffScalars + S_PRIORSPEECHPROB,
                       (size_t)kStreamDwords * 4, sizeof(float), (size_t)b->S,
                       hipMemcpyDeviceToHost));
+  return ASP_OK;
+}
+
+int AspNsBatch_SetSplit(AspNsBatch* b, int parts) {
+  if (!b || parts < 1 || parts > 4) return fail(ASP_ERR_PARAM, "SetSplit: parts must be 1..4");
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->fork_ev) HIP_TRY(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
+  for (int i = 0; i < parts - 1; ++i) {
+    if (!b->side[i]) HIP_TRY(hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking));
+    if (!b->join_ev[i]) HIP_TRY(hipEventCreateWithFlags(&b->join_ev[i], hipEventDisableTiming));
+  }
+  b->split = parts;
   return ASP_OK;
 }
 

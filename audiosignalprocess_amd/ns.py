@@ -46,6 +46,7 @@ def load_library():
         "AspNsBatch_ImportState": [vp, ip, C.POINTER(AspNsState)],
         "AspNsBatch_prior_speech_probability": [vp, vp],
         "AspNsBatch_SetStream": [vp, vp],
+        "AspNsBatch_SetSplit": [vp, ip],
         "AspNsBatch_Synchronize": [vp],
         "AspNsBatch_TimedSteps": [vp, vp, vp, ip, ip, fp],
         "AspNs_DeviceAlloc": [C.POINTER(vp), C.c_size_t, ip],
@@ -173,6 +174,9 @@ class NsBatch:
 
     def set_stream(self, hip_stream):
         _check(self.lib.AspNsBatch_SetStream(self.h, C.c_void_p(hip_stream)), "AspNsBatch_SetStream")
+
+    def set_split(self, parts):
+        _check(self.lib.AspNsBatch_SetSplit(self.h, parts), "AspNsBatch_SetSplit")
 
     def synchronize(self):
         _check(self.lib.AspNsBatch_Synchronize(self.h), "AspNsBatch_Synchronize")

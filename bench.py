@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--streams-per-gpu", type=int, default=4096)
     ap.add_argument("--ring", type=int, default=100, help="distinct input frames resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
     ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256"],
                     help="ns = the headline metric (default); bt* = secondary BlockThresholding line")
     args = ap.parse_args()
@@ -177,6 +178,8 @@ def main():
     del x
     ns = NsBatch(S, device=local_rank, policy=1)
     ns.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.split > 1:
+        ns.set_split(args.split)
 
     def barrier():
         torch.cuda.synchronize()
@@ -202,7 +205,9 @@ def main():
 
     if rank == 0:
         frames = S * world * args.steps
-        launch_s = ev_max / max(args.steps, 1)  # average duration of one fused launch
+        # average duration of one fused frame step (= of each of its `split` concurrent
+        # sub-launches, which run side by side on their own HIP streams)
+        launch_s = ev_max / max(args.steps, 1)
         achieved = ALGO_BYTES_PER_FRAME * S / launch_s / 1e9
         line = {
             "metric": "audio frames/sec (10 ms @16 kHz) Wiener NS",
@@ -224,6 +229,7 @@ def main():
                 "streams_per_gpu": S,
                 "total_streams": S * world,
                 "input_ring_frames": ring,
+                "sub_launches_per_step": args.split,
                 "parallelism": "stream-sharded x%d, no collectives" % world,
             },
             "roofline": {

@@ -141,6 +141,10 @@ int AspNsBatch_prior_speech_probability(AspNsBatch* b, float* out);
 /* Launch stream control: by default the batch owns a private HIP stream.
  * SetStream adopts a caller-owned hipStream_t (passed as void*). */
 int AspNsBatch_SetStream(AspNsBatch* b, void* hip_stream);
+/* Issue the fused step of a large batch as `parts` (1..4) independent
+ * sub-launches on separate HIP streams (streams never interact, so results are
+ * unchanged); lets one part's memory phases overlap another part's arithmetic. */
+int AspNsBatch_SetSplit(AspNsBatch* b, int parts);
 void* AspNsBatch_GetStream(AspNsBatch* b);
 int AspNsBatch_Synchronize(AspNsBatch* b);
 

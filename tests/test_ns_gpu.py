@@ -395,3 +395,18 @@ def test_device_exp_tanh_sqrt_exhaustive(ns):
                                  (10, 9, 0, 0x7f800001, "sqrt")]:
         bad, ex = _sweep_all_floats(lib, fa, fb, lo, hi)
         assert bad == 0, (name, bad, [hex(b) for b in ex[:8]])
+
+
+def test_split_launch_is_identical(ns):
+    """The fused step issued as 2..4 sub-launches on separate HIP streams gives the same bits."""
+    S, F = 256, 30
+    x = ns_frames(S, F, stream0=900)
+    ref = ns.NsBatch(S, policy=1)
+    y_ref = ref.analyze_process(x)
+    for parts in (2, 3, 4):
+        g = ns.NsBatch(S, policy=1)
+        g.set_split(parts)
+        assert np.array_equal(g.analyze_process(x), y_ref), parts
+        assert state_diff(g.export_state(S - 1), ref.export_state(S - 1)) == {}
+        g.close()
+    ref.close()
