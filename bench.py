@@ -240,7 +240,11 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "kernel": "ns_frame_kernel<true,true>",
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * S,
+                # one frame step = `concurrent_launches` launches of this kernel side by side
+                # (one per HIP stream, S / concurrent_launches streams each); each lasts about
+                # one step, so achieved = concurrent_launches * bytes_per_launch / avg_launch
+                "concurrent_launches": args.split,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * S // max(args.split, 1),
                 "avg_launch_us": launch_s * 1e6,
             },
         }
