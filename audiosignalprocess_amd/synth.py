@@ -62,3 +62,32 @@ def bt_samples(num_streams, num_samples, stream0=0, t0=0):
     w = 0.02 * (1.0 + 0.1 * (s % 16).astype(np.float64))
     x = 0.2 * np.sin(w[:, None] * t[None, :]) * gate[None, :] + 0.08 * n
     return np.ascontiguousarray(x.astype(np.float32))
+
+
+def aec_frames(num_streams, num_frames, stream0=0):
+    """AEC input (far, near), float-S16 units, each [num_frames][num_streams][160] float32.
+
+    far = A(f) n_far, A = 4000 when floor(f/150) is odd else 40;
+    near = 0.5 far[t-40-(s mod 16)] + 0.25 far[t-90] + 100 n_near
+           (+ 1500 sin(0.05 t) when floor(f/200) mod 3 == 2)        (SURVEY.md section 8(d)).
+    """
+    s = np.arange(stream0, stream0 + num_streams, dtype=np.int64)
+    T = 160 * num_frames
+    n_far = _lcg_uniform((12345 + 7919 * s) & 0xFFFFFFFF, 0, T)
+    n_near = _lcg_uniform((987654321 + 104729 * s) & 0xFFFFFFFF, 0, T)
+    t = np.arange(T, dtype=np.float64)
+    f = np.floor(t / 160.0).astype(np.int64)
+    amp = np.where((f // 150) % 2 == 1, 4000.0, 40.0)
+    far = n_far * amp[None, :]
+    near = 100.0 * n_near
+    for k in range(num_streams):
+        d1 = 40 + int(s[k] % 16)
+        near[k, d1:] += 0.5 * far[k, :-d1]
+        near[k, 90:] += 0.25 * far[k, :-90]
+    talk = ((f // 200) % 3 == 2)
+    near += (1500.0 * np.sin(0.05 * t) * talk)[None, :]
+
+    def shape(a):
+        return np.ascontiguousarray(a.astype(np.float32).reshape(num_streams, num_frames, 160).transpose(1, 0, 2))
+
+    return shape(far), shape(near)

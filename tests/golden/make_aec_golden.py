@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/aec_golden.npz from the REFERENCE AEC build (oracle/_ref/libaec_ref.so:
+the reference's aec_core.c, aec_rdft.c, echo_cancellation.c, ring_buffer.c ... compiled in place,
+plain-C path forced).  Build-container only.  The reference ships no vectors for this path
+(SURVEY.md section 4); these are outputs of the reference itself:
+
+  far_i16, near_i16 [F][S][160] int16   synthetic far / near-end PCM (SURVEY 8(d) generator)
+  out_f32           [F][S][160] float32 WebRtcAec_BufferFarend + WebRtcAec_Process output
+                                        (msInSndCardBuf = 0, skew = 0, test_aec_module.cpp:67-88)
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from audiosignalprocess_amd.synth import aec_frames  # noqa: E402
+from tests.oracle_lib import RefAec, have_aec_ref  # noqa: E402
+
+S, F = 2, 700
+
+
+def main():
+    assert have_aec_ref(), "build oracle/_ref first (make -C oracle)"
+    far, near = aec_frames(S, F)
+    far = np.clip(np.rint(far), -32768, 32767).astype(np.int16)
+    near = np.clip(np.rint(near), -32768, 32767).astype(np.int16)
+    out = np.empty((F, S, 160), np.float32)
+    for s in range(S):
+        r = RefAec()
+        out[:, s] = r.run(far[:, s].astype(np.float32), near[:, s].astype(np.float32))
+    path = os.path.join(ROOT, "tests", "golden", "aec_golden.npz")
+    np.savez_compressed(path, far_i16=far, near_i16=near, out_f32=out)
+    # echo return loss enhancement over the double-talk-free loud far-end stretch, for the record
+    seg = slice(160, 290)
+    e_in = (near[seg].astype(np.float64) ** 2).mean()
+    e_out = (out[seg].astype(np.float64) ** 2).mean()
+    print("wrote", path, os.path.getsize(path), "bytes; ERLE %.1f dB" % (10 * np.log10(e_in / e_out)))
+
+
+if __name__ == "__main__":
+    main()

@@ -271,3 +271,42 @@ class OracleBt:
 
     def hann(self):
         return np.ctypeslib.as_array(self.lib.bt_oracle_hann(self.h), shape=(self.win,)).copy()
+
+
+# ------------------------------------------------------------------------- AEC
+AEC_REF_SO = os.path.join(ORACLE_DIR, "_ref", "libaec_ref.so")
+_aec_ref = None
+
+
+def have_aec_ref():
+    return os.path.exists(AEC_REF_SO)
+
+
+class RefAec:
+    """One stream through the compiled reference echo canceller (plain-C path)."""
+
+    def __init__(self, fs=16000):
+        global _aec_ref
+        if _aec_ref is None:
+            lib = C.CDLL(AEC_REF_SO)
+            lib.ref_aec_create.restype = C.c_void_p
+            lib.ref_aec_create.argtypes = [C.c_int32]
+            lib.ref_aec_free.argtypes = [C.c_void_p]
+            lib.ref_aec_run.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int16]
+            _aec_ref = lib
+        self.lib = _aec_ref
+        self.h = self.lib.ref_aec_create(fs)
+        assert self.h
+
+    def run(self, far, near, delay_ms=0):
+        far = np.ascontiguousarray(far, np.float32)
+        near = np.ascontiguousarray(near, np.float32)
+        assert far.shape == near.shape and far.shape[1] == BLOCKL
+        out = np.empty_like(near)
+        self.lib.ref_aec_run(self.h, far, near, out, far.shape[0], delay_ms)
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_aec_free(self.h)
+            self.h = None
