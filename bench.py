@@ -27,6 +27,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_FRAME = 15716  # frame-synchronous NS model
+# HBM bytes per stream-frame of ns_frame_kernel<true,true> from the PMC counters FETCH_SIZE /
+# WRITE_SIZE (separate rocprofv3 --pmc passes, tools/traffic_ns.sh), calibrated on the kernel's own
+# known byte count at 32768 streams as MI355X_MICROARCH.md prescribes for access widths it does not
+# cover; see profiles/README.md ("HBM traffic of the NS kernel").  Measured once per round, not live.
+PMC_TRAFFIC_BYTES_PER_FRAME = (4.832 * 1.638 + 9.158 / 1.09) * 1024
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -238,7 +243,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": PMC_TRAFFIC_BYTES_PER_FRAME * S / max(args.split, 1),
+                "traffic_source": "profiles/README.md (PMC passes of round 1, per launch)",
                 "kernel": "ns_frame_kernel<true,true>",
                 # one frame step = `concurrent_launches` launches of this kernel side by side
                 # (one per HIP stream, S / concurrent_launches streams each); each lasts about
