@@ -21,7 +21,8 @@ namespace aspbt {
 size_t macroblock_lds_bytes(int n);
 hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const float* in,
                                 float* out, int num_streams, int frames, int threshold,
-                                int in_stride, int out_stride, hipStream_t s);
+                                int in_stride, int out_stride, hipStream_t s,
+                                unsigned long long* stamps = nullptr);
 hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int inverse,
                           const BtTables* T, hipStream_t s);
 }  // namespace aspbt
@@ -255,6 +256,24 @@ int AspBtBatch_TimedSteps(AspBtBatch* b, const float* in, float* out, int blocks
   BT_TRY(hipEventRecord(b->ev1, b->stream));
   BT_TRY(hipEventSynchronize(b->ev1));
   BT_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+  return ASP_OK;
+}
+
+// Diagnostic: one macroblock launch with phase time stamps of workgroup 0 (s_memtime ticks).
+int AspBtBatch_DebugStamps(AspBtBatch* b, const float* in_dev, float* out_dev,
+                           unsigned long long* stamps11) {
+  if (!b || !in_dev || !out_dev || !stamps11) return bt_fail(ASP_ERR_PARAM, "DebugStamps: bad argument");
+  BT_TRY(hipSetDevice(b->device));
+  unsigned long long* d = nullptr;
+  BT_TRY(hipMalloc((void**)&d, 11 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d, 0, 11 * sizeof(unsigned long long));
+  if (e == hipSuccess)
+    e = launch_bt_macroblock(b->win, b->state, b->tables, in_dev, out_dev, b->S, 8, 1, b->macro,
+                             b->macro, b->stream, d);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e == hipSuccess) e = hipMemcpy(stamps11, d, 11 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return bt_fail(ASP_ERR_HIP, "DebugStamps", e);
   return ASP_OK;
 }
 

@@ -186,14 +186,80 @@ __device__ __forceinline__ void real_merge_inverse(const cpx* freq, cpx* work,
   }
 }
 
+// Sequential (rows outer, columns inner) sum of one TT x FF block of a [8][16] tile stored
+// with element stride ES and row stride 16 * ES; fully unrolled so the LDS reads pipeline
+// while the adds keep the reference's order (energy_real_STFT / power_STFT, .c:303-338).
+template <int TT, int FF, int ES>
+__device__ __forceinline__ float block_sum(const float* tile, int r0, int c0) {
+  float acc = 0.0f;
+#pragma unroll
+  for (int r = 0; r < TT; ++r)
+#pragma unroll
+    for (int c = 0; c < FF; ++c) acc += tile[((r0 + r) * 16 + (c0 + c)) * ES];
+  return acc;
+}
+
+// SURE of segmentation (T, F) for one macro-column (.c:378-400).
+template <int T, int F, int ES>
+__device__ __forceinline__ float sure_of(const float* tile, const BtSeg sg) {
+  constexpr int TT = 8 >> T, FF = 16 >> F;
+  float SURE_real = 0.0f;
+  for (int ii = 0; ii < (1 << T); ii++)
+    for (int jj = 0; jj < (1 << F); jj++) {
+      const float energy_real = block_sum<TT, FF, ES>(tile, TT * ii, FF * jj);
+      SURE_real += sg.size_blk + sg.temp / energy_real * (float)(energy_real > sg.thr) +
+                   (energy_real - sg.two_size) * (float)(energy_real <= sg.thr);
+    }
+  return SURE_real;
+}
+
+template <int ES>
+__device__ __forceinline__ float sure_dispatch(int c, const float* tile, const BtSeg sg) {
+  switch (c) {
+    case 0: return sure_of<0, 0, ES>(tile, sg);
+    case 1: return sure_of<0, 1, ES>(tile, sg);
+    case 2: return sure_of<0, 2, ES>(tile, sg);
+    case 3: return sure_of<0, 3, ES>(tile, sg);
+    case 4: return sure_of<0, 4, ES>(tile, sg);
+    case 5: return sure_of<1, 0, ES>(tile, sg);
+    case 6: return sure_of<1, 1, ES>(tile, sg);
+    case 7: return sure_of<1, 2, ES>(tile, sg);
+    case 8: return sure_of<1, 3, ES>(tile, sg);
+    case 9: return sure_of<1, 4, ES>(tile, sg);
+    case 10: return sure_of<2, 0, ES>(tile, sg);
+    case 11: return sure_of<2, 1, ES>(tile, sg);
+    case 12: return sure_of<2, 2, ES>(tile, sg);
+    case 13: return sure_of<2, 3, ES>(tile, sg);
+    default: return sure_of<2, 4, ES>(tile, sg);
+  }
+}
+
+template <int ES>
+__device__ __forceinline__ float block_sum_dispatch(int c, const float* tile, int ii, int jj) {
+#define BT_CASE(k, T, F) \
+  case k: return block_sum<(8 >> T), (16 >> F), ES>(tile, (8 >> T) * ii, (16 >> F) * jj);
+  switch (c) {
+    BT_CASE(0, 0, 0) BT_CASE(1, 0, 1) BT_CASE(2, 0, 2) BT_CASE(3, 0, 3) BT_CASE(4, 0, 4)
+    BT_CASE(5, 1, 0) BT_CASE(6, 1, 1) BT_CASE(7, 1, 2) BT_CASE(8, 1, 3) BT_CASE(9, 1, 4)
+    BT_CASE(10, 2, 0) BT_CASE(11, 2, 1) BT_CASE(12, 2, 2) BT_CASE(13, 2, 3)
+    default: return block_sum<2, 1, ES>(tile, 2 * ii, jj);
+  }
+#undef BT_CASE
+}
+
 // --------------------------------------------------------------------------
 // One macroblock (frames = 8, threshold = 1) or one flush (frames < 8, threshold = 0)
 // of every stream.
 template <int N>
 __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
     float* __restrict__ state, const BtTables* __restrict__ Tb, const float* __restrict__ in,
-    float* __restrict__ out, int frames, int threshold, int in_stride, int out_stride) {
+    float* __restrict__ out, int frames, int threshold, int in_stride, int out_stride,
+    unsigned long long* __restrict__ stamps) {
   constexpr int NC = N / 2, HALF = N / 2, NB = N / 2 + 1;
+  // diagnostic phase stamps (never enabled by the product entry points): workgroup 0, thread 0
+#define BT_STAMP(k)                                                                   \
+  if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
+  BT_STAMP(0)
   constexpr int NCOL = (N - 1) / 2 / 16;  // macro-columns of 16 bins (.c:493)
   extern __shared__ __align__(16) unsigned char smem[];
   cpx* coef = reinterpret_cast<cpx*>(smem);  // [8][NB]
@@ -227,14 +293,17 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
     work[fr * NC + kiss_position<NC>(n)] = z;
   }
   __syncthreads();
+  BT_STAMP(1)
   // carry the last HALF input samples (after every thread has read the old tail)
   for (int i = tid; i < HALF; i += NC) {
     const int p = total + i;  // position in B of the new tail
     st[kOffInTail + i] = p < HALF ? st[kOffInTail + p] : x[p - HALF];
   }
   kiss_stages<NC>(work, tw_f, frames, false, tid);
+  BT_STAMP(2)
   real_split_forward<NC>(work, coef, sup_f, frames, tid);
   __syncthreads();
+  BT_STAMP(3)
 
   if (threshold) {
     // ---- squared normalised real parts, laid out [row * 16 + bin][column] so that the
@@ -252,29 +321,20 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
       sq[w] = v2;
     }
     __syncthreads();
+    BT_STAMP(4)
     // ---- SURE of the 15 dyadic segmentations of every macro-column (.c:354-401).  A wave
-    // takes whole segmentations (wave-uniform loop bounds), lane = macro-column; every sum
-    // runs in the reference's order: blocks ii-major / jj-minor, rows outer, columns inner.
+    // takes whole segmentations (block shape is a compile-time constant inside the switch, so
+    // the block sums unroll and their LDS reads pipeline), lane = macro-column; every sum runs
+    // in the reference's order: blocks ii-major / jj-minor, rows outer, columns inner.
     {
       const int wave = tid >> 6, lane = tid & 63, nwaves = NC / 64;
       for (int c = wave; c < 15; c += nwaves) {
-        const int T = c / 5, F = c % 5;
-        const int TT = 8 >> T, FF = 16 >> F;
-        const BtSeg sg = P.seg[T][F];
-        const int m = lane % SQW;
-        float SURE_real = 0.0f;
-        for (int ii = 0; ii < (1 << T); ii++)
-          for (int jj = 0; jj < (1 << F); jj++) {
-            float energy_real = 0.0f;
-            for (int r = TT * ii; r < TT * (ii + 1); r++)
-              for (int cc = FF * jj; cc < FF * (jj + 1); cc++) energy_real += sq[(r * 16 + cc) * SQW + m];
-            SURE_real += sg.size_blk + sg.temp / energy_real * (float)(energy_real > sg.thr) +
-                         (energy_real - sg.two_size) * (float)(energy_real <= sg.thr);
-          }
-        if (lane < NCOL) sure[lane * 15 + c] = SURE_real;
+        const float v = sure_dispatch<SQW>(c, sq + (lane % SQW), P.seg[c / 5][c % 5]);
+        if (lane < NCOL) sure[lane * 15 + c] = v;
       }
     }
     __syncthreads();
+    BT_STAMP(5)
     // ---- DC column and the bins past the last whole macro-column (.c:501-506, 518-532)
     for (int w = tid; w < 1 + (NB - (1 + NCOL * 16)); w += NC) {
       const int col = w == 0 ? 0 : (1 + NCOL * 16) + (w - 1);
@@ -290,37 +350,56 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
         thre[t * NB + col].i = coef[t * NB + col].i * a;
       }
     }
-    // ---- argmin (first wins, .c:404-416) + Stein attenuation of the chosen blocks (.c:421-454)
-    for (int w = tid; w < NCOL * 64; w += NC) {
-      const int m = w / 64, sb = w % 64;
-      float best = sure[m * 15];
-      int bc = 0;
-      for (int c = 1; c < 15; ++c)
-        if (sure[m * 15 + c] < best) {
-          best = sure[m * 15 + c];
-          bc = c;
-        }
-      const int T = bc / 5, F = bc % 5;
-      if (sb < (1 << (T + F))) {
-        const int TT = 8 >> T, FF = 16 >> F;
-        const int ii = sb >> F, jj = sb & ((1 << F) - 1);
+    // ---- argmin (first wins, .c:404-416) + Stein attenuation of the chosen blocks
+    // (.c:421-454).  One wave per macro-column: the 128 squared magnitudes go to a per-wave
+    // LDS tile in parallel, the <= 64 block powers are summed from it one block per lane (in
+    // the reference's order), then all lanes scale their two coefficients.
+    {
+      const int wave = tid >> 6, lane = tid & 63, nwaves = NC / 64;
+      float* pw = sure + NCOL * 15 + 16 + wave * (128 + 64);  // [128] powers + [64] gains
+      float* av = pw + 128;
+      for (int m = wave; m < NCOL; m += nwaves) {
         const int base = 1 + m * 16;
-        float power = 0.0f;
-        for (int r = TT * ii; r < TT * (ii + 1); r++)
-          for (int cc = FF * jj; cc < FF * (jj + 1); cc++) {
-            const float re = coef[r * NB + base + cc].r, im = coef[r * NB + base + cc].i;
-            power += re * re + im * im;
+        float best = sure[m * 15];
+        int bc = 0;
+        for (int c = 1; c < 15; ++c)
+          if (sure[m * 15 + c] < best) {
+            best = sure[m * 15 + c];
+            bc = c;
           }
-        float a = (float)(1.0 - (double)(P.seg[T][F].a_const / power));
-        a = a * (float)(a > 0);
-        for (int r = TT * ii; r < TT * (ii + 1); r++)
-          for (int cc = FF * jj; cc < FF * (jj + 1); cc++) {
-            thre[r * NB + base + cc].r = coef[r * NB + base + cc].r * a;
-            thre[r * NB + base + cc].i = coef[r * NB + base + cc].i * a;
-          }
+        const int T = bc / 5, F = bc % 5;
+        cpx ce[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = lane + 64 * h;  // e = r * 16 + cc
+          ce[h] = coef[(e >> 4) * NB + base + (e & 15)];
+          pw[e] = ce[h].r * ce[h].r + ce[h].i * ce[h].i;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < (1 << (T + F))) {
+          const float power = block_sum_dispatch<1>(bc, pw, lane >> F, lane & ((1 << F) - 1));
+          float a = (float)(1.0 - (double)(P.seg[T][F].a_const / power));
+          av[lane] = a * (float)(a > 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = lane + 64 * h, r = e >> 4, cc = e & 15;
+          const float a = av[((r >> (3 - T)) << F) + (cc >> (4 - F))];
+          thre[r * NB + base + cc].r = ce[h].r * a;
+          thre[r * NB + base + cc].i = ce[h].i * a;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
     __syncthreads();
+    BT_STAMP(6)
     // ---- empirical Wiener on bins 0 .. N/2-1, Nyquist untouched (.c:469-486)
     for (int w = tid; w < 8 * NC; w += NC) {
       const int t = w / NC, f = w % NC;
@@ -333,10 +412,13 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
     __syncthreads();
   }
 
+  BT_STAMP(7)
   // ---- inverse STFT + overlap-add (blockThreshold_inverse_STFT, .c:284-300)
   real_merge_inverse<NC>(coef, work, sup_i, frames, tid);
   __syncthreads();
+  BT_STAMP(8)
   kiss_stages<NC>(work, tw_i, frames, true, tid);
+  BT_STAMP(9)
   const float* td = reinterpret_cast<const float*>(work);  // frame fr sample j at fr*N + j
   const float inv_n = 1.0f / (float)N;  // N is a power of two: x * (1/N) == x / N exactly
   for (int q = tid; q < total + HALF; q += NC) {
@@ -352,6 +434,8 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
   __syncthreads();
   for (int i = tid; i < HALF; i += NC)
     st[kOffOutTail + i] = threshold ? sure[i] : 0.0f;  // a flush leaves the tail cleared (.c:656-672)
+  BT_STAMP(10)
+#undef BT_STAMP
 }
 
 // kiss_fftr / kiss_fftri seam: one workgroup per row.
@@ -404,13 +488,15 @@ namespace aspbt {
 
 size_t macroblock_lds_bytes(int n) {
   const int nb = n / 2 + 1, ncol = (n - 1) / 2 / 16;
-  size_t sure = (size_t)(ncol * 15 > n / 2 ? ncol * 15 : n / 2) * sizeof(float);
+  const size_t need = (size_t)ncol * 15 + 16 + (size_t)(n / 2 / 64) * 192;
+  size_t sure = (need > (size_t)n / 2 ? need : (size_t)n / 2) * sizeof(float);
   return (size_t)2 * 8 * nb * 8 + sure;
 }
 
 hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const float* in,
                                 float* out, int num_streams, int frames, int threshold,
-                                int in_stride, int out_stride, hipStream_t s) {
+                                int in_stride, int out_stride, hipStream_t s,
+                                unsigned long long* stamps) {
   const size_t lds = macroblock_lds_bytes(n);
   if (n == 1024) {
     static bool attr_set = false;
@@ -421,10 +507,10 @@ hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const fl
       attr_set = true;
     }
     hipLaunchKernelGGL(bt_macroblock_kernel<1024>, dim3(num_streams), dim3(512), lds, s, state, T,
-                       in, out, frames, threshold, in_stride, out_stride);
+                       in, out, frames, threshold, in_stride, out_stride, stamps);
   } else {
     hipLaunchKernelGGL(bt_macroblock_kernel<256>, dim3(num_streams), dim3(128), lds, s, state, T,
-                       in, out, frames, threshold, in_stride, out_stride);
+                       in, out, frames, threshold, in_stride, out_stride, stamps);
   }
   return hipGetLastError();
 }
