@@ -528,13 +528,17 @@ int AspNsBatch_set_policy(AspNsBatch* b, int mode) {
 }
 
 // `steps` fused frame steps on device buffers; step k reads/writes ring slot k % ring.
-static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, int steps) {
-  const size_t per = (size_t)b->S * kBlockL;
+static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, int steps,
+                       bool io16 = false) {
+  // offsets below are in float units; int16 frames are half as wide
+  const size_t per = (size_t)b->S * kBlockL / (io16 ? 2 : 1);
+  const int kmode = io16 ? 3 : 2;
+  const size_t sper = io16 ? kBlockL / 2 : kBlockL;  // one stream's frame, in float units
   const int parts = (b->split > 1 && b->S >= 8 * b->split) ? b->split : 1;
   if (parts == 1) {
     for (int k = 0; k < steps; ++k) {
       const size_t off = per * (size_t)(k % ring);
-      HIP_TRY(launch_ns_frame(2, b->state, b->hist, b->tables, din + off, dout + off, b->S,
+      HIP_TRY(launch_ns_frame(kmode, b->state, b->hist, b->tables, din + off, dout + off, b->S,
                               b->stream));
     }
     return ASP_OK;
@@ -550,10 +554,9 @@ static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, i
     for (int p = 0; p < parts; ++p) {
       hipStream_t st = p == 0 ? b->stream : b->side[p - 1];
       const int s0 = base[p], n = base[p + 1] - base[p];
-      HIP_TRY(launch_ns_frame(2, b->state + (size_t)s0 * kStreamDwords,
+      HIP_TRY(launch_ns_frame(kmode, b->state + (size_t)s0 * kStreamDwords,
                               b->hist + (size_t)s0 * kHistDwords, b->tables,
-                              din + off + (size_t)s0 * kBlockL, dout + off + (size_t)s0 * kBlockL,
-                              n, st));
+                              din + off + (size_t)s0 * sper, dout + off + (size_t)s0 * sper, n, st));
     }
   }
   for (int p = 1; p < parts; ++p) {
@@ -625,6 +628,35 @@ int AspNsBatch_AnalyzeProcess(AspNsBatch* b, const float* in, float* out, int nu
   if (rc) return rc;
   if (!in || !out || num_frames < 0) return fail(ASP_ERR_PARAM, "AnalyzeProcess: bad argument");
   return run_frames(b, 2, in, out, num_frames, mem);
+}
+
+int AspNsBatch_AnalyzeProcessS16(AspNsBatch* b, const int16_t* in, int16_t* out, int num_frames,
+                                 int mem) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!in || !out || num_frames < 0) return fail(ASP_ERR_PARAM, "AnalyzeProcessS16: bad argument");
+  if (!b->paired)
+    return fail(ASP_ERR_STATE, "AnalyzeProcessS16 needs streams driven only through the fused step");
+  if (num_frames == 0) return ASP_OK;
+  const size_t bytes = (size_t)b->S * kBlockL * sizeof(int16_t) * (size_t)num_frames;
+  const float* din = reinterpret_cast<const float*>(in);
+  float* dout = reinterpret_cast<float*>(out);
+  if (mem == ASP_MEM_HOST) {
+    rc = ensure_stage(b, (size_t)(num_frames + 1) / 2);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->stage_in, in, bytes, hipMemcpyHostToDevice, b->stream));
+    din = b->stage_in;
+    dout = b->stage_out;
+  } else if (mem != ASP_MEM_DEVICE) {
+    return fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  }
+  rc = fused_steps(b, din, dout, num_frames, num_frames, true);
+  if (rc) return rc;
+  if (mem == ASP_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(out, b->stage_out, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return ASP_OK;
 }
 
 int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames_in_ring,

@@ -510,7 +510,27 @@ __device__ __noinline__ PriorModel close_histogram_window(int32_t* __restrict__ 
 //                  test_ns_module.cpp:97-99.  One forward FFT serves both.
 //   DO_A only    : WebRtcNs_AnalyzeCore.
 //   DO_P only    : WebRtcNs_ProcessCore (one band).
-template <bool DO_A, bool DO_P>
+// IO16: frames are int16 PCM in HBM (the WAV drivers' format): the int16 -> float-S16 load is
+// value preserving (channel_buffer.cc:43-53) and the store applies FloatS16ToS16
+// (audio_util.h:41-49) after the WEBRTC_SPL_SAT of ns_core.c:1357-1359.
+__device__ __forceinline__ short float_s16_to_s16(float v) {
+  const float kMaxRound = 32767 - 0.5f, kMinRound = -32768 + 0.5f;
+  if (v > 0) return v >= kMaxRound ? (short)32767 : (short)(v + 0.5f);
+  return v <= kMinRound ? (short)-32768 : (short)(v - 0.5f);
+}
+template <bool IO16>
+__device__ __forceinline__ void store_pair(float* y, int idx, float a, float b) {
+  if (IO16) {
+    short2 v;
+    v.x = float_s16_to_s16(a);
+    v.y = float_s16_to_s16(b);
+    *reinterpret_cast<short2*>(reinterpret_cast<short*>(y) + idx) = v;
+  } else {
+    *reinterpret_cast<float2*>(y + idx) = make_float2(a, b);
+  }
+}
+
+template <bool DO_A, bool DO_P, bool IO16 = false>
 __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ state,
                                                        int32_t* __restrict__ hist_all,
                                                        const NsTables* __restrict__ T,
@@ -535,9 +555,20 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
 
   // ---- sliding analysis buffer: [96 carried samples | 160 new], lane l owns 4l..4l+3
   float* hbuf = st + ((DO_A) ? kOffAnaHist : kOffDataHist);
-  const float* src =
-      lane < 24 ? hbuf + 4 * lane : in + (size_t)stream * kBlockL + 4 * (lane - 24);
-  const float4 s4 = *reinterpret_cast<const float4*>(src);
+  float4 s4;
+  if (IO16) {
+    const short* in16 = reinterpret_cast<const short*>(in) + (size_t)stream * kBlockL;
+    if (lane < 24) {
+      s4 = *reinterpret_cast<const float4*>(hbuf + 4 * lane);
+    } else {
+      const short4 q = *reinterpret_cast<const short4*>(in16 + 4 * (lane - 24));
+      s4 = make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w);
+    }
+  } else {
+    const float* src =
+        lane < 24 ? hbuf + 4 * lane : in + (size_t)stream * kBlockL + 4 * (lane - 24);
+    s4 = *reinterpret_cast<const float4*>(src);
+  }
   const float4 w4 = *reinterpret_cast<const float4*>(T->window + 4 * lane);
 
   // ---- state rows (issued early; consumed after the FFT)
@@ -585,13 +616,14 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     // Process: emit the synthesis tail (ns_core.c:1239-1264).
     if (DO_P) {
       float* sy = st + kOffSynt;
-      float* y = out + (size_t)stream * kBlockL;
+      float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * kBlockL)
+                      : out + (size_t)stream * kBlockL;
       float2 o01 = carry;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       o01.x = o01.x > 32767 ? 32767 : (o01.x < -32768 ? -32768 : o01.x);
       o01.y = o01.y > 32767 ? 32767 : (o01.y < -32768 ? -32768 : o01.y);
-      *reinterpret_cast<float2*>(y + 2 * lane) = o01;
-      if (lane < 16) *reinterpret_cast<float2*>(y + 128 + 2 * lane) = make_float2(0.f, 0.f);
+      store_pair<IO16>(y, 2 * lane, o01.x, o01.y);
+      if (lane < 16) store_pair<IO16>(y, 128 + 2 * lane, 0.f, 0.f);
       if (lane < 48) *reinterpret_cast<float2*>(sy + 2 * lane) = make_float2(0.f, 0.f);
     }
     return;
@@ -1050,7 +1082,8 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     const float2 wlo = *reinterpret_cast<const float2*>(T->window + 2 * lane);
     const float2 whi = *reinterpret_cast<const float2*>(T->window + 128 + 2 * lane);
     float* sy = st + kOffSynt;
-    float* y = out + (size_t)stream * kBlockL;
+    float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * kBlockL)
+                    : out + (size_t)stream * kBlockL;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // carry was read long ago; keep it so
     float o0 = carry.x + factor * (wlo.x * td0);
     float o1 = carry.y + factor * (wlo.y * td1);
@@ -1061,11 +1094,11 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     }
     o0 = o0 > 32767 ? 32767 : (o0 < -32768 ? -32768 : o0);
     o1 = o1 > 32767 ? 32767 : (o1 < -32768 ? -32768 : o1);
-    *reinterpret_cast<float2*>(y + 2 * lane) = make_float2(o0, o1);
+    store_pair<IO16>(y, 2 * lane, o0, o1);
     if (lane < 16) {
       o2 = o2 > 32767 ? 32767 : (o2 < -32768 ? -32768 : o2);
       o3 = o3 > 32767 ? 32767 : (o3 < -32768 ? -32768 : o3);
-      *reinterpret_cast<float2*>(y + 128 + 2 * lane) = make_float2(o2, o3);
+      store_pair<IO16>(y, 128 + 2 * lane, o2, o3);
     }
   }
 
@@ -1190,6 +1223,10 @@ hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables
     case 1:
       hipLaunchKernelGGL((ns_frame_kernel<false, true>), grid, block, 0, s, state, hist, T, in,
                          out, num_streams);
+      break;
+    case 3:
+      hipLaunchKernelGGL((ns_frame_kernel<true, true, true>), grid, block, 0, s, state, hist, T,
+                         in, out, num_streams);
       break;
     default:
       hipLaunchKernelGGL((ns_frame_kernel<true, true>), grid, block, 0, s, state, hist, T, in,

@@ -42,6 +42,7 @@ def load_library():
         "AspNsBatch_Analyze": [vp, vp, ip],
         "AspNsBatch_Process": [vp, vp, vp, ip],
         "AspNsBatch_AnalyzeProcess": [vp, vp, vp, ip, ip],
+        "AspNsBatch_AnalyzeProcessS16": [vp, vp, vp, ip, ip],
         "AspNsBatch_ExportState": [vp, ip, C.POINTER(AspNsState)],
         "AspNsBatch_ImportState": [vp, ip, C.POINTER(AspNsState)],
         "AspNsBatch_prior_speech_probability": [vp, vp],
@@ -156,6 +157,16 @@ class NsBatch:
         out = np.empty_like(frames)
         _check(self.lib.AspNsBatch_AnalyzeProcess(self.h, _ptr(frames), _ptr(out), F, MEM_HOST),
                "AspNsBatch_AnalyzeProcess")
+        return out
+
+    def analyze_process_s16(self, pcm):
+        """pcm [F][S][160] int16 -> denoised int16 of the same shape (fused step, PCM in/out)."""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        F = pcm.shape[0]
+        assert pcm.shape == (F, self.S, BLOCKL)
+        out = np.empty_like(pcm)
+        _check(self.lib.AspNsBatch_AnalyzeProcessS16(self.h, _ptr(pcm), _ptr(out), F, MEM_HOST),
+               "AspNsBatch_AnalyzeProcessS16")
         return out
 
     # -- device-pointer path (asynchronous on the batch's stream)

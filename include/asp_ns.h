@@ -133,6 +133,13 @@ int AspNsBatch_Process(AspNsBatch* b, const float* in, float* out, int mem);
 int AspNsBatch_AnalyzeProcess(AspNsBatch* b, const float* in, float* out,
                               int num_frames, int mem);
 
+/* The same fused step on int16 PCM frames, [num_frames][num_streams][160] int16: what the
+ * WAV drivers move (test_ns_module.cpp:85-106).  int16 -> float-S16 on load is value
+ * preserving (channel_buffer.cc:43-53); the store applies FloatS16ToS16 rounding
+ * (audio_util.h:41-49).  Halves the frame bytes crossing HBM / PCIe. */
+int AspNsBatch_AnalyzeProcessS16(AspNsBatch* b, const int16_t* in, int16_t* out,
+                                 int num_frames, int mem);
+
 int AspNsBatch_ExportState(AspNsBatch* b, int stream, AspNsState* out);
 int AspNsBatch_ImportState(AspNsBatch* b, int stream, const AspNsState* in);
 /* priorSpeechProb of every stream (noise_suppression.c:57-66), out[num_streams]. */

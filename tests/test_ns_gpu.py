@@ -410,3 +410,57 @@ def test_split_launch_is_identical(ns):
         assert state_diff(g.export_state(S - 1), ref.export_state(S - 1)) == {}
         g.close()
     ref.close()
+
+
+def test_int16_pcm_path(ns, golden):
+    """PCM in / PCM out fused into the kernel's loads and stores == float path + FloatS16ToS16,
+    and within 1 LSB of the reference driver's WAV output."""
+    pcm = golden["in_i16"]
+    F, S, _ = pcm.shape
+    g16 = ns.NsBatch(S, policy=1)
+    y16 = g16.analyze_process_s16(pcm)
+    gf = ns.NsBatch(S, policy=1)
+    yf = gf.analyze_process(pcm.astype(np.float32))
+    pos = np.where(yf >= np.float32(32766.5), 32767, (yf + np.float32(0.5)).astype(np.int32))
+    neg = np.where(yf <= np.float32(-32767.5), -32768, (yf - np.float32(0.5)).astype(np.int32))
+    assert np.array_equal(y16, np.where(yf > 0, pos, neg).astype(np.int16))
+    ref = golden["wav_out_i16"][:F * 160].reshape(F, 160)
+    d = np.abs(y16[:, 0].astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.999
+    assert state_diff(g16.export_state(1), gf.export_state(1)) == {}
+    g16.close()
+    gf.close()
+
+
+def test_batched_wav_driver(ns, golden, tmp_path):
+    """drivers/ns_batch_wav: several WAV files as one GPU batch; every output equals what the
+    per-stream reference driver semantics give (incl. the stale extra frame), within 1 LSB."""
+    from audiosignalprocess_amd.build import build_drivers
+
+    exe = [e for e in build_drivers() if e.endswith("ns_batch_wav")][0]
+    pcm = golden["wav_in_i16"]
+
+    def wav(samples):
+        return b"RIFF" + struct.pack("<i", 36 + samples.nbytes) + b"WAVE" + \
+            struct.pack("<4sihhiihh", b"fmt ", 16, 1, 1, 16000, 32000, 2, 16) + \
+            b"data" + struct.pack("<i", samples.nbytes) + samples.tobytes()
+
+    (tmp_path / "in").mkdir()
+    (tmp_path / "out").mkdir()
+    lens = [pcm.size, 160 * 300 + 77, 160 * 41]
+    for k, n in enumerate(lens):
+        (tmp_path / "in" / ("s%d.wav" % k)).write_bytes(wav(pcm[:n]))
+    subprocess.run([exe, str(tmp_path / "out")] + [str(tmp_path / "in" / ("s%d.wav" % k)) for k in range(3)],
+                   check=True, stdout=subprocess.DEVNULL)
+    ref_full = golden["wav_out_i16"]
+    for k, n in enumerate(lens):
+        out = np.frombuffer((tmp_path / "out" / ("s%d.wav" % k)).read_bytes()[44:], dtype=np.int16)
+        frames = n // 160 + 1
+        assert out.size == frames * 160
+        # all but the last (stale / partial) frame are plain prefixes of the reference output
+        m = (frames - 1) * 160
+        d = np.abs(out[:m].astype(np.int32) - ref_full[:m].astype(np.int32))
+        # start-up frames carry most of the reduction-order LSB flips (0.15 % of samples in the
+        # first 41 frames, 0.02 % over 300), never more than 1 LSB
+        assert d.max() <= 1 and (d == 0).mean() >= 0.997, k
+    assert np.abs(out.astype(np.int32)).max() > 0
