@@ -22,6 +22,9 @@ using namespace aspns;
 namespace aspns {
 hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables* T,
                            const float* in, float* out, int num_streams, hipStream_t s);
+hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTables* T,
+                            const float* in, float* out, int num_streams, hipStream_t s,
+                            unsigned long long* stamps = nullptr);
 hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_set_policy(float* state, int num_streams, int mode, float overdrive,
                                 float denoiseBound, int gainmap, hipStream_t s);
@@ -173,6 +176,50 @@ void build_tables(NsTables* T) {
   T->sum_log_i = sli;
   T->sum_log_i_square = slis;
   for (int j = 0; j < 64; ++j) T->exp2_64[j] = exp2((double)j / 64.0);
+  // full-butterfly twiddles of the two-streams-per-wave kernel: block index B of pass 0/1/2 is
+  // lane, lane >> 2, lane >> 4 (same twiddle cases as above, fft4g.c:1008-1102 / 1114-1229)
+  for (int pass = 0; pass < 3; ++pass)
+    for (int lane = 0; lane < 32; ++lane) {
+      const int B = pass == 0 ? lane : (pass == 1 ? lane >> 2 : lane >> 4);
+      float* e = T->tw2[pass][lane];
+      e[0] = 1.f; e[1] = 0.f; e[2] = 1.f; e[3] = 0.f; e[4] = 1.f; e[5] = 0.f; e[6] = 0.f; e[7] = 0.f;
+      if (B == 1) {
+        e[0] = w[2];
+        e[2] = 0.f;
+        e[3] = 1.f;
+        e[6] = 1.f;
+      } else if (B >= 2) {
+        const int u = B >> 1;
+        const float wk2r = w[2 * u], wk2i = w[2 * u + 1];
+        if ((B & 1) == 0) {
+          const float w1r = w[4 * u], w1i = w[4 * u + 1];
+          e[0] = w1r; e[1] = w1i; e[2] = wk2r; e[3] = wk2i;
+          e[4] = w1r - 2 * wk2i * w1i;
+          e[5] = 2 * wk2i * w1r - w1i;
+        } else {
+          const float w1r = w[4 * u + 2], w1i = w[4 * u + 3];
+          e[0] = w1r; e[1] = w1i; e[2] = -wk2i; e[3] = wk2r;
+          e[4] = w1r - 2 * wk2r * w1i;
+          e[5] = 2 * wk2r * w1r - w1i;
+        }
+      }
+    }
+  for (int lane = 0; lane < 32; ++lane)
+    for (int t = 0; t < 4; ++t) {
+      const int g = lane >> 4, pq = (lane & 15) + 16 * t;  // element E = pq + 64 g
+      float wkr = 0.f, wki = 0.f;
+      if (pq != 0) {
+        if (g == 0) {  // j side, j = pq (fft4g.c:1245-1246)
+          wkr = 0.5f - c[64 - pq];
+          wki = c[pq];
+        } else {       // k side of pair j = 64 - pq
+          wkr = 0.5f - c[pq];
+          wki = c[64 - pq];
+        }
+      }
+      T->spl[lane][t][0] = wkr;
+      T->spl[lane][t][1] = wki;
+    }
 }
 
 constexpr int kMaxDevices = 64;
@@ -383,6 +430,7 @@ struct AspNsBatch {
   // sub-launches on separate HIP streams, so one part's load/store phases
   // overlap another part's arithmetic (streams never interact).
   int split = 1;
+  bool dual = true;  // fused paired step through the two-streams-per-wave kernel
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
 };
@@ -527,25 +575,41 @@ int AspNsBatch_set_policy(AspNsBatch* b, int mode) {
   return ASP_OK;
 }
 
+// One fused paired frame step over streams [s0, s0 + n) of the batch.
+static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float* dout, int s0, int n,
+                               hipStream_t st) {
+  const size_t sper = io16 ? kBlockL / 2 : kBlockL;  // one stream's frame in float units
+  float* state = b->state + (size_t)s0 * kStreamDwords;
+  int32_t* hist = b->hist + (size_t)s0 * kHistDwords;
+  const float* in = din + (size_t)s0 * sper;
+  float* out = dout + (size_t)s0 * sper;
+  if (!b->dual || n < 2) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
+  const int even = n & ~1;
+  hipError_t e = launch_ns_frame2(io16, state, hist, b->tables, in, out, even, st);
+  if (e == hipSuccess && even != n)  // the odd last stream: one-stream-per-wave kernel
+    e = launch_ns_frame(io16 ? 3 : 2, state + (size_t)even * kStreamDwords,
+                        hist + (size_t)even * kHistDwords, b->tables, in + (size_t)even * sper,
+                        out + (size_t)even * sper, 1, st);
+  return e;
+}
+
 // `steps` fused frame steps on device buffers; step k reads/writes ring slot k % ring.
 static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, int steps,
                        bool io16 = false) {
   // offsets below are in float units; int16 frames are half as wide
   const size_t per = (size_t)b->S * kBlockL / (io16 ? 2 : 1);
-  const int kmode = io16 ? 3 : 2;
-  const size_t sper = io16 ? kBlockL / 2 : kBlockL;  // one stream's frame, in float units
+
   const int parts = (b->split > 1 && b->S >= 8 * b->split) ? b->split : 1;
   if (parts == 1) {
     for (int k = 0; k < steps; ++k) {
       const size_t off = per * (size_t)(k % ring);
-      HIP_TRY(launch_ns_frame(kmode, b->state, b->hist, b->tables, din + off, dout + off, b->S,
-                              b->stream));
+      HIP_TRY(fused_launch(b, io16, din + off, dout + off, 0, b->S, b->stream));
     }
     return ASP_OK;
   }
-  // parts are multiples of 4 streams (one workgroup = 4 streams)
+  // parts are multiples of 8 streams (one workgroup = 8 streams in the two-per-wave kernel)
   int base[5];
-  for (int p = 0; p <= parts; ++p) base[p] = (int)(((long long)b->S * p / parts) / 4 * 4);
+  for (int p = 0; p <= parts; ++p) base[p] = (int)(((long long)b->S * p / parts) / 8 * 8);
   base[parts] = b->S;
   HIP_TRY(hipEventRecord(b->fork_ev, b->stream));
   for (int p = 1; p < parts; ++p) HIP_TRY(hipStreamWaitEvent(b->side[p - 1], b->fork_ev, 0));
@@ -554,9 +618,7 @@ static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, i
     for (int p = 0; p < parts; ++p) {
       hipStream_t st = p == 0 ? b->stream : b->side[p - 1];
       const int s0 = base[p], n = base[p + 1] - base[p];
-      HIP_TRY(launch_ns_frame(kmode, b->state + (size_t)s0 * kStreamDwords,
-                              b->hist + (size_t)s0 * kHistDwords, b->tables,
-                              din + off + (size_t)s0 * sper, dout + off + (size_t)s0 * sper, n, st));
+      HIP_TRY(fused_launch(b, io16, din + off, dout + off, s0, n, st));
     }
   }
   for (int p = 1; p < parts; ++p) {
@@ -733,6 +795,32 @@ int AspNsBatch_SetSplit(AspNsBatch* b, int parts) {
     if (!b->join_ev[i]) HIP_TRY(hipEventCreateWithFlags(&b->join_ev[i], hipEventDisableTiming));
   }
   b->split = parts;
+  return ASP_OK;
+}
+
+// Diagnostic: one fused step of the two-per-wave kernel with phase stamps of wave 0 (16 values).
+int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
+                           unsigned long long* stamps16) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!in_dev || !out_dev || !stamps16 || !b->paired || (b->S & 1))
+    return fail(ASP_ERR_PARAM, "DebugStamps: bad argument");
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 16 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d, 0, 16 * sizeof(unsigned long long));
+  if (e == hipSuccess)
+    e = launch_ns_frame2(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e == hipSuccess) e = hipMemcpy(stamps16, d, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "DebugStamps", e);
+  return ASP_OK;
+}
+
+int AspNsBatch_SetKernel(AspNsBatch* b, int streams_per_wave) {
+  if (!b || (streams_per_wave != 1 && streams_per_wave != 2))
+    return fail(ASP_ERR_PARAM, "SetKernel: streams_per_wave must be 1 or 2");
+  b->dual = streams_per_wave == 2;
   return ASP_OK;
 }
 

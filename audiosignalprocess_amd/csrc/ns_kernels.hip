@@ -26,229 +26,15 @@
 // Compile with -ffp-contract=off: parity depends on unfused mul/add.
 #include <hip/hip_runtime.h>
 
+#include "ns_device.h"
 #include "ns_layout.h"
 
 using namespace aspns;
 
 namespace {
 
-// ns/defines.h:19-48, same (float)<double literal> spelling as the reference
-#define NS_QUANTILE (float)0.25
-#define NS_END_STARTUP_LONG 200
-#define NS_END_STARTUP_SHORT 50
-#define NS_FACTOR (float)40.0
-#define NS_WIDTH (float)0.01
-#define NS_DD_PR_SNR (float)0.98
-#define NS_LRT_TAVG (float)0.50
-#define NS_SPECT_FL_TAVG (float)0.30
-#define NS_SPECT_DIFF_TAVG (float)0.30
-#define NS_PRIOR_UPDATE (float)0.10
-#define NS_NOISE_UPDATE (float)0.90
-#define NS_SPEECH_UPDATE (float)0.99
-#define NS_WIDTH_PR_MAP (float)4.0
-#define NS_PROB_RANGE (float)0.20
-#define NS_GAMMA_PAUSE (float)0.05
-#define NS_B_LIM (float)0.5
-#define NS_START_BAND 5
+using namespace aspns_dev;
 
-__device__ __forceinline__ float xorf(float x, uint32_t m) {
-  return __uint_as_float(__float_as_uint(x) ^ m);
-}
-
-// Orders the wave's own LDS traffic for the compiler; the hardware executes
-// one wave's DS instructions in order, so no s_barrier is needed.
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float lane_bcast(float v, int lane) {  // lane: compile-time constant
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-// Wave64 all-reduce with the association of an ascending xor-butterfly
-// (xor 1, 2, 4, 8, 16, 32; every lane ends with the same value), which
-// oracle/ns_oracle.c reproduces in ASP_NS_REDUCE_TREE mode.  Steps 1 and 2 are
-// DPP quad permutes; after them a quad is uniform, so the half-row and row
-// mirrors deliver exactly the xor-4 / xor-8 partners' values; the four uniform
-// row sums are then combined through scalar broadcasts as (r0+r1)+(r2+r3).
-__device__ __forceinline__ float wave_sum(float v) {
-  v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]  == xor 1
-  v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]  == xor 2
-  v = v + dpp_move<0x141>(v);  // row_half_mirror      == xor 4 (quads uniform)
-  v = v + dpp_move<0x140>(v);  // row_mirror           == xor 8 (octets uniform)
-  const float r0 = lane_bcast(v, 0), r1 = lane_bcast(v, 16);
-  const float r2 = lane_bcast(v, 32), r3 = lane_bcast(v, 48);
-  return (r0 + r1) + (r2 + r3);
-}
-
-// Correctly rounded a / d for a divisor shared by the whole wave: `rd` is the
-// correctly rounded reciprocal of d (one exact division per wave), then
-// Markstein's q0 = a*rd, r = a - d*q0, q = q0 + r*rd is the rounded quotient
-// (needs no range scaling here: |a/d| and d stay far from the float limits).
-__device__ __forceinline__ float div_by_uniform(float a, float d, float rd) {
-  const float q0 = a * rd;
-  const float r = __builtin_fmaf(-d, q0, a);
-  return __builtin_fmaf(r, rd, q0);
-}
-
-// Correctly rounded n / d without the range scaling / special-case fix-up of
-// the generic expansion: the same Newton + residual arithmetic hipcc emits for
-// `/` (v_rcp, two reciprocal refinements, two quotient corrections), valid
-// while d and n/d are normal floats away from the range limits -- true for
-// every use below (denominators are x + 1e-4, 1 + x, overdrive + x or a
-// density > 0 with int16-range audio).  Checked against `/` on the device over
-// full mantissa sweeps (tests/test_ns_gpu.py).
-__device__ __forceinline__ float fdiv(float n, float d) {
-  const float r0 = __builtin_amdgcn_rcpf(d);
-  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-  const float r1 = __builtin_fmaf(e0, r0, r0);
-  const float q0 = n * r1;
-  const float e1 = __builtin_fmaf(-d, q0, n);
-  const float q1 = __builtin_fmaf(e1, r1, q0);
-  const float e2 = __builtin_fmaf(-d, q1, n);
-  return __builtin_fmaf(e2, r1, q1);
-}
-#define DIV129(a) div_by_uniform((a), 129.0f, 1.0f / 129.0f)
-
-// (float)log((double)x), the reference's idiom (ns_core.c:228,540,681,1096), for
-// positive finite normal x.  Lean fp64 evaluation:
-//   x = 2^e m, m in [sqrt(1/2), sqrt(2)); s = (m-1)/(m+1) (quotient from a float
-//   reciprocal plus an exact fp64 residual); log m = 2s + s z P(z), z = s^2.
-// Its error is a few 2^-52, so the float rounding is decided unless the fp64
-// value sits within 2^-44 (relative) of a rounding boundary; those cases
-// (about 3e-6 of inputs) and non-normal inputs are redone with the fp64 libm log,
-// which makes the result identical to (float)log((double)x) from ocml for every
-// float (checked exhaustively in tests/test_ns_gpu.py).
-__device__ __forceinline__ double log_lean_f64(float x) {
-  const int xb = __float_as_int(x);
-  int e = ((xb >> 23) & 0xff) - 127;
-  float mf = __int_as_float((xb & 0x007fffff) | 0x3f800000);  // [1, 2)
-  const bool big = mf > 1.41421356f;
-  mf = big ? mf * 0.5f : mf;  // exact
-  e += big ? 1 : 0;
-  const float ff = mf - 1.0f;  // exact (Sterbenz)
-  const float gf = mf + 1.0f;  // rounded to float; the residual below uses g exactly in fp64
-  const double g = (double)mf + 1.0;
-  const double c = (double)__builtin_amdgcn_rcpf(gf);
-  const double f = (double)ff;
-  const double s0 = f * c;                        // exact: 24 x 24 bits
-  const double d = __builtin_fma(g, c, -1.0);     // exact: g c - 1, |d| < 2^-22
-  double s = __builtin_fma(-s0, d, s0);           // s0 (1 - d + d^2)
-  s = __builtin_fma(s0 * d, d, s);
-  const double z = s * s;
-  double p = 2.0 / 21.0;
-  p = __builtin_fma(p, z, 2.0 / 19.0);
-  p = __builtin_fma(p, z, 2.0 / 17.0);
-  p = __builtin_fma(p, z, 2.0 / 15.0);
-  p = __builtin_fma(p, z, 2.0 / 13.0);
-  p = __builtin_fma(p, z, 2.0 / 11.0);
-  p = __builtin_fma(p, z, 2.0 / 9.0);
-  p = __builtin_fma(p, z, 2.0 / 7.0);
-  p = __builtin_fma(p, z, 2.0 / 5.0);
-  p = __builtin_fma(p, z, 2.0 / 3.0);
-  const double lm = __builtin_fma(s * z, p, s + s);
-  const double ed = (double)e;
-  const double ln2_hi = 0x1.62e42fefa38p-1;   // 41 significant bits: e * ln2_hi is exact
-  const double ln2_lo = 0x1.ef35793c7673p-45;
-  return __builtin_fma(ed, ln2_hi, __builtin_fma(ed, ln2_lo, lm));
-}
-
-__device__ __forceinline__ bool f64_rounds_safely_to_f32(double y) {
-  // the 29 bits dropped by the conversion; unsafe when they are within 2^9
-  // (= 2^-44 relative) of the half-way pattern 0x10000000
-  const unsigned lo = (unsigned)__double2loint(y) & 0x1fffffffu;
-  return ((lo - 0x0ffffe00u) > 0x400u);
-}
-
-// exp((double)x) for a float x with |x| <= 87 (float result normal), lean fp64:
-// k = rint(64 x / ln 2), r = x - k ln2/64 (|r| <= 0.0055), e^r by a degree-5
-// polynomial, 2^(k/64) from a 64-entry table.  Relative error < 2^-51.
-__device__ __forceinline__ double exp_lean_f64(float xf, const double* __restrict__ t64) {
-  const double x = (double)xf;
-  const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);
-  const int k = (int)kd;
-  double r = __builtin_fma(-kd, 0x1.62e42ff000000p-7, x);  // exact: 32-bit constant
-  r = __builtin_fma(-kd, -0x1.718432a1b0e26p-41, r);
-  double q = 1.0 / 120.0;
-  q = __builtin_fma(q, r, 1.0 / 24.0);
-  q = __builtin_fma(q, r, 1.0 / 6.0);
-  q = __builtin_fma(q, r, 0.5);
-  const double p = __builtin_fma(q, r * r, r);
-  const double T = t64[k & 63];
-  return __builtin_amdgcn_ldexp(__builtin_fma(T, p, T), k >> 6);
-}
-
-// (float)exp((double)x), the reference's idiom (ns_core.c:266,278,551,745).
-__device__ __forceinline__ float exp_f32_via_f64(float x, const double* __restrict__ t64) {
-  const bool in_range = fabsf(x) <= 87.0f;  // false for NaN too
-  const double y = exp_lean_f64(in_range ? x : 0.0f, t64);
-  const bool ok = in_range && f64_rounds_safely_to_f32(y);
-  float r = (float)y;
-  if (__builtin_expect(!ok, 0)) r = (float)exp((double)x);
-  return r;
-}
-
-// (float)tanh((double)a), the reference's idiom (ns_core.c:698,713,725).
-//   |a| < 2^-5 : odd series through a^9 (next term < 2^-57 relative)
-//   else       : u = exp(-2|a|), tanh = (1 - u) / (1 + u), quotient by a float
-//                reciprocal refined twice in fp64 plus one residual correction.
-__device__ __forceinline__ float tanh_f32_via_f64(float a, const double* __restrict__ t64) {
-  const float ax = fabsf(a);
-  const bool finite_ok = ax <= 40.0f;  // beyond: |tanh| rounds to 1, left to libm; NaN too
-  const double ad = (double)ax;
-  const double a2 = ad * ad;
-  double sr = 0x1.664f4882c10fap-6;                 // 62/2835
-  sr = __builtin_fma(sr, a2, -0x1.ba1ba1ba1ba1cp-5);  // -17/315
-  sr = __builtin_fma(sr, a2, 0x1.1111111111111p-3);   // 2/15
-  sr = __builtin_fma(sr, a2, -0x1.5555555555555p-2);  // -1/3
-  const double t_small = __builtin_fma(ad * a2, sr, ad);
-  const double u = exp_lean_f64(finite_ok ? -2.0f * ax : 0.0f, t64);
-  const double num = 1.0 - u, den = 1.0 + u;
-  double rc = (double)__builtin_amdgcn_rcpf((float)den);
-  rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
-  rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
-  double qv = num * rc;
-  qv = __builtin_fma(__builtin_fma(-qv, den, num), rc, qv);
-  const double t = ax < 0.03125f ? t_small : qv;
-  const bool ok = finite_ok && f64_rounds_safely_to_f32(t);
-  float r = __builtin_copysignf((float)t, a);
-  if (__builtin_expect(!ok, 0)) r = (float)tanh((double)a);
-  return r;
-}
-
-// Correctly rounded sqrtf for x >= 0 (Newton on v_rsq with exact residuals).
-// The residual arithmetic underflows below about 2^-102, so inputs under
-// 2^-100 (never produced by int16-range audio) take the generic sqrtf; with
-// that, equal to sqrtf for every non-negative float (checked exhaustively).
-__device__ __forceinline__ float fsqrt(float x) {
-  const float r = __builtin_amdgcn_rsqf(x);
-  float g = x * r;
-  float h = 0.5f * r;
-  const float e = __builtin_fmaf(-h, g, 0.5f);
-  g = __builtin_fmaf(g, e, g);
-  h = __builtin_fmaf(h, e, h);
-  const float d = __builtin_fmaf(-g, g, x);
-  g = __builtin_fmaf(d, h, g);
-  float res = (x == 0.0f || x == __builtin_inff()) ? x : g;
-  if (__builtin_expect(x < 0x1p-100f && x > 0.0f, 0)) res = sqrtf(x);
-  return res;
-}
-
-__device__ __forceinline__ float log_f32_via_f64(float x) {
-  const unsigned ax = __float_as_uint(x);
-  const bool normal_pos = (ax - 0x00800000u) < 0x7f000000u;  // [2^-126, inf)
-  const double y = log_lean_f64(x);
-  const bool ok = normal_pos && f64_rounds_safely_to_f32(y);
-  float r = (float)y;
-  if (__builtin_expect(!ok, 0)) r = (float)log((double)x);
-  return r;
-}
 
 struct FftLane {
   float4 tw0, tw1, tw2;  // (tAr, tAi, tBr, tBi) for passes 1..3
@@ -384,120 +170,6 @@ __device__ __forceinline__ void rdft256_inv(float2* buf, const FftLane& L, int l
   const float2 a = buf[lane], c = buf[lane + 64];
   lo = make_float2(a.x + c.x, -a.y - c.y);  // fft4g.c:989-997
   hi = make_float2(a.x - c.x, -a.y + c.y);
-}
-
-// --------------------------------------------------------------------------
-// Histogram window close: FeatureParameterExtraction(self, 1), ns_core.c:337-517.
-// Runs once per 500 frames per stream.  Zero bins cannot change any of the
-// running sums / peaks, so only non-empty bins are visited, in bin order, which
-// keeps the reference's sequential float sums and tie-breaking exactly.
-struct PriorModel {
-  float p0, p1, p3, p4, p5, p6;
-};
-
-__device__ __noinline__ PriorModel close_histogram_window(int32_t* __restrict__ hist, int lane,
-                                                          int updateWindow, bool zero_after,
-                                                          PriorModel pm) {
-  // ---- LRT histogram, :340-373
-  float avgHistLrt = 0.f, avgHistLrtCompl = 0.f, avgSquareHistLrt = 0.f;
-  int numHistLrt = 0;
-  for (int r = 0; r < 16; ++r) {
-    const int i = r * 64 + lane;
-    const int v = i < kHist ? hist[i] : 0;
-    unsigned long long m = __ballot(v != 0);
-    while (m) {
-      const int p = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int hv = __shfl(v, p, 64);
-      const float binMid = ((float)(r * 64 + p) + 0.5f) * 0.1f;
-      if (binMid <= 1.f) {
-        avgHistLrt += hv * binMid;
-        numHistLrt += hv;
-      }
-      avgSquareHistLrt += hv * binMid * binMid;
-      avgHistLrtCompl += hv * binMid;
-    }
-  }
-  if (numHistLrt > 0) avgHistLrt = avgHistLrt / ((float)numHistLrt);
-  avgHistLrtCompl = avgHistLrtCompl / ((float)updateWindow);
-  avgSquareHistLrt = avgSquareHistLrt / ((float)updateWindow);
-  const float fluctLrt = avgSquareHistLrt - avgHistLrt * avgHistLrtCompl;
-  if (fluctLrt < 0.05f) {
-    pm.p0 = 1.f;
-  } else {
-    pm.p0 = 1.2f * avgHistLrt;
-    if (pm.p0 < 0.2f) pm.p0 = 0.2f;
-    if (pm.p0 > 1.f) pm.p0 = 1.f;
-  }
-  // ---- two dominant peaks of the flatness and difference histograms, :378-432
-  float pos1[2], pos2[2];
-  int wt1[2], wt2[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int32_t* hh = hist + (k + 1) * kHistStride;
-    const float binSize = k == 0 ? 0.05f : 0.1f;
-    int maxPeak1 = 0, maxPeak2 = 0;
-    pos1[k] = 0.f;
-    pos2[k] = 0.f;
-    wt1[k] = 0;
-    wt2[k] = 0;
-    for (int r = 0; r < 16; ++r) {
-      const int i = r * 64 + lane;
-      const int v = i < kHist ? hh[i] : 0;
-      unsigned long long m = __ballot(v != 0);
-      while (m) {
-        const int p = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int hv = __shfl(v, p, 64);
-        const float binMid = ((float)(r * 64 + p) + 0.5f) * binSize;
-        if (hv > maxPeak1) {
-          maxPeak2 = maxPeak1;
-          wt2[k] = wt1[k];
-          pos2[k] = pos1[k];
-          maxPeak1 = hv;
-          wt1[k] = hv;
-          pos1[k] = binMid;
-        } else if (hv > maxPeak2) {
-          maxPeak2 = hv;
-          wt2[k] = hv;
-          pos2[k] = binMid;
-        }
-      }
-    }
-  }
-  const int thresWeight = (int)(0.3 * updateWindow);  // :67-70
-  // ---- flatness, :435-463
-  int useFlat = 1;
-  if ((fabsf(pos2[0] - pos1[0]) < 2 * 0.05f) && (wt2[0] > 0.5f * wt1[0])) {
-    wt1[0] += wt2[0];
-    pos1[0] = 0.5f * (pos1[0] + pos2[0]);
-  }
-  if (wt1[0] < thresWeight || pos1[0] < 0.6f) useFlat = 0;
-  if (useFlat == 1) {
-    pm.p1 = 0.9f * pos1[0];
-    if (pm.p1 < 0.1f) pm.p1 = 0.1f;
-    if (pm.p1 > 0.95f) pm.p1 = 0.95f;
-  }
-  // ---- template difference, :467-498
-  int useDiff = 1;
-  if ((fabsf(pos2[1] - pos1[1]) < 2 * 0.1f) && (wt2[1] > 0.5f * wt1[1])) {
-    wt1[1] += wt2[1];
-    pos1[1] = 0.5f * (pos1[1] + pos2[1]);
-  }
-  pm.p3 = 1.2f * pos1[1];
-  if (wt1[1] < thresWeight) useDiff = 0;
-  if (pm.p3 < 0.16f) pm.p3 = 0.16f;
-  if (pm.p3 > 1.f) pm.p3 = 1.f;
-  if (fluctLrt < 0.05f) useDiff = 0;
-  const float featureSum = (float)(1 + useFlat + useDiff);  // :504-507
-  pm.p4 = 1.f / featureSum;
-  pm.p5 = ((float)useFlat) / featureSum;
-  pm.p6 = ((float)useDiff) / featureSum;
-  if (zero_after) {  // :510-516
-    for (int k = 0; k < 3; ++k)
-      for (int r = 0; r < 16; ++r) hist[k * kHistStride + r * 64 + lane] = 0;
-  }
-  return pm;
 }
 
 // --------------------------------------------------------------------------

@@ -75,6 +75,9 @@ struct NsTables {
   float sum_log_i_square;
   float pad[2];
   double exp2_64[64];         // 2^(j/64), range-reduction table of the lean exp
+  // two-streams-per-wave kernel (ns_kernels2.hip): one full butterfly per lane and pass
+  float tw2[3][32][8];        // (w1r, w1i, w2r, w2i, w3r, w3i, diag, 0)
+  float spl[32][4][2];        // real-split (wkr, wki) of element (lane & 15) + 16 t + 64 (lane >> 4)
 };
 
 }  // namespace aspns

@@ -48,6 +48,7 @@ def load_library():
         "AspNsBatch_prior_speech_probability": [vp, vp],
         "AspNsBatch_SetStream": [vp, vp],
         "AspNsBatch_SetSplit": [vp, ip],
+        "AspNsBatch_SetKernel": [vp, ip],
         "AspNsBatch_Synchronize": [vp],
         "AspNsBatch_TimedSteps": [vp, vp, vp, ip, ip, fp],
         "AspNs_DeviceAlloc": [C.POINTER(vp), C.c_size_t, ip],
@@ -118,7 +119,7 @@ class DeviceBuffer:
 class NsBatch:
     """N independent 16 kHz noise-suppressor streams on one GPU."""
 
-    def __init__(self, num_streams, device=0, fs=16000, policy=None):
+    def __init__(self, num_streams, device=0, fs=16000, policy=None, streams_per_wave=None):
         self.lib = load_library()
         self.S = int(num_streams)
         self.device = device
@@ -128,6 +129,8 @@ class NsBatch:
         self.init(fs)
         if policy is not None:
             self.set_policy(policy)
+        if streams_per_wave is not None:
+            self.set_kernel(streams_per_wave)
 
     def init(self, fs=16000):
         _check(self.lib.AspNsBatch_Init(self.h, fs), "AspNsBatch_Init")
@@ -188,6 +191,9 @@ class NsBatch:
 
     def set_split(self, parts):
         _check(self.lib.AspNsBatch_SetSplit(self.h, parts), "AspNsBatch_SetSplit")
+
+    def set_kernel(self, streams_per_wave):
+        _check(self.lib.AspNsBatch_SetKernel(self.h, streams_per_wave), "AspNsBatch_SetKernel")
 
     def synchronize(self):
         _check(self.lib.AspNsBatch_Synchronize(self.h), "AspNsBatch_Synchronize")

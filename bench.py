@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--ring", type=int, default=100, help="distinct input frames resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
+    ap.add_argument("--streams-per-wave", type=int, default=2, choices=[1, 2],
+                    help="fused-step kernel: 2 = two streams per wave64 (default), 1 = one")
     ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256"],
                     help="ns = the headline metric (default); bt* = secondary BlockThresholding line")
     args = ap.parse_args()
@@ -181,7 +183,7 @@ def main():
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.empty_like(d_in)
     del x
-    ns = NsBatch(S, device=local_rank, policy=1)
+    ns = NsBatch(S, device=local_rank, policy=1, streams_per_wave=args.streams_per_wave)
     ns.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.split > 1:
         ns.set_split(args.split)
@@ -245,7 +247,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": PMC_TRAFFIC_BYTES_PER_FRAME * S / max(args.split, 1),
                 "traffic_source": "profiles/README.md (PMC passes of round 1, per launch)",
-                "kernel": "ns_frame_kernel<true,true>",
+                "kernel": "ns_frame2_kernel<false>" if args.streams_per_wave == 2 else "ns_frame_kernel<true,true>",
                 # one frame step = `concurrent_launches` launches of this kernel side by side
                 # (one per HIP stream, S / concurrent_launches streams each); each lasts about
                 # one step, so achieved = concurrent_launches * bytes_per_launch / avg_launch

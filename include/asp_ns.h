@@ -152,6 +152,10 @@ int AspNsBatch_SetStream(AspNsBatch* b, void* hip_stream);
  * sub-launches on separate HIP streams (streams never interact, so results are
  * unchanged); lets one part's memory phases overlap another part's arithmetic. */
 int AspNsBatch_SetSplit(AspNsBatch* b, int parts);
+/* Which fused-step kernel serves AnalyzeProcess: 2 (default) = two streams per wave64,
+ * 1 = one stream per wave64.  Same arithmetic; the ~10 cross-bin sums per frame are
+ * associated over 32 resp. 64 lanes, so outputs agree to reduction-order rounding. */
+int AspNsBatch_SetKernel(AspNsBatch* b, int streams_per_wave);
 void* AspNsBatch_GetStream(AspNsBatch* b);
 int AspNsBatch_Synchronize(AspNsBatch* b);
 
