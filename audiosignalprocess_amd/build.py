@@ -79,6 +79,17 @@ def build_drivers(verbose=False):
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
         built.append(exe)
+    # C++ client of the header-only APM_NS class (include/apm_ns.h)
+    src = os.path.join(ROOT, "drivers", "apm_ns_raw.cpp")
+    exe = os.path.join(out_dir, "apm_ns_raw")
+    if _stale(exe, [src, LIB, os.path.join(ROOT, "include", "apm_ns.h")]):
+        cmd = ["g++", "-O2", "-std=c++11", "-Wall", "-I" + os.path.join(ROOT, "include"), src,
+               "-L" + LIBDIR, "-lasp_amd", "-Wl,-rpath,$ORIGIN/../../audiosignalprocess_amd/lib",
+               "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    built.append(exe)
     return built
 
 

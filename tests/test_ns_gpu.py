@@ -546,3 +546,46 @@ def test_dual_then_unfused_continues(ns):
         o.analyze(x[f])
         assert np.array_equal(g.process(x[f]), o.process(x[f])), f
     g.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# libapm's APM_NS class (include/apm_ns.h over the C-ABI): channels of an interleaved capture
+# stream are the streams of one batch.
+def test_apm_ns_class_interleaved_capture(ns, golden, tmp_path):
+    """drivers/apm_ns_raw drives APM_NS::processCaptureStream (short and float overloads) on a
+    3-channel interleaved capture; equals the per-channel int16 path bit for bit, with the
+    FloatToS16 / S16ToFloat conversions of audio_util.h:27-39 around it for float input."""
+    from audiosignalprocess_amd.build import build_drivers
+
+    exe = [e for e in build_drivers() if e.endswith("apm_ns_raw")][0]
+    pcm = golden["wav_in_i16"]
+    F, C3 = 120, 3
+    planar = np.stack([pcm[o:o + F * 160] for o in (0, 4000, 9000)])           # [C][F*160]
+    inter = np.ascontiguousarray(planar.T)                                     # [F*160][C]
+    for mode in (0, 2):
+        b = ns.NsBatch(C3, policy=mode)
+        want = b.analyze_process_s16(planar.reshape(C3, F, 160).transpose(1, 0, 2))  # [F][C][160]
+        want_inter = want.transpose(0, 2, 1).reshape(F * 160, C3)
+        (tmp_path / "in.s16").write_bytes(inter.tobytes())
+        subprocess.run([exe, str(tmp_path / "in.s16"), str(tmp_path / "out.s16"), str(C3), str(mode), "s16"],
+                       check=True)
+        got = np.frombuffer((tmp_path / "out.s16").read_bytes(), np.int16).reshape(F * 160, C3)
+        assert np.array_equal(got, want_inter), mode
+        assert not np.array_equal(got, inter)
+
+    # float overload: x in [-1, 1]; choose x = s / 32768 so FloatToS16 is easy to restate
+    x = (inter.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    v = x
+    pos = np.where(v >= 1, 32767, (v * np.float32(32767) + np.float32(0.5)).astype(np.float32)).astype(np.int64)
+    neg = np.where(v <= -1, -32768, (-v * np.float32(-32768) - np.float32(0.5)).astype(np.float32)).astype(np.int64)
+    s16 = np.where(v > 0, pos, neg).astype(np.int16)                           # trunc toward zero
+    b = ns.NsBatch(C3, policy=1)
+    den = b.analyze_process_s16(np.ascontiguousarray(s16.T).reshape(C3, F, 160).transpose(1, 0, 2))
+    den = den.transpose(0, 2, 1).reshape(F * 160, C3)
+    k_max = np.float32(1.0) / np.float32(32767)
+    k_min = np.float32(1.0) / np.float32(-32768)
+    want_f = den.astype(np.float32) * np.where(den > 0, k_max, -k_min).astype(np.float32)
+    (tmp_path / "in.f32").write_bytes(x.tobytes())
+    subprocess.run([exe, str(tmp_path / "in.f32"), str(tmp_path / "out.f32"), str(C3), "1", "f32"], check=True)
+    got_f = np.frombuffer((tmp_path / "out.f32").read_bytes(), np.float32).reshape(F * 160, C3)
+    assert np.array_equal(got_f, want_f)
