@@ -86,3 +86,55 @@ class AspBtState(C.Structure):
     """include/asp_bt.h: AspBtState (carried state between macroblocks)."""
 
     _fields_ = [("win_size", C.c_int32), ("inbuf_tail", C.c_float * 512), ("out_tail", C.c_float * 512)]
+
+
+class AecConfig(C.Structure):
+    """include/asp_aec.h: AecConfig (echo_cancellation.h:37-43)."""
+
+    _fields_ = [("nlpMode", C.c_int16), ("skewMode", C.c_int16), ("metricsMode", C.c_int16),
+                ("delay_logging", C.c_int)]
+
+
+class AspAecState(C.Structure):
+    """include/asp_aec.h: AspAecState (per-stream float state of AecCore)."""
+
+    _fields_ = [
+        ("dBuf", C.c_float * 128), ("eBuf", C.c_float * 128),
+        ("xPow", C.c_float * 65), ("dPow", C.c_float * 65), ("dMinPow", C.c_float * 65),
+        ("dInitMinPow", C.c_float * 65),
+        ("xfBuf", C.c_float * (2 * 12 * 65)), ("wfBuf", C.c_float * (2 * 12 * 65)),
+        ("sde", C.c_float * (65 * 2)), ("sxd", C.c_float * (65 * 2)),
+        ("xfwBuf", C.c_float * (12 * 65 * 2)),
+        ("sx", C.c_float * 65), ("sd", C.c_float * 65), ("se", C.c_float * 65),
+        ("outBuf", C.c_float * 64),
+        ("hNlFbMin", C.c_float), ("hNlFbLocalMin", C.c_float), ("hNlXdAvgMin", C.c_float),
+        ("overDrive", C.c_float), ("overDriveSm", C.c_float),
+        ("hNlNewMin", C.c_int32), ("hNlMinCtr", C.c_int32),
+        ("delayIdx", C.c_int32), ("stNearState", C.c_int32), ("echoState", C.c_int32),
+        ("divergeState", C.c_int32),
+        ("xfBufBlockPos", C.c_int32), ("noiseEstCtr", C.c_int32), ("delayEstCtr", C.c_int32),
+        ("seed", C.c_uint32),
+    ]
+
+
+class AspAecControl(C.Structure):
+    """include/asp_aec.h: AspAecControl (integer control plane shared by a batch)."""
+
+    _fields_ = [(n, C.c_int32) for n in (
+        "startup_phase", "checkBuffSize", "bufSizeStart", "knownDelay", "filtDelay",
+        "timeForDelayChange", "lastDelayDiff", "counter", "sum", "firstVal", "checkBufSizeCtr",
+        "system_delay", "core_knownDelay",
+        "far_read", "far_write", "far_wrap", "pre_read", "pre_write", "pre_wrap",
+        "near_read", "near_write", "near_wrap", "out_read", "out_write", "out_wrap",
+        "blocks_processed")]
+
+
+def aec_state_arrays(st):
+    """AspAecState -> {field: numpy array / scalar} for comparisons."""
+    import numpy as np
+
+    out = {}
+    for name, ctype in st._fields_:
+        v = getattr(st, name)
+        out[name] = np.ctypeslib.as_array(v).copy() if hasattr(v, "_length_") else v
+    return out

@@ -1,0 +1,175 @@
+/*
+ * asp_aec.h -- C-ABI of the MI355X batched acoustic echo canceller: the reference's
+ * WebRTC AEC (partitioned-block frequency-domain adaptive filter + non-linear
+ * processor), WebRtc_AMP_Port/webrtc/modules/audio_processing/aec/.
+ *
+ * Layer 1: the reference's per-stream API, signature-identical
+ * (aec/include/echo_cancellation.h:79-247).  A handle is a batch of one stream.
+ * Layer 2: AspAecBatch_*, N independent streams fed in lock-step: the integer control
+ * plane of the reference (start-up phase, system-delay bookkeeping, ring read/write
+ * positions: echo_cancellation.c:594-742,816-867, aec_core.c:1618-1778) depends only on
+ * the call sequence and the reported delays, so one host copy serves every stream of a
+ * batch; the per-stream float state and the four ring buffers live in HBM.
+ *
+ * Built configuration = what test_aec_module.cpp:60-88 runs: 8 or 16 kHz (one band),
+ * 12 partitions, reported-delay mode, no skew compensation, no delay logging, metrics
+ * off.  Anything else is refused with the reference's own error codes.
+ */
+#ifndef ASP_AEC_H_
+#define ASP_AEC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A translation unit that already included the reference's own echo_cancellation.h keeps its
+ * (identical) layer-1 declarations. */
+#ifndef WEBRTC_MODULES_AUDIO_PROCESSING_AEC_INCLUDE_ECHO_CANCELLATION_H_
+/* echo_cancellation.h:17-24 */
+#define AEC_UNSPECIFIED_ERROR 12000
+#define AEC_UNSUPPORTED_FUNCTION_ERROR 12001
+#define AEC_UNINITIALIZED_ERROR 12002
+#define AEC_NULL_POINTER_ERROR 12003
+#define AEC_BAD_PARAMETER_ERROR 12004
+#define AEC_BAD_PARAMETER_WARNING 12050
+
+/* ---------------------------------------------------------------- layer 1 */
+enum { kAecNlpConservative = 0, kAecNlpModerate, kAecNlpAggressive }; /* echo_cancellation.h:26-30 */
+enum { kAecFalse = 0, kAecTrue };                                      /* echo_cancellation.h:32-35 */
+
+typedef struct {
+  int16_t nlpMode;      /* default kAecNlpModerate */
+  int16_t skewMode;     /* default kAecFalse       */
+  int16_t metricsMode;  /* default kAecFalse       */
+  int delay_logging;    /* default kAecFalse       */
+} AecConfig;            /* echo_cancellation.h:37-43 */
+
+typedef struct {
+  int instant;
+  int average;
+  int max;
+  int min;
+} AecLevel; /* echo_cancellation.h:45-50 */
+
+typedef struct {
+  AecLevel rerl;
+  AecLevel erl;
+  AecLevel erle;
+  AecLevel aNlp;
+} AecMetrics; /* echo_cancellation.h:52-57 */
+
+struct AecCore;
+
+int32_t WebRtcAec_Create(void** aecInst);                                       /* .h:79  */
+int32_t WebRtcAec_Free(void* aecInst);                                          /* .h:93  */
+int32_t WebRtcAec_Init(void* aecInst, int32_t sampFreq, int32_t scSampFreq);    /* .h:109 */
+int32_t WebRtcAec_BufferFarend(void* aecInst, const float* farend, int16_t nrOfSamples); /* .h:126 */
+int32_t WebRtcAec_Process(void* aecInst, const float* const* nearend, int num_bands,
+                          float* const* out, int16_t nrOfSamples, int16_t msInSndCardBuf,
+                          int32_t skew);                                        /* .h:153 */
+int WebRtcAec_set_config(void* handle, AecConfig config);                       /* .h:175 */
+int WebRtcAec_get_echo_status(void* handle, int* status);                       /* .h:191 */
+/* Metrics are off in this build (metricsMode must stay kAecFalse): GetMetrics reports the
+ * reference's initial values (kOffsetLevel = -100), GetDelayMetrics fails with
+ * AEC_UNSUPPORTED_FUNCTION_ERROR exactly as the reference does with logging disabled. */
+int WebRtcAec_GetMetrics(void* handle, AecMetrics* metrics);                    /* .h:207 */
+int WebRtcAec_GetDelayMetrics(void* handle, int* median, int* std);             /* .h:224 */
+int32_t WebRtcAec_get_error_code(void* aecInst);                                /* .h:237 */
+/* The reference returns its internal AecCore; here it is an opaque token that is only
+ * valid as an argument of the layer-1 functions of this library. */
+struct AecCore* WebRtcAec_aec_core(void* handle);                               /* .h:247 */
+#endif /* reference header not included */
+
+#define ASP_AEC_PART_LEN 64    /* aec_core.h:21 */
+#define ASP_AEC_PART_LEN1 65   /* aec_core.h:22 */
+#define ASP_AEC_PART_LEN2 128  /* aec_core.h:23 */
+#define ASP_AEC_FRAME_LEN 80   /* aec_core.h:20 */
+#define ASP_AEC_PARTITIONS 12  /* kNormalNumPartitions, aec_core_internal.h:25 */
+#define ASP_AEC_FAR_SLOTS 250  /* kBufSizePartitions, aec_core.c:37 */
+
+/* ---------------------------------------------------------------- layer 2 */
+typedef struct AspAecBatch AspAecBatch;
+
+/* Per-stream float state between blocks, canonical field names of AecCore
+ * (aec_core_internal.h:52-164).  Checkpoint unit and parity-test unit. */
+typedef struct AspAecState {
+  float dBuf[128];
+  float eBuf[128];
+  float xPow[65];
+  float dPow[65];
+  float dMinPow[65];
+  float dInitMinPow[65];
+  float xfBuf[2][12 * 65];
+  float wfBuf[2][12 * 65];
+  float sde[65][2];
+  float sxd[65][2];
+  float xfwBuf[12 * 65][2];
+  float sx[65];
+  float sd[65];
+  float se[65];
+  float outBuf[64];
+  float hNlFbMin, hNlFbLocalMin, hNlXdAvgMin;
+  float overDrive, overDriveSm;
+  int32_t hNlNewMin, hNlMinCtr;
+  int32_t delayIdx, stNearState, echoState, divergeState;
+  int32_t xfBufBlockPos, noiseEstCtr, delayEstCtr;
+  uint32_t seed;
+} AspAecState;
+
+/* Integer control plane shared by all streams of a batch (one Aec + the integer part of
+ * AecCore), exposed for the parity tests. */
+typedef struct AspAecControl {
+  int32_t startup_phase, checkBuffSize, bufSizeStart, knownDelay, filtDelay;
+  int32_t timeForDelayChange, lastDelayDiff, counter, sum, firstVal, checkBufSizeCtr;
+  int32_t system_delay, core_knownDelay;
+  int32_t far_read, far_write, far_wrap;       /* far_buf / far_buf_windowed (lock-step) */
+  int32_t pre_read, pre_write, pre_wrap;       /* far_pre_buf                            */
+  int32_t near_read, near_write, near_wrap;    /* nearFrBuf                              */
+  int32_t out_read, out_write, out_wrap;       /* outFrBuf                               */
+  int32_t blocks_processed;
+} AspAecControl;
+
+int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device);
+int AspAecBatch_Free(AspAecBatch* b);
+/* WebRtcAec_Init for every stream; sampFreq 8000 or 16000. */
+int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq);
+int AspAecBatch_set_config(AspAecBatch* b, AecConfig config);
+int AspAecBatch_num_streams(const AspAecBatch* b);
+/* WebRtcAec_BufferFarend for every stream: farend [num_streams][nrOfSamples] float-S16,
+ * nrOfSamples 80 or 160.  mem: 0 host, 1 device (asp_ns.h ASP_MEM_*). */
+int AspAecBatch_BufferFarend(AspAecBatch* b, const float* farend, int nrOfSamples, int mem);
+/* WebRtcAec_Process for every stream: nearend / out [num_streams][nrOfSamples]; in-place
+ * allowed.  Returns 0 / -1 like the reference (-1 with AEC_BAD_PARAMETER_WARNING still
+ * processes, echo_cancellation.c:367-375). */
+int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nrOfSamples,
+                        int msInSndCardBuf, int32_t skew, int mem);
+/* num_frames x (BufferFarend + Process) on [num_frames][num_streams][n] buffers: the loop of
+ * test_aec_module.cpp:75-88 in one call (amortises launches; device or host memory). */
+int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, float* out,
+                    int nrOfSamples, int num_frames, int msInSndCardBuf, int mem);
+int AspAecBatch_get_echo_status(AspAecBatch* b, int* status /* [num_streams] */);
+int AspAecBatch_get_error_code(const AspAecBatch* b);
+int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out);
+int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in);
+int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* out);
+int AspAecBatch_Synchronize(AspAecBatch* b);
+/* `steps` frames of Run over a ring of `frames_in_ring` device frames, bracketed by
+ * hipEvents on the launch stream; elapsed_ms of the whole region (bench.py). */
+int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nearend, float* out,
+                           int nrOfSamples, int frames_in_ring, int steps, float* elapsed_ms);
+
+/* aec_rdft_forward_128 / aec_rdft_inverse_128 (aec_rdft.c:539-556) on `count` rows of 128
+ * floats, in place semantics (src -> dst), host pointers.  Parity-test seam. */
+int AspAec_rdft128_batch(const float* src, float* dst, int isgn, int count, int device);
+/* Host-built constant tables (parity tests compare them with the oracle's and the reference's):
+ * which: 0 rdft_w[64], 1 rdft_wk3ri_first[16], 2 rdft_wk3ri_second[16], 3 sqrtHanning[65],
+ * 4 weightCurve[65], 5 overDriveCurve[65].  Returns the number of floats written. */
+int AspAec_host_table(int which, float* out, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASP_AEC_H_ */

@@ -1,0 +1,1213 @@
+/*
+ * aec_oracle.c -- CPU restatement of the reference's WebRTC AEC.
+ * TEST INFRASTRUCTURE ONLY (see aec_oracle.h).  Parity: PINNED against the reference build
+ * oracle/_ref/libaec_ref.so (bit-exact, tests/test_aec_oracle.py).
+ *
+ * Paths below are relative to WebRtc_AMP_Port/webrtc/ ; "core" = modules/audio_processing/aec/
+ * aec_core.c, "ec" = .../aec/echo_cancellation.c, "rdft" = .../aec/aec_rdft.c,
+ * "ring" = common_audio/ring_buffer.c.
+ *
+ * Covered configuration (what test_aec_module.cpp:60-88 runs): one band (8 / 16 kHz), 12
+ * partitions, reported-delay mode, no skew resampling, no delay logging, metrics off.
+ * Compile with -ffp-contract=off.
+ */
+#include "aec_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PART_LEN 64
+#define PART_LEN1 65
+#define PART_LEN2 128
+#define FRAME_LEN 80
+#define NPART 12
+#define FAR_SLOTS 250
+#define PRE_LEN (PART_LEN2 + 4 * FRAME_LEN) /* ec:146-147, aec_resampler.h:20 */
+#define FRBUF_LEN (FRAME_LEN + PART_LEN)     /* core:1299 */
+
+/* ------------------------------------------------------------------ tables */
+static float g_w[64];        /* rdft_w,            rdft:32-49  */
+static float g_wk3_a[16];    /* rdft_wk3ri_first,  rdft:50-55  */
+static float g_wk3_b[16];    /* rdft_wk3ri_second, rdft:56-61  */
+static float g_hann[65];     /* WebRtcAec_sqrtHanning, core:53-70   */
+static float g_weight[65];   /* WebRtcAec_weightCurve, core:75-84   */
+static float g_odrive[65];   /* WebRtcAec_overDriveCurve, core:89-98 */
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+
+static unsigned bitrev(unsigned x, int bits) {
+  unsigned r = 0;
+  for (int b = 0; b < bits; ++b) r |= ((x >> b) & 1u) << (bits - 1 - b);
+  return r;
+}
+
+/* A table printed by Matlab's fprintf('%.<d>f') and re-read by the C compiler as a float
+ * literal: reproduce the decimal round trip. */
+static float via_text(double v, int decimals) {
+  char buf[48];
+  snprintf(buf, sizeof buf, "%.*f", decimals, v);
+  return strtof(buf, NULL);
+}
+
+static void build_tables(void) {
+  /* The reference's tables "used to be computed at run-time" (rdft:29-31) by Ooura's makewt /
+   * makect for n = 128 (utility/fft4g.c:642-690 is the same code at n = 256): */
+  float tmp[32];
+  const int nw = 32, nwh = 16, nc = 32, nch = 16;
+  float delta = (float)atan(1.0f) / nwh;
+  tmp[0] = 1;
+  tmp[1] = 0;
+  tmp[nwh] = (float)cos(delta * nwh);
+  tmp[nwh + 1] = tmp[nwh];
+  for (int j = 2; j < nwh; j += 2) {
+    float x = (float)cos(delta * j);
+    float y = (float)sin(delta * j);
+    tmp[j] = x;
+    tmp[j + 1] = y;
+    tmp[nw - j] = y;
+    tmp[nw - j + 1] = x;
+  }
+  for (int j = 0; j < 16; ++j) { /* bitrv2(nw, ...) = bit reversal of the 16 complex entries */
+    unsigned r = bitrev((unsigned)j, 4);
+    g_w[2 * j] = tmp[2 * r];
+    g_w[2 * j + 1] = tmp[2 * r + 1];
+  }
+  delta = (float)atan(1.0f) / nch;
+  g_w[32] = (float)cos(delta * nch);
+  g_w[32 + nch] = 0.5f * g_w[32];
+  for (int j = 1; j < nch; j++) {
+    g_w[32 + j] = 0.5f * (float)cos(delta * j);
+    g_w[32 + nc - j] = 0.5f * (float)sin(delta * j);
+  }
+  /* The reference freezes the table as decimal text (rdft:32-49); against makewt / makect
+   * evaluated with this libm the text differs by one unit in the last place at eight entries.
+   * That is data of the reference, applied here as data: */
+  {
+    static const signed char nudge[8][2] = {{4, 1}, {7, 1}, {20, 1}, {27, 1},
+                                            {40, 1}, {41, -1}, {42, 1}, {47, 1}};
+    for (int k = 0; k < 8; ++k) {
+      int32_t bits;
+      memcpy(&bits, &g_w[nudge[k][0]], sizeof bits);
+      bits += nudge[k][1];
+      memcpy(&g_w[nudge[k][0]], &bits, sizeof bits);
+    }
+  }
+  /* wk3 = wk1 - 2 wk2i wk1i etc. (fft4g.c:1054-1055,1081-1082), tabulated by the reference */
+  for (int k1 = 0; k1 < 16; k1 += 2) {
+    const int k2 = 2 * k1;
+    const float wk2r = g_w[k1], wk2i = g_w[k1 + 1];
+    float wk1r = g_w[k2], wk1i = g_w[k2 + 1];
+    g_wk3_a[k1] = wk1r - 2 * wk2i * wk1i;
+    g_wk3_a[k1 + 1] = 2 * wk2i * wk1r - wk1i;
+    wk1r = g_w[k2 + 2];
+    wk1i = g_w[k2 + 3];
+    g_wk3_b[k1] = wk1r - 2 * wk2r * wk1i;
+    g_wk3_b[k1 + 1] = 2 * wk2r * wk1r - wk1i;
+  }
+  /* core:50-70: square root of a Hann window, first half: 65 entries sin(pi k / 128) printed
+   * %.14f */
+  for (int k = 0; k <= 64; ++k) g_hann[k] = via_text(sin(M_PI * k / 128.0), 14);
+  /* core:72-74: weightCurve = [0 ; 0.3 * sqrt(linspace(0,1,64))' + 0.1], printed %.4f */
+  g_weight[0] = 0.f;
+  for (int k = 1; k <= 64; ++k) g_weight[k] = via_text(0.3 * sqrt((k - 1) / 63.0) + 0.1, 4);
+  /* core:86-88: overDriveCurve = sqrt(linspace(0,1,65))' + 1, printed %.4f */
+  for (int k = 0; k <= 64; ++k) g_odrive[k] = via_text(sqrt(k / 64.0) + 1.0, 4);
+}
+
+static void ensure_tables(void) { pthread_once(&g_once, build_tables); }
+
+const float* asp_aec_oracle_table(int which) {
+  ensure_tables();
+  switch (which) {
+    case 0: return g_w;
+    case 1: return g_wk3_a;
+    case 2: return g_wk3_b;
+    case 3: return g_hann;
+    case 4: return g_weight;
+    case 5: return g_odrive;
+    default: return NULL;
+  }
+}
+
+/* --------------------------------------------------------------------- FFT */
+/* One radix-4 pass over 64 complex points at complex stride l: cft1st_128 (l = 1, rdft:201-311)
+ * and cftmdl_128 (l = 4, rdft:313-444).  Blocks of 4l points, B = 0: no twiddles; B = 1: the
+ * w[2] block; B = 2u / 2u+1: twiddles w[2u], w[4u] (+2) and the tabulated wk3. */
+static void cft_pass64(float* a, int l) {
+  const int N = 64, bs = 4 * l;
+  for (int B = 0; B * bs < N; ++B) {
+    int kind = 2;
+    float ws = 0.f, w1r = 0.f, w1i = 0.f, w2r = 0.f, w2i = 0.f, w3r = 0.f, w3i = 0.f;
+    if (B == 0) {
+      kind = 0;
+    } else if (B == 1) {
+      kind = 1;
+      ws = g_w[2];
+    } else {
+      const int k1 = 2 * (B >> 1), k2 = 2 * k1;
+      const float wk2r = g_w[k1], wk2i = g_w[k1 + 1];
+      if ((B & 1) == 0) {
+        w1r = g_w[k2];
+        w1i = g_w[k2 + 1];
+        w3r = g_wk3_a[k1];
+        w3i = g_wk3_a[k1 + 1];
+        w2r = wk2r;
+        w2i = wk2i;
+      } else {
+        w1r = g_w[k2 + 2];
+        w1i = g_w[k2 + 3];
+        w3r = g_wk3_b[k1];
+        w3i = g_wk3_b[k1 + 1];
+        w2r = -wk2i;
+        w2i = wk2r;
+      }
+    }
+    for (int q = 0; q < l; ++q) {
+      float* e0 = a + 2 * (B * bs + q);
+      float* e1 = e0 + 2 * l;
+      float* e2 = e1 + 2 * l;
+      float* e3 = e2 + 2 * l;
+      float x0r = e0[0] + e1[0], x0i = e0[1] + e1[1];
+      float x1r = e0[0] - e1[0], x1i = e0[1] - e1[1];
+      float x2r = e2[0] + e3[0], x2i = e2[1] + e3[1];
+      float x3r = e2[0] - e3[0], x3i = e2[1] - e3[1];
+      e0[0] = x0r + x2r;
+      e0[1] = x0i + x2i;
+      if (kind == 0) {
+        e2[0] = x0r - x2r;
+        e2[1] = x0i - x2i;
+        e1[0] = x1r - x3i;
+        e1[1] = x1i + x3r;
+        e3[0] = x1r + x3i;
+        e3[1] = x1i - x3r;
+      } else if (kind == 1) {
+        float yr, yi;
+        e2[0] = x2i - x0i;
+        e2[1] = x0r - x2r;
+        yr = x1r - x3i;
+        yi = x1i + x3r;
+        e1[0] = ws * (yr - yi);
+        e1[1] = ws * (yr + yi);
+        yr = x3i + x1r;
+        yi = x3r - x1i;
+        e3[0] = ws * (yi - yr);
+        e3[1] = ws * (yi + yr);
+      } else {
+        float yr, yi;
+        x0r -= x2r;
+        x0i -= x2i;
+        e2[0] = w2r * x0r - w2i * x0i;
+        e2[1] = w2r * x0i + w2i * x0r;
+        yr = x1r - x3i;
+        yi = x1i + x3r;
+        e1[0] = w1r * yr - w1i * yi;
+        e1[1] = w1r * yi + w1i * yr;
+        yr = x1r + x3i;
+        yi = x1i - x3r;
+        e3[0] = w3r * yr - w3i * yi;
+        e3[1] = w3r * yi + w3i * yr;
+      }
+    }
+  }
+}
+
+/* bitrv2_128 (rdft:124-199) is the bit reversal of the 64 complex indices. */
+static void bit_reverse64(float* a) {
+  for (int i = 0; i < 64; ++i) {
+    const int r = (int)bitrev((unsigned)i, 6);
+    if (r > i) {
+      const float tr = a[2 * i], ti = a[2 * i + 1];
+      a[2 * i] = a[2 * r];
+      a[2 * i + 1] = a[2 * r + 1];
+      a[2 * r] = tr;
+      a[2 * r + 1] = ti;
+    }
+  }
+}
+
+/* cftfsub_128 / cftbsub_128 (rdft:446-507): two radix-4 passes and the twiddle-free last one. */
+static void cft64(float* a, int backward) {
+  cft_pass64(a, 1);
+  cft_pass64(a, 4);
+  for (int q = 0; q < 16; ++q) {
+    float* e0 = a + 2 * q;
+    float* e1 = e0 + 32;
+    float* e2 = e1 + 32;
+    float* e3 = e2 + 32;
+    if (!backward) {
+      const float x0r = e0[0] + e1[0], x0i = e0[1] + e1[1];
+      const float x1r = e0[0] - e1[0], x1i = e0[1] - e1[1];
+      const float x2r = e2[0] + e3[0], x2i = e2[1] + e3[1];
+      const float x3r = e2[0] - e3[0], x3i = e2[1] - e3[1];
+      e0[0] = x0r + x2r;
+      e0[1] = x0i + x2i;
+      e2[0] = x0r - x2r;
+      e2[1] = x0i - x2i;
+      e1[0] = x1r - x3i;
+      e1[1] = x1i + x3r;
+      e3[0] = x1r + x3i;
+      e3[1] = x1i - x3r;
+    } else {
+      const float x0r = e0[0] + e1[0], x0i = -e0[1] - e1[1];
+      const float x1r = e0[0] - e1[0], x1i = -e0[1] + e1[1];
+      const float x2r = e2[0] + e3[0], x2i = e2[1] + e3[1];
+      const float x3r = e2[0] - e3[0], x3i = e2[1] - e3[1];
+      e0[0] = x0r + x2r;
+      e0[1] = x0i - x2i;
+      e2[0] = x0r - x2r;
+      e2[1] = x0i + x2i;
+      e1[0] = x1r - x3i;
+      e1[1] = x1i - x3r;
+      e3[0] = x1r + x3i;
+      e3[1] = x1i + x3r;
+    }
+  }
+}
+
+void asp_aec_oracle_rdft128(float* a, int isgn) {
+  const float* c = g_w + 32;
+  ensure_tables();
+  if (isgn >= 0) { /* aec_rdft_forward_128, rdft:539-547 */
+    float xi;
+    bit_reverse64(a);
+    cft64(a, 0);
+    for (int j1 = 1, j2 = 2; j2 < 64; j1 += 1, j2 += 2) { /* rftfsub_128, rdft:509-527 */
+      const int k2 = 128 - j2, k1 = 32 - j1;
+      const float wkr = 0.5f - c[k1], wki = c[j1];
+      const float xr = a[j2] - a[k2], xim = a[j2 + 1] + a[k2 + 1];
+      const float yr = wkr * xr - wki * xim, yi = wkr * xim + wki * xr;
+      a[j2] -= yr;
+      a[j2 + 1] -= yi;
+      a[k2] += yr;
+      a[k2 + 1] -= yi;
+    }
+    xi = a[0] - a[1];
+    a[0] += a[1];
+    a[1] = xi;
+  } else { /* aec_rdft_inverse_128, rdft:549-556 */
+    a[1] = 0.5f * (a[0] - a[1]);
+    a[0] -= a[1];
+    a[1] = -a[1]; /* rftbsub_128, rdft:529-537 */
+    for (int j1 = 1, j2 = 2; j2 < 64; j1 += 1, j2 += 2) {
+      const int k2 = 128 - j2, k1 = 32 - j1;
+      const float wkr = 0.5f - c[k1], wki = c[j1];
+      const float xr = a[j2] - a[k2], xim = a[j2 + 1] + a[k2 + 1];
+      const float yr = wkr * xr + wki * xim, yi = wkr * xim - wki * xr;
+      a[j2] = a[j2] - yr;
+      a[j2 + 1] = yi - a[j2 + 1];
+      a[k2] = yr + a[k2];
+      a[k2 + 1] = yi - a[k2 + 1];
+    }
+    a[65] = -a[65];
+    bit_reverse64(a);
+    cft64(a, 1);
+  }
+}
+
+/* -------------------------------------------------------------- ring buffers */
+/* ring:20-249 with positions kept apart from the data (the batched build keeps exactly this
+ * integer part on the host). */
+typedef struct RingPos {
+  int read, write, wrap, count; /* wrap: 0 SAME_WRAP, 1 DIFF_WRAP */
+} RingPos;
+
+static void rp_init(RingPos* r, int count) {
+  r->read = 0;
+  r->write = 0;
+  r->wrap = 0;
+  r->count = count;
+}
+static int rp_avail_read(const RingPos* r) { /* ring:231-240 */
+  return r->wrap == 0 ? r->write - r->read : r->count - r->read + r->write;
+}
+static int rp_avail_write(const RingPos* r) { return r->count - rp_avail_read(r); }
+static int rp_move_read(RingPos* r, int n) { /* ring:195-228 */
+  const int free_elements = rp_avail_write(r), readable = rp_avail_read(r);
+  int pos = r->read;
+  if (n > readable) n = readable;
+  if (n < -free_elements) n = -free_elements;
+  pos += n;
+  if (pos > r->count) {
+    pos -= r->count;
+    r->wrap = 0;
+  }
+  if (pos < 0) {
+    pos += r->count;
+    r->wrap = 1;
+  }
+  r->read = pos;
+  return n;
+}
+static int ring_write(RingPos* r, float* data, int ef, const float* src, int n) { /* ring:161-192 */
+  const int free_elements = rp_avail_write(r);
+  const int write_elements = free_elements < n ? free_elements : n;
+  int m = write_elements;
+  const int margin = r->count - r->write;
+  if (write_elements > margin) {
+    memcpy(data + (size_t)r->write * ef, src, (size_t)margin * ef * sizeof(float));
+    r->write = 0;
+    m -= margin;
+    r->wrap = 1;
+  }
+  memcpy(data + (size_t)r->write * ef, src + (size_t)(write_elements - m) * ef,
+         (size_t)m * ef * sizeof(float));
+  r->write += m;
+  return write_elements;
+}
+static int ring_read(RingPos* r, const float* data, int ef, float* dst, int n) { /* ring:37-60,112-158 */
+  const int readable = rp_avail_read(r);
+  const int read_elements = readable < n ? readable : n;
+  const int margin = r->count - r->read;
+  if (read_elements > margin) {
+    memcpy(dst, data + (size_t)r->read * ef, (size_t)margin * ef * sizeof(float));
+    memcpy(dst + (size_t)margin * ef, data, (size_t)(read_elements - margin) * ef * sizeof(float));
+  } else {
+    memcpy(dst, data + (size_t)r->read * ef, (size_t)read_elements * ef * sizeof(float));
+  }
+  rp_move_read(r, read_elements);
+  return read_elements;
+}
+
+/* ------------------------------------------------------------------ object */
+struct AspAecOracle {
+  AspAecState st;
+  /* Aec (ec, echo_cancellation_internal.h:17-65) */
+  int sampFreq, scSampFreq, splitSampFreq, rate_factor, initFlag, lastError, farend_started;
+  int skewMode;
+  int bufSizeStart, knownDelay, timeForDelayChange, startup_phase, checkBuffSize, sum;
+  int16_t counter, firstVal, checkBufSizeCtr, msInSndCardBuf, filtDelay, lastDelayDiff;
+  /* integer part of AecCore */
+  int system_delay, core_knownDelay, mult, nlp_mode, metricsMode, delay_logging;
+  float normal_mu, normal_error_threshold;
+  int blocks_processed;
+  RingPos pre_pos, far_pos, near_pos, out_pos;
+  float pre[PRE_LEN];
+  float far[FAR_SLOTS][2 * PART_LEN1];
+  float farw[FAR_SLOTS][2 * PART_LEN1];
+  float nearfr[FRBUF_LEN];
+  float outfr[FRBUF_LEN];
+};
+
+static const int kInitCheck = 42;      /* ec:59 */
+static const int kMaxTrustedDelayMs = 500; /* ec:53 */
+static const int kMaxBufSizeStart = 62;    /* ec:57 */
+static const int kSampMsNb = 8;            /* ec:58 */
+
+AspAecOracle* asp_aec_oracle_create(void) { /* ec:121-168 */
+  AspAecOracle* o = (AspAecOracle*)calloc(1, sizeof *o);
+  ensure_tables();
+  if (o) {
+    o->initFlag = 0;
+    o->lastError = 0;
+  }
+  return o;
+}
+
+void asp_aec_oracle_free(AspAecOracle* o) { free(o); }
+
+static int far_move_read(AspAecOracle* o, int elements) { /* WebRtcAec_MoveFarReadPtr, core:1637-1645 */
+  const int moved = rp_move_read(&o->far_pos, elements);
+  o->system_delay -= moved * PART_LEN;
+  return moved;
+}
+
+static void init_core(AspAecOracle* o, int sampFreq) { /* WebRtcAec_InitAec, core:1460-1615 */
+  AspAecState* s = &o->st;
+  if (sampFreq == 8000) {
+    o->normal_mu = 0.6f;
+    o->normal_error_threshold = 2e-6f;
+  } else {
+    o->normal_mu = 0.5f;
+    o->normal_error_threshold = 1.5e-6f;
+  }
+  rp_init(&o->near_pos, FRBUF_LEN);
+  rp_init(&o->out_pos, FRBUF_LEN);
+  rp_init(&o->far_pos, FAR_SLOTS);
+  memset(o->nearfr, 0, sizeof o->nearfr);
+  memset(o->outfr, 0, sizeof o->outfr);
+  memset(o->far, 0, sizeof o->far);
+  memset(o->farw, 0, sizeof o->farw);
+  o->system_delay = 0;
+  o->delay_logging = 0;
+  o->nlp_mode = 1;
+  o->mult = sampFreq / 8000; /* one band: core:1553-1557 */
+  o->core_knownDelay = 0;
+  memset(s, 0, sizeof *s);
+  for (int i = 0; i < PART_LEN1; i++) s->dMinPow[i] = 1.0e6f;
+  for (int i = 0; i < PART_LEN1; i++) s->sd[i] = 1;
+  for (int i = 0; i < PART_LEN1; i++) s->sx[i] = 1;
+  s->hNlFbMin = 1;
+  s->hNlFbLocalMin = 1;
+  s->hNlXdAvgMin = 1;
+  s->hNlNewMin = 0;
+  s->hNlMinCtr = 0;
+  s->overDrive = 2;
+  s->overDriveSm = 2;
+  s->delayIdx = 0;
+  s->stNearState = 0;
+  s->echoState = 0;
+  s->divergeState = 0;
+  s->seed = 777;
+  s->delayEstCtr = 0;
+  s->xfBufBlockPos = 0;
+  s->noiseEstCtr = 0;
+  o->metricsMode = 0;
+  o->blocks_processed = 0;
+}
+
+int asp_aec_oracle_set_config(AspAecOracle* o, AecConfig config) { /* ec:410-438 */
+  if (o->initFlag != kInitCheck) {
+    o->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  if (config.skewMode != kAecFalse && config.skewMode != kAecTrue) {
+    o->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  o->skewMode = config.skewMode;
+  if (config.nlpMode != kAecNlpConservative && config.nlpMode != kAecNlpModerate &&
+      config.nlpMode != kAecNlpAggressive) {
+    o->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  if (config.metricsMode != kAecFalse && config.metricsMode != kAecTrue) {
+    o->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  if (config.delay_logging != kAecFalse && config.delay_logging != kAecTrue) {
+    o->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  if (config.skewMode || config.metricsMode || config.delay_logging) {
+    /* outside the covered configuration (header) */
+    o->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
+    return -1;
+  }
+  o->nlp_mode = config.nlpMode; /* WebRtcAec_SetConfigCore, core:1844-1858 */
+  return 0;
+}
+
+int asp_aec_oracle_init(AspAecOracle* o, int32_t sampFreq, int32_t scSampFreq) { /* ec:196-276 */
+  AecConfig cfg;
+  if (sampFreq != 8000 && sampFreq != 16000 && sampFreq != 32000 && sampFreq != 48000) {
+    o->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  if (sampFreq > 16000) { /* multi-band: outside the covered configuration */
+    o->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
+    return -1;
+  }
+  o->sampFreq = sampFreq;
+  if (scSampFreq < 1 || scSampFreq > 96000) {
+    o->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  o->scSampFreq = scSampFreq;
+  init_core(o, sampFreq);
+  rp_init(&o->pre_pos, PRE_LEN);
+  memset(o->pre, 0, sizeof o->pre);
+  rp_move_read(&o->pre_pos, -PART_LEN); /* start overlap, ec:226 */
+  o->initFlag = kInitCheck;
+  o->splitSampFreq = sampFreq;
+  o->rate_factor = o->splitSampFreq / 8000;
+  o->sum = 0;
+  o->counter = 0;
+  o->checkBuffSize = 1;
+  o->firstVal = 0;
+  o->startup_phase = 1; /* reported_delay_enabled, core:1527-1531 */
+  o->bufSizeStart = 0;
+  o->checkBufSizeCtr = 0;
+  o->msInSndCardBuf = 0;
+  o->filtDelay = -1;
+  o->timeForDelayChange = 0;
+  o->knownDelay = 0;
+  o->lastDelayDiff = 0;
+  o->farend_started = 0;
+  cfg.nlpMode = kAecNlpModerate;
+  cfg.skewMode = kAecFalse;
+  cfg.metricsMode = kAecFalse;
+  cfg.delay_logging = kAecFalse;
+  if (asp_aec_oracle_set_config(o, cfg) == -1) {
+    o->lastError = AEC_UNSPECIFIED_ERROR;
+    return -1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------- block maths */
+static void window128(float* x) { /* TimeToFrequency window branch, core:779-784 */
+  for (int i = 0; i < PART_LEN; i++) {
+    x[i] *= g_hann[i];
+    x[PART_LEN + i] *= g_hann[PART_LEN - i];
+  }
+}
+
+static void unpack_spectrum(const float* t, float f[2][PART_LEN1]) { /* core:786-795 */
+  f[1][0] = 0;
+  f[1][PART_LEN] = 0;
+  f[0][0] = t[0];
+  f[0][PART_LEN] = t[1];
+  for (int i = 1; i < PART_LEN; i++) {
+    f[0][i] = t[2 * i];
+    f[1][i] = t[2 * i + 1];
+  }
+}
+
+static void buffer_farend_partition(AspAecOracle* o, const float* farend) { /* core:1618-1635 */
+  float fft[PART_LEN2];
+  float xf[2][PART_LEN1];
+  if (rp_avail_write(&o->far_pos) < 1) far_move_read(o, 1);
+  memcpy(fft, farend, sizeof fft);
+  asp_aec_oracle_rdft128(fft, 1);
+  unpack_spectrum(fft, xf);
+  {
+    RingPos keep = o->far_pos; /* far_buf and far_buf_windowed move in lock-step */
+    ring_write(&keep, &o->far[0][0], 2 * PART_LEN1, &xf[0][0], 1);
+  }
+  memcpy(fft, farend, sizeof fft);
+  window128(fft);
+  asp_aec_oracle_rdft128(fft, 1);
+  unpack_spectrum(fft, xf);
+  ring_write(&o->far_pos, &o->farw[0][0], 2 * PART_LEN1, &xf[0][0], 1);
+}
+
+static int partition_delay(const AspAecState* s) { /* core:294-318 */
+  float wfEnMax = 0;
+  int delay = 0;
+  for (int i = 0; i < NPART; i++) {
+    const int pos = i * PART_LEN1;
+    float wfEn = 0;
+    for (int j = 0; j < PART_LEN1; j++)
+      wfEn += s->wfBuf[0][pos + j] * s->wfBuf[0][pos + j] + s->wfBuf[1][pos + j] * s->wfBuf[1][pos + j];
+    if (wfEn > wfEnMax) {
+      wfEnMax = wfEn;
+      delay = i;
+    }
+  }
+  return delay;
+}
+
+static void sort_floats(float* v, int n) { /* qsort + CmpFloat, core:140-145,956 */
+  for (int i = 1; i < n; ++i) {
+    const float x = v[i];
+    int j = i - 1;
+    while (j >= 0 && v[j] > x) {
+      v[j + 1] = v[j];
+      --j;
+    }
+    v[j + 1] = x;
+  }
+}
+
+static void nonlinear_processing(AspAecOracle* o, float* output, const float* noisePow) { /* core:852-1082 */
+  AspAecState* s = &o->st;
+  float efw[2][PART_LEN1], xfw[2][PART_LEN1], dfw[2][PART_LEN1];
+  float fft[PART_LEN2];
+  float cohde[PART_LEN1], cohxd[PART_LEN1], hNl[PART_LEN1];
+  float hNlPref[24];
+  float hNlDeAvg, hNlXdAvg, hNlFb = 0, hNlFbLow = 0;
+  const float prefBandQuant = 0.75f, prefBandQuantLow = 0.5f;
+  const int prefBandSize = 24 / o->mult, minPrefBand = 4 / o->mult;
+  static const float kMinOverDrive[3] = {1.0f, 2.0f, 5.0f}; /* kNormalMinOverDrive, core:108 */
+  static const float kTargetSupp[3] = {-6.9f, -11.5f, -18.4f}; /* core:104 */
+  static const float kCoef[2][2] = {{0.9f, 0.1f}, {0.93f, 0.07f}}; /* core:111-112 */
+  const float* gc = kCoef[o->mult - 1];
+  const int delayEstInterval = 10 * o->mult;
+  float* xfw_raw = &s->xfwBuf[0][0];
+  float sdSum = 0, seSum = 0;
+  int i;
+
+  s->delayEstCtr++;
+  if (s->delayEstCtr == delayEstInterval) s->delayEstCtr = 0;
+
+  /* partition 0 of xfwBuf was filled by process_block (core:886-891) */
+
+  /* SubbandCoherence, core:411-449 */
+  if (s->delayEstCtr == 0) s->delayIdx = partition_delay(s);
+  memcpy(xfw, xfw_raw + (size_t)s->delayIdx * 2 * PART_LEN1, sizeof xfw);
+  memcpy(fft, s->dBuf, sizeof fft);
+  window128(fft);
+  asp_aec_oracle_rdft128(fft, 1);
+  dfw[0][0] = fft[0]; /* StoreAsComplex, core:398-409 */
+  dfw[1][0] = 0;
+  for (i = 1; i < PART_LEN; i++) {
+    dfw[0][i] = fft[2 * i];
+    dfw[1][i] = fft[2 * i + 1];
+  }
+  dfw[0][PART_LEN] = fft[1];
+  dfw[1][PART_LEN] = 0;
+  memcpy(fft, s->eBuf, sizeof fft);
+  window128(fft);
+  asp_aec_oracle_rdft128(fft, 1);
+  efw[0][0] = fft[0];
+  efw[1][0] = 0;
+  for (i = 1; i < PART_LEN; i++) {
+    efw[0][i] = fft[2 * i];
+    efw[1][i] = fft[2 * i + 1];
+  }
+  efw[0][PART_LEN] = fft[1];
+  efw[1][PART_LEN] = 0;
+
+  /* SmoothedPSD, core:332-385 */
+  for (i = 0; i < PART_LEN1; i++) {
+    float xx;
+    s->sd[i] = gc[0] * s->sd[i] + gc[1] * (dfw[0][i] * dfw[0][i] + dfw[1][i] * dfw[1][i]);
+    s->se[i] = gc[0] * s->se[i] + gc[1] * (efw[0][i] * efw[0][i] + efw[1][i] * efw[1][i]);
+    xx = xfw[0][i] * xfw[0][i] + xfw[1][i] * xfw[1][i];
+    s->sx[i] = gc[0] * s->sx[i] + gc[1] * (xx > 15 ? xx : 15); /* WebRtcAec_kMinFarendPSD */
+    s->sde[i][0] = gc[0] * s->sde[i][0] + gc[1] * (dfw[0][i] * efw[0][i] + dfw[1][i] * efw[1][i]);
+    s->sde[i][1] = gc[0] * s->sde[i][1] + gc[1] * (dfw[0][i] * efw[1][i] - dfw[1][i] * efw[0][i]);
+    s->sxd[i][0] = gc[0] * s->sxd[i][0] + gc[1] * (dfw[0][i] * xfw[0][i] + dfw[1][i] * xfw[1][i]);
+    s->sxd[i][1] = gc[0] * s->sxd[i][1] + gc[1] * (dfw[0][i] * xfw[1][i] - dfw[1][i] * xfw[0][i]);
+    sdSum += s->sd[i];
+    seSum += s->se[i];
+  }
+  s->divergeState = (s->divergeState ? 1.05f : 1.0f) * seSum > sdSum;
+  if (s->divergeState) memcpy(efw, dfw, sizeof efw);
+  if (seSum > (19.95f * sdSum)) memset(s->wfBuf, 0, sizeof s->wfBuf);
+
+  for (i = 0; i < PART_LEN1; i++) { /* core:439-448 */
+    cohde[i] = (s->sde[i][0] * s->sde[i][0] + s->sde[i][1] * s->sde[i][1]) / (s->sd[i] * s->se[i] + 1e-10f);
+    cohxd[i] = (s->sxd[i][0] * s->sxd[i][0] + s->sxd[i][1] * s->sxd[i][1]) / (s->sx[i] * s->sd[i] + 1e-10f);
+  }
+
+  hNlXdAvg = 0; /* core:895-907 */
+  for (i = minPrefBand; i < prefBandSize + minPrefBand; i++) hNlXdAvg += cohxd[i];
+  hNlXdAvg /= prefBandSize;
+  hNlXdAvg = 1 - hNlXdAvg;
+  hNlDeAvg = 0;
+  for (i = minPrefBand; i < prefBandSize + minPrefBand; i++) hNlDeAvg += cohde[i];
+  hNlDeAvg /= prefBandSize;
+
+  if (hNlXdAvg < 0.75f && hNlXdAvg < s->hNlXdAvgMin) s->hNlXdAvgMin = hNlXdAvg;
+  if (hNlDeAvg > 0.98f && hNlXdAvg > 0.9f) {
+    s->stNearState = 1;
+  } else if (hNlDeAvg < 0.95f || hNlXdAvg < 0.8f) {
+    s->stNearState = 0;
+  }
+
+  if (s->hNlXdAvgMin == 1) { /* core:919-935 */
+    s->echoState = 0;
+    s->overDrive = kMinOverDrive[o->nlp_mode];
+    if (s->stNearState == 1) {
+      memcpy(hNl, cohde, sizeof hNl);
+      hNlFb = hNlDeAvg;
+      hNlFbLow = hNlDeAvg;
+    } else {
+      for (i = 0; i < PART_LEN1; i++) hNl[i] = 1 - cohxd[i];
+      hNlFb = hNlXdAvg;
+      hNlFbLow = hNlXdAvg;
+    }
+  } else { /* core:936-960 */
+    if (s->stNearState == 1) {
+      s->echoState = 0;
+      memcpy(hNl, cohde, sizeof hNl);
+      hNlFb = hNlDeAvg;
+      hNlFbLow = hNlDeAvg;
+    } else {
+      s->echoState = 1;
+      for (i = 0; i < PART_LEN1; i++) {
+        const float a = cohde[i], b = 1 - cohxd[i];
+        hNl[i] = a < b ? a : b;
+      }
+      memcpy(hNlPref, &hNl[minPrefBand], sizeof(float) * prefBandSize);
+      sort_floats(hNlPref, prefBandSize);
+      hNlFb = hNlPref[(int)floor(prefBandQuant * (prefBandSize - 1))];
+      hNlFbLow = hNlPref[(int)floor(prefBandQuantLow * (prefBandSize - 1))];
+    }
+  }
+
+  /* core:962-992 */
+  if (hNlFbLow < 0.6f && hNlFbLow < s->hNlFbLocalMin) {
+    s->hNlFbLocalMin = hNlFbLow;
+    s->hNlFbMin = hNlFbLow;
+    s->hNlNewMin = 1;
+    s->hNlMinCtr = 0;
+  }
+  {
+    const float a = s->hNlFbLocalMin + 0.0008f / o->mult;
+    const float b = s->hNlXdAvgMin + 0.0006f / o->mult;
+    s->hNlFbLocalMin = a < 1 ? a : 1;
+    s->hNlXdAvgMin = b < 1 ? b : 1;
+  }
+  if (s->hNlNewMin == 1) s->hNlMinCtr++;
+  if (s->hNlMinCtr == 2) {
+    float v;
+    s->hNlNewMin = 0;
+    s->hNlMinCtr = 0;
+    v = kTargetSupp[o->nlp_mode] / ((float)log(s->hNlFbMin + 1e-10f) + 1e-10f);
+    s->overDrive = v > kMinOverDrive[o->nlp_mode] ? v : kMinOverDrive[o->nlp_mode];
+  }
+  if (s->overDrive < s->overDriveSm) {
+    s->overDriveSm = 0.99f * s->overDriveSm + 0.01f * s->overDrive;
+  } else {
+    s->overDriveSm = 0.9f * s->overDriveSm + 0.1f * s->overDrive;
+  }
+
+  /* OverdriveAndSuppress, core:271-292 */
+  for (i = 0; i < PART_LEN1; i++) {
+    if (hNl[i] > hNlFb) hNl[i] = g_weight[i] * hNlFb + (1 - g_weight[i]) * hNl[i];
+    hNl[i] = powf(hNl[i], s->overDriveSm * g_odrive[i]);
+    efw[0][i] *= hNl[i];
+    efw[1][i] *= hNl[i];
+    efw[1][i] *= -1;
+  }
+
+  /* ComfortNoise (one band), core:461-500 */
+  {
+    float rnd[PART_LEN];
+    float u[PART_LEN1][2];
+    const float pi2 = 6.28318530717959f;
+    for (i = 0; i < PART_LEN; i++) { /* WebRtcSpl_RandUArray, randomization_functions.c:93-115 */
+      s->seed = (s->seed * 69069u + 1u) & 0x7fffffffu;
+      rnd[i] = ((float)(int16_t)(s->seed >> 16)) / 32768;
+    }
+    u[0][0] = 0;
+    u[0][1] = 0;
+    for (i = 1; i < PART_LEN1; i++) {
+      const float tmp = pi2 * rnd[i - 1];
+      const float noise = sqrtf(noisePow[i]);
+      u[i][0] = noise * cosf(tmp);
+      u[i][1] = -noise * sinf(tmp);
+    }
+    u[PART_LEN][1] = 0;
+    for (i = 0; i < PART_LEN1; i++) {
+      const float r = 1 - hNl[i] * hNl[i];
+      const float tmp = sqrtf(r > 0 ? r : 0);
+      efw[0][i] += tmp * u[i][0];
+      efw[1][i] += tmp * u[i][1];
+    }
+  }
+
+  /* inverse error fft, overlap-add, saturate: core:1006-1030 */
+  fft[0] = efw[0][0];
+  fft[1] = efw[0][PART_LEN];
+  for (i = 1; i < PART_LEN; i++) {
+    fft[2 * i] = efw[0][i];
+    fft[2 * i + 1] = -efw[1][i];
+  }
+  asp_aec_oracle_rdft128(fft, -1);
+  {
+    const float scale = 2.0f / PART_LEN2;
+    for (i = 0; i < PART_LEN; i++) {
+      float v;
+      fft[i] *= scale;
+      fft[i] = fft[i] * g_hann[i] + s->outBuf[i];
+      fft[PART_LEN + i] *= scale;
+      s->outBuf[i] = fft[PART_LEN + i] * g_hann[PART_LEN - i];
+      v = fft[i];
+      output[i] = v > 32767 ? 32767 : (v < -32768 ? -32768 : v); /* WEBRTC_SPL_SAT */
+    }
+  }
+
+  /* core:1069-1081 */
+  memcpy(s->dBuf, s->dBuf + PART_LEN, sizeof(float) * PART_LEN);
+  memcpy(s->eBuf, s->eBuf + PART_LEN, sizeof(float) * PART_LEN);
+  memmove(xfw_raw + 2 * PART_LEN1, xfw_raw, sizeof(float) * 2 * PART_LEN1 * (NPART - 1));
+}
+
+static void process_block(AspAecOracle* o) { /* core:1084-1287 */
+  AspAecState* s = &o->st;
+  float fft[PART_LEN2];
+  float xf[2][PART_LEN1], yf[2][PART_LEN1], ef[2][PART_LEN1], df[2][PART_LEN1];
+  float nearend[PART_LEN], y[PART_LEN], e[PART_LEN], output[PART_LEN];
+  const float gPow[2] = {0.9f, 0.1f};
+  const int noiseInitBlocks = 500 * o->mult;
+  const float step = 0.1f, ramp = 1.0002f;
+  const float gInitNoise[2] = {0.999f, 0.001f};
+  const float* noisePow = s->dMinPow;
+  int i;
+
+  ring_read(&o->near_pos, o->nearfr, 1, nearend, PART_LEN);
+  memcpy(s->dBuf + PART_LEN, nearend, sizeof nearend);
+
+  /* one element of far_buf now and the same element of far_buf_windowed in the NLP
+   * (core:1137, 888): both rings move in lock-step, so read both here */
+  {
+    RingPos keep = o->far_pos;
+    ring_read(&keep, &o->far[0][0], 2 * PART_LEN1, &xf[0][0], 1);
+  }
+  {
+    float xfw_now[2 * PART_LEN1];
+    ring_read(&o->far_pos, &o->farw[0][0], 2 * PART_LEN1, xfw_now, 1);
+    memcpy(&s->xfwBuf[0][0], xfw_now, sizeof xfw_now); /* core:891 */
+  }
+
+  memcpy(fft, s->dBuf, sizeof fft); /* near fft, core:1140-1141 */
+  asp_aec_oracle_rdft128(fft, 1);
+  unpack_spectrum(fft, df);
+
+  for (i = 0; i < PART_LEN1; i++) { /* core:1144-1156 */
+    const float far_spectrum = (xf[0][i] * xf[0][i]) + (xf[1][i] * xf[1][i]);
+    const float near_spectrum = df[0][i] * df[0][i] + df[1][i] * df[1][i];
+    s->xPow[i] = gPow[0] * s->xPow[i] + gPow[1] * NPART * far_spectrum;
+    s->dPow[i] = gPow[0] * s->dPow[i] + gPow[1] * near_spectrum;
+  }
+  if (s->noiseEstCtr > 50) { /* core:1159-1168 */
+    for (i = 0; i < PART_LEN1; i++) {
+      if (s->dPow[i] < s->dMinPow[i]) {
+        s->dMinPow[i] = (s->dPow[i] + step * (s->dMinPow[i] - s->dPow[i])) * ramp;
+      } else {
+        s->dMinPow[i] *= ramp;
+      }
+    }
+  }
+  if (s->noiseEstCtr < noiseInitBlocks) { /* core:1172-1186 */
+    noisePow = s->dInitMinPow;
+    s->noiseEstCtr++;
+    for (i = 0; i < PART_LEN1; i++) {
+      if (s->dMinPow[i] > s->dInitMinPow[i]) {
+        s->dInitMinPow[i] = gInitNoise[0] * s->dInitMinPow[i] + gInitNoise[1] * s->dMinPow[i];
+      } else {
+        s->dInitMinPow[i] = s->dMinPow[i];
+      }
+    }
+  }
+
+  s->xfBufBlockPos--; /* core:1203-1214 */
+  if (s->xfBufBlockPos == -1) s->xfBufBlockPos = NPART - 1;
+  memcpy(s->xfBuf[0] + s->xfBufBlockPos * PART_LEN1, xf[0], sizeof(float) * PART_LEN1);
+  memcpy(s->xfBuf[1] + s->xfBufBlockPos * PART_LEN1, xf[1], sizeof(float) * PART_LEN1);
+
+  memset(yf, 0, sizeof yf);
+  for (i = 0; i < NPART; i++) { /* FilterFar, core:147-169 */
+    int xPos = (i + s->xfBufBlockPos) * PART_LEN1;
+    const int pos = i * PART_LEN1;
+    if (i + s->xfBufBlockPos >= NPART) xPos -= NPART * PART_LEN1;
+    for (int j = 0; j < PART_LEN1; j++) {
+      yf[0][j] += s->xfBuf[0][xPos + j] * s->wfBuf[0][pos + j] - s->xfBuf[1][xPos + j] * s->wfBuf[1][pos + j];
+      yf[1][j] += s->xfBuf[0][xPos + j] * s->wfBuf[1][pos + j] + s->xfBuf[1][xPos + j] * s->wfBuf[0][pos + j];
+    }
+  }
+
+  fft[0] = yf[0][0]; /* core:1222-1238 */
+  fft[1] = yf[0][PART_LEN];
+  for (i = 1; i < PART_LEN; i++) {
+    fft[2 * i] = yf[0][i];
+    fft[2 * i + 1] = yf[1][i];
+  }
+  asp_aec_oracle_rdft128(fft, -1);
+  {
+    const float scale = 2.0f / PART_LEN2;
+    for (i = 0; i < PART_LEN; i++) y[i] = fft[PART_LEN + i] * scale;
+  }
+  for (i = 0; i < PART_LEN; i++) e[i] = nearend[i] - y[i];
+
+  memcpy(s->eBuf + PART_LEN, e, sizeof e); /* error fft, core:1241-1254 */
+  memset(fft, 0, sizeof(float) * PART_LEN);
+  memcpy(fft + PART_LEN, e, sizeof e);
+  asp_aec_oracle_rdft128(fft, 1);
+  unpack_spectrum(fft, ef);
+
+  { /* ScaleErrorSignal, core:171-193 */
+    const float mu = o->normal_mu, error_threshold = o->normal_error_threshold;
+    for (i = 0; i < PART_LEN1; i++) {
+      float abs_ef;
+      ef[0][i] /= (s->xPow[i] + 1e-10f);
+      ef[1][i] /= (s->xPow[i] + 1e-10f);
+      abs_ef = sqrtf(ef[0][i] * ef[0][i] + ef[1][i] * ef[1][i]);
+      if (abs_ef > error_threshold) {
+        abs_ef = error_threshold / (abs_ef + 1e-10f);
+        ef[0][i] *= abs_ef;
+        ef[1][i] *= abs_ef;
+      }
+      ef[0][i] *= mu;
+      ef[1][i] *= mu;
+    }
+  }
+
+  for (i = 0; i < NPART; i++) { /* FilterAdaptation, core:221-269 */
+    int xPos = (i + s->xfBufBlockPos) * PART_LEN1;
+    const int pos = i * PART_LEN1;
+    int j;
+    if (i + s->xfBufBlockPos >= NPART) xPos -= NPART * PART_LEN1;
+    for (j = 0; j < PART_LEN; j++) {
+      const float aRe = s->xfBuf[0][xPos + j], aIm = -s->xfBuf[1][xPos + j];
+      fft[2 * j] = aRe * ef[0][j] - aIm * ef[1][j];
+      fft[2 * j + 1] = aRe * ef[1][j] + aIm * ef[0][j];
+    }
+    {
+      const float aRe = s->xfBuf[0][xPos + PART_LEN], aIm = -s->xfBuf[1][xPos + PART_LEN];
+      fft[1] = aRe * ef[0][PART_LEN] - aIm * ef[1][PART_LEN];
+    }
+    asp_aec_oracle_rdft128(fft, -1);
+    memset(fft + PART_LEN, 0, sizeof(float) * PART_LEN);
+    {
+      const float scale = 2.0f / PART_LEN2;
+      for (j = 0; j < PART_LEN; j++) fft[j] *= scale;
+    }
+    asp_aec_oracle_rdft128(fft, 1);
+    s->wfBuf[0][pos] += fft[0];
+    s->wfBuf[0][pos + PART_LEN] += fft[1];
+    for (j = 1; j < PART_LEN; j++) {
+      s->wfBuf[0][pos + j] += fft[2 * j];
+      s->wfBuf[1][pos + j] += fft[2 * j + 1];
+    }
+  }
+
+  nonlinear_processing(o, output, noisePow);
+  ring_write(&o->out_pos, o->outfr, 1, output, PART_LEN); /* core:1276 */
+  o->blocks_processed++;
+}
+
+/* ------------------------------------------------------------ frame plumbing */
+static void process_frames(AspAecOracle* o, const float* nearend, int num_samples, int knownDelay,
+                           float* out) { /* WebRtcAec_ProcessFrames, core:1647-1778 */
+  for (int j = 0; j < num_samples; j += FRAME_LEN) {
+    int out_elements;
+    ring_write(&o->near_pos, o->nearfr, 1, nearend + j, FRAME_LEN);
+    if (o->system_delay < FRAME_LEN) far_move_read(o, -(o->mult + 1));
+    {
+      const int move_elements = (o->core_knownDelay - knownDelay - 32) / PART_LEN;
+      const int moved_elements = rp_move_read(&o->far_pos, move_elements);
+      o->core_knownDelay -= moved_elements * PART_LEN;
+    }
+    while (rp_avail_read(&o->near_pos) >= PART_LEN) process_block(o);
+    o->system_delay -= FRAME_LEN;
+    out_elements = rp_avail_read(&o->out_pos);
+    if (out_elements < FRAME_LEN) rp_move_read(&o->out_pos, out_elements - FRAME_LEN);
+    ring_read(&o->out_pos, o->outfr, 1, out + j, FRAME_LEN);
+  }
+}
+
+static void est_buf_delay_normal(AspAecOracle* o) { /* EstBufDelayNormal, ec:816-867 */
+  const int nSampSndCard = o->msInSndCardBuf * kSampMsNb * o->rate_factor;
+  int current_delay = nSampSndCard - o->system_delay;
+  int delay_difference;
+  current_delay += FRAME_LEN * o->rate_factor;
+  if (current_delay < PART_LEN) current_delay += far_move_read(o, 1) * PART_LEN;
+  o->filtDelay = o->filtDelay < 0 ? 0 : o->filtDelay;
+  {
+    const int16_t v = (int16_t)(0.8 * o->filtDelay + 0.2 * current_delay);
+    o->filtDelay = v > 0 ? v : 0;
+  }
+  delay_difference = o->filtDelay - o->knownDelay;
+  if (delay_difference > 224) {
+    if (o->lastDelayDiff < 96) {
+      o->timeForDelayChange = 0;
+    } else {
+      o->timeForDelayChange++;
+    }
+  } else if (delay_difference < 96 && o->knownDelay > 0) {
+    if (o->lastDelayDiff > 224) {
+      o->timeForDelayChange = 0;
+    } else {
+      o->timeForDelayChange++;
+    }
+  } else {
+    o->timeForDelayChange = 0;
+  }
+  o->lastDelayDiff = (int16_t)delay_difference;
+  if (o->timeForDelayChange > 25) {
+    const int v = (int)o->filtDelay - 160;
+    o->knownDelay = v > 0 ? v : 0;
+  }
+}
+
+int asp_aec_oracle_buffer_farend(AspAecOracle* o, const float* farend, int nrOfSamples) { /* ec:278-339 */
+  if (farend == NULL) {
+    o->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (o->initFlag != kInitCheck) {
+    o->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  if (nrOfSamples != 80 && nrOfSamples != 160) {
+    o->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  o->farend_started = 1;
+  o->system_delay += nrOfSamples;
+  ring_write(&o->pre_pos, o->pre, 1, farend, nrOfSamples);
+  while (rp_avail_read(&o->pre_pos) >= PART_LEN2) {
+    float tmp[PART_LEN2];
+    ring_read(&o->pre_pos, o->pre, 1, tmp, PART_LEN2);
+    buffer_farend_partition(o, tmp);
+    rp_move_read(&o->pre_pos, -PART_LEN);
+  }
+  return 0;
+}
+
+static int process_normal(AspAecOracle* o, const float* nearend, float* out, int nrOfSamples,
+                          int16_t msInSndCardBuf) { /* ProcessNormal, ec:594-742 */
+  const int nBlocks10ms = nrOfSamples / (FRAME_LEN * o->rate_factor);
+  msInSndCardBuf = msInSndCardBuf > kMaxTrustedDelayMs ? kMaxTrustedDelayMs : msInSndCardBuf;
+  msInSndCardBuf += 10;
+  o->msInSndCardBuf = msInSndCardBuf;
+  if (o->startup_phase) {
+    if (nearend != out) memcpy(out, nearend, sizeof(float) * nrOfSamples);
+    if (o->checkBuffSize) {
+      double lim;
+      o->checkBufSizeCtr++;
+      if (o->counter == 0) {
+        o->firstVal = o->msInSndCardBuf;
+        o->sum = 0;
+      }
+      lim = 0.2 * o->msInSndCardBuf;
+      if (lim < kSampMsNb) lim = kSampMsNb;
+      if (abs(o->firstVal - o->msInSndCardBuf) < lim) {
+        o->sum += o->msInSndCardBuf;
+        o->counter++;
+      } else {
+        o->counter = 0;
+      }
+      if (o->counter * nBlocks10ms >= 6) {
+        const int v = (3 * o->sum * o->rate_factor * 8) / (4 * o->counter * PART_LEN);
+        o->bufSizeStart = v < kMaxBufSizeStart ? v : kMaxBufSizeStart;
+        o->checkBuffSize = 0;
+      }
+      if (o->checkBufSizeCtr * nBlocks10ms > 50) {
+        const int v = (o->msInSndCardBuf * o->rate_factor * 3) / 40;
+        o->bufSizeStart = v < kMaxBufSizeStart ? v : kMaxBufSizeStart;
+        o->checkBuffSize = 0;
+      }
+    }
+    if (!o->checkBuffSize) {
+      const int overhead_elements = o->system_delay / PART_LEN - o->bufSizeStart;
+      if (overhead_elements == 0) {
+        o->startup_phase = 0;
+      } else if (overhead_elements > 0) {
+        far_move_read(o, overhead_elements);
+        o->startup_phase = 0;
+      }
+    }
+  } else {
+    est_buf_delay_normal(o);
+    process_frames(o, nearend, nrOfSamples, o->knownDelay, out);
+  }
+  return 0;
+}
+
+int asp_aec_oracle_process(AspAecOracle* o, const float* nearend, float* out, int nrOfSamples,
+                           int msInSndCardBuf, int32_t skew) { /* WebRtcAec_Process, ec:341-408 */
+  int retVal = 0;
+  (void)skew;
+  if (out == NULL) {
+    o->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (o->initFlag != kInitCheck) {
+    o->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  if (nrOfSamples != 80 && nrOfSamples != 160) {
+    o->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  if (msInSndCardBuf < 0) {
+    msInSndCardBuf = 0;
+    o->lastError = AEC_BAD_PARAMETER_WARNING;
+    retVal = -1;
+  } else if (msInSndCardBuf > kMaxTrustedDelayMs) {
+    o->lastError = AEC_BAD_PARAMETER_WARNING;
+    retVal = -1;
+  }
+  if (process_normal(o, nearend, out, nrOfSamples, (int16_t)msInSndCardBuf) != 0) retVal = -1;
+  return retVal;
+}
+
+int asp_aec_oracle_echo_status(const AspAecOracle* o) { return o->st.echoState; }
+int asp_aec_oracle_error_code(const AspAecOracle* o) { return o->lastError; }
+
+void asp_aec_oracle_export(const AspAecOracle* o, AspAecState* st, AspAecControl* c) {
+  if (st) *st = o->st;
+  if (c) {
+    c->startup_phase = o->startup_phase;
+    c->checkBuffSize = o->checkBuffSize;
+    c->bufSizeStart = o->bufSizeStart;
+    c->knownDelay = o->knownDelay;
+    c->filtDelay = o->filtDelay;
+    c->timeForDelayChange = o->timeForDelayChange;
+    c->lastDelayDiff = o->lastDelayDiff;
+    c->counter = o->counter;
+    c->sum = o->sum;
+    c->firstVal = o->firstVal;
+    c->checkBufSizeCtr = o->checkBufSizeCtr;
+    c->system_delay = o->system_delay;
+    c->core_knownDelay = o->core_knownDelay;
+    c->far_read = o->far_pos.read;
+    c->far_write = o->far_pos.write;
+    c->far_wrap = o->far_pos.wrap;
+    c->pre_read = o->pre_pos.read;
+    c->pre_write = o->pre_pos.write;
+    c->pre_wrap = o->pre_pos.wrap;
+    c->near_read = o->near_pos.read;
+    c->near_write = o->near_pos.write;
+    c->near_wrap = o->near_pos.wrap;
+    c->out_read = o->out_pos.read;
+    c->out_write = o->out_pos.write;
+    c->out_wrap = o->out_pos.wrap;
+    c->blocks_processed = o->blocks_processed;
+  }
+}
+
+void asp_aec_oracle_import(AspAecOracle* o, const AspAecState* st) { o->st = *st; }
+
+int asp_aec_oracle_run(AspAecOracle* o, const float* far, const float* near, float* out, int F,
+                       int n, int delay_ms) {
+  int rc = 0;
+  for (int f = 0; f < F; ++f) {
+    rc |= asp_aec_oracle_buffer_farend(o, far + (size_t)f * n, n);
+    rc |= asp_aec_oracle_process(o, near + (size_t)f * n, out + (size_t)f * n, n, delay_ms, 0);
+  }
+  return rc;
+}
+
+/* ---------------------------------------------------------------- threaded */
+typedef struct Shard {
+  int s0, s1, S, F, n, delay_ms, rc;
+  int32_t fs;
+  const float *far, *near;
+  float* out;
+} Shard;
+
+static void* shard_main(void* p) {
+  Shard* sh = (Shard*)p;
+  for (int s = sh->s0; s < sh->s1; ++s) {
+    AspAecOracle* o = asp_aec_oracle_create();
+    if (!o || asp_aec_oracle_init(o, sh->fs, 48000) != 0) {
+      sh->rc = -1;
+      asp_aec_oracle_free(o);
+      return NULL;
+    }
+    for (int f = 0; f < sh->F; ++f) {
+      const size_t off = ((size_t)f * sh->S + s) * sh->n;
+      asp_aec_oracle_buffer_farend(o, sh->far + off, sh->n);
+      asp_aec_oracle_process(o, sh->near + off, sh->out + off, sh->n, sh->delay_ms, 0);
+    }
+    asp_aec_oracle_free(o);
+  }
+  return NULL;
+}
+
+int asp_aec_oracle_run_mt(int num_streams, const float* far, const float* near, float* out, int F,
+                          int n, int delay_ms, int32_t fs, int threads) {
+  pthread_t tid[256];
+  Shard sh[256];
+  int rc = 0;
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  if (threads > num_streams) threads = num_streams;
+  for (int t = 0; t < threads; ++t) {
+    sh[t].s0 = (int)((long long)num_streams * t / threads);
+    sh[t].s1 = (int)((long long)num_streams * (t + 1) / threads);
+    sh[t].S = num_streams;
+    sh[t].F = F;
+    sh[t].n = n;
+    sh[t].delay_ms = delay_ms;
+    sh[t].fs = fs;
+    sh[t].far = far;
+    sh[t].near = near;
+    sh[t].out = out;
+    sh[t].rc = 0;
+    pthread_create(&tid[t], NULL, shard_main, &sh[t]);
+  }
+  for (int t = 0; t < threads; ++t) {
+    pthread_join(tid[t], NULL);
+    rc |= sh[t].rc;
+  }
+  return rc;
+}

@@ -42,3 +42,90 @@ int ref_aec_run(void* h, const float* far, const float* near, float* out, int F,
   }
   return rc;
 }
+
+/* ---- state export for the parity tests (field copies only, no algorithm) ---- */
+#include "asp_aec.h"
+#include "webrtc/common_audio/ring_buffer.h"
+#include "webrtc/modules/audio_processing/aec/aec_core_internal.h"
+#include "webrtc/modules/audio_processing/aec/echo_cancellation_internal.h"
+
+int ref_aec_frame(void* h, const float* far, const float* near, float* out, int n,
+                  int16_t delay_ms) {
+  float nbuf[160], obuf[160];
+  const float* np[1] = {nbuf};
+  float* op[1] = {obuf};
+  int rc;
+  memcpy(nbuf, near, sizeof(float) * n);
+  rc = WebRtcAec_BufferFarend(h, far, (int16_t)n);
+  rc |= WebRtcAec_Process(h, np, 1, op, (int16_t)n, delay_ms, 0);
+  memcpy(out, obuf, sizeof(float) * n);
+  return rc;
+}
+
+int ref_aec_set_nlp(void* h, int mode) {
+  AecConfig c;
+  c.nlpMode = (int16_t)mode;
+  c.skewMode = kAecFalse;
+  c.metricsMode = kAecFalse;
+  c.delay_logging = kAecFalse;
+  return WebRtcAec_set_config(h, c);
+}
+
+void ref_aec_export(void* h, AspAecState* st, AspAecControl* c) {
+  const Aec* a = (const Aec*)h;
+  const AecCore* k = a->aec;
+  memset(st, 0, sizeof *st);
+  memcpy(st->dBuf, k->dBuf, sizeof st->dBuf);
+  memcpy(st->eBuf, k->eBuf, sizeof st->eBuf);
+  memcpy(st->xPow, k->xPow, sizeof st->xPow);
+  memcpy(st->dPow, k->dPow, sizeof st->dPow);
+  memcpy(st->dMinPow, k->dMinPow, sizeof st->dMinPow);
+  memcpy(st->dInitMinPow, k->dInitMinPow, sizeof st->dInitMinPow);
+  memcpy(st->xfBuf[0], k->xfBuf[0], sizeof st->xfBuf[0]);
+  memcpy(st->xfBuf[1], k->xfBuf[1], sizeof st->xfBuf[1]);
+  memcpy(st->wfBuf[0], k->wfBuf[0], sizeof st->wfBuf[0]);
+  memcpy(st->wfBuf[1], k->wfBuf[1], sizeof st->wfBuf[1]);
+  memcpy(st->sde, k->sde, sizeof st->sde);
+  memcpy(st->sxd, k->sxd, sizeof st->sxd);
+  memcpy(st->xfwBuf, k->xfwBuf, sizeof st->xfwBuf);
+  memcpy(st->sx, k->sx, sizeof st->sx);
+  memcpy(st->sd, k->sd, sizeof st->sd);
+  memcpy(st->se, k->se, sizeof st->se);
+  memcpy(st->outBuf, k->outBuf, sizeof st->outBuf);
+  st->hNlFbMin = k->hNlFbMin;
+  st->hNlFbLocalMin = k->hNlFbLocalMin;
+  st->hNlXdAvgMin = k->hNlXdAvgMin;
+  st->overDrive = k->overDrive;
+  st->overDriveSm = k->overDriveSm;
+  st->hNlNewMin = k->hNlNewMin;
+  st->hNlMinCtr = k->hNlMinCtr;
+  st->delayIdx = k->delayIdx;
+  st->stNearState = k->stNearState;
+  st->echoState = k->echoState;
+  st->divergeState = k->divergeState;
+  st->xfBufBlockPos = k->xfBufBlockPos;
+  st->noiseEstCtr = k->noiseEstCtr;
+  st->delayEstCtr = k->delayEstCtr;
+  st->seed = k->seed;
+  if (c) {
+    memset(c, 0, sizeof *c);
+    c->startup_phase = a->startup_phase;
+    c->checkBuffSize = a->checkBuffSize;
+    c->bufSizeStart = a->bufSizeStart;
+    c->knownDelay = a->knownDelay;
+    c->filtDelay = a->filtDelay;
+    c->timeForDelayChange = a->timeForDelayChange;
+    c->lastDelayDiff = a->lastDelayDiff;
+    c->counter = a->counter;
+    c->sum = a->sum;
+    c->firstVal = a->firstVal;
+    c->checkBufSizeCtr = a->checkBufSizeCtr;
+    c->system_delay = k->system_delay;
+    c->core_knownDelay = k->knownDelay;
+    /* ring positions are private to ring_buffer.c; the readable counts are the public view */
+    c->far_read = (int32_t)WebRtc_available_read(k->far_buf);
+    c->pre_read = (int32_t)WebRtc_available_read(a->far_pre_buf);
+    c->near_read = (int32_t)WebRtc_available_read(k->nearFrBuf);
+    c->out_read = (int32_t)WebRtc_available_read(k->outFrBuf);
+  }
+}

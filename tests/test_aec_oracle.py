@@ -1,22 +1,33 @@
-"""CPU suite: the AEC reference oracle (row c of SURVEY section 8) is pinned for the next round.
+"""CPU suite: the AEC oracle.
 
-No HIP AEC path exists yet; what is checked here is that the reference build under oracle/_ref
-reproduces the committed golden vectors bit for bit (so the fixture and its generator stay in
-sync) and that the fixture shows the behaviour the kernels will have to match."""
+oracle/aec_oracle.c is this repository's restatement of the reference AEC; it is PINNED here
+against (a) the reference build oracle/_ref/libaec_ref.so run live (when present: the build
+container), bit for bit on outputs, float state and control-plane integers, and (b) the committed
+golden vectors tests/golden/aec_golden.npz (outputs of that same reference build), which travel."""
+import os
+
 import numpy as np
 import pytest
 
+from audiosignalprocess_amd._abi import aec_state_arrays
+from audiosignalprocess_amd.synth import aec_frames
 from tests import oracle_lib
 
 needs_ref = pytest.mark.skipif(not oracle_lib.have_aec_ref(), reason="oracle/_ref/libaec_ref.so not built here")
 
+TABLES = [(0, "rdft_w", 64), (1, "rdft_wk3ri_first", 16), (2, "rdft_wk3ri_second", 16),
+          (3, "WebRtcAec_sqrtHanning", 65), (4, "WebRtcAec_weightCurve", 65),
+          (5, "WebRtcAec_overDriveCurve", 65)]
+
 
 @pytest.fixture(scope="module")
 def aec_golden():
-    import os
-
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     return dict(np.load(os.path.join(root, "tests", "golden", "aec_golden.npz")))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
 def test_golden_shapes_and_echo_suppression(aec_golden):
@@ -36,4 +47,134 @@ def test_reference_reproduces_golden_bitwise(aec_golden):
     far, near = aec_golden["far_i16"].astype(np.float32), aec_golden["near_i16"].astype(np.float32)
     for s in range(far.shape[1]):
         out = oracle_lib.RefAec().run(far[:, s], near[:, s])
-        assert np.array_equal(out.view(np.uint32), aec_golden["out_f32"][:, s].view(np.uint32))
+        assert np.array_equal(_bits(out), _bits(aec_golden["out_f32"][:, s]))
+
+
+def test_oracle_reproduces_golden_bitwise(aec_golden):
+    """The restatement against the reference's own outputs (travels to the GPU box)."""
+    far, near = aec_golden["far_i16"].astype(np.float32), aec_golden["near_i16"].astype(np.float32)
+    for s in range(far.shape[1]):
+        out = oracle_lib.OracleAec().run(far[:, s], near[:, s])
+        assert np.array_equal(_bits(out), _bits(aec_golden["out_f32"][:, s])), s
+
+
+def test_oracle_tables_known_values():
+    """Spot values of the generated tables against the decimal text of aec_rdft.c:32-61 and
+    aec_core.c:53-98 (data, quoted to the printed precision)."""
+    w = oracle_lib.aec_oracle_table(0, 64)
+    assert w[0] == 1.0 and w[1] == 0.0
+    assert abs(w[2] - 0.7071067691) < 1e-9 and abs(w[4] - 0.9238795638) < 1e-9
+    assert abs(w[32] - 0.7071067691) < 1e-9 and abs(w[33] - 0.4993977249) < 1e-9
+    assert abs(w[63] - 0.0245338380) < 1e-9
+    h = oracle_lib.aec_oracle_table(3, 65)
+    assert h[0] == 0.0 and h[64] == 1.0 and h[1] == np.float32(0.02454122852291)
+    assert oracle_lib.aec_oracle_table(4, 65)[2] == np.float32(0.1378)
+    assert oracle_lib.aec_oracle_table(5, 65)[1] == np.float32(1.1250)
+
+
+@needs_ref
+def test_oracle_tables_equal_reference_symbols():
+    ref = oracle_lib.RefAec()
+    for which, name, n in TABLES:
+        assert np.array_equal(_bits(oracle_lib.aec_oracle_table(which, n)), _bits(ref.table(name, n))), name
+
+
+def _fft_inputs():
+    rng = np.random.default_rng(3)
+    rows = [np.sin(np.arange(128, dtype=np.float32)),          # unittest_real_fft.cpp:29-31 style input
+            np.eye(1, 128, 0, dtype=np.float32)[0], np.ones(128, np.float32),
+            np.cos(np.pi * np.arange(128)).astype(np.float32)]
+    rows += list((rng.standard_normal((12, 128)) * 3000).astype(np.float32))
+    return np.stack(rows)
+
+
+@needs_ref
+def test_oracle_rdft128_equals_reference():
+    ref = oracle_lib.RefAec()   # Create() installs the plain-C function table (aec_rdft_init)
+    x = _fft_inputs()
+    for isgn in (1, -1):
+        assert np.array_equal(_bits(oracle_lib.aec_oracle_rdft128(x, isgn)), _bits(ref.rdft128(x, isgn)))
+
+
+def test_oracle_rdft128_against_numpy():
+    x = _fft_inputs()
+    X = oracle_lib.aec_oracle_rdft128(x, 1).astype(np.float64)
+    want = np.fft.rfft(x.astype(np.float64), axis=1)
+    scale = np.abs(want).max(axis=1)
+    # Ooura packing: a[0] = R0, a[1] = R64, a[2k] = Re, a[2k+1] = -Im of the textbook transform
+    assert np.abs(X[:, 0] - want[:, 0].real).max() <= 1e-5 * scale.max()
+    assert np.abs(X[:, 1] - want[:, 64].real).max() <= 1e-5 * scale.max()
+    assert (np.abs(X[:, 2::2] - want[:, 1:64].real).max(axis=1) <= 1e-6 * scale).all()
+    assert (np.abs(X[:, 3::2] + want[:, 1:64].imag).max(axis=1) <= 1e-6 * scale).all()
+    # inverse(forward(x)) * 2/128 == x
+    back = oracle_lib.aec_oracle_rdft128(oracle_lib.aec_oracle_rdft128(x, 1), -1) * np.float32(2.0 / 128)
+    assert np.abs(back - x).max() <= 2e-6 * np.abs(x).max()
+
+
+def _compare_states(a, b):
+    sa, ca = a.export()
+    sb, cb = b.export()
+    da, db = aec_state_arrays(sa), aec_state_arrays(sb)
+    for k in da:
+        if isinstance(da[k], np.ndarray):
+            assert np.array_equal(_bits(da[k]), _bits(db[k])), k
+        else:
+            assert da[k] == db[k], k
+    for k in ("startup_phase", "checkBuffSize", "bufSizeStart", "knownDelay", "filtDelay",
+              "timeForDelayChange", "lastDelayDiff", "counter", "sum", "firstVal", "checkBufSizeCtr",
+              "system_delay", "core_knownDelay"):
+        assert getattr(ca, k) == getattr(cb, k), k
+    return ca, cb
+
+
+@needs_ref
+@pytest.mark.parametrize("fs,n,delay,nlp", [(16000, 160, 0, 1), (16000, 80, 40, 2), (8000, 80, 0, 0),
+                                             (16000, 160, 120, 1)])
+def test_oracle_equals_reference_live(fs, n, delay, nlp):
+    """Free-running, frame by frame: outputs, float state and control-plane integers bit-equal,
+    through the start-up phase, delay changes (incl. out-of-range reports) and both rates."""
+    F = 420
+    far, near = aec_frames(3, F * 160 // n if n == 80 else F)
+    far = far.reshape(-1, 3, 160)[:, 2].reshape(-1, n)[:F]
+    near = near.reshape(-1, 3, 160)[:, 2].reshape(-1, n)[:F]
+    ref, ora = oracle_lib.RefAec(fs), oracle_lib.OracleAec(fs)
+    assert ref.set_nlp(nlp) == 0 and ora.set_nlp(nlp) == 0
+    for f in range(F):
+        d = delay
+        if f in (200, 201):
+            d = 700        # > kMaxTrustedDelayMs: warning -1, still processes (echo_cancellation.c:367-375)
+        if f == 250:
+            d = -5         # negative: clamped to 0 with a warning
+        if 300 <= f < 360:
+            d = delay + 60  # a sustained change drives EstBufDelayNormal's knownDelay update
+        o_ref, rc_ref = ref.frame(far[f], near[f], d)
+        o_ora, rc_ora = ora.frame(far[f], near[f], d)
+        assert rc_ref == rc_ora, f
+        assert np.array_equal(_bits(o_ref), _bits(o_ora)), f
+        if f % 35 == 0 or f == F - 1:
+            ca, cb = _compare_states(ref, ora)
+            # the reference's ring positions are private; compare the readable counts
+            wrap = lambda r, w, wr, n_: (w - r) if wr == 0 else (n_ - r + w)
+            assert ca.far_read == wrap(cb.far_read, cb.far_write, cb.far_wrap, 250)
+            assert ca.pre_read == wrap(cb.pre_read, cb.pre_write, cb.pre_wrap, 448)
+            assert ca.near_read == wrap(cb.near_read, cb.near_write, cb.near_wrap, 144)
+            assert ca.out_read == wrap(cb.out_read, cb.out_write, cb.out_wrap, 144)
+
+
+def test_oracle_error_behaviour():
+    """Return codes and lastError of echo_cancellation.c:196-215,278-300,341-375,410-438."""
+    o = oracle_lib.OracleAec(16000)
+    z = np.zeros(160, np.float32)
+    out, rc = o.frame(z[:100], z[:100])
+    assert rc == -1 and o.error_code() == 12004
+    assert oracle_lib.OracleAec(44100).init_rc == -1
+    assert oracle_lib.OracleAec(16000, sc_fs=0).init_rc == -1
+    assert o.set_nlp(3) == -1 and o.error_code() == 12004
+    assert o.set_nlp(1, metrics=1) == -1 and o.error_code() == 12001   # outside the built configuration
+    assert o.set_nlp(2) == 0
+
+
+def test_oracle_threaded_runner_matches_single(aec_golden):
+    far, near = aec_golden["far_i16"][:120].astype(np.float32), aec_golden["near_i16"][:120].astype(np.float32)
+    out = oracle_lib.aec_oracle_run_mt(far, near, threads=2)
+    assert np.array_equal(_bits(out), _bits(aec_golden["out_f32"][:120]))
