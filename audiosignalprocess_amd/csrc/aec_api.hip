@@ -1,0 +1,1049 @@
+// aec_api.hip -- host side of include/asp_aec.h: constant tables, the batch handle with the
+// reference's integer control plane (echo_cancellation.c:196-409,594-742,816-867;
+// aec_core.c:1618-1778; ring positions of common_audio/ring_buffer.c) and the reference's
+// per-stream WebRtcAec_* symbols as a batch of one.  The control plane runs once per call for
+// the whole batch and turns every call into launch descriptors (aec_layout.h: FarOps /
+// ProcOps); all sample and spectrum data stays in HBM.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "aec_layout.h"
+#include "asp_aec.h"
+#include "asp_ns.h"
+
+using namespace aspaec;
+
+namespace aspaec {
+hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, const float* farend,
+                             int num_streams, const FarOps& ops, hipStream_t s);
+hipError_t launch_aec_process(float* state, const float* far_ring, const AecTables* T,
+                              const float* nearend, float* out, int num_streams, int nrOfSamples,
+                              const ProcOps& ops, hipStream_t s);
+hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
+                              hipStream_t s);
+}  // namespace aspaec
+
+namespace {
+
+thread_local char g_aec_err[512] = "";
+int aec_fail(int code, const char* what, hipError_t e = hipSuccess) {
+  if (e != hipSuccess)
+    snprintf(g_aec_err, sizeof g_aec_err, "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(g_aec_err, sizeof g_aec_err, "%s", what);
+  fprintf(stderr, "asp_aec: %s\n", g_aec_err);
+  return code;
+}
+#define AEC_TRY(expr)                                             \
+  do {                                                            \
+    hipError_t e_ = (expr);                                       \
+    if (e_ != hipSuccess) return aec_fail(ASP_ERR_HIP, #expr, e_); \
+  } while (0)
+
+// ------------------------------------------------------------------ tables
+// NOTE: C++ translation unit; every libm call casts to double explicitly so the arithmetic is
+// that of the reference's C (see ns_api.hip).
+unsigned bitrev(unsigned x, int bits) {
+  unsigned r = 0;
+  for (int b = 0; b < bits; ++b) r |= ((x >> b) & 1u) << (bits - 1 - b);
+  return r;
+}
+
+float via_text(double v, int decimals) {  // a table frozen as '%.<d>f' text and re-read as float
+  char buf[48];
+  snprintf(buf, sizeof buf, "%.*f", decimals, v);
+  return strtof(buf, nullptr);
+}
+
+void build_tables(AecTables* T) {
+  memset(T, 0, sizeof *T);
+  // Ooura makewt / makect for n = 128, the code the reference's frozen rdft_w came from
+  // (aec_rdft.c:29-49; utility/fft4g.c:642-690 is the same code)
+  float tmp[32];
+  const int nw = 32, nwh = 16, nc = 32, nch = 16;
+  float delta = (float)atan((double)1.0f) / nwh;
+  tmp[0] = 1;
+  tmp[1] = 0;
+  tmp[nwh] = (float)cos((double)(delta * nwh));
+  tmp[nwh + 1] = tmp[nwh];
+  for (int j = 2; j < nwh; j += 2) {
+    const float x = (float)cos((double)(delta * j));
+    const float y = (float)sin((double)(delta * j));
+    tmp[j] = x;
+    tmp[j + 1] = y;
+    tmp[nw - j] = y;
+    tmp[nw - j + 1] = x;
+  }
+  for (int j = 0; j < 16; ++j) {
+    const unsigned r = bitrev((unsigned)j, 4);
+    T->w[2 * j] = tmp[2 * r];
+    T->w[2 * j + 1] = tmp[2 * r + 1];
+  }
+  delta = (float)atan((double)1.0f) / nch;
+  T->w[32] = (float)cos((double)(delta * nch));
+  T->w[32 + nch] = 0.5f * T->w[32];
+  for (int j = 1; j < nch; j++) {
+    T->w[32 + j] = 0.5f * (float)cos((double)(delta * j));
+    T->w[32 + nc - j] = 0.5f * (float)sin((double)(delta * j));
+  }
+  {
+    // the frozen text differs from the evaluation above by one unit in the last place at eight
+    // entries (data of the reference, aec_rdft.c:32-49)
+    static const signed char nudge[8][2] = {{4, 1}, {7, 1}, {20, 1}, {27, 1},
+                                            {40, 1}, {41, -1}, {42, 1}, {47, 1}};
+    for (int k = 0; k < 8; ++k) {
+      int32_t bits;
+      memcpy(&bits, &T->w[nudge[k][0]], sizeof bits);
+      bits += nudge[k][1];
+      memcpy(&T->w[nudge[k][0]], &bits, sizeof bits);
+    }
+  }
+  for (int k1 = 0; k1 < 16; k1 += 2) {  // rdft_wk3ri_first / _second (aec_rdft.c:50-61)
+    const int k2 = 2 * k1;
+    const float wk2r = T->w[k1], wk2i = T->w[k1 + 1];
+    float wk1r = T->w[k2], wk1i = T->w[k2 + 1];
+    T->wk3a[k1] = wk1r - 2 * wk2i * wk1i;
+    T->wk3a[k1 + 1] = 2 * wk2i * wk1r - wk1i;
+    wk1r = T->w[k2 + 2];
+    wk1i = T->w[k2 + 3];
+    T->wk3b[k1] = wk1r - 2 * wk2r * wk1i;
+    T->wk3b[k1 + 1] = 2 * wk2r * wk1r - wk1i;
+  }
+  for (int k = 0; k <= 64; ++k) {  // aec_core.c:50-98
+    T->hann[k] = via_text(sin(M_PI * (double)k / 128.0), 14);
+    T->weight[k] = k == 0 ? 0.f : via_text(0.3 * sqrt((double)(k - 1) / 63.0) + 0.1, 4);
+    T->odrive[k] = via_text(sqrt((double)k / 64.0) + 1.0, 4);
+  }
+  uint32_t a = 1, c = 0;  // WebRtcSpl_RandU jump-ahead (randomization_functions.c:93-100)
+  for (int k = 0; k < 64; ++k) {
+    c = c * 69069u + 1u;
+    a = a * 69069u;
+    T->lcg_a[k] = a;
+    T->lcg_c[k] = c;
+  }
+}
+
+// ------------------------------------------------------------ ring positions
+struct RingPos {  // common_audio/ring_buffer.c:26-33 without the data
+  int read, write, wrap, count;
+};
+void rp_init(RingPos* r, int count) {
+  r->read = 0;
+  r->write = 0;
+  r->wrap = 0;
+  r->count = count;
+}
+int rp_avail_read(const RingPos* r) {
+  return r->wrap == 0 ? r->write - r->read : r->count - r->read + r->write;
+}
+int rp_avail_write(const RingPos* r) { return r->count - rp_avail_read(r); }
+int rp_move_read(RingPos* r, int n) {  // WebRtc_MoveReadPtr, ring_buffer.c:195-228
+  const int free_elements = rp_avail_write(r), readable = rp_avail_read(r);
+  int pos = r->read;
+  if (n > readable) n = readable;
+  if (n < -free_elements) n = -free_elements;
+  pos += n;
+  if (pos > r->count) {
+    pos -= r->count;
+    r->wrap = 0;
+  }
+  if (pos < 0) {
+    pos += r->count;
+    r->wrap = 1;
+  }
+  r->read = pos;
+  return n;
+}
+// WebRtc_WriteBuffer positions (ring_buffer.c:161-192): returns the elements written; *start is
+// the position the first element lands on (the device adds i modulo count).
+int rp_write(RingPos* r, int n, int* start) {
+  const int free_elements = rp_avail_write(r);
+  const int write_elements = free_elements < n ? free_elements : n;
+  int m = write_elements;
+  const int margin = r->count - r->write;
+  *start = r->write;
+  if (write_elements > margin) {
+    r->write = 0;
+    m -= margin;
+    r->wrap = 1;
+  }
+  r->write += m;
+  return write_elements;
+}
+// WebRtc_ReadBuffer positions (ring_buffer.c:112-158)
+int rp_read(RingPos* r, int n, int* start) {
+  const int readable = rp_avail_read(r);
+  const int read_elements = readable < n ? readable : n;
+  *start = r->read;
+  rp_move_read(r, read_elements);
+  return read_elements;
+}
+
+const int kInitCheck = 42;           // echo_cancellation.c:59
+const int kMaxTrustedDelayMs = 500;  // :53
+const int kMaxBufSizeStart = 62;     // :57
+const int kSampMsNb = 8;             // :58
+
+}  // namespace
+
+struct AspAecBatch {
+  int S = 0, device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  float* state = nullptr;     // [S][kStateDwords]
+  float* far_ring = nullptr;  // [kFarSlots][S][kFarSlotDwords]
+  AecTables* tables = nullptr;
+  float *stage_far = nullptr, *stage_near = nullptr, *stage_out = nullptr;  // [S][160]
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // Aec (echo_cancellation_internal.h:17-65)
+  int sampFreq = 0, scSampFreq = 0, splitSampFreq = 0, rate_factor = 0, initFlag = 0, lastError = 0;
+  int farend_started = 0, skewMode = 0;
+  int bufSizeStart = 0, knownDelay = 0, timeForDelayChange = 0, startup_phase = 0, checkBuffSize = 0, sum = 0;
+  int16_t counter = 0, firstVal = 0, checkBufSizeCtr = 0, msInSndCardBuf = 0, filtDelay = 0, lastDelayDiff = 0;
+  // integer part of AecCore (aec_core_internal.h:52-164)
+  int system_delay = 0, core_knownDelay = 0, mult = 0, nlp_mode = 1;
+  float normal_mu = 0.f, normal_error_threshold = 0.f;
+  int xf_pos = 0, xfw_head = 0, blocks_processed = 0;
+  RingPos pre_pos{}, far_pos{}, near_pos{}, out_pos{};
+};
+
+namespace {
+
+int far_move_read(AspAecBatch* b, int elements) {  // WebRtcAec_MoveFarReadPtr, aec_core.c:1637-1645
+  const int moved = rp_move_read(&b->far_pos, elements);
+  b->system_delay -= moved * kPartLen;
+  return moved;
+}
+
+size_t state_bytes(const AspAecBatch* b) { return (size_t)b->S * kStateDwords * sizeof(float); }
+size_t far_bytes(const AspAecBatch* b) {
+  return (size_t)kFarSlots * b->S * kFarSlotDwords * sizeof(float);
+}
+
+// ---- AspAecState <-> device block
+void pack_stream(const AspAecBatch* b, const AspAecState* s, float* blk) {
+  memset(blk, 0, kStateDwords * sizeof(float));
+  float* rows = blk + kOffRows;
+  auto put_row = [&](int r, const float* src) { memcpy(rows + r * kRow, src, 65 * sizeof(float)); };
+  put_row(R_XPOW, s->xPow);
+  put_row(R_DPOW, s->dPow);
+  put_row(R_DMINPOW, s->dMinPow);
+  put_row(R_DINITMINPOW, s->dInitMinPow);
+  put_row(R_SX, s->sx);
+  put_row(R_SD, s->sd);
+  put_row(R_SE, s->se);
+  for (int i = 0; i < 65; ++i) {
+    rows[R_SDE_RE * kRow + i] = s->sde[i][0];
+    rows[R_SDE_IM * kRow + i] = s->sde[i][1];
+    rows[R_SXD_RE * kRow + i] = s->sxd[i][0];
+    rows[R_SXD_IM * kRow + i] = s->sxd[i][1];
+  }
+  for (int a = 0; a < kNumPart; ++a) {  // logical age a: canonical (c + a) % 12 -> physical (h + a) % 12
+    const int pc = (s->xfBufBlockPos + a) % kNumPart, ph = (b->xf_pos + a) % kNumPart;
+    put_row(R_XF_RE + ph, s->xfBuf[0] + pc * 65);
+    put_row(R_XF_IM + ph, s->xfBuf[1] + pc * 65);
+  }
+  for (int i = 0; i < kNumPart; ++i) {
+    put_row(R_WF_RE + i, s->wfBuf[0] + i * 65);
+    put_row(R_WF_IM + i, s->wfBuf[1] + i * 65);
+  }
+  {
+    // canonical partition a >= 1 holds the block of age a - 1 (aec_core.c:1079-1081); physical
+    // age g sits at (xfw_head + g) % 12
+    const float* raw = &s->xfwBuf[0][0];
+    for (int a = 1; a < kNumPart; ++a) {
+      const int ph = (b->xfw_head + a - 1) % kNumPart;
+      put_row(R_XFW + 2 * ph, raw + a * 130);
+      put_row(R_XFW + 2 * ph + 1, raw + a * 130 + 65);
+    }
+  }
+  memcpy(blk + kOffDBuf, s->dBuf, 64 * sizeof(float));
+  memcpy(blk + kOffEBuf, s->eBuf, 64 * sizeof(float));
+  memcpy(blk + kOffOutBuf, s->outBuf, 64 * sizeof(float));
+  float* sc = blk + kOffScalars;
+  int32_t* sci = reinterpret_cast<int32_t*>(sc);
+  sc[S_HNLFBMIN] = s->hNlFbMin;
+  sc[S_HNLFBLOCALMIN] = s->hNlFbLocalMin;
+  sc[S_HNLXDAVGMIN] = s->hNlXdAvgMin;
+  sc[S_OVERDRIVE] = s->overDrive;
+  sc[S_OVERDRIVESM] = s->overDriveSm;
+  sci[S_HNLNEWMIN] = s->hNlNewMin;
+  sci[S_HNLMINCTR] = s->hNlMinCtr;
+  sci[S_DELAYIDX] = s->delayIdx;
+  sci[S_STNEARSTATE] = s->stNearState;
+  sci[S_ECHOSTATE] = s->echoState;
+  sci[S_DIVERGESTATE] = s->divergeState;
+  sci[S_NOISEESTCTR] = s->noiseEstCtr;
+  sci[S_DELAYESTCTR] = s->delayEstCtr;
+  reinterpret_cast<uint32_t*>(sc)[S_SEED] = s->seed;
+}
+
+void unpack_stream(const AspAecBatch* b, const float* blk, AspAecState* s) {
+  memset(s, 0, sizeof *s);
+  const float* rows = blk + kOffRows;
+  auto get_row = [&](int r, float* dst) { memcpy(dst, rows + r * kRow, 65 * sizeof(float)); };
+  get_row(R_XPOW, s->xPow);
+  get_row(R_DPOW, s->dPow);
+  get_row(R_DMINPOW, s->dMinPow);
+  get_row(R_DINITMINPOW, s->dInitMinPow);
+  get_row(R_SX, s->sx);
+  get_row(R_SD, s->sd);
+  get_row(R_SE, s->se);
+  for (int i = 0; i < 65; ++i) {
+    s->sde[i][0] = rows[R_SDE_RE * kRow + i];
+    s->sde[i][1] = rows[R_SDE_IM * kRow + i];
+    s->sxd[i][0] = rows[R_SXD_RE * kRow + i];
+    s->sxd[i][1] = rows[R_SXD_IM * kRow + i];
+  }
+  for (int i = 0; i < kNumPart; ++i) {
+    get_row(R_XF_RE + i, s->xfBuf[0] + i * 65);
+    get_row(R_XF_IM + i, s->xfBuf[1] + i * 65);
+    get_row(R_WF_RE + i, s->wfBuf[0] + i * 65);
+    get_row(R_WF_IM + i, s->wfBuf[1] + i * 65);
+  }
+  s->xfBufBlockPos = b->xf_pos;
+  {
+    float* raw = &s->xfwBuf[0][0];
+    for (int a = 0; a < kNumPart; ++a) {
+      const int ph = (b->xfw_head + (a == 0 ? 0 : a - 1)) % kNumPart;
+      get_row(R_XFW + 2 * ph, raw + a * 130);
+      get_row(R_XFW + 2 * ph + 1, raw + a * 130 + 65);
+    }
+  }
+  memcpy(s->dBuf, blk + kOffDBuf, 64 * sizeof(float));
+  memcpy(s->dBuf + 64, blk + kOffDBuf, 64 * sizeof(float));  // the copy left by aec_core.c:1070
+  memcpy(s->eBuf, blk + kOffEBuf, 64 * sizeof(float));
+  memcpy(s->eBuf + 64, blk + kOffEBuf, 64 * sizeof(float));
+  memcpy(s->outBuf, blk + kOffOutBuf, 64 * sizeof(float));
+  const float* sc = blk + kOffScalars;
+  const int32_t* sci = reinterpret_cast<const int32_t*>(sc);
+  s->hNlFbMin = sc[S_HNLFBMIN];
+  s->hNlFbLocalMin = sc[S_HNLFBLOCALMIN];
+  s->hNlXdAvgMin = sc[S_HNLXDAVGMIN];
+  s->overDrive = sc[S_OVERDRIVE];
+  s->overDriveSm = sc[S_OVERDRIVESM];
+  s->hNlNewMin = sci[S_HNLNEWMIN];
+  s->hNlMinCtr = sci[S_HNLMINCTR];
+  s->delayIdx = sci[S_DELAYIDX];
+  s->stNearState = sci[S_STNEARSTATE];
+  s->echoState = sci[S_ECHOSTATE];
+  s->divergeState = sci[S_DIVERGESTATE];
+  s->noiseEstCtr = sci[S_NOISEESTCTR];
+  s->delayEstCtr = sci[S_DELAYESTCTR];
+  s->seed = reinterpret_cast<const uint32_t*>(sc)[S_SEED];
+}
+
+void init_canonical(AspAecState* s) {  // WebRtcAec_InitAec float state, aec_core.c:1562-1610
+  memset(s, 0, sizeof *s);
+  for (int i = 0; i < 65; i++) s->dMinPow[i] = 1.0e6f;
+  for (int i = 0; i < 65; i++) s->sd[i] = 1;
+  for (int i = 0; i < 65; i++) s->sx[i] = 1;
+  s->hNlFbMin = 1;
+  s->hNlFbLocalMin = 1;
+  s->hNlXdAvgMin = 1;
+  s->overDrive = 2;
+  s->overDriveSm = 2;
+  s->seed = 777;
+}
+
+// WebRtcAec_BufferFarend control plane (echo_cancellation.c:278-339) -> launches on device data.
+int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n) {
+  b->farend_started = 1;
+  b->system_delay += n;
+  FarOps ops;
+  memset(&ops, 0, sizeof ops);
+  ops.n = rp_write(&b->pre_pos, n, &ops.wpos);
+  bool pending = true;
+  while (rp_avail_read(&b->pre_pos) >= kPartLen2) {
+    int rpos;
+    rp_read(&b->pre_pos, kPartLen2, &rpos);
+    if (rp_avail_write(&b->far_pos) < 1) far_move_read(b, 1);  // aec_core.c:1622-1625
+    int slot;
+    rp_write(&b->far_pos, 1, &slot);
+    if (slot >= kFarSlots) slot -= kFarSlots;
+    ops.rpos[ops.nparts] = rpos;
+    ops.slot[ops.nparts] = slot;
+    ops.nparts++;
+    rp_move_read(&b->pre_pos, -kPartLen);  // overlap, echo_cancellation.c:336
+    if (ops.nparts == 3) {
+      AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
+      memset(&ops, 0, sizeof ops);
+      pending = false;
+    }
+  }
+  if (pending || ops.nparts > 0)
+    AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
+  return 0;
+}
+
+void est_buf_delay_normal(AspAecBatch* b) {  // echo_cancellation.c:816-867
+  const int nSampSndCard = b->msInSndCardBuf * kSampMsNb * b->rate_factor;
+  int current_delay = nSampSndCard - b->system_delay;
+  current_delay += kFrameLen * b->rate_factor;
+  if (current_delay < kPartLen) current_delay += far_move_read(b, 1) * kPartLen;
+  b->filtDelay = b->filtDelay < 0 ? 0 : b->filtDelay;
+  {
+    const int16_t v = (int16_t)(0.8 * b->filtDelay + 0.2 * current_delay);
+    b->filtDelay = v > 0 ? v : 0;
+  }
+  const int delay_difference = b->filtDelay - b->knownDelay;
+  if (delay_difference > 224) {
+    if (b->lastDelayDiff < 96) {
+      b->timeForDelayChange = 0;
+    } else {
+      b->timeForDelayChange++;
+    }
+  } else if (delay_difference < 96 && b->knownDelay > 0) {
+    if (b->lastDelayDiff > 224) {
+      b->timeForDelayChange = 0;
+    } else {
+      b->timeForDelayChange++;
+    }
+  } else {
+    b->timeForDelayChange = 0;
+  }
+  b->lastDelayDiff = (int16_t)delay_difference;
+  if (b->timeForDelayChange > 25) {
+    const int v = (int)b->filtDelay - 160;
+    b->knownDelay = v > 0 ? v : 0;
+  }
+}
+
+// WebRtcAec_ProcessFrames control plane (aec_core.c:1647-1778) -> one launch.
+int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n) {
+  ProcOps ops;
+  memset(&ops, 0, sizeof ops);
+  ops.mult = b->mult;
+  ops.nlp_mode = b->nlp_mode;
+  ops.mu = b->normal_mu;
+  ops.error_threshold = b->normal_error_threshold;
+  for (int j = 0; j < n; j += kFrameLen) {
+    SubFrame& sf = ops.sub[ops.nsub++];
+    rp_write(&b->near_pos, kFrameLen, &sf.near_wpos);
+    if (b->system_delay < kFrameLen) far_move_read(b, -(b->mult + 1));
+    {
+      const int move_elements = (b->core_knownDelay - b->knownDelay - 32) / kPartLen;
+      const int moved_elements = rp_move_read(&b->far_pos, move_elements);
+      b->core_knownDelay -= moved_elements * kPartLen;
+    }
+    while (rp_avail_read(&b->near_pos) >= kPartLen) {
+      if (sf.nblocks >= 2) return aec_fail(ASP_ERR_STATE, "more than two blocks in one sub-frame");
+      BlockOp& op = sf.blk[sf.nblocks++];
+      rp_read(&b->near_pos, kPartLen, &op.near_rpos);
+      int slot;
+      rp_read(&b->far_pos, 1, &slot);
+      op.far_slot = slot >= kFarSlots ? slot - kFarSlots : slot;
+      b->xf_pos = b->xf_pos == 0 ? kNumPart - 1 : b->xf_pos - 1;  // aec_core.c:1203-1207
+      b->xfw_head = (b->xfw_head + kNumPart - 1) % kNumPart;
+      op.xf_pos = b->xf_pos;
+      op.xfw_head = b->xfw_head;
+      rp_write(&b->out_pos, kPartLen, &op.out_wpos);
+      b->blocks_processed++;
+    }
+    b->system_delay -= kFrameLen;
+    const int out_elements = rp_avail_read(&b->out_pos);
+    if (out_elements < kFrameLen) rp_move_read(&b->out_pos, out_elements - kFrameLen);
+    rp_read(&b->out_pos, kFrameLen, &sf.out_rpos);
+  }
+  AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, b->stream));
+  return 0;
+}
+
+// ProcessNormal (echo_cancellation.c:594-742) on device buffers.
+int process_normal_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n,
+                          int16_t msInSndCardBuf) {
+  const int nBlocks10ms = n / (kFrameLen * b->rate_factor);
+  msInSndCardBuf = msInSndCardBuf > kMaxTrustedDelayMs ? kMaxTrustedDelayMs : msInSndCardBuf;
+  msInSndCardBuf += 10;
+  b->msInSndCardBuf = msInSndCardBuf;
+  if (b->startup_phase) {
+    if (near_dev != out_dev)
+      AEC_TRY(hipMemcpyAsync(out_dev, near_dev, (size_t)b->S * n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    if (b->checkBuffSize) {
+      b->checkBufSizeCtr++;
+      if (b->counter == 0) {
+        b->firstVal = b->msInSndCardBuf;
+        b->sum = 0;
+      }
+      double lim = 0.2 * b->msInSndCardBuf;
+      if (lim < kSampMsNb) lim = kSampMsNb;
+      if (abs(b->firstVal - b->msInSndCardBuf) < lim) {
+        b->sum += b->msInSndCardBuf;
+        b->counter++;
+      } else {
+        b->counter = 0;
+      }
+      if (b->counter * nBlocks10ms >= 6) {
+        const int v = (3 * b->sum * b->rate_factor * 8) / (4 * b->counter * kPartLen);
+        b->bufSizeStart = v < kMaxBufSizeStart ? v : kMaxBufSizeStart;
+        b->checkBuffSize = 0;
+      }
+      if (b->checkBufSizeCtr * nBlocks10ms > 50) {
+        const int v = (b->msInSndCardBuf * b->rate_factor * 3) / 40;
+        b->bufSizeStart = v < kMaxBufSizeStart ? v : kMaxBufSizeStart;
+        b->checkBuffSize = 0;
+      }
+    }
+    if (!b->checkBuffSize) {
+      const int overhead_elements = b->system_delay / kPartLen - b->bufSizeStart;
+      if (overhead_elements == 0) {
+        b->startup_phase = 0;
+      } else if (overhead_elements > 0) {
+        far_move_read(b, overhead_elements);
+        b->startup_phase = 0;
+      }
+    }
+    return 0;
+  }
+  est_buf_delay_normal(b);
+  return process_frames_device(b, near_dev, out_dev, n);
+}
+
+// WebRtcAec_Process checks (echo_cancellation.c:341-375); *rc is the reference's return value.
+int process_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n, int msInSndCardBuf,
+                   int* rc) {
+  *rc = 0;
+  if (msInSndCardBuf < 0) {
+    msInSndCardBuf = 0;
+    b->lastError = AEC_BAD_PARAMETER_WARNING;
+    *rc = -1;
+  } else if (msInSndCardBuf > kMaxTrustedDelayMs) {
+    b->lastError = AEC_BAD_PARAMETER_WARNING;
+    *rc = -1;
+  }
+  return process_normal_device(b, near_dev, out_dev, n, (int16_t)msInSndCardBuf);
+}
+
+int check_running(AspAecBatch* b, const void* p, int n) {
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  if (p == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (b->initFlag != kInitCheck) {
+    b->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  if (n != 80 && n != 160) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device) {
+  if (!out || num_streams <= 0) return aec_fail(ASP_ERR_PARAM, "AspAecBatch_Create: bad argument");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return aec_fail(ASP_ERR_NO_DEVICE, "no HIP device: the echo canceller has no CPU fallback");
+  if (device < 0 || device >= count) return aec_fail(ASP_ERR_PARAM, "device ordinal out of range");
+  AEC_TRY(hipSetDevice(device));
+  AspAecBatch* b = new AspAecBatch();
+  b->S = num_streams;
+  b->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  b->own_stream = e == hipSuccess;
+  if (e == hipSuccess) e = hipMalloc((void**)&b->state, state_bytes(b));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->far_ring, far_bytes(b));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->tables, sizeof(AecTables));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->stage_far, (size_t)num_streams * 160 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->stage_near, (size_t)num_streams * 160 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out, (size_t)num_streams * 160 * sizeof(float));
+  if (e == hipSuccess) e = hipEventCreate(&b->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+  if (e == hipSuccess) {
+    AecTables T;
+    build_tables(&T);
+    e = hipMemcpy(b->tables, &T, sizeof T, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    AspAecBatch_Free(b);
+    return aec_fail(ASP_ERR_HIP, "AspAecBatch_Create", e);
+  }
+  *out = b;
+  return ASP_OK;
+}
+
+int AspAecBatch_Free(AspAecBatch* b) {
+  if (!b) return -1;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->state) (void)hipFree(b->state);
+  if (b->far_ring) (void)hipFree(b->far_ring);
+  if (b->tables) (void)hipFree(b->tables);
+  if (b->stage_far) (void)hipFree(b->stage_far);
+  if (b->stage_near) (void)hipFree(b->stage_near);
+  if (b->stage_out) (void)hipFree(b->stage_out);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->stream && b->own_stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return 0;
+}
+
+int AspAecBatch_num_streams(const AspAecBatch* b) { return b ? b->S : 0; }
+int AspAecBatch_get_error_code(const AspAecBatch* b) { return b ? b->lastError : AEC_NULL_POINTER_ERROR; }
+
+int AspAecBatch_set_config(AspAecBatch* b, AecConfig config) {  // echo_cancellation.c:410-438
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  if (b->initFlag != kInitCheck) {
+    b->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  if (config.skewMode != kAecFalse && config.skewMode != kAecTrue) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  b->skewMode = config.skewMode;
+  if (config.nlpMode != kAecNlpConservative && config.nlpMode != kAecNlpModerate &&
+      config.nlpMode != kAecNlpAggressive) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  if (config.metricsMode != kAecFalse && config.metricsMode != kAecTrue) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  if (config.delay_logging != kAecFalse && config.delay_logging != kAecTrue) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  if (config.skewMode || config.metricsMode || config.delay_logging) {
+    b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;  // outside the built configuration (asp_aec.h)
+    return -1;
+  }
+  b->nlp_mode = config.nlpMode;  // WebRtcAec_SetConfigCore, aec_core.c:1844-1858
+  return 0;
+}
+
+int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  // echo_cancellation.c:196-276
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  if (sampFreq != 8000 && sampFreq != 16000 && sampFreq != 32000 && sampFreq != 48000) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  if (sampFreq > 16000) {  // band-split rates are not built (asp_aec.h)
+    b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
+    return -1;
+  }
+  b->sampFreq = sampFreq;
+  if (scSampFreq < 1 || scSampFreq > 96000) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  b->scSampFreq = scSampFreq;
+  // WebRtcAec_InitAec, aec_core.c:1460-1615
+  if (sampFreq == 8000) {
+    b->normal_mu = 0.6f;
+    b->normal_error_threshold = 2e-6f;
+  } else {
+    b->normal_mu = 0.5f;
+    b->normal_error_threshold = 1.5e-6f;
+  }
+  rp_init(&b->near_pos, kFrBufLen);
+  rp_init(&b->out_pos, kFrBufLen);
+  rp_init(&b->far_pos, kFarSlots);
+  b->system_delay = 0;
+  b->nlp_mode = 1;
+  b->mult = sampFreq / 8000;
+  b->core_knownDelay = 0;
+  b->xf_pos = 0;
+  b->xfw_head = 0;
+  b->blocks_processed = 0;
+  AEC_TRY(hipSetDevice(b->device));
+  {
+    AspAecState s0;
+    init_canonical(&s0);
+    std::vector<float> blk(kStateDwords);
+    pack_stream(b, &s0, blk.data());
+    std::vector<float> all((size_t)b->S * kStateDwords);
+    for (int s = 0; s < b->S; ++s) memcpy(all.data() + (size_t)s * kStateDwords, blk.data(), kStateDwords * sizeof(float));
+    AEC_TRY(hipStreamSynchronize(b->stream));
+    AEC_TRY(hipMemcpy(b->state, all.data(), state_bytes(b), hipMemcpyHostToDevice));
+    AEC_TRY(hipMemset(b->far_ring, 0, far_bytes(b)));  // WebRtc_InitBuffer zeroes the rings
+  }
+  rp_init(&b->pre_pos, kPreLen);
+  rp_move_read(&b->pre_pos, -kPartLen);  // start overlap, echo_cancellation.c:226
+  b->initFlag = kInitCheck;
+  b->splitSampFreq = sampFreq;
+  b->rate_factor = b->splitSampFreq / 8000;
+  b->sum = 0;
+  b->counter = 0;
+  b->checkBuffSize = 1;
+  b->firstVal = 0;
+  b->startup_phase = 1;
+  b->bufSizeStart = 0;
+  b->checkBufSizeCtr = 0;
+  b->msInSndCardBuf = 0;
+  b->filtDelay = -1;
+  b->timeForDelayChange = 0;
+  b->knownDelay = 0;
+  b->lastDelayDiff = 0;
+  b->farend_started = 0;
+  AecConfig cfg;
+  cfg.nlpMode = kAecNlpModerate;
+  cfg.skewMode = kAecFalse;
+  cfg.metricsMode = kAecFalse;
+  cfg.delay_logging = kAecFalse;
+  if (AspAecBatch_set_config(b, cfg) == -1) {
+    b->lastError = AEC_UNSPECIFIED_ERROR;
+    return -1;
+  }
+  return 0;
+}
+
+int AspAecBatch_BufferFarend(AspAecBatch* b, const float* farend, int nrOfSamples, int mem) {
+  const int chk = check_running(b, farend, nrOfSamples);
+  if (chk != 0) return chk;
+  AEC_TRY(hipSetDevice(b->device));
+  const float* dev = farend;
+  if (mem == ASP_MEM_HOST) {
+    AEC_TRY(hipMemcpyAsync(b->stage_far, farend, (size_t)b->S * nrOfSamples * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    dev = b->stage_far;
+  }
+  const int rc = buffer_farend_device(b, dev, nrOfSamples);
+  if (rc != 0) return rc;
+  if (mem == ASP_MEM_HOST) AEC_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nrOfSamples,
+                        int msInSndCardBuf, int32_t skew, int mem) {
+  (void)skew;
+  if (b && out == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  const int chk = check_running(b, nearend, nrOfSamples);
+  if (chk != 0) return chk;
+  AEC_TRY(hipSetDevice(b->device));
+  const size_t bytes = (size_t)b->S * nrOfSamples * sizeof(float);
+  const float* nd = nearend;
+  float* od = out;
+  if (mem == ASP_MEM_HOST) {
+    AEC_TRY(hipMemcpyAsync(b->stage_near, nearend, bytes, hipMemcpyHostToDevice, b->stream));
+    nd = b->stage_near;
+    od = b->stage_out;
+  }
+  int rc = 0;
+  const int err = process_device(b, nd, od, nrOfSamples, msInSndCardBuf, &rc);
+  if (err != 0) return err;
+  if (mem == ASP_MEM_HOST) {
+    AEC_TRY(hipMemcpyAsync(out, od, bytes, hipMemcpyDeviceToHost, b->stream));
+    AEC_TRY(hipStreamSynchronize(b->stream));
+  }
+  return rc;
+}
+
+int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, float* out,
+                    int nrOfSamples, int num_frames, int msInSndCardBuf, int mem) {
+  if (b && out == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  int chk = check_running(b, farend, nrOfSamples);
+  if (chk == 0) chk = check_running(b, nearend, nrOfSamples);
+  if (chk != 0) return chk;
+  if (num_frames < 0) return aec_fail(ASP_ERR_PARAM, "Run: num_frames < 0");
+  AEC_TRY(hipSetDevice(b->device));
+  const size_t per = (size_t)b->S * nrOfSamples;
+  int rc_all = 0;
+  if (mem == ASP_MEM_HOST) {
+    // stream the frames through device staging in chunks of up to 64 frames
+    const int chunk = 64;
+    float *dfar = nullptr, *dnear = nullptr, *dout = nullptr;
+    AEC_TRY(hipMalloc((void**)&dfar, per * chunk * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&dnear, per * chunk * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, per * chunk * sizeof(float));
+    int err = e == hipSuccess ? 0 : aec_fail(ASP_ERR_HIP, "Run: staging", e);
+    for (int f0 = 0; err == 0 && f0 < num_frames; f0 += chunk) {
+      const int nf = num_frames - f0 < chunk ? num_frames - f0 : chunk;
+      e = hipMemcpyAsync(dfar, farend + per * f0, per * nf * sizeof(float), hipMemcpyHostToDevice, b->stream);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(dnear, nearend + per * f0, per * nf * sizeof(float), hipMemcpyHostToDevice, b->stream);
+      if (e != hipSuccess) {
+        err = aec_fail(ASP_ERR_HIP, "Run: upload", e);
+        break;
+      }
+      for (int f = 0; f < nf && err == 0; ++f) {
+        int rc = 0;
+        err = buffer_farend_device(b, dfar + per * f, nrOfSamples);
+        if (err == 0) err = process_device(b, dnear + per * f, dout + per * f, nrOfSamples, msInSndCardBuf, &rc);
+        rc_all |= rc;
+      }
+      if (err == 0) {
+        e = hipMemcpyAsync(out + per * f0, dout, per * nf * sizeof(float), hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) err = aec_fail(ASP_ERR_HIP, "Run: download", e);
+      }
+    }
+    (void)hipStreamSynchronize(b->stream);
+    if (dfar) (void)hipFree(dfar);
+    if (dnear) (void)hipFree(dnear);
+    if (dout) (void)hipFree(dout);
+    if (err != 0) return err;
+    return rc_all;
+  }
+  for (int f = 0; f < num_frames; ++f) {
+    int rc = 0;
+    int err = buffer_farend_device(b, farend + per * f, nrOfSamples);
+    if (err == 0) err = process_device(b, nearend + per * f, out + per * f, nrOfSamples, msInSndCardBuf, &rc);
+    if (err != 0) return err;
+    rc_all |= rc;
+  }
+  return rc_all;
+}
+
+int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nearend, float* out,
+                           int nrOfSamples, int frames_in_ring, int steps, float* elapsed_ms) {
+  if (!b || !farend || !nearend || !out || frames_in_ring <= 0 || steps < 0 || !elapsed_ms)
+    return aec_fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
+  if (check_running(b, farend, nrOfSamples) != 0) return -1;
+  AEC_TRY(hipSetDevice(b->device));
+  const size_t per = (size_t)b->S * nrOfSamples;
+  AEC_TRY(hipEventRecord(b->ev0, b->stream));
+  for (int k = 0; k < steps; ++k) {
+    const size_t off = per * (size_t)(k % frames_in_ring);
+    int rc = 0;
+    int err = buffer_farend_device(b, farend + off, nrOfSamples);
+    if (err == 0) err = process_device(b, nearend + off, out + off, nrOfSamples, 0, &rc);
+    if (err != 0) return err;
+  }
+  AEC_TRY(hipEventRecord(b->ev1, b->stream));
+  AEC_TRY(hipEventSynchronize(b->ev1));
+  AEC_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+  return ASP_OK;
+}
+
+int AspAecBatch_Synchronize(AspAecBatch* b) {
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  return ASP_OK;
+}
+
+int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out) {
+  if (!b || !out || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ExportState: bad argument");
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  std::vector<float> blk(kStateDwords);
+  AEC_TRY(hipMemcpy(blk.data(), b->state + (size_t)stream * kStateDwords, kStateDwords * sizeof(float), hipMemcpyDeviceToHost));
+  unpack_stream(b, blk.data(), out);
+  return ASP_OK;
+}
+
+int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in) {
+  if (!b || !in || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ImportState: bad argument");
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  std::vector<float> blk(kStateDwords), cur(kStateDwords);
+  AEC_TRY(hipMemcpy(cur.data(), b->state + (size_t)stream * kStateDwords, kStateDwords * sizeof(float), hipMemcpyDeviceToHost));
+  pack_stream(b, in, blk.data());
+  // the time-domain rings are not part of AspAecState: keep the stream's own
+  memcpy(blk.data() + kOffPre, cur.data() + kOffPre, (kStateDwords - kOffPre) * sizeof(float));
+  AEC_TRY(hipMemcpy(b->state + (size_t)stream * kStateDwords, blk.data(), kStateDwords * sizeof(float), hipMemcpyHostToDevice));
+  return ASP_OK;
+}
+
+int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* c) {
+  if (!b || !c) return aec_fail(ASP_ERR_PARAM, "GetControl: bad argument");
+  c->startup_phase = b->startup_phase;
+  c->checkBuffSize = b->checkBuffSize;
+  c->bufSizeStart = b->bufSizeStart;
+  c->knownDelay = b->knownDelay;
+  c->filtDelay = b->filtDelay;
+  c->timeForDelayChange = b->timeForDelayChange;
+  c->lastDelayDiff = b->lastDelayDiff;
+  c->counter = b->counter;
+  c->sum = b->sum;
+  c->firstVal = b->firstVal;
+  c->checkBufSizeCtr = b->checkBufSizeCtr;
+  c->system_delay = b->system_delay;
+  c->core_knownDelay = b->core_knownDelay;
+  c->far_read = b->far_pos.read;
+  c->far_write = b->far_pos.write;
+  c->far_wrap = b->far_pos.wrap;
+  c->pre_read = b->pre_pos.read;
+  c->pre_write = b->pre_pos.write;
+  c->pre_wrap = b->pre_pos.wrap;
+  c->near_read = b->near_pos.read;
+  c->near_write = b->near_pos.write;
+  c->near_wrap = b->near_pos.wrap;
+  c->out_read = b->out_pos.read;
+  c->out_write = b->out_pos.write;
+  c->out_wrap = b->out_pos.wrap;
+  c->blocks_processed = b->blocks_processed;
+  return ASP_OK;
+}
+
+int AspAecBatch_get_echo_status(AspAecBatch* b, int* status) {
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  if (status == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (b->initFlag != kInitCheck) {
+    b->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  for (int s = 0; s < b->S; ++s) {
+    int32_t v = 0;
+    AEC_TRY(hipMemcpy(&v, b->state + (size_t)s * kStateDwords + kOffScalars + S_ECHOSTATE, sizeof v, hipMemcpyDeviceToHost));
+    status[s] = v;
+  }
+  return 0;
+}
+
+int AspAec_rdft128_batch(const float* src, float* dst, int isgn, int count, int device) {
+  if (!src || !dst || count <= 0) return aec_fail(ASP_ERR_PARAM, "rdft128_batch: bad argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return aec_fail(ASP_ERR_NO_DEVICE, "no HIP device: the echo canceller has no CPU fallback");
+  AEC_TRY(hipSetDevice(device));
+  float *d_in = nullptr, *d_out = nullptr;
+  AecTables* d_t = nullptr;
+  const size_t bytes = (size_t)count * 128 * sizeof(float);
+  AecTables T;
+  build_tables(&T);
+  hipError_t e = hipMalloc((void**)&d_in, bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_out, bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_t, sizeof T);
+  if (e == hipSuccess) e = hipMemcpy(d_t, &T, sizeof T, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_in, src, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_aec_rdft128(d_in, d_out, isgn, count, d_t, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(dst, d_out, bytes, hipMemcpyDeviceToHost);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (d_t) (void)hipFree(d_t);
+  if (e != hipSuccess) return aec_fail(ASP_ERR_HIP, "rdft128_batch", e);
+  return ASP_OK;
+}
+
+int AspAec_host_table(int which, float* out, int capacity) {
+  AecTables T;
+  build_tables(&T);
+  const float* src = nullptr;
+  int n = 0;
+  switch (which) {
+    case 0: src = T.w; n = 64; break;
+    case 1: src = T.wk3a; n = 16; break;
+    case 2: src = T.wk3b; n = 16; break;
+    case 3: src = T.hann; n = 65; break;
+    case 4: src = T.weight; n = 65; break;
+    case 5: src = T.odrive; n = 65; break;
+    default: return aec_fail(ASP_ERR_PARAM, "host_table: unknown table");
+  }
+  if (!out || capacity < n) return aec_fail(ASP_ERR_PARAM, "host_table: buffer too small");
+  memcpy(out, src, n * sizeof(float));
+  return n;
+}
+
+// ------------------------------------------------------------------ layer 1
+// The reference's per-stream API: a handle is a batch of one stream, host buffers.
+int32_t WebRtcAec_Create(void** aecInst) {  // echo_cancellation.c:121-168
+  if (aecInst == nullptr) return -1;
+  AspAecBatch* b = nullptr;
+  if (AspAecBatch_Create(&b, 1, 0) != ASP_OK) {
+    *aecInst = nullptr;
+    return -1;
+  }
+  *aecInst = b;
+  return 0;
+}
+
+int32_t WebRtcAec_Free(void* aecInst) {
+  if (aecInst == nullptr) return -1;
+  return AspAecBatch_Free((AspAecBatch*)aecInst);
+}
+
+int32_t WebRtcAec_Init(void* aecInst, int32_t sampFreq, int32_t scSampFreq) {
+  return AspAecBatch_Init((AspAecBatch*)aecInst, sampFreq, scSampFreq) == 0 ? 0 : -1;
+}
+
+int32_t WebRtcAec_BufferFarend(void* aecInst, const float* farend, int16_t nrOfSamples) {
+  return AspAecBatch_BufferFarend((AspAecBatch*)aecInst, farend, nrOfSamples, ASP_MEM_HOST) == 0 ? 0 : -1;
+}
+
+int32_t WebRtcAec_Process(void* aecInst, const float* const* nearend, int num_bands,
+                          float* const* out, int16_t nrOfSamples, int16_t msInSndCardBuf,
+                          int32_t skew) {
+  AspAecBatch* b = (AspAecBatch*)aecInst;
+  if (b == nullptr) return -1;
+  if (out == nullptr || nearend == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (num_bands != 1) {  // the reference asserts aec->num_bands == num_bands (aec_core.c:1677)
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  return AspAecBatch_Process(b, nearend[0], out[0], nrOfSamples, msInSndCardBuf, skew, ASP_MEM_HOST) == 0 ? 0 : -1;
+}
+
+int WebRtcAec_set_config(void* handle, AecConfig config) {
+  return AspAecBatch_set_config((AspAecBatch*)handle, config) == 0 ? 0 : -1;
+}
+
+int WebRtcAec_get_echo_status(void* handle, int* status) {
+  return AspAecBatch_get_echo_status((AspAecBatch*)handle, status) == 0 ? 0 : -1;
+}
+
+int WebRtcAec_GetMetrics(void* handle, AecMetrics* metrics) {  // echo_cancellation.c:456-548
+  AspAecBatch* b = (AspAecBatch*)handle;
+  if (b == nullptr) return -1;
+  if (metrics == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (b->initFlag != kInitCheck) {
+    b->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  // metrics are off: the statistics stay at InitStats' values (aec_core.c:560-583), which the
+  // reference reports as instant = max = min = average = kOffsetLevel (-100)
+  const AecLevel init = {-100, -100, -100, -100};
+  metrics->rerl = init;
+  metrics->erl = init;
+  metrics->erle = init;
+  metrics->aNlp = init;
+  return 0;
+}
+
+int WebRtcAec_GetDelayMetrics(void* handle, int* median, int* std) {  // echo_cancellation.c:550-571
+  AspAecBatch* b = (AspAecBatch*)handle;
+  if (b == nullptr) return -1;
+  if (median == nullptr || std == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (b->initFlag != kInitCheck) {
+    b->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;  // delay logging is disabled
+  return -1;
+}
+
+int32_t WebRtcAec_get_error_code(void* aecInst) {
+  return AspAecBatch_get_error_code((AspAecBatch*)aecInst);
+}
+
+struct AecCore* WebRtcAec_aec_core(void* handle) {
+  return reinterpret_cast<struct AecCore*>(handle);
+}
+
+}  // extern "C"

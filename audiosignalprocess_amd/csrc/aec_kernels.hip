@@ -1,0 +1,921 @@
+// aec_kernels.hip -- gfx950 kernels of the batched acoustic echo canceller.  Replaces, for many
+// independent streams per launch,
+//   WebRtcAec_BufferFarendPartition / TimeToFrequency           (aec_core.c:1618-1635, 772-795)
+//   ProcessBlock: FilterFar, ScaleErrorSignal, FilterAdaptation (aec_core.c:1084-1287, 147-269)
+//   NonLinearProcessing: SubbandCoherence, SmoothedPSD, PartitionDelay, OverdriveAndSuppress,
+//   ComfortNoise                                                (aec_core.c:852-1082, 271-500)
+//   aec_rdft_forward_128 / aec_rdft_inverse_128                 (aec_rdft.c:124-556)
+// and the ring-buffer copies of WebRtcAec_BufferFarend / WebRtcAec_ProcessFrames whose positions
+// the host control plane (aec_api.hip) computes.
+//
+// Mapping: one wave64 per stream, four streams per 256-thread workgroup, no workgroup barrier
+// after the table staging.  Per-bin work puts bin q on lane q (bin 64 is a second trip of
+// lane 0); the local arrays of the reference live in a 9 KB LDS region private to the wave.
+// A 128-point real FFT is 16 radix-4 butterflies per pass, so four transforms run side by side
+// in a wave (lane = 16 * transform + butterfly): the 12 + 12 transforms of the constrained
+// filter update take six such rounds.  Every butterfly performs the reference's float operations
+// in the reference's order and every cross-bin sum (band averages, PSD sums, partition energies)
+// is accumulated by one lane in the reference's order, so spectra, the adaptive filter and the
+// NLP state are bit-identical to oracle/aec_oracle.c; only powf / cosf / sinf are evaluated in
+// fp64 and rounded (libm's float versions are not correctly rounded everywhere).
+//
+// Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "aec_layout.h"
+
+using namespace aspaec;
+
+namespace {
+
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------ LDS map
+constexpr int kTileStride = 66;                 // float2 per transform tile (64 + 2 pad)
+constexpr int kLdsTile = 0;                     // 4 tiles: 4 * 66 float2 = 528 floats
+constexpr int kLdsRows = 4 * kTileStride * 2;   // per-bin rows of 66 floats
+enum LRow { L_XFR = 0, L_XFI, L_DFR, L_DFI, L_YFR, L_YFI, L_EFR, L_EFI, L_XPOW, L_XWR, L_XWI,
+            L_COHDE, L_COHXD, L_HNL, L_T0, L_T1, L_NROWS };
+constexpr int kLRow = 66;
+constexpr int kLdsDbuf = kLdsRows + L_NROWS * kLRow;  // 128
+constexpr int kLdsEbuf = kLdsDbuf + 128;              // 128
+constexpr int kLdsMisc = kLdsEbuf + 128;              // 16
+constexpr int kLdsWave = kLdsMisc + 16;               // 1856 floats = 7 424 B per wave
+static_assert(kNumPart * kLRow <= kLdsRows + 9 * kLRow, "partition-energy rows overlay");
+
+struct SharedTables {
+  float w[64], wk3a[16], wk3b[16], hann[68], weight[68], odrive[68];
+  uint32_t lcg_a[64], lcg_c[64];
+};
+
+// ---------------------------------------------------------------- butterflies
+struct Tw {
+  float w1r, w1i, w2r, w2i, w3r, w3i;
+};
+
+// Radix-4 butterfly of cft1st_128 / cftmdl_128 for block B of a pass (aec_rdft.c:201-444):
+// B = 0 no twiddles, B = 1 the w[2] block, B = 2u / 2u + 1 general.
+__device__ __forceinline__ void bfly(float2& e0, float2& e1, float2& e2, float2& e3, int B,
+                                     const SharedTables& T) {
+  float x0r = e0.x + e1.x, x0i = e0.y + e1.y;
+  const float x1r = e0.x - e1.x, x1i = e0.y - e1.y;
+  const float x2r = e2.x + e3.x, x2i = e2.y + e3.y;
+  const float x3r = e2.x - e3.x, x3i = e2.y - e3.y;
+  e0.x = x0r + x2r;
+  e0.y = x0i + x2i;
+  if (B == 0) {
+    e2.x = x0r - x2r;
+    e2.y = x0i - x2i;
+    e1.x = x1r - x3i;
+    e1.y = x1i + x3r;
+    e3.x = x1r + x3i;
+    e3.y = x1i - x3r;
+  } else if (B == 1) {
+    const float ws = T.w[2];
+    float yr, yi;
+    e2.x = x2i - x0i;
+    e2.y = x0r - x2r;
+    yr = x1r - x3i;
+    yi = x1i + x3r;
+    e1.x = ws * (yr - yi);
+    e1.y = ws * (yr + yi);
+    yr = x3i + x1r;
+    yi = x3r - x1i;
+    e3.x = ws * (yi - yr);
+    e3.y = ws * (yi + yr);
+  } else {
+    const int k1 = 2 * (B >> 1), k2 = 2 * k1;
+    const float wk2r = T.w[k1], wk2i = T.w[k1 + 1];
+    Tw t;
+    if ((B & 1) == 0) {
+      t.w1r = T.w[k2];
+      t.w1i = T.w[k2 + 1];
+      t.w3r = T.wk3a[k1];
+      t.w3i = T.wk3a[k1 + 1];
+      t.w2r = wk2r;
+      t.w2i = wk2i;
+    } else {
+      t.w1r = T.w[k2 + 2];
+      t.w1i = T.w[k2 + 3];
+      t.w3r = T.wk3b[k1];
+      t.w3i = T.wk3b[k1 + 1];
+      t.w2r = -wk2i;
+      t.w2i = wk2r;
+    }
+    float yr, yi;
+    x0r -= x2r;
+    x0i -= x2i;
+    e2.x = t.w2r * x0r - t.w2i * x0i;
+    e2.y = t.w2r * x0i + t.w2i * x0r;
+    yr = x1r - x3i;
+    yi = x1i + x3r;
+    e1.x = t.w1r * yr - t.w1i * yi;
+    e1.y = t.w1r * yi + t.w1i * yr;
+    yr = x1r + x3i;
+    yi = x1i - x3r;
+    e3.x = t.w3r * yr - t.w3i * yi;
+    e3.y = t.w3r * yi + t.w3i * yr;
+  }
+}
+
+// Last pass of cftfsub_128 / cftbsub_128 (aec_rdft.c:446-507).
+__device__ __forceinline__ void bfly_last(float2& e0, float2& e1, float2& e2, float2& e3,
+                                          bool backward) {
+  if (!backward) {
+    const float x0r = e0.x + e1.x, x0i = e0.y + e1.y;
+    const float x1r = e0.x - e1.x, x1i = e0.y - e1.y;
+    const float x2r = e2.x + e3.x, x2i = e2.y + e3.y;
+    const float x3r = e2.x - e3.x, x3i = e2.y - e3.y;
+    e0.x = x0r + x2r;
+    e0.y = x0i + x2i;
+    e2.x = x0r - x2r;
+    e2.y = x0i - x2i;
+    e1.x = x1r - x3i;
+    e1.y = x1i + x3r;
+    e3.x = x1r + x3i;
+    e3.y = x1i - x3r;
+  } else {
+    const float x0r = e0.x + e1.x, x0i = -e0.y - e1.y;
+    const float x1r = e0.x - e1.x, x1i = -e0.y + e1.y;
+    const float x2r = e2.x + e3.x, x2i = e2.y + e3.y;
+    const float x3r = e2.x - e3.x, x3i = e2.y - e3.y;
+    e0.x = x0r + x2r;
+    e0.y = x0i - x2i;
+    e2.x = x0r - x2r;
+    e2.y = x0i + x2i;
+    e1.x = x1r - x3i;
+    e1.y = x1i - x3r;
+    e3.x = x1r + x3i;
+    e3.y = x1i + x3r;
+  }
+}
+
+__device__ __forceinline__ int rev6(int x) { return (int)(__brev((unsigned)x) >> 26); }
+
+// The three radix-4 passes of four transforms at once; t = this lane's tile, b = butterfly.
+__device__ __forceinline__ void cft64_quad(float2* t, int b, bool backward, const SharedTables& T) {
+  {  // cft1st_128 on the bit-reversed input (bitrv2_128, aec_rdft.c:124-199)
+    const int i0 = 4 * b;
+    float2 a0 = t[rev6(i0)], a1 = t[rev6(i0 + 1)], a2 = t[rev6(i0 + 2)], a3 = t[rev6(i0 + 3)];
+    bfly(a0, a1, a2, a3, b, T);
+    t[i0] = a0;
+    t[i0 + 1] = a1;
+    t[i0 + 2] = a2;
+    t[i0 + 3] = a3;
+  }
+  wave_fence();
+  {  // cftmdl_128, l = 4 complex
+    const int i0 = 16 * (b >> 2) + (b & 3);
+    float2 a0 = t[i0], a1 = t[i0 + 4], a2 = t[i0 + 8], a3 = t[i0 + 12];
+    bfly(a0, a1, a2, a3, b >> 2, T);
+    t[i0] = a0;
+    t[i0 + 4] = a1;
+    t[i0 + 8] = a2;
+    t[i0 + 12] = a3;
+  }
+  wave_fence();
+  {
+    float2 a0 = t[b], a1 = t[b + 16], a2 = t[b + 32], a3 = t[b + 48];
+    bfly_last(a0, a1, a2, a3, backward);
+    t[b] = a0;
+    t[b + 16] = a1;
+    t[b + 32] = a2;
+    t[b + 48] = a3;
+  }
+  wave_fence();
+}
+
+// aec_rdft_forward_128 (aec_rdft.c:539-547) of the four tiles of this wave, in place.
+__device__ __forceinline__ void rdft_fwd_quad(float* wl, int lane, const SharedTables& T) {
+  float2* t = reinterpret_cast<float2*>(wl + kLdsTile) + (lane >> 4) * kTileStride;
+  const int b = lane & 15;
+  const float* c = T.w + 32;
+  cft64_quad(t, b, false, T);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {  // rftfsub_128 (aec_rdft.c:509-527), pairs (j1, 64 - j1)
+    const int j1 = b + 1 + 16 * r;
+    if (j1 < 32) {
+      const int k = 64 - j1;
+      const float wkr = 0.5f - c[32 - j1], wki = c[j1];
+      float2 aj = t[j1], ak = t[k];
+      const float xr = aj.x - ak.x, xi = aj.y + ak.y;
+      const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
+      aj.x -= yr;
+      aj.y -= yi;
+      ak.x += yr;
+      ak.y -= yi;
+      t[j1] = aj;
+      t[k] = ak;
+    } else {  // a[0], a[1] (aec_rdft.c:544-546)
+      float2 a0 = t[0];
+      const float xi = a0.x - a0.y;
+      a0.x += a0.y;
+      a0.y = xi;
+      t[0] = a0;
+    }
+  }
+  wave_fence();
+}
+
+// aec_rdft_inverse_128 (aec_rdft.c:549-556) of the four tiles, in place (unscaled).
+__device__ __forceinline__ void rdft_inv_quad(float* wl, int lane, const SharedTables& T) {
+  float2* t = reinterpret_cast<float2*>(wl + kLdsTile) + (lane >> 4) * kTileStride;
+  const int b = lane & 15;
+  const float* c = T.w + 32;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {  // rftbsub_128 (aec_rdft.c:529-537)
+    const int j1 = b + 1 + 16 * r;
+    if (j1 < 32) {
+      const int k = 64 - j1;
+      const float wkr = 0.5f - c[32 - j1], wki = c[j1];
+      float2 aj = t[j1], ak = t[k];
+      const float xr = aj.x - ak.x, xi = aj.y + ak.y;
+      const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
+      aj.x = aj.x - yr;
+      aj.y = yi - aj.y;
+      ak.x = yr + ak.x;
+      ak.y = yi - ak.y;
+      t[j1] = aj;
+      t[k] = ak;
+    } else {
+      float2 a0 = t[0], am = t[32];
+      a0.y = 0.5f * (a0.x - a0.y);
+      a0.x -= a0.y;
+      a0.y = -a0.y;
+      am.y = -am.y;  // a[65] = -a[65]
+      t[0] = a0;
+      t[32] = am;
+    }
+  }
+  wave_fence();
+  cft64_quad(t, b, true, T);
+}
+
+__device__ __forceinline__ float* lrow(float* wl, int r) { return wl + kLdsRows + r * kLRow; }
+__device__ __forceinline__ float2* tile(float* wl, int f) {
+  return reinterpret_cast<float2*>(wl + kLdsTile) + f * kTileStride;
+}
+
+// Spectrum of tile f -> planar rows (TimeToFrequency reorder / StoreAsComplex, aec_core.c:786-795).
+__device__ __forceinline__ void unpack_tile(float* wl, int f, float* re, float* im, int lane) {
+  const float2 v = tile(wl, f)[lane];
+  if (lane == 0) {
+    re[0] = v.x;
+    im[0] = 0.f;
+    re[64] = v.y;
+    im[64] = 0.f;
+  } else {
+    re[lane] = v.x;
+    im[lane] = v.y;
+  }
+}
+
+__device__ __forceinline__ void stage_tables(SharedTables& S, const AecTables* __restrict__ G) {
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+    S.w[i] = G->w[i];
+    S.lcg_a[i] = G->lcg_a[i];
+    S.lcg_c[i] = G->lcg_c[i];
+  }
+  for (int i = threadIdx.x; i < 16; i += blockDim.x) {
+    S.wk3a[i] = G->wk3a[i];
+    S.wk3b[i] = G->wk3b[i];
+  }
+  for (int i = threadIdx.x; i < 68; i += blockDim.x) {
+    S.hann[i] = G->hann[i];
+    S.weight[i] = G->weight[i];
+    S.odrive[i] = G->odrive[i];
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int ring_idx(int pos, int i, int count) {
+  int p = pos + i;
+  while (p >= count) p -= count;
+  return p;
+}
+
+// ------------------------------------------------------------------ far end
+// WebRtcAec_BufferFarend for every stream: append to far_pre, then transform the partitions the
+// host scheduled (plain and sqrt-Hann windowed) into their far-ring slots.
+__global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ state,
+                                                         float* __restrict__ far_ring,
+                                                         const AecTables* __restrict__ G,
+                                                         const float* __restrict__ farend,
+                                                         int num_streams, FarOps ops) {
+  __shared__ SharedTables T;
+  __shared__ float lds[4 * kLdsWave];
+  stage_tables(T, G);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  float* wl = lds + wave * kLdsWave;
+  float* st = state + (size_t)stream * kStateDwords;
+  float* pre = st + kOffPre;
+  for (int i = lane; i < ops.n; i += 64) pre[ring_idx(ops.wpos, i, kPreLen)] = farend[(size_t)stream * ops.n + i];
+  // the partitions below read samples other lanes of this wave just wrote: order through L2
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  for (int p = 0; p < ops.nparts; ++p) {
+    // 128 samples of far_pre -> tile 0 (plain) and tile 1 (windowed, aec_core.c:779-784)
+    float* t0 = reinterpret_cast<float*>(tile(wl, 0));
+    float* t1 = reinterpret_cast<float*>(tile(wl, 1));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = lane + 64 * h;
+      const float x = pre[ring_idx(ops.rpos[p], i, kPreLen)];
+      t0[i] = x;
+      t1[i] = x * (h == 0 ? T.hann[i] : T.hann[128 - i]);
+    }
+    wave_fence();
+    rdft_fwd_quad(wl, lane, T);
+    float* slot = far_ring + ((size_t)ops.slot[p] * num_streams + stream) * kFarSlotDwords;
+    unpack_tile(wl, 0, slot, slot + kRow, lane);
+    unpack_tile(wl, 1, slot + 2 * kRow, slot + 3 * kRow, lane);
+    wave_fence();
+  }
+}
+
+// --------------------------------------------------------------- transcendentals
+// (float)pow / cos / sin evaluated in fp64: correctly rounded up to double rounding; glibc's powf /
+// cosf / sinf (<= 0.52 / 0.56 ulp) differ from that in rare last-place cases.
+__device__ __forceinline__ float powf_via_f64(float x, float y) { return (float)pow((double)x, (double)y); }
+__device__ __forceinline__ float cosf_via_f64(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float sinf_via_f64(float x) { return (float)sin((double)x); }
+
+// One ProcessBlock + NonLinearProcessing for this wave's stream.
+__device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
+                                              const float* __restrict__ far_slot,
+                                              const SharedTables& T, const BlockOp& op, int mult,
+                                              int nlp_mode, float mu, float error_threshold,
+                                              int lane) {
+  float* rows = st + kOffRows;
+  float* sc = st + kOffScalars;
+  int32_t* sci = reinterpret_cast<int32_t*>(sc);
+  float* dbuf = wl + kLdsDbuf;
+  float* ebuf = wl + kLdsEbuf;
+  float* misc = wl + kLdsMisc;
+  float* XFR = lrow(wl, L_XFR);
+  float* XFI = lrow(wl, L_XFI);
+  float* DFR = lrow(wl, L_DFR);
+  float* DFI = lrow(wl, L_DFI);
+  float* YFR = lrow(wl, L_YFR);
+  float* YFI = lrow(wl, L_YFI);
+  float* EFR = lrow(wl, L_EFR);
+  float* EFI = lrow(wl, L_EFI);
+  float* XPW = lrow(wl, L_XPOW);
+  float* XWR = lrow(wl, L_XWR);
+  float* XWI = lrow(wl, L_XWI);
+  float* COHDE = lrow(wl, L_COHDE);
+  float* COHXD = lrow(wl, L_COHXD);
+  float* HNL = lrow(wl, L_HNL);
+  float* T0 = lrow(wl, L_T0);
+  float* T1 = lrow(wl, L_T1);
+  const float scale = 2.0f / 128;
+
+  // ---- near block (aec_core.c:1114-1124) and the far spectra of this block (:1137, 888-891)
+  const float ne = st[kOffNearFr + ring_idx(op.near_rpos, lane, kFrBufLen)];
+  dbuf[lane] = st[kOffDBuf + lane];
+  dbuf[64 + lane] = ne;
+  ebuf[lane] = st[kOffEBuf + lane];
+  for (int bin = lane; bin < 65; bin += 64) {
+    XFR[bin] = far_slot[bin];
+    XFI[bin] = far_slot[kRow + bin];
+    const float wr = far_slot[2 * kRow + bin], wi = far_slot[3 * kRow + bin];
+    XWR[bin] = wr;
+    XWI[bin] = wi;
+    rows[(R_XFW + 2 * op.xfw_head) * kRow + bin] = wr;
+    rows[(R_XFW + 2 * op.xfw_head + 1) * kRow + bin] = wi;
+  }
+  wave_fence();
+
+  // ---- near fft (aec_core.c:1140-1141)
+  {
+    const float2 v = {dbuf[2 * lane], dbuf[2 * lane + 1]};
+    tile(wl, 0)[lane] = v;
+  }
+  wave_fence();
+  rdft_fwd_quad(wl, lane, T);
+  unpack_tile(wl, 0, DFR, DFI, lane);
+  wave_fence();
+
+  // ---- power smoothing and noise floor (aec_core.c:1144-1186)
+  int noiseEstCtr = sci[S_NOISEESTCTR];
+  const bool noise_track = noiseEstCtr > 50;
+  const bool noise_init = noiseEstCtr < 500 * mult;
+  for (int bin = lane; bin < 65; bin += 64) {
+    const float xr = XFR[bin], xi = XFI[bin];
+    const float far_spectrum = (xr * xr) + (xi * xi);
+    const float near_spectrum = DFR[bin] * DFR[bin] + DFI[bin] * DFI[bin];
+    const float xp = 0.9f * rows[R_XPOW * kRow + bin] + 0.1f * kNumPart * far_spectrum;
+    const float dp = 0.9f * rows[R_DPOW * kRow + bin] + 0.1f * near_spectrum;
+    rows[R_XPOW * kRow + bin] = xp;
+    rows[R_DPOW * kRow + bin] = dp;
+    XPW[bin] = xp;
+    float dmin = rows[R_DMINPOW * kRow + bin];
+    if (noise_track) {
+      if (dp < dmin) {
+        dmin = (dp + 0.1f * (dmin - dp)) * 1.0002f;
+      } else {
+        dmin *= 1.0002f;
+      }
+      rows[R_DMINPOW * kRow + bin] = dmin;
+    }
+    float npow = dmin;
+    if (noise_init) {
+      float dinit = rows[R_DINITMINPOW * kRow + bin];
+      if (dmin > dinit) {
+        dinit = 0.999f * dinit + 0.001f * dmin;
+      } else {
+        dinit = dmin;
+      }
+      rows[R_DINITMINPOW * kRow + bin] = dinit;
+      npow = dinit;
+    }
+    T1[bin] = npow;  // aec->noisePow for the comfort noise (kept until the NLP)
+    // ---- buffer xf (aec_core.c:1203-1214)
+    rows[(R_XF_RE + op.xf_pos) * kRow + bin] = xr;
+    rows[(R_XF_IM + op.xf_pos) * kRow + bin] = xi;
+  }
+  if (noise_init) noiseEstCtr++;
+
+  // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
+  for (int bin = lane; bin < 65; bin += 64) {
+    float yr = 0.f, yi = 0.f;
+    for (int i = 0; i < kNumPart; ++i) {
+      int px = i + op.xf_pos;
+      if (px >= kNumPart) px -= kNumPart;
+      const float ar = i == 0 ? XFR[bin] : rows[(R_XF_RE + px) * kRow + bin];
+      const float ai = i == 0 ? XFI[bin] : rows[(R_XF_IM + px) * kRow + bin];
+      const float br = rows[(R_WF_RE + i) * kRow + bin], bi = rows[(R_WF_IM + i) * kRow + bin];
+      yr += ar * br - ai * bi;
+      yi += ar * bi + ai * br;
+    }
+    YFR[bin] = yr;
+    YFI[bin] = yi;
+  }
+  wave_fence();
+
+  // ---- echo estimate and error (aec_core.c:1222-1238)
+  {
+    float2 v;
+    v.x = YFR[lane];
+    v.y = lane == 0 ? YFR[64] : YFI[lane];
+    tile(wl, 0)[lane] = v;
+  }
+  wave_fence();
+  rdft_inv_quad(wl, lane, T);
+  const float y = reinterpret_cast<float*>(tile(wl, 0))[64 + lane] * scale;
+  const float e = ne - y;
+  wave_fence();
+
+  // ---- error fft (aec_core.c:1241-1254)
+  ebuf[64 + lane] = e;
+  {
+    float* tf = reinterpret_cast<float*>(tile(wl, 0));
+    tf[lane] = 0.f;
+    tf[64 + lane] = e;
+  }
+  wave_fence();
+  rdft_fwd_quad(wl, lane, T);
+  unpack_tile(wl, 0, EFR, EFI, lane);
+  wave_fence();
+
+  // ---- ScaleErrorSignal (aec_core.c:171-193)
+  for (int bin = lane; bin < 65; bin += 64) {
+    float er = EFR[bin], ei = EFI[bin];
+    const float den = XPW[bin] + 1e-10f;
+    er /= den;
+    ei /= den;
+    float abs_ef = sqrtf(er * er + ei * ei);
+    if (abs_ef > error_threshold) {
+      abs_ef = error_threshold / (abs_ef + 1e-10f);
+      er *= abs_ef;
+      ei *= abs_ef;
+    }
+    er *= mu;
+    ei *= mu;
+    EFR[bin] = er;
+    EFI[bin] = ei;
+  }
+  wave_fence();
+
+  // ---- FilterAdaptation (aec_core.c:221-269): four partitions per round
+  for (int g = 0; g < kNumPart / 4; ++g) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = 4 * g + k;
+      int px = i + op.xf_pos;
+      if (px >= kNumPart) px -= kNumPart;
+      const float ar = i == 0 ? XFR[lane] : rows[(R_XF_RE + px) * kRow + lane];
+      const float ai = -(i == 0 ? XFI[lane] : rows[(R_XF_IM + px) * kRow + lane]);
+      float2 v;
+      v.x = ar * EFR[lane] - ai * EFI[lane];
+      v.y = ar * EFI[lane] + ai * EFR[lane];
+      if (lane == 0) {
+        const float cr = i == 0 ? XFR[64] : rows[(R_XF_RE + px) * kRow + 64];
+        const float ci = -(i == 0 ? XFI[64] : rows[(R_XF_IM + px) * kRow + 64]);
+        v.y = cr * EFR[64] - ci * EFI[64];
+      }
+      tile(wl, k)[lane] = v;
+    }
+    wave_fence();
+    rdft_inv_quad(wl, lane, T);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float2 v = tile(wl, k)[lane];
+      if (lane < 32) {
+        v.x *= scale;
+        v.y *= scale;
+      } else {
+        v.x = 0.f;
+        v.y = 0.f;
+      }
+      tile(wl, k)[lane] = v;
+    }
+    wave_fence();
+    rdft_fwd_quad(wl, lane, T);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = 4 * g + k;
+      const float2 v = tile(wl, k)[lane];
+      rows[(R_WF_RE + i) * kRow + lane] += v.x;
+      if (lane == 0) {
+        rows[(R_WF_RE + i) * kRow + 64] += v.y;
+      } else {
+        rows[(R_WF_IM + i) * kRow + lane] += v.y;
+      }
+    }
+    wave_fence();
+  }
+
+  // =================================================== NonLinearProcessing (aec_core.c:852-1082)
+  int delayEstCtr = sci[S_DELAYESTCTR] + 1;
+  if (delayEstCtr == 10 * mult) delayEstCtr = 0;
+  int delayIdx = sci[S_DELAYIDX];
+  if (delayEstCtr == 0) {  // PartitionDelay (aec_core.c:294-318)
+    float* pe = wl + kLdsTile;  // 12 rows of 66 overlaying the tiles and the dead rows
+    for (int i = 0; i < kNumPart; ++i)
+      for (int bin = lane; bin < 65; bin += 64) {
+        const float wr = rows[(R_WF_RE + i) * kRow + bin], wi = rows[(R_WF_IM + i) * kRow + bin];
+        pe[i * kLRow + bin] = wr * wr + wi * wi;
+      }
+    wave_fence();
+    if (lane < kNumPart) {
+      float wfEn = 0.f;
+      for (int j = 0; j < 65; ++j) wfEn += pe[lane * kLRow + j];
+      misc[lane] = wfEn;
+    }
+    wave_fence();
+    float wfEnMax = 0.f;
+    delayIdx = 0;
+    for (int i = 0; i < kNumPart; ++i) {
+      const float v = misc[i];
+      if (v > wfEnMax) {
+        wfEnMax = v;
+        delayIdx = i;
+      }
+    }
+    wave_fence();
+  }
+
+  // ---- windowed near / error spectra (aec_core.c:428-436)
+  {
+    float* t0 = reinterpret_cast<float*>(tile(wl, 0));
+    float* t1 = reinterpret_cast<float*>(tile(wl, 1));
+    t0[lane] = dbuf[lane] * T.hann[lane];
+    t0[64 + lane] = dbuf[64 + lane] * T.hann[64 - lane];
+    t1[lane] = ebuf[lane] * T.hann[lane];
+    t1[64 + lane] = ebuf[64 + lane] * T.hann[64 - lane];
+  }
+  wave_fence();
+  rdft_fwd_quad(wl, lane, T);
+  unpack_tile(wl, 0, DFR, DFI, lane);  // dfw
+  unpack_tile(wl, 1, EFR, EFI, lane);  // efw
+  wave_fence();
+
+  // ---- SmoothedPSD + coherence (aec_core.c:332-385, 438-448)
+  const float g0 = mult == 1 ? 0.9f : 0.93f, g1 = mult == 1 ? 0.1f : 0.07f;  // aec_core.c:111-112
+  int pd = op.xfw_head + delayIdx;
+  if (pd >= kNumPart) pd -= kNumPart;
+  for (int bin = lane; bin < 65; bin += 64) {
+    const float dr = DFR[bin], di = DFI[bin], er = EFR[bin], ei = EFI[bin];
+    const float xr = delayIdx == 0 ? XWR[bin] : rows[(R_XFW + 2 * pd) * kRow + bin];
+    const float xi = delayIdx == 0 ? XWI[bin] : rows[(R_XFW + 2 * pd + 1) * kRow + bin];
+    const float sd = g0 * rows[R_SD * kRow + bin] + g1 * (dr * dr + di * di);
+    const float se = g0 * rows[R_SE * kRow + bin] + g1 * (er * er + ei * ei);
+    const float xx = xr * xr + xi * xi;
+    const float sx = g0 * rows[R_SX * kRow + bin] + g1 * (xx > 15.f ? xx : 15.f);
+    const float sde_r = g0 * rows[R_SDE_RE * kRow + bin] + g1 * (dr * er + di * ei);
+    const float sde_i = g0 * rows[R_SDE_IM * kRow + bin] + g1 * (dr * ei - di * er);
+    const float sxd_r = g0 * rows[R_SXD_RE * kRow + bin] + g1 * (dr * xr + di * xi);
+    const float sxd_i = g0 * rows[R_SXD_IM * kRow + bin] + g1 * (dr * xi - di * xr);
+    rows[R_SD * kRow + bin] = sd;
+    rows[R_SE * kRow + bin] = se;
+    rows[R_SX * kRow + bin] = sx;
+    rows[R_SDE_RE * kRow + bin] = sde_r;
+    rows[R_SDE_IM * kRow + bin] = sde_i;
+    rows[R_SXD_RE * kRow + bin] = sxd_r;
+    rows[R_SXD_IM * kRow + bin] = sxd_i;
+    T0[bin] = sd;
+    XPW[bin] = se;
+    COHDE[bin] = (sde_r * sde_r + sde_i * sde_i) / (sd * se + 1e-10f);
+    COHXD[bin] = (sxd_r * sxd_r + sxd_i * sxd_i) / (sx * sd + 1e-10f);
+  }
+  wave_fence();
+  const int prefBandSize = 24 / mult, minPrefBand = 4 / mult;
+  if (lane < 4) {  // the four sequential sums of the reference, one lane each
+    const float* src = lane == 0 ? T0 : lane == 1 ? XPW : lane == 2 ? COHXD : COHDE;
+    const int lo = lane < 2 ? 0 : minPrefBand, hi = lane < 2 ? 65 : prefBandSize + minPrefBand;
+    float acc = 0.f;
+    for (int j = lo; j < hi; ++j) acc += src[j];
+    misc[lane] = acc;
+  }
+  wave_fence();
+  const float sdSum = misc[0], seSum = misc[1];
+  float hNlXdAvg = misc[2], hNlDeAvg = misc[3];
+  wave_fence();
+  int divergeState = sci[S_DIVERGESTATE];
+  divergeState = (divergeState ? 1.05f : 1.0f) * seSum > sdSum;
+  if (divergeState) {
+    for (int bin = lane; bin < 65; bin += 64) {
+      EFR[bin] = DFR[bin];
+      EFI[bin] = DFI[bin];
+    }
+  }
+  if (seSum > (19.95f * sdSum)) {
+    for (int i = 0; i < 2 * kNumPart; ++i)
+      for (int bin = lane; bin < 65; bin += 64) rows[(R_WF_RE + i) * kRow + bin] = 0.f;
+  }
+
+  // ---- aec_core.c:895-960
+  hNlXdAvg /= prefBandSize;
+  hNlXdAvg = 1 - hNlXdAvg;
+  hNlDeAvg /= prefBandSize;
+  float hNlXdAvgMin = sc[S_HNLXDAVGMIN];
+  int stNearState = sci[S_STNEARSTATE];
+  int echoState;
+  float overDrive = sc[S_OVERDRIVE];
+  if (hNlXdAvg < 0.75f && hNlXdAvg < hNlXdAvgMin) hNlXdAvgMin = hNlXdAvg;
+  if (hNlDeAvg > 0.98f && hNlXdAvg > 0.9f) {
+    stNearState = 1;
+  } else if (hNlDeAvg < 0.95f || hNlXdAvg < 0.8f) {
+    stNearState = 0;
+  }
+  const float minOverDrive = nlp_mode == 0 ? 1.0f : nlp_mode == 1 ? 2.0f : 5.0f;
+  const float targetSupp = nlp_mode == 0 ? -6.9f : nlp_mode == 1 ? -11.5f : -18.4f;
+  float hNlFb, hNlFbLow;
+  int hnl_kind;  // 0: cohde, 1: 1 - cohxd, 2: min of both
+  if (hNlXdAvgMin == 1) {
+    echoState = 0;
+    overDrive = minOverDrive;
+    if (stNearState == 1) {
+      hnl_kind = 0;
+      hNlFb = hNlDeAvg;
+      hNlFbLow = hNlDeAvg;
+    } else {
+      hnl_kind = 1;
+      hNlFb = hNlXdAvg;
+      hNlFbLow = hNlXdAvg;
+    }
+  } else if (stNearState == 1) {
+    echoState = 0;
+    hnl_kind = 0;
+    hNlFb = hNlDeAvg;
+    hNlFbLow = hNlDeAvg;
+  } else {
+    echoState = 1;
+    hnl_kind = 2;
+    hNlFb = 0.f;
+    hNlFbLow = 0.f;
+  }
+  for (int bin = lane; bin < 65; bin += 64) {
+    const float a = COHDE[bin], b = 1 - COHXD[bin];
+    HNL[bin] = hnl_kind == 0 ? a : hnl_kind == 1 ? b : (a < b ? a : b);
+  }
+  wave_fence();
+  if (hnl_kind == 2) {
+    // order statistics of the preferred band (qsort + pick, aec_core.c:953-959) by rank counting
+    const int iFb = (int)floorf(0.75f * (prefBandSize - 1)), iLow = (int)floorf(0.5f * (prefBandSize - 1));
+    if (lane < prefBandSize) {
+      const float v = HNL[minPrefBand + lane];
+      int rank = 0;
+      for (int j = 0; j < prefBandSize; ++j) {
+        const float u = HNL[minPrefBand + j];
+        rank += (u < v) || (u == v && j < lane);
+      }
+      if (rank == iFb) misc[4] = v;
+      if (rank == iLow) misc[5] = v;
+    }
+    wave_fence();
+    hNlFb = misc[4];
+    hNlFbLow = misc[5];
+    wave_fence();
+  }
+
+  // ---- aec_core.c:962-992
+  float hNlFbLocalMin = sc[S_HNLFBLOCALMIN], hNlFbMin = sc[S_HNLFBMIN];
+  int hNlNewMin = sci[S_HNLNEWMIN], hNlMinCtr = sci[S_HNLMINCTR];
+  float overDriveSm = sc[S_OVERDRIVESM];
+  if (hNlFbLow < 0.6f && hNlFbLow < hNlFbLocalMin) {
+    hNlFbLocalMin = hNlFbLow;
+    hNlFbMin = hNlFbLow;
+    hNlNewMin = 1;
+    hNlMinCtr = 0;
+  }
+  {
+    const float a = hNlFbLocalMin + 0.0008f / mult, b = hNlXdAvgMin + 0.0006f / mult;
+    hNlFbLocalMin = a < 1 ? a : 1;
+    hNlXdAvgMin = b < 1 ? b : 1;
+  }
+  if (hNlNewMin == 1) hNlMinCtr++;
+  if (hNlMinCtr == 2) {
+    hNlNewMin = 0;
+    hNlMinCtr = 0;
+    const float v = targetSupp / ((float)log((double)(hNlFbMin + 1e-10f)) + 1e-10f);
+    overDrive = v > minOverDrive ? v : minOverDrive;
+  }
+  if (overDrive < overDriveSm) {
+    overDriveSm = 0.99f * overDriveSm + 0.01f * overDrive;
+  } else {
+    overDriveSm = 0.9f * overDriveSm + 0.1f * overDrive;
+  }
+
+  // ---- OverdriveAndSuppress + ComfortNoise (aec_core.c:271-292, 461-500)
+  const uint32_t seed = reinterpret_cast<uint32_t*>(sc)[S_SEED];
+  for (int bin = lane; bin < 65; bin += 64) {
+    float h = HNL[bin];
+    if (h > hNlFb) h = T.weight[bin] * hNlFb + (1 - T.weight[bin]) * h;
+    h = powf_via_f64(h, overDriveSm * T.odrive[bin]);
+    float er = EFR[bin] * h, ei = EFI[bin] * h;
+    ei *= -1;
+    float ur = 0.f, ui = 0.f;
+    if (bin > 0) {
+      // rand[bin - 1]: the LCG after `bin` steps (randomization_functions.c:93-115)
+      const uint32_t s = (T.lcg_a[bin - 1] * seed + T.lcg_c[bin - 1]) & 0x7fffffffu;
+      const float rnd = ((float)(int16_t)(s >> 16)) / 32768;
+      const float tmp = 6.28318530717959f * rnd;
+      const float noise = sqrtf(T1[bin]);
+      ur = noise * cosf_via_f64(tmp);
+      ui = -noise * sinf_via_f64(tmp);
+      if (bin == 64) ui = 0.f;
+    }
+    const float r = 1 - h * h;
+    const float tmp2 = sqrtf(r > 0 ? r : 0);
+    er += tmp2 * ur;
+    ei += tmp2 * ui;
+    EFR[bin] = er;
+    EFI[bin] = ei;
+  }
+  const uint32_t new_seed = (T.lcg_a[63] * seed + T.lcg_c[63]) & 0x7fffffffu;
+  wave_fence();
+
+  // ---- inverse error fft, overlap-add, saturation (aec_core.c:1006-1030)
+  {
+    float2 v;
+    v.x = EFR[lane];
+    v.y = lane == 0 ? EFR[64] : -EFI[lane];
+    tile(wl, 0)[lane] = v;
+  }
+  wave_fence();
+  rdft_inv_quad(wl, lane, T);
+  {
+    const float* tf = reinterpret_cast<const float*>(tile(wl, 0));
+    float a = tf[lane] * scale;
+    a = a * T.hann[lane] + st[kOffOutBuf + lane];
+    const float b = tf[64 + lane] * scale;
+    st[kOffOutBuf + lane] = b * T.hann[64 - lane];
+    const float o = a > 32767.f ? 32767.f : (a < -32768.f ? -32768.f : a);
+    st[kOffOutFr + ring_idx(op.out_wpos, lane, kFrBufLen)] = o;
+  }
+  // ---- carry the block (aec_core.c:1069-1081; the xfwBuf shift is the host's circular head)
+  st[kOffDBuf + lane] = ne;
+  st[kOffEBuf + lane] = e;
+  if (lane == 0) {
+    sc[S_HNLFBMIN] = hNlFbMin;
+    sc[S_HNLFBLOCALMIN] = hNlFbLocalMin;
+    sc[S_HNLXDAVGMIN] = hNlXdAvgMin;
+    sc[S_OVERDRIVE] = overDrive;
+    sc[S_OVERDRIVESM] = overDriveSm;
+    sci[S_HNLNEWMIN] = hNlNewMin;
+    sci[S_HNLMINCTR] = hNlMinCtr;
+    sci[S_DELAYIDX] = delayIdx;
+    sci[S_STNEARSTATE] = stNearState;
+    sci[S_ECHOSTATE] = echoState;
+    sci[S_DIVERGESTATE] = divergeState;
+    sci[S_NOISEESTCTR] = noiseEstCtr;
+    sci[S_DELAYESTCTR] = delayEstCtr;
+    reinterpret_cast<uint32_t*>(sc)[S_SEED] = new_seed;
+  }
+  wave_fence();
+}
+
+// WebRtcAec_ProcessFrames for every stream (running phase): per 80-sample sub-frame append the
+// near samples, run the scheduled blocks, emit 80 output samples.
+__global__ __launch_bounds__(256) void aec_process_kernel(float* __restrict__ state,
+                                                          const float* __restrict__ far_ring,
+                                                          const AecTables* __restrict__ G,
+                                                          const float* __restrict__ nearend,
+                                                          float* __restrict__ out, int num_streams,
+                                                          int nrOfSamples, ProcOps ops) {
+  __shared__ SharedTables T;
+  __shared__ float lds[4 * kLdsWave];
+  stage_tables(T, G);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  float* wl = lds + wave * kLdsWave;
+  float* st = state + (size_t)stream * kStateDwords;
+  const float* nin = nearend + (size_t)stream * nrOfSamples;
+  float* o = out + (size_t)stream * nrOfSamples;
+  for (int s = 0; s < ops.nsub; ++s) {
+    const SubFrame& sf = ops.sub[s];
+    // near samples of this sub-frame are read into registers first: `out` may alias `nearend`
+    const float n0 = nin[80 * s + lane];
+    const float n1 = lane < 16 ? nin[80 * s + 64 + lane] : 0.f;
+    st[kOffNearFr + ring_idx(sf.near_wpos, lane, kFrBufLen)] = n0;
+    if (lane < 16) st[kOffNearFr + ring_idx(sf.near_wpos, 64 + lane, kFrBufLen)] = n1;
+    // ring traffic between lanes of this wave goes through L2: order it at agent scope
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int k = 0; k < sf.nblocks; ++k) {
+      const BlockOp& op = sf.blk[k];
+      const float* slot = far_ring + ((size_t)op.far_slot * num_streams + stream) * kFarSlotDwords;
+      process_block(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    o[80 * s + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, lane, kFrBufLen)];
+    if (lane < 16) o[80 * s + 64 + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, 64 + lane, kFrBufLen)];
+  }
+}
+
+// aec_rdft_forward_128 / inverse_128 seam: four rows per wave.
+__global__ __launch_bounds__(256) void aec_rdft128_kernel(const float* __restrict__ src,
+                                                          float* __restrict__ dst, int isgn,
+                                                          int count,
+                                                          const AecTables* __restrict__ G) {
+  __shared__ SharedTables T;
+  __shared__ float lds[4 * kLdsWave];
+  stage_tables(T, G);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* wl = lds + wave * kLdsWave;
+  const int row0 = (blockIdx.x * 4 + wave) * 4;
+  for (int f = 0; f < 4; ++f) {
+    const int row = row0 + f;
+    float2 v = {0.f, 0.f};
+    if (row < count) {
+      v.x = src[(size_t)row * 128 + 2 * lane];
+      v.y = src[(size_t)row * 128 + 2 * lane + 1];
+    }
+    tile(wl, f)[lane] = v;
+  }
+  wave_fence();
+  if (isgn >= 0) {
+    rdft_fwd_quad(wl, lane, T);
+  } else {
+    rdft_inv_quad(wl, lane, T);
+  }
+  for (int f = 0; f < 4; ++f) {
+    const int row = row0 + f;
+    if (row < count) {
+      const float2 v = tile(wl, f)[lane];
+      dst[(size_t)row * 128 + 2 * lane] = v.x;
+      dst[(size_t)row * 128 + 2 * lane + 1] = v.y;
+    }
+  }
+}
+
+}  // namespace
+
+namespace aspaec {
+
+hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, const float* farend,
+                             int num_streams, const FarOps& ops, hipStream_t s) {
+  hipLaunchKernelGGL(aec_farend_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
+                     far_ring, T, farend, num_streams, ops);
+  return hipGetLastError();
+}
+
+hipError_t launch_aec_process(float* state, const float* far_ring, const AecTables* T,
+                              const float* nearend, float* out, int num_streams, int nrOfSamples,
+                              const ProcOps& ops, hipStream_t s) {
+  hipLaunchKernelGGL(aec_process_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
+                     far_ring, T, nearend, out, num_streams, nrOfSamples, ops);
+  return hipGetLastError();
+}
+
+hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(aec_rdft128_kernel, dim3((count + 15) / 16), dim3(256), 0, s, src, dst, isgn,
+                     count, T);
+  return hipGetLastError();
+}
+
+}  // namespace aspaec

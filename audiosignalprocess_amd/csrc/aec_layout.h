@@ -1,0 +1,100 @@
+// aec_layout.h -- HBM layout of the batched echo canceller and the launch descriptors shared by
+// aec_kernels.hip (device) and aec_api.hip (host control plane).
+//
+// Per stream (all float / int32 dwords, one contiguous block of kStateDwords):
+//   rows of kRow = 68 dwords holding 65 bins each (lane q <-> bin q, bin 64 at [64]):
+//     xPow dPow dMinPow dInitMinPow sx sd se sde.re sde.im sxd.re sxd.im           (11 rows)
+//     xfBuf  re[12] im[12]   -- partition p at physical index p (circular, xfBufBlockPos on host)
+//     wfBuf  re[12] im[12]
+//     xfwBuf [12] x {re, im} -- circular, newest at physical index `xfw_head` (host)
+//   dBuf[128] eBuf[128] outBuf[64]
+//   scalars[32]: see S_* below
+//   rings: far_pre[448] nearFr[144] outFr[144]   (positions live on the host)
+// Far-end spectra ring: separate allocation [250 slots][stream][4 rows of kRow]:
+//   plain re, plain im, windowed re, windowed im  (far_buf / far_buf_windowed, aec_core.c:1330-1341)
+#pragma once
+#include <stdint.h>
+
+namespace aspaec {
+
+constexpr int kPartLen = 64, kPartLen1 = 65, kPartLen2 = 128, kFrameLen = 80, kNumPart = 12;
+constexpr int kFarSlots = 250;              // kBufSizePartitions, aec_core.c:37
+constexpr int kPreLen = 128 + 4 * 80;       // far_pre_buf, echo_cancellation.c:146-147
+constexpr int kFrBufLen = 80 + 64;          // nearFrBuf / outFrBuf, aec_core.c:1299-1305
+constexpr int kRow = 68;
+
+enum Row {
+  R_XPOW = 0, R_DPOW, R_DMINPOW, R_DINITMINPOW, R_SX, R_SD, R_SE, R_SDE_RE, R_SDE_IM, R_SXD_RE,
+  R_SXD_IM,
+  R_XF_RE,                          // 12 rows
+  R_XF_IM = R_XF_RE + kNumPart,     // 12 rows
+  R_WF_RE = R_XF_IM + kNumPart,
+  R_WF_IM = R_WF_RE + kNumPart,
+  R_XFW = R_WF_IM + kNumPart,       // 24 rows: partition p -> rows R_XFW + 2p (re), + 2p + 1 (im)
+  R_COUNT = R_XFW + 2 * kNumPart    // 83
+};
+
+constexpr int kOffRows = 0;
+constexpr int kOffDBuf = R_COUNT * kRow;          // 5644
+constexpr int kOffEBuf = kOffDBuf + 128;
+constexpr int kOffOutBuf = kOffEBuf + 128;
+constexpr int kOffScalars = kOffOutBuf + 64;
+constexpr int kOffPre = kOffScalars + 32;
+constexpr int kOffNearFr = kOffPre + kPreLen;
+constexpr int kOffOutFr = kOffNearFr + kFrBufLen;
+constexpr int kStateDwords = ((kOffOutFr + kFrBufLen + 63) / 64) * 64;  // 6784 dwords = 27 136 B
+
+enum Scalar {
+  S_HNLFBMIN = 0, S_HNLFBLOCALMIN, S_HNLXDAVGMIN, S_OVERDRIVE, S_OVERDRIVESM,  // float
+  S_HNLNEWMIN, S_HNLMINCTR, S_DELAYIDX, S_STNEARSTATE, S_ECHOSTATE, S_DIVERGESTATE,  // int
+  S_NOISEESTCTR, S_DELAYESTCTR, S_SEED
+};
+
+constexpr int kFarSlotDwords = 4 * kRow;  // per stream per slot
+
+// Constant tables (host-built, aec_api.hip; the kernels stage them in LDS).
+struct AecTables {
+  float w[64];         // rdft_w, aec_rdft.c:32-49
+  float wk3a[16];      // rdft_wk3ri_first
+  float wk3b[16];      // rdft_wk3ri_second
+  float hann[68];      // WebRtcAec_sqrtHanning[65]
+  float weight[68];    // WebRtcAec_weightCurve[65]
+  float odrive[68];    // WebRtcAec_overDriveCurve[65]
+  uint32_t lcg_a[64];  // 69069^(k+1) mod 2^32
+  uint32_t lcg_c[64];  // sum_{i<=k} 69069^i mod 2^32
+};
+
+// One WebRtcAec_BufferFarend call (echo_cancellation.c:278-339) as the device sees it.
+struct FarOps {
+  int32_t n;         // samples appended to far_pre (80 / 160); 0: nothing to append
+  int32_t wpos;      // write position in far_pre before the append
+  int32_t nparts;    // partitions transformed by this call (0..3)
+  int32_t rpos[3];   // far_pre read position of each partition's 128 samples
+  int32_t slot[3];   // far ring slot each partition is written to
+};
+
+struct BlockOp {     // one ProcessBlock (aec_core.c:1084-1287)
+  int32_t near_rpos; // nearFrBuf read position of the 64 new samples
+  int32_t far_slot;  // far ring slot consumed
+  int32_t out_wpos;  // outFrBuf write position
+  int32_t xf_pos;    // xfBufBlockPos after its decrement
+  int32_t xfw_head;  // physical xfwBuf partition receiving this block's windowed far spectrum
+};
+
+struct SubFrame {    // one FRAME_LEN iteration of WebRtcAec_ProcessFrames (aec_core.c:1679-1777)
+  int32_t near_wpos;
+  int32_t nblocks;   // 0..2
+  BlockOp blk[2];
+  int32_t out_rpos;  // outFrBuf read position after the stuffing step
+};
+
+// One WebRtcAec_Process call in the running (non start-up) phase.
+struct ProcOps {
+  int32_t nsub;      // 1 or 2 sub-frames of 80 samples
+  int32_t mult;      // sampFreq / 8000
+  int32_t nlp_mode;
+  float mu, error_threshold;
+  SubFrame sub[2];
+};
+
+}  // namespace aspaec

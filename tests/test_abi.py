@@ -18,7 +18,7 @@ def declared_functions(header):
     return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", txt)))
 
 
-@pytest.mark.parametrize("header", ["asp_ns.h", "wav_io.h"])
+@pytest.mark.parametrize("header", ["asp_ns.h", "wav_io.h", "asp_bt.h", "asp_aec.h"])
 def test_every_declared_symbol_is_exported(built_lib, header):
     lib = C.CDLL(built_lib)
     names = declared_functions(header)
@@ -32,8 +32,23 @@ def test_reference_symbol_names_present(built_lib):
     for n in ["WebRtcNs_Create", "WebRtcNs_Free", "WebRtcNs_Init", "WebRtcNs_set_policy",
               "WebRtcNs_Analyze", "WebRtcNs_Process", "WebRtcNs_prior_speech_probability",
               "search_ID", "read_header", "write_header", "read_samples", "write_samples",
-              "print_header"]:
+              "print_header",
+              # aec/include/echo_cancellation.h:79-247
+              "WebRtcAec_Create", "WebRtcAec_Free", "WebRtcAec_Init", "WebRtcAec_BufferFarend",
+              "WebRtcAec_Process", "WebRtcAec_set_config", "WebRtcAec_get_echo_status",
+              "WebRtcAec_GetMetrics", "WebRtcAec_GetDelayMetrics", "WebRtcAec_get_error_code",
+              "WebRtcAec_aec_core"]:
         assert hasattr(lib, n), n
+
+
+def test_aec_host_tables_match_oracle(built_lib):
+    """FFT twiddles, sqrt-Hann window and NLP curves the AEC kernels consume == the oracle's, which
+    tests/test_aec_oracle.py pins to the reference's own symbols."""
+    from audiosignalprocess_amd import aec
+
+    for which, n in [(0, 64), (1, 16), (2, 16), (3, 65), (4, 65), (5, 65)]:
+        a, b = aec.host_table(which, n), oracle_lib.aec_oracle_table(which, n)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), which
 
 
 def test_host_tables_match_oracle(built_lib):
@@ -71,6 +86,11 @@ def test_no_device_fails_loudly(built_lib):
         ns.NsBatch(4)
     h = C.c_void_p()
     assert lib.WebRtcNs_Create(C.byref(h)) == -1
+    from audiosignalprocess_amd import aec
+
+    with pytest.raises(ns.AspError):
+        aec.AecBatch(2)
+    assert lib.WebRtcAec_Create(C.byref(h)) == -1
 
 
 def test_wav_io_roundtrip(built_lib, tmp_path):
