@@ -24,7 +24,7 @@ hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, 
                              int num_streams, const FarOps& ops, hipStream_t s);
 hipError_t launch_aec_process(float* state, const float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
-                              const ProcOps& ops, hipStream_t s);
+                              const ProcOps& ops, hipStream_t s, unsigned long long* stamps = nullptr);
 hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
                               hipStream_t s);
 }  // namespace aspaec
@@ -211,6 +211,7 @@ struct AspAecBatch {
   float normal_mu = 0.f, normal_error_threshold = 0.f;
   int xf_pos = 0, xfw_head = 0, blocks_processed = 0;
   RingPos pre_pos{}, far_pos{}, near_pos{}, out_pos{};
+  unsigned long long* debug_stamps = nullptr;  // diagnostic only (AspAecBatch_DebugStamps)
 };
 
 namespace {
@@ -451,7 +452,8 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
     if (out_elements < kFrameLen) rp_move_read(&b->out_pos, out_elements - kFrameLen);
     rp_read(&b->out_pos, kFrameLen, &sf.out_rpos);
   }
-  AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, b->stream));
+  AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, b->stream,
+                             b->debug_stamps));
   return 0;
 }
 
@@ -905,6 +907,29 @@ int AspAecBatch_get_echo_status(AspAecBatch* b, int* status) {
     status[s] = v;
   }
   return 0;
+}
+
+// Diagnostic: one BufferFarend + Process on device frames with phase time stamps (s_memtime
+// ticks) of stream 0's first block.
+int AspAecBatch_DebugStamps(AspAecBatch* b, const float* far_dev, const float* near_dev, float* out_dev,
+                            unsigned long long* stamps16) {
+  if (!b || !far_dev || !near_dev || !out_dev || !stamps16) return aec_fail(ASP_ERR_PARAM, "DebugStamps: bad argument");
+  AEC_TRY(hipSetDevice(b->device));
+  unsigned long long* d = nullptr;
+  AEC_TRY(hipMalloc((void**)&d, 16 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d, 0, 16 * sizeof(unsigned long long));
+  int err = 0, rc = 0;
+  if (e == hipSuccess) {
+    b->debug_stamps = d;
+    err = buffer_farend_device(b, far_dev, 160);
+    if (err == 0) err = process_device(b, near_dev, out_dev, 160, 0, &rc);
+    b->debug_stamps = nullptr;
+    e = hipStreamSynchronize(b->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpy(stamps16, d, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return aec_fail(ASP_ERR_HIP, "DebugStamps", e);
+  return err;
 }
 
 int AspAec_rdft128_batch(const float* src, float* dst, int isgn, int count, int device) {

@@ -28,6 +28,10 @@ using namespace aspaec;
 
 namespace {
 
+// Per-bin loops: trip 0 puts bin q on lane q, trip 1 is bin 64 computed by every lane (uniform
+// values, identical stores), so both trips are straight-line code whose loads overlap.
+#define BINS_2TRIPS _Pragma("unroll") for (int t_ = 0, bin = lane; t_ < 2; ++t_, bin = 64)
+
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -316,10 +320,10 @@ __global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ sta
   float* st = state + (size_t)stream * kStateDwords;
   float* pre = st + kOffPre;
   for (int i = lane; i < ops.n; i += 64) pre[ring_idx(ops.wpos, i, kPreLen)] = farend[(size_t)stream * ops.n + i];
-  // the partitions below read samples other lanes of this wave just wrote: order through L2
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  // the partitions below read samples other lanes of this wave just wrote: order them (same CU, same L1: workgroup scope; agent scope would flush the XCD L2)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   for (int p = 0; p < ops.nparts; ++p) {
     // 128 samples of far_pre -> tile 0 (plain) and tile 1 (windowed, aec_core.c:779-784)
     float* t0 = reinterpret_cast<float*>(tile(wl, 0));
@@ -343,16 +347,20 @@ __global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ sta
 // --------------------------------------------------------------- transcendentals
 // (float)pow / cos / sin evaluated in fp64: correctly rounded up to double rounding; glibc's powf /
 // cosf / sinf (<= 0.52 / 0.56 ulp) differ from that in rare last-place cases.
-__device__ __forceinline__ float powf_via_f64(float x, float y) { return (float)pow((double)x, (double)y); }
-__device__ __forceinline__ float cosf_via_f64(float x) { return (float)cos((double)x); }
-__device__ __forceinline__ float sinf_via_f64(float x) { return (float)sin((double)x); }
+__device__ __attribute__((noinline)) float powf_via_f64(float x, float y) { return (float)pow((double)x, (double)y); }
+__device__ __attribute__((noinline)) float cosf_via_f64(float x) { return (float)cos((double)x); }
+__device__ __attribute__((noinline)) float sinf_via_f64(float x) { return (float)sin((double)x); }
 
 // One ProcessBlock + NonLinearProcessing for this wave's stream.
-__device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
+__device__ __attribute__((noinline)) void process_block(float* __restrict__ st, float* __restrict__ wl,
                                               const float* __restrict__ far_slot,
                                               const SharedTables& T, const BlockOp& op, int mult,
                                               int nlp_mode, float mu, float error_threshold,
-                                              int lane) {
+                                              int lane, unsigned long long* stamps) {
+  // diagnostic phase stamps (never enabled by the product entry points)
+#define AEC_STAMP(k) \
+  if (stamps != nullptr) stamps[k] = __builtin_amdgcn_s_memtime();
+  AEC_STAMP(0)
   float* rows = st + kOffRows;
   float* sc = st + kOffScalars;
   int32_t* sci = reinterpret_cast<int32_t*>(sc);
@@ -382,7 +390,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   dbuf[lane] = st[kOffDBuf + lane];
   dbuf[64 + lane] = ne;
   ebuf[lane] = st[kOffEBuf + lane];
-  for (int bin = lane; bin < 65; bin += 64) {
+  BINS_2TRIPS {
     XFR[bin] = far_slot[bin];
     XFI[bin] = far_slot[kRow + bin];
     const float wr = far_slot[2 * kRow + bin], wi = far_slot[3 * kRow + bin];
@@ -393,6 +401,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   }
   wave_fence();
 
+  AEC_STAMP(1)
   // ---- near fft (aec_core.c:1140-1141)
   {
     const float2 v = {dbuf[2 * lane], dbuf[2 * lane + 1]};
@@ -403,11 +412,12 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   unpack_tile(wl, 0, DFR, DFI, lane);
   wave_fence();
 
+  AEC_STAMP(2)
   // ---- power smoothing and noise floor (aec_core.c:1144-1186)
   int noiseEstCtr = sci[S_NOISEESTCTR];
   const bool noise_track = noiseEstCtr > 50;
   const bool noise_init = noiseEstCtr < 500 * mult;
-  for (int bin = lane; bin < 65; bin += 64) {
+  BINS_2TRIPS {
     const float xr = XFR[bin], xi = XFI[bin];
     const float far_spectrum = (xr * xr) + (xi * xi);
     const float near_spectrum = DFR[bin] * DFR[bin] + DFI[bin] * DFI[bin];
@@ -443,8 +453,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   }
   if (noise_init) noiseEstCtr++;
 
+  AEC_STAMP(3)
   // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
-  for (int bin = lane; bin < 65; bin += 64) {
+  BINS_2TRIPS {
     float yr = 0.f, yi = 0.f;
     for (int i = 0; i < kNumPart; ++i) {
       int px = i + op.xf_pos;
@@ -460,6 +471,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   }
   wave_fence();
 
+  AEC_STAMP(4)
   // ---- echo estimate and error (aec_core.c:1222-1238)
   {
     float2 v;
@@ -473,6 +485,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   const float e = ne - y;
   wave_fence();
 
+  AEC_STAMP(5)
   // ---- error fft (aec_core.c:1241-1254)
   ebuf[64 + lane] = e;
   {
@@ -485,8 +498,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   unpack_tile(wl, 0, EFR, EFI, lane);
   wave_fence();
 
+  AEC_STAMP(6)
   // ---- ScaleErrorSignal (aec_core.c:171-193)
-  for (int bin = lane; bin < 65; bin += 64) {
+  BINS_2TRIPS {
     float er = EFR[bin], ei = EFI[bin];
     const float den = XPW[bin] + 1e-10f;
     er /= den;
@@ -504,6 +518,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   }
   wave_fence();
 
+  AEC_STAMP(7)
   // ---- FilterAdaptation (aec_core.c:221-269): four partitions per round
   for (int g = 0; g < kNumPart / 4; ++g) {
 #pragma unroll
@@ -516,10 +531,11 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       float2 v;
       v.x = ar * EFR[lane] - ai * EFI[lane];
       v.y = ar * EFI[lane] + ai * EFR[lane];
-      if (lane == 0) {
+      {
         const float cr = i == 0 ? XFR[64] : rows[(R_XF_RE + px) * kRow + 64];
         const float ci = -(i == 0 ? XFI[64] : rows[(R_XF_IM + px) * kRow + 64]);
-        v.y = cr * EFR[64] - ci * EFI[64];
+        const float p64 = cr * EFR[64] - ci * EFI[64];
+        if (lane == 0) v.y = p64;
       }
       tile(wl, k)[lane] = v;
     }
@@ -543,16 +559,17 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     for (int k = 0; k < 4; ++k) {
       const int i = 4 * g + k;
       const float2 v = tile(wl, k)[lane];
-      rows[(R_WF_RE + i) * kRow + lane] += v.x;
-      if (lane == 0) {
-        rows[(R_WF_RE + i) * kRow + 64] += v.y;
-      } else {
-        rows[(R_WF_IM + i) * kRow + lane] += v.y;
-      }
+      // lane 0 carries (fft[0], fft[1]) = updates of the real parts of bins 0 and 64
+      const int col = lane == 0 ? 64 : lane;
+      const int rsel = lane == 0 ? R_WF_RE : R_WF_IM;
+      const float w0 = rows[(R_WF_RE + i) * kRow + lane], w1 = rows[(rsel + i) * kRow + col];
+      rows[(R_WF_RE + i) * kRow + lane] = w0 + v.x;
+      rows[(rsel + i) * kRow + col] = w1 + v.y;
     }
     wave_fence();
   }
 
+  AEC_STAMP(8)
   // =================================================== NonLinearProcessing (aec_core.c:852-1082)
   int delayEstCtr = sci[S_DELAYESTCTR] + 1;
   if (delayEstCtr == 10 * mult) delayEstCtr = 0;
@@ -560,7 +577,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   if (delayEstCtr == 0) {  // PartitionDelay (aec_core.c:294-318)
     float* pe = wl + kLdsTile;  // 12 rows of 66 overlaying the tiles and the dead rows
     for (int i = 0; i < kNumPart; ++i)
-      for (int bin = lane; bin < 65; bin += 64) {
+      BINS_2TRIPS {
         const float wr = rows[(R_WF_RE + i) * kRow + bin], wi = rows[(R_WF_IM + i) * kRow + bin];
         pe[i * kLRow + bin] = wr * wr + wi * wi;
       }
@@ -583,6 +600,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     wave_fence();
   }
 
+  AEC_STAMP(9)
   // ---- windowed near / error spectra (aec_core.c:428-436)
   {
     float* t0 = reinterpret_cast<float*>(tile(wl, 0));
@@ -598,11 +616,12 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   unpack_tile(wl, 1, EFR, EFI, lane);  // efw
   wave_fence();
 
+  AEC_STAMP(10)
   // ---- SmoothedPSD + coherence (aec_core.c:332-385, 438-448)
   const float g0 = mult == 1 ? 0.9f : 0.93f, g1 = mult == 1 ? 0.1f : 0.07f;  // aec_core.c:111-112
   int pd = op.xfw_head + delayIdx;
   if (pd >= kNumPart) pd -= kNumPart;
-  for (int bin = lane; bin < 65; bin += 64) {
+  BINS_2TRIPS {
     const float dr = DFR[bin], di = DFI[bin], er = EFR[bin], ei = EFI[bin];
     const float xr = delayIdx == 0 ? XWR[bin] : rows[(R_XFW + 2 * pd) * kRow + bin];
     const float xi = delayIdx == 0 ? XWI[bin] : rows[(R_XFW + 2 * pd + 1) * kRow + bin];
@@ -642,16 +661,17 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   int divergeState = sci[S_DIVERGESTATE];
   divergeState = (divergeState ? 1.05f : 1.0f) * seSum > sdSum;
   if (divergeState) {
-    for (int bin = lane; bin < 65; bin += 64) {
+    BINS_2TRIPS {
       EFR[bin] = DFR[bin];
       EFI[bin] = DFI[bin];
     }
   }
   if (seSum > (19.95f * sdSum)) {
     for (int i = 0; i < 2 * kNumPart; ++i)
-      for (int bin = lane; bin < 65; bin += 64) rows[(R_WF_RE + i) * kRow + bin] = 0.f;
+      BINS_2TRIPS rows[(R_WF_RE + i) * kRow + bin] = 0.f;
   }
 
+  AEC_STAMP(11)
   // ---- aec_core.c:895-960
   hNlXdAvg /= prefBandSize;
   hNlXdAvg = 1 - hNlXdAvg;
@@ -693,7 +713,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     hNlFb = 0.f;
     hNlFbLow = 0.f;
   }
-  for (int bin = lane; bin < 65; bin += 64) {
+  BINS_2TRIPS {
     const float a = COHDE[bin], b = 1 - COHXD[bin];
     HNL[bin] = hnl_kind == 0 ? a : hnl_kind == 1 ? b : (a < b ? a : b);
   }
@@ -745,9 +765,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     overDriveSm = 0.9f * overDriveSm + 0.1f * overDrive;
   }
 
+  AEC_STAMP(12)
   // ---- OverdriveAndSuppress + ComfortNoise (aec_core.c:271-292, 461-500)
   const uint32_t seed = reinterpret_cast<uint32_t*>(sc)[S_SEED];
-  for (int bin = lane; bin < 65; bin += 64) {
+  BINS_2TRIPS {
     float h = HNL[bin];
     if (h > hNlFb) h = T.weight[bin] * hNlFb + (1 - T.weight[bin]) * h;
     h = powf_via_f64(h, overDriveSm * T.odrive[bin]);
@@ -774,6 +795,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   const uint32_t new_seed = (T.lcg_a[63] * seed + T.lcg_c[63]) & 0x7fffffffu;
   wave_fence();
 
+  AEC_STAMP(13)
   // ---- inverse error fft, overlap-add, saturation (aec_core.c:1006-1030)
   {
     float2 v;
@@ -792,6 +814,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     const float o = a > 32767.f ? 32767.f : (a < -32768.f ? -32768.f : a);
     st[kOffOutFr + ring_idx(op.out_wpos, lane, kFrBufLen)] = o;
   }
+  AEC_STAMP(14)
   // ---- carry the block (aec_core.c:1069-1081; the xfwBuf shift is the host's circular head)
   st[kOffDBuf + lane] = ne;
   st[kOffEBuf + lane] = e;
@@ -812,16 +835,19 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     reinterpret_cast<uint32_t*>(sc)[S_SEED] = new_seed;
   }
   wave_fence();
+  AEC_STAMP(15)
+#undef AEC_STAMP
 }
 
 // WebRtcAec_ProcessFrames for every stream (running phase): per 80-sample sub-frame append the
 // near samples, run the scheduled blocks, emit 80 output samples.
-__global__ __launch_bounds__(256) void aec_process_kernel(float* __restrict__ state,
+__global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__ state,
                                                           const float* __restrict__ far_ring,
                                                           const AecTables* __restrict__ G,
                                                           const float* __restrict__ nearend,
                                                           float* __restrict__ out, int num_streams,
-                                                          int nrOfSamples, ProcOps ops) {
+                                                          int nrOfSamples, ProcOps ops,
+                                                          unsigned long long* __restrict__ stamps) {
   __shared__ SharedTables T;
   __shared__ float lds[4 * kLdsWave];
   stage_tables(T, G);
@@ -839,17 +865,18 @@ __global__ __launch_bounds__(256) void aec_process_kernel(float* __restrict__ st
     const float n1 = lane < 16 ? nin[80 * s + 64 + lane] : 0.f;
     st[kOffNearFr + ring_idx(sf.near_wpos, lane, kFrBufLen)] = n0;
     if (lane < 16) st[kOffNearFr + ring_idx(sf.near_wpos, 64 + lane, kFrBufLen)] = n1;
-    // ring traffic between lanes of this wave goes through L2: order it at agent scope
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // ring traffic between lanes of this wave goes through L2: order it at workgroup scope (same CU and L1; agent scope would flush the XCD L2)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     for (int k = 0; k < sf.nblocks; ++k) {
       const BlockOp& op = sf.blk[k];
       const float* slot = far_ring + ((size_t)op.far_slot * num_streams + stream) * kFarSlotDwords;
-      process_block(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      process_block(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane,
+                    (stamps != nullptr && stream == 0 && s == 0 && k == 0 && lane == 0) ? stamps : nullptr);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     o[80 * s + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, lane, kFrBufLen)];
     if (lane < 16) o[80 * s + 64 + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, 64 + lane, kFrBufLen)];
@@ -905,9 +932,9 @@ hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, 
 
 hipError_t launch_aec_process(float* state, const float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
-                              const ProcOps& ops, hipStream_t s) {
+                              const ProcOps& ops, hipStream_t s, unsigned long long* stamps) {
   hipLaunchKernelGGL(aec_process_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
-                     far_ring, T, nearend, out, num_streams, nrOfSamples, ops);
+                     far_ring, T, nearend, out, num_streams, nrOfSamples, ops, stamps);
   return hipGetLastError();
 }
 

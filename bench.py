@@ -136,6 +136,61 @@ def bench_bt(args):
     print(json.dumps(line), flush=True)
 
 
+def bench_aec(args):
+    """Secondary line (BASELINE config 4): 10 ms / 16 kHz frames per second through the echo
+    canceller (WebRtcAec_BufferFarend + WebRtcAec_Process per frame), 1 GPU."""
+    import torch
+
+    from audiosignalprocess_amd.aec import AecBatch
+    from audiosignalprocess_amd.synth import aec_frames
+
+    S = args.streams_per_gpu
+    ring = 40
+    far1, near1 = aec_frames(64, ring)                      # 64 distinct streams, tiled over S
+    idx = np.arange(S) % 64
+    d_far = torch.from_numpy(np.ascontiguousarray(far1[:, idx])).cuda()
+    d_near = torch.from_numpy(np.ascontiguousarray(near1[:, idx])).cuda()
+    d_out = torch.empty_like(d_near)
+    g = AecBatch(S, 16000)
+    steps, warm = max(args.steps // 4, 10), max(args.warmup // 2, 80)   # warm-up passes the start-up phase
+    g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, warm)
+    torch.cuda.synchronize()
+    assert g.control().startup_phase == 0
+    t0 = time.perf_counter()
+    ev_ms = g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert bool(torch.isfinite(d_out).all())
+    algo = 71400                        # SURVEY.md 8(d): 2.5 blocks x 28 560 B per 10 ms frame
+    step_s = ev_ms / 1e3 / steps
+    achieved = algo * S / step_s / 1e9
+    line = {
+        "metric": "AEC 10 ms frames/sec (secondary)", "value": S * steps / wall, "unit": "frames/s",
+        "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * wall / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "WebRTC AEC (test_aec_module): 10 ms/16 kHz far+near frames, %d concurrent "
+                               "streams on 1 MI355X, 12 partitions, one far-end launch + one process "
+                               "launch per frame" % S},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "aec_process_kernel (+ aec_farend_kernel, both inside the timed step)",
+                     "algorithmic_bytes_per_launch": algo * S, "avg_launch_us": step_s * 1e6},
+    }
+    if not args.no_cpu_baseline:
+        from tests import oracle_lib
+        cores = host_cores()
+        Sc, Fc = 16 * cores, 300
+        farc, nearc = aec_frames(Sc, Fc)
+        t0 = time.perf_counter()
+        oracle_lib.aec_oracle_run_mt(farc, nearc, threads=cores)
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": Sc * Fc / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+                                "sample": "%d streams x %d frames through oracle/aec_oracle.c (bit-exact "
+                                          "restatement of the reference), %d pthreads" % (Sc, Fc, cores)}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,9 +202,11 @@ def main():
     ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
     ap.add_argument("--streams-per-wave", type=int, default=2, choices=[1, 2],
                     help="fused-step kernel: 2 = two streams per wave64 (default), 1 = one")
-    ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256"],
-                    help="ns = the headline metric (default); bt* = secondary BlockThresholding line")
+    ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256", "aec"],
+                    help="ns = the headline metric (default); bt* / aec = secondary lines")
     args = ap.parse_args()
+    if args.workload == "aec":
+        return bench_aec(args)
     if args.workload != "ns":
         return bench_bt(args)
 
