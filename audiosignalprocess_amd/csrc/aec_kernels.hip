@@ -48,7 +48,8 @@ constexpr int kLRow = 66;
 constexpr int kLdsDbuf = kLdsRows + L_NROWS * kLRow;  // 128
 constexpr int kLdsEbuf = kLdsDbuf + 128;              // 128
 constexpr int kLdsMisc = kLdsEbuf + 128;              // 16
-constexpr int kLdsWave = kLdsMisc + 16;               // 1856 floats = 7 424 B per wave
+constexpr int kLdsC64 = kLdsMisc + 16;                // bin 64 of every state row (84)
+constexpr int kLdsWave = kLdsC64 + 84;                // 1940 floats = 7 760 B per wave
 static_assert(kNumPart * kLRow <= kLdsRows + 9 * kLRow, "partition-energy rows overlay");
 
 struct SharedTables {
@@ -384,20 +385,47 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   float* T0 = lrow(wl, L_T0);
   float* T1 = lrow(wl, L_T1);
   const float scale = 2.0f / 128;
+  // State rows: trip 0 (bin = lane) goes to HBM, trip 1 (bin 64) to a per-wave LDS copy of the
+  // bin-64 column that is gathered once per block and scattered back at its end.
+  float* c64 = wl + kLdsC64;
+#define ROW_LD(r) (t_ == 0 ? rows[(r) * kRow + lane] : c64[r])
+#define ROW_ST(r, v)                         \
+  do {                                       \
+    if (t_ == 0) {                           \
+      rows[(r) * kRow + lane] = (v);         \
+    } else {                                 \
+      c64[r] = (v);                          \
+    }                                        \
+  } while (0)
+  for (int r = lane; r < R_COUNT; r += 64) c64[r] = rows[r * kRow + 64];
+  // the lane's own bins of the far-spectrum history and of the filter stay in registers from
+  // here to the end of the filter update (logical partition order)
+  float xr[kNumPart], xi[kNumPart], wr[kNumPart], wi[kNumPart];
+#pragma unroll
+  for (int i = 0; i < kNumPart; ++i) {
+    int px = i + op.xf_pos;
+    if (px >= kNumPart) px -= kNumPart;
+    xr[i] = rows[(R_XF_RE + px) * kRow + lane];  // i = 0 is replaced by this block's spectrum
+    xi[i] = rows[(R_XF_IM + px) * kRow + lane];
+    wr[i] = rows[(R_WF_RE + i) * kRow + lane];
+    wi[i] = rows[(R_WF_IM + i) * kRow + lane];
+  }
 
   // ---- near block (aec_core.c:1114-1124) and the far spectra of this block (:1137, 888-891)
   const float ne = st[kOffNearFr + ring_idx(op.near_rpos, lane, kFrBufLen)];
   dbuf[lane] = st[kOffDBuf + lane];
   dbuf[64 + lane] = ne;
   ebuf[lane] = st[kOffEBuf + lane];
+  xr[0] = far_slot[lane];
+  xi[0] = far_slot[kRow + lane];
   BINS_2TRIPS {
     XFR[bin] = far_slot[bin];
     XFI[bin] = far_slot[kRow + bin];
     const float wr = far_slot[2 * kRow + bin], wi = far_slot[3 * kRow + bin];
     XWR[bin] = wr;
     XWI[bin] = wi;
-    rows[(R_XFW + 2 * op.xfw_head) * kRow + bin] = wr;
-    rows[(R_XFW + 2 * op.xfw_head + 1) * kRow + bin] = wi;
+    ROW_ST((R_XFW + 2 * op.xfw_head), wr);
+    ROW_ST((R_XFW + 2 * op.xfw_head + 1), wi);
   }
   wave_fence();
 
@@ -421,35 +449,35 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     const float xr = XFR[bin], xi = XFI[bin];
     const float far_spectrum = (xr * xr) + (xi * xi);
     const float near_spectrum = DFR[bin] * DFR[bin] + DFI[bin] * DFI[bin];
-    const float xp = 0.9f * rows[R_XPOW * kRow + bin] + 0.1f * kNumPart * far_spectrum;
-    const float dp = 0.9f * rows[R_DPOW * kRow + bin] + 0.1f * near_spectrum;
-    rows[R_XPOW * kRow + bin] = xp;
-    rows[R_DPOW * kRow + bin] = dp;
+    const float xp = 0.9f * ROW_LD(R_XPOW) + 0.1f * kNumPart * far_spectrum;
+    const float dp = 0.9f * ROW_LD(R_DPOW) + 0.1f * near_spectrum;
+    ROW_ST(R_XPOW, xp);
+    ROW_ST(R_DPOW, dp);
     XPW[bin] = xp;
-    float dmin = rows[R_DMINPOW * kRow + bin];
+    float dmin = ROW_LD(R_DMINPOW);
     if (noise_track) {
       if (dp < dmin) {
         dmin = (dp + 0.1f * (dmin - dp)) * 1.0002f;
       } else {
         dmin *= 1.0002f;
       }
-      rows[R_DMINPOW * kRow + bin] = dmin;
+      ROW_ST(R_DMINPOW, dmin);
     }
     float npow = dmin;
     if (noise_init) {
-      float dinit = rows[R_DINITMINPOW * kRow + bin];
+      float dinit = ROW_LD(R_DINITMINPOW);
       if (dmin > dinit) {
         dinit = 0.999f * dinit + 0.001f * dmin;
       } else {
         dinit = dmin;
       }
-      rows[R_DINITMINPOW * kRow + bin] = dinit;
+      ROW_ST(R_DINITMINPOW, dinit);
       npow = dinit;
     }
     T1[bin] = npow;  // aec->noisePow for the comfort noise (kept until the NLP)
     // ---- buffer xf (aec_core.c:1203-1214)
-    rows[(R_XF_RE + op.xf_pos) * kRow + bin] = xr;
-    rows[(R_XF_IM + op.xf_pos) * kRow + bin] = xi;
+    ROW_ST((R_XF_RE + op.xf_pos), xr);
+    ROW_ST((R_XF_IM + op.xf_pos), xi);
   }
   if (noise_init) noiseEstCtr++;
 
@@ -457,12 +485,14 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
   BINS_2TRIPS {
     float yr = 0.f, yi = 0.f;
+#pragma unroll
     for (int i = 0; i < kNumPart; ++i) {
       int px = i + op.xf_pos;
       if (px >= kNumPart) px -= kNumPart;
-      const float ar = i == 0 ? XFR[bin] : rows[(R_XF_RE + px) * kRow + bin];
-      const float ai = i == 0 ? XFI[bin] : rows[(R_XF_IM + px) * kRow + bin];
-      const float br = rows[(R_WF_RE + i) * kRow + bin], bi = rows[(R_WF_IM + i) * kRow + bin];
+      const float ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
+      const float ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
+      const float br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
+      const float bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
       yr += ar * br - ai * bi;
       yi += ar * bi + ai * br;
     }
@@ -526,14 +556,13 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
       const int i = 4 * g + k;
       int px = i + op.xf_pos;
       if (px >= kNumPart) px -= kNumPart;
-      const float ar = i == 0 ? XFR[lane] : rows[(R_XF_RE + px) * kRow + lane];
-      const float ai = -(i == 0 ? XFI[lane] : rows[(R_XF_IM + px) * kRow + lane]);
+      const float ar = xr[i], ai = -xi[i];
       float2 v;
       v.x = ar * EFR[lane] - ai * EFI[lane];
       v.y = ar * EFI[lane] + ai * EFR[lane];
       {
-        const float cr = i == 0 ? XFR[64] : rows[(R_XF_RE + px) * kRow + 64];
-        const float ci = -(i == 0 ? XFI[64] : rows[(R_XF_IM + px) * kRow + 64]);
+        const float cr = i == 0 ? XFR[64] : c64[R_XF_RE + px];
+        const float ci = -(i == 0 ? XFI[64] : c64[R_XF_IM + px]);
         const float p64 = cr * EFR[64] - ci * EFI[64];
         if (lane == 0) v.y = p64;
       }
@@ -560,13 +589,19 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
       const int i = 4 * g + k;
       const float2 v = tile(wl, k)[lane];
       // lane 0 carries (fft[0], fft[1]) = updates of the real parts of bins 0 and 64
-      const int col = lane == 0 ? 64 : lane;
-      const int rsel = lane == 0 ? R_WF_RE : R_WF_IM;
-      const float w0 = rows[(R_WF_RE + i) * kRow + lane], w1 = rows[(rsel + i) * kRow + col];
-      rows[(R_WF_RE + i) * kRow + lane] = w0 + v.x;
-      rows[(rsel + i) * kRow + col] = w1 + v.y;
+      wr[i] += v.x;
+      if (lane == 0) {
+        c64[R_WF_RE + i] += v.y;
+      } else {
+        wi[i] += v.y;
+      }
     }
     wave_fence();
+  }
+#pragma unroll
+  for (int i = 0; i < kNumPart; ++i) {
+    rows[(R_WF_RE + i) * kRow + lane] = wr[i];
+    rows[(R_WF_IM + i) * kRow + lane] = wi[i];
   }
 
   AEC_STAMP(8)
@@ -578,7 +613,7 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     float* pe = wl + kLdsTile;  // 12 rows of 66 overlaying the tiles and the dead rows
     for (int i = 0; i < kNumPart; ++i)
       BINS_2TRIPS {
-        const float wr = rows[(R_WF_RE + i) * kRow + bin], wi = rows[(R_WF_IM + i) * kRow + bin];
+        const float wr = ROW_LD((R_WF_RE + i)), wi = ROW_LD((R_WF_IM + i));
         pe[i * kLRow + bin] = wr * wr + wi * wi;
       }
     wave_fence();
@@ -623,23 +658,23 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   if (pd >= kNumPart) pd -= kNumPart;
   BINS_2TRIPS {
     const float dr = DFR[bin], di = DFI[bin], er = EFR[bin], ei = EFI[bin];
-    const float xr = delayIdx == 0 ? XWR[bin] : rows[(R_XFW + 2 * pd) * kRow + bin];
-    const float xi = delayIdx == 0 ? XWI[bin] : rows[(R_XFW + 2 * pd + 1) * kRow + bin];
-    const float sd = g0 * rows[R_SD * kRow + bin] + g1 * (dr * dr + di * di);
-    const float se = g0 * rows[R_SE * kRow + bin] + g1 * (er * er + ei * ei);
+    const float xr = delayIdx == 0 ? XWR[bin] : ROW_LD((R_XFW + 2 * pd));
+    const float xi = delayIdx == 0 ? XWI[bin] : ROW_LD((R_XFW + 2 * pd + 1));
+    const float sd = g0 * ROW_LD(R_SD) + g1 * (dr * dr + di * di);
+    const float se = g0 * ROW_LD(R_SE) + g1 * (er * er + ei * ei);
     const float xx = xr * xr + xi * xi;
-    const float sx = g0 * rows[R_SX * kRow + bin] + g1 * (xx > 15.f ? xx : 15.f);
-    const float sde_r = g0 * rows[R_SDE_RE * kRow + bin] + g1 * (dr * er + di * ei);
-    const float sde_i = g0 * rows[R_SDE_IM * kRow + bin] + g1 * (dr * ei - di * er);
-    const float sxd_r = g0 * rows[R_SXD_RE * kRow + bin] + g1 * (dr * xr + di * xi);
-    const float sxd_i = g0 * rows[R_SXD_IM * kRow + bin] + g1 * (dr * xi - di * xr);
-    rows[R_SD * kRow + bin] = sd;
-    rows[R_SE * kRow + bin] = se;
-    rows[R_SX * kRow + bin] = sx;
-    rows[R_SDE_RE * kRow + bin] = sde_r;
-    rows[R_SDE_IM * kRow + bin] = sde_i;
-    rows[R_SXD_RE * kRow + bin] = sxd_r;
-    rows[R_SXD_IM * kRow + bin] = sxd_i;
+    const float sx = g0 * ROW_LD(R_SX) + g1 * (xx > 15.f ? xx : 15.f);
+    const float sde_r = g0 * ROW_LD(R_SDE_RE) + g1 * (dr * er + di * ei);
+    const float sde_i = g0 * ROW_LD(R_SDE_IM) + g1 * (dr * ei - di * er);
+    const float sxd_r = g0 * ROW_LD(R_SXD_RE) + g1 * (dr * xr + di * xi);
+    const float sxd_i = g0 * ROW_LD(R_SXD_IM) + g1 * (dr * xi - di * xr);
+    ROW_ST(R_SD, sd);
+    ROW_ST(R_SE, se);
+    ROW_ST(R_SX, sx);
+    ROW_ST(R_SDE_RE, sde_r);
+    ROW_ST(R_SDE_IM, sde_i);
+    ROW_ST(R_SXD_RE, sxd_r);
+    ROW_ST(R_SXD_IM, sxd_i);
     T0[bin] = sd;
     XPW[bin] = se;
     COHDE[bin] = (sde_r * sde_r + sde_i * sde_i) / (sd * se + 1e-10f);
@@ -668,7 +703,7 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   }
   if (seSum > (19.95f * sdSum)) {
     for (int i = 0; i < 2 * kNumPart; ++i)
-      BINS_2TRIPS rows[(R_WF_RE + i) * kRow + bin] = 0.f;
+      BINS_2TRIPS ROW_ST((R_WF_RE + i), 0.f);
   }
 
   AEC_STAMP(11)
@@ -835,8 +870,11 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     reinterpret_cast<uint32_t*>(sc)[S_SEED] = new_seed;
   }
   wave_fence();
+  for (int r = lane; r < R_COUNT; r += 64) rows[r * kRow + 64] = c64[r];
   AEC_STAMP(15)
 #undef AEC_STAMP
+#undef ROW_LD
+#undef ROW_ST
 }
 
 // WebRtcAec_ProcessFrames for every stream (running phase): per 80-sample sub-frame append the
