@@ -133,6 +133,30 @@ def bench_bt(args):
                      "kernel": "bt_macroblock_kernel<%d>" % n,
                      "algorithmic_bytes_per_launch": algo * S, "avg_launch_us": launch_s * 1e6},
     }
+    if not args.no_cpu_baseline:
+        # the CPU restatement (oracle/bt_oracle.c; the reference itself is unbuildable here, DESIGN.md
+        # section 2), one stream-channel per thread; ctypes releases the GIL inside the C calls
+        from concurrent.futures import ThreadPoolExecutor
+
+        from tests.oracle_lib import OracleBt
+        cores = host_cores()
+        per, reps = (100, 30) if n == 1024 else (400, 30)
+        blocks = per * reps
+        xs = bt_samples(cores, per * g.macro)
+
+        def one(ch):
+            o = OracleBt(n)
+            for _ in range(reps):
+                o.run(xs[ch])
+        OracleBt(n).run(xs[0][:g.macro])          # table construction outside the timed region
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(one, range(cores)))
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": cores * blocks / dt, "unit": "macroblocks/s", "cores": cores,
+                                "kind": "port",
+                                "sample": "%d stream-channels x %d macroblocks through oracle/bt_oracle.c, "
+                                          "one thread each" % (cores, blocks)}
     print(json.dumps(line), flush=True)
 
 
