@@ -228,3 +228,34 @@ def test_scale_4096_streams_identical_inputs(aec):
         ref = out[:, k]
         assert np.array_equal(_bits(out[:, k::4]), _bits(np.broadcast_to(ref[:, None], out[:, k::4].shape)))
     assert not np.array_equal(out[F - 1, 0], near1[F - 1, 0])
+
+
+def test_wav_driver_end_to_end(aec, aec_golden, tmp_path):
+    """drivers/test_aec_module (the reference's test_aec_module.cpp loop in C over WebRtcAec_*):
+    mic.wav + speaker.wav -> result.wav equals the reference's float output rounded by
+    FloatS16ToS16, within 1 LSB on < 0.1 % of samples (powf/cosf/sinf last places)."""
+    import struct
+    import subprocess
+
+    from audiosignalprocess_amd.build import build_drivers
+
+    exe = [e for e in build_drivers() if e.endswith("test_aec_module")][0]
+    F = 400
+    far, near = aec_golden["far_i16"][:F, 0].reshape(-1), aec_golden["near_i16"][:F, 0].reshape(-1)
+
+    def wav(samples):
+        return b"RIFF" + struct.pack("<i", 36 + samples.nbytes) + b"WAVE" + \
+            struct.pack("<4sihhiihh", b"fmt ", 16, 1, 1, 16000, 32000, 2, 16) + \
+            b"data" + struct.pack("<i", samples.nbytes) + samples.tobytes()
+
+    (tmp_path / "mic.wav").write_bytes(wav(near))
+    (tmp_path / "spk.wav").write_bytes(wav(far))
+    subprocess.run([exe, str(tmp_path / "mic.wav"), str(tmp_path / "spk.wav"), str(tmp_path / "out.wav"), "-q"],
+                   check=True, stdout=subprocess.DEVNULL)
+    out = np.frombuffer((tmp_path / "out.wav").read_bytes()[44:], dtype=np.int16)
+    assert out.size == (F + 1) * 160          # the feof loop emits one extra (stale) frame
+    want = aec_golden["out_f32"][:F, 0].reshape(-1)
+    want_i16 = np.where(want > 0, np.floor(want + np.float32(0.5)), np.ceil(want - np.float32(0.5)))
+    want_i16 = np.clip(want_i16, -32768, 32767).astype(np.int32)
+    d = np.abs(out[:F * 160].astype(np.int32) - want_i16)
+    assert d.max() <= 1 and (d == 0).mean() >= 0.999
