@@ -43,7 +43,7 @@ constexpr int kTileStride = 66;                 // float2 per transform tile (64
 constexpr int kLdsTile = 0;                     // 4 tiles: 4 * 66 float2 = 528 floats
 constexpr int kLdsRows = 4 * kTileStride * 2;   // per-bin rows of 66 floats
 enum LRow { L_XFR = 0, L_XFI, L_DFR, L_DFI, L_YFR, L_YFI, L_EFR, L_EFI, L_XPOW, L_XWR, L_XWI,
-            L_COHDE, L_COHXD, L_HNL, L_T0, L_T1, L_NROWS };
+            L_COHDE, L_COHXD, L_HNL, L_T0, L_T1, L_DWR, L_DWI, L_EWR, L_EWI, L_NROWS };
 constexpr int kLRow = 66;
 constexpr int kLdsDbuf = kLdsRows + L_NROWS * kLRow;  // 128
 constexpr int kLdsEbuf = kLdsDbuf + 128;              // 128
@@ -384,6 +384,10 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   float* HNL = lrow(wl, L_HNL);
   float* T0 = lrow(wl, L_T0);
   float* T1 = lrow(wl, L_T1);
+  float* DWR = lrow(wl, L_DWR);  // windowed near spectrum (NLP)
+  float* DWI = lrow(wl, L_DWI);
+  float* EWR = lrow(wl, L_EWR);  // windowed error spectrum (NLP)
+  float* EWI = lrow(wl, L_EWI);
   const float scale = 2.0f / 128;
   // State rows: trip 0 (bin = lane) goes to HBM, trip 1 (bin 64) to a per-wave LDS copy of the
   // bin-64 column that is gathered once per block and scattered back at its end.
@@ -397,7 +401,12 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
       c64[r] = (v);                          \
     }                                        \
   } while (0)
-  for (int r = lane; r < R_COUNT; r += 64) c64[r] = rows[r * kRow + 64];
+  // ---- near block (aec_core.c:1114-1124) and the far spectra of this block (:1137, 888-891)
+  const float ne = st[kOffNearFr + ring_idx(op.near_rpos, lane, kFrBufLen)];
+  dbuf[lane] = st[kOffDBuf + lane];
+  dbuf[64 + lane] = ne;
+  ebuf[lane] = st[kOffEBuf + lane];
+  // issued after the few loads the first FFT needs, consumed much later
   // the lane's own bins of the far-spectrum history and of the filter stay in registers from
   // here to the end of the filter update (logical partition order)
   float xr[kNumPart], xi[kNumPart], wr[kNumPart], wi[kNumPart];
@@ -411,11 +420,24 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     wi[i] = rows[(R_WF_IM + i) * kRow + lane];
   }
 
-  // ---- near block (aec_core.c:1114-1124) and the far spectra of this block (:1137, 888-891)
-  const float ne = st[kOffNearFr + ring_idx(op.near_rpos, lane, kFrBufLen)];
-  dbuf[lane] = st[kOffDBuf + lane];
-  dbuf[64 + lane] = ne;
-  ebuf[lane] = st[kOffEBuf + lane];
+  for (int r = lane; r < R_COUNT; r += 64) c64[r] = rows[r * kRow + 64];
+  wave_fence();
+
+  AEC_STAMP(1)
+  // ---- near fft (aec_core.c:1140-1141)
+  {
+    // plain (aec_core.c:1140) and sqrt-Hann windowed (aec_core.c:428-431) near spectra side by side
+    const float2 v = {dbuf[2 * lane], dbuf[2 * lane + 1]};
+    tile(wl, 0)[lane] = v;
+    float* t1 = reinterpret_cast<float*>(tile(wl, 1));
+    t1[lane] = dbuf[lane] * T.hann[lane];
+    t1[64 + lane] = dbuf[64 + lane] * T.hann[64 - lane];
+  }
+  wave_fence();
+  rdft_fwd_quad(wl, lane, T);
+  unpack_tile(wl, 0, DFR, DFI, lane);
+  unpack_tile(wl, 1, DWR, DWI, lane);
+  // the far spectra of this block (their loads were in flight during the transform)
   xr[0] = far_slot[lane];
   xi[0] = far_slot[kRow + lane];
   BINS_2TRIPS {
@@ -427,17 +449,6 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     ROW_ST((R_XFW + 2 * op.xfw_head), wr);
     ROW_ST((R_XFW + 2 * op.xfw_head + 1), wi);
   }
-  wave_fence();
-
-  AEC_STAMP(1)
-  // ---- near fft (aec_core.c:1140-1141)
-  {
-    const float2 v = {dbuf[2 * lane], dbuf[2 * lane + 1]};
-    tile(wl, 0)[lane] = v;
-  }
-  wave_fence();
-  rdft_fwd_quad(wl, lane, T);
-  unpack_tile(wl, 0, DFR, DFI, lane);
   wave_fence();
 
   AEC_STAMP(2)
@@ -519,13 +530,18 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   // ---- error fft (aec_core.c:1241-1254)
   ebuf[64 + lane] = e;
   {
+    // zero-padded (aec_core.c:1241-1246) and windowed (aec_core.c:433-436) error spectra side by side
     float* tf = reinterpret_cast<float*>(tile(wl, 0));
     tf[lane] = 0.f;
     tf[64 + lane] = e;
+    float* t1 = reinterpret_cast<float*>(tile(wl, 1));
+    t1[lane] = ebuf[lane] * T.hann[lane];
+    t1[64 + lane] = e * T.hann[64 - lane];
   }
   wave_fence();
   rdft_fwd_quad(wl, lane, T);
   unpack_tile(wl, 0, EFR, EFI, lane);
+  unpack_tile(wl, 1, EWR, EWI, lane);
   wave_fence();
 
   AEC_STAMP(6)
@@ -636,20 +652,7 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   }
 
   AEC_STAMP(9)
-  // ---- windowed near / error spectra (aec_core.c:428-436)
-  {
-    float* t0 = reinterpret_cast<float*>(tile(wl, 0));
-    float* t1 = reinterpret_cast<float*>(tile(wl, 1));
-    t0[lane] = dbuf[lane] * T.hann[lane];
-    t0[64 + lane] = dbuf[64 + lane] * T.hann[64 - lane];
-    t1[lane] = ebuf[lane] * T.hann[lane];
-    t1[64 + lane] = ebuf[64 + lane] * T.hann[64 - lane];
-  }
-  wave_fence();
-  rdft_fwd_quad(wl, lane, T);
-  unpack_tile(wl, 0, DFR, DFI, lane);  // dfw
-  unpack_tile(wl, 1, EFR, EFI, lane);  // efw
-  wave_fence();
+  // (the windowed near / error spectra were computed next to the plain ones above)
 
   AEC_STAMP(10)
   // ---- SmoothedPSD + coherence (aec_core.c:332-385, 438-448)
@@ -657,7 +660,7 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   int pd = op.xfw_head + delayIdx;
   if (pd >= kNumPart) pd -= kNumPart;
   BINS_2TRIPS {
-    const float dr = DFR[bin], di = DFI[bin], er = EFR[bin], ei = EFI[bin];
+    const float dr = DWR[bin], di = DWI[bin], er = EWR[bin], ei = EWI[bin];
     const float xr = delayIdx == 0 ? XWR[bin] : ROW_LD((R_XFW + 2 * pd));
     const float xi = delayIdx == 0 ? XWI[bin] : ROW_LD((R_XFW + 2 * pd + 1));
     const float sd = g0 * ROW_LD(R_SD) + g1 * (dr * dr + di * di);
@@ -697,8 +700,8 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   divergeState = (divergeState ? 1.05f : 1.0f) * seSum > sdSum;
   if (divergeState) {
     BINS_2TRIPS {
-      EFR[bin] = DFR[bin];
-      EFI[bin] = DFI[bin];
+      EWR[bin] = DWR[bin];
+      EWI[bin] = DWI[bin];
     }
   }
   if (seSum > (19.95f * sdSum)) {
@@ -807,7 +810,7 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     float h = HNL[bin];
     if (h > hNlFb) h = T.weight[bin] * hNlFb + (1 - T.weight[bin]) * h;
     h = powf_via_f64(h, overDriveSm * T.odrive[bin]);
-    float er = EFR[bin] * h, ei = EFI[bin] * h;
+    float er = EWR[bin] * h, ei = EWI[bin] * h;
     ei *= -1;
     float ur = 0.f, ui = 0.f;
     if (bin > 0) {
@@ -824,8 +827,8 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     const float tmp2 = sqrtf(r > 0 ? r : 0);
     er += tmp2 * ur;
     ei += tmp2 * ui;
-    EFR[bin] = er;
-    EFI[bin] = ei;
+    EWR[bin] = er;
+    EWI[bin] = ei;
   }
   const uint32_t new_seed = (T.lcg_a[63] * seed + T.lcg_c[63]) & 0x7fffffffu;
   wave_fence();
@@ -834,8 +837,8 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   // ---- inverse error fft, overlap-add, saturation (aec_core.c:1006-1030)
   {
     float2 v;
-    v.x = EFR[lane];
-    v.y = lane == 0 ? EFR[64] : -EFI[lane];
+    v.x = EWR[lane];
+    v.y = lane == 0 ? EWR[64] : -EWI[lane];
     tile(wl, 0)[lane] = v;
   }
   wave_fence();
