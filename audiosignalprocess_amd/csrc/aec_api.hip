@@ -231,7 +231,10 @@ size_t far_bytes(const AspAecBatch* b) {
 void pack_stream(const AspAecBatch* b, const AspAecState* s, float* blk) {
   memset(blk, 0, kStateDwords * sizeof(float));
   float* rows = blk + kOffRows;
-  auto put_row = [&](int r, const float* src) { memcpy(rows + r * kRow, src, 65 * sizeof(float)); };
+  auto put_row = [&](int r, const float* src) {
+    memcpy(rows + r * kRowS, src, 64 * sizeof(float));
+    blk[kOffC64 + r] = src[64];
+  };
   put_row(R_XPOW, s->xPow);
   put_row(R_DPOW, s->dPow);
   put_row(R_DMINPOW, s->dMinPow);
@@ -239,11 +242,18 @@ void pack_stream(const AspAecBatch* b, const AspAecState* s, float* blk) {
   put_row(R_SX, s->sx);
   put_row(R_SD, s->sd);
   put_row(R_SE, s->se);
-  for (int i = 0; i < 65; ++i) {
-    rows[R_SDE_RE * kRow + i] = s->sde[i][0];
-    rows[R_SDE_IM * kRow + i] = s->sde[i][1];
-    rows[R_SXD_RE * kRow + i] = s->sxd[i][0];
-    rows[R_SXD_IM * kRow + i] = s->sxd[i][1];
+  {
+    float tmp[4][65];
+    for (int i = 0; i < 65; ++i) {
+      tmp[0][i] = s->sde[i][0];
+      tmp[1][i] = s->sde[i][1];
+      tmp[2][i] = s->sxd[i][0];
+      tmp[3][i] = s->sxd[i][1];
+    }
+    put_row(R_SDE_RE, tmp[0]);
+    put_row(R_SDE_IM, tmp[1]);
+    put_row(R_SXD_RE, tmp[2]);
+    put_row(R_SXD_IM, tmp[3]);
   }
   for (int a = 0; a < kNumPart; ++a) {  // logical age a: canonical (c + a) % 12 -> physical (h + a) % 12
     const int pc = (s->xfBufBlockPos + a) % kNumPart, ph = (b->xf_pos + a) % kNumPart;
@@ -288,7 +298,10 @@ void pack_stream(const AspAecBatch* b, const AspAecState* s, float* blk) {
 void unpack_stream(const AspAecBatch* b, const float* blk, AspAecState* s) {
   memset(s, 0, sizeof *s);
   const float* rows = blk + kOffRows;
-  auto get_row = [&](int r, float* dst) { memcpy(dst, rows + r * kRow, 65 * sizeof(float)); };
+  auto get_row = [&](int r, float* dst) {
+    memcpy(dst, rows + r * kRowS, 64 * sizeof(float));
+    dst[64] = blk[kOffC64 + r];
+  };
   get_row(R_XPOW, s->xPow);
   get_row(R_DPOW, s->dPow);
   get_row(R_DMINPOW, s->dMinPow);
@@ -296,11 +309,18 @@ void unpack_stream(const AspAecBatch* b, const float* blk, AspAecState* s) {
   get_row(R_SX, s->sx);
   get_row(R_SD, s->sd);
   get_row(R_SE, s->se);
-  for (int i = 0; i < 65; ++i) {
-    s->sde[i][0] = rows[R_SDE_RE * kRow + i];
-    s->sde[i][1] = rows[R_SDE_IM * kRow + i];
-    s->sxd[i][0] = rows[R_SXD_RE * kRow + i];
-    s->sxd[i][1] = rows[R_SXD_IM * kRow + i];
+  {
+    float tmp[4][65];
+    get_row(R_SDE_RE, tmp[0]);
+    get_row(R_SDE_IM, tmp[1]);
+    get_row(R_SXD_RE, tmp[2]);
+    get_row(R_SXD_IM, tmp[3]);
+    for (int i = 0; i < 65; ++i) {
+      s->sde[i][0] = tmp[0][i];
+      s->sde[i][1] = tmp[1][i];
+      s->sxd[i][0] = tmp[2][i];
+      s->sxd[i][1] = tmp[3][i];
+    }
   }
   for (int i = 0; i < kNumPart; ++i) {
     get_row(R_XF_RE + i, s->xfBuf[0] + i * 65);

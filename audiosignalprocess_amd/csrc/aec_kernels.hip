@@ -392,11 +392,11 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   // State rows: trip 0 (bin = lane) goes to HBM, trip 1 (bin 64) to a per-wave LDS copy of the
   // bin-64 column that is gathered once per block and scattered back at its end.
   float* c64 = wl + kLdsC64;
-#define ROW_LD(r) (t_ == 0 ? rows[(r) * kRow + lane] : c64[r])
+#define ROW_LD(r) (t_ == 0 ? rows[(r) * kRowS + lane] : c64[r])
 #define ROW_ST(r, v)                         \
   do {                                       \
     if (t_ == 0) {                           \
-      rows[(r) * kRow + lane] = (v);         \
+      rows[(r) * kRowS + lane] = (v);        \
     } else {                                 \
       c64[r] = (v);                          \
     }                                        \
@@ -414,13 +414,13 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   for (int i = 0; i < kNumPart; ++i) {
     int px = i + op.xf_pos;
     if (px >= kNumPart) px -= kNumPart;
-    xr[i] = rows[(R_XF_RE + px) * kRow + lane];  // i = 0 is replaced by this block's spectrum
-    xi[i] = rows[(R_XF_IM + px) * kRow + lane];
-    wr[i] = rows[(R_WF_RE + i) * kRow + lane];
-    wi[i] = rows[(R_WF_IM + i) * kRow + lane];
+    xr[i] = rows[(R_XF_RE + px) * kRowS + lane];  // i = 0 is replaced by this block's spectrum
+    xi[i] = rows[(R_XF_IM + px) * kRowS + lane];
+    wr[i] = rows[(R_WF_RE + i) * kRowS + lane];
+    wi[i] = rows[(R_WF_IM + i) * kRowS + lane];
   }
 
-  for (int r = lane; r < R_COUNT; r += 64) c64[r] = rows[r * kRow + 64];
+  for (int r = lane; r < R_COUNT; r += 64) c64[r] = st[kOffC64 + r];
   wave_fence();
 
   AEC_STAMP(1)
@@ -616,8 +616,8 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   }
 #pragma unroll
   for (int i = 0; i < kNumPart; ++i) {
-    rows[(R_WF_RE + i) * kRow + lane] = wr[i];
-    rows[(R_WF_IM + i) * kRow + lane] = wi[i];
+    rows[(R_WF_RE + i) * kRowS + lane] = wr[i];
+    rows[(R_WF_IM + i) * kRowS + lane] = wi[i];
   }
 
   AEC_STAMP(8)
@@ -873,7 +873,7 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     reinterpret_cast<uint32_t*>(sc)[S_SEED] = new_seed;
   }
   wave_fence();
-  for (int r = lane; r < R_COUNT; r += 64) rows[r * kRow + 64] = c64[r];
+  for (int r = lane; r < R_COUNT; r += 64) st[kOffC64 + r] = c64[r];
   AEC_STAMP(15)
 #undef AEC_STAMP
 #undef ROW_LD

@@ -2,7 +2,8 @@
 // aec_kernels.hip (device) and aec_api.hip (host control plane).
 //
 // Per stream (all float / int32 dwords, one contiguous block of kStateDwords):
-//   rows of kRow = 68 dwords holding 65 bins each (lane q <-> bin q, bin 64 at [64]):
+//   rows of kRowS = 64 dwords (256-byte aligned) holding bins 0..63 (lane q <-> bin q); bin 64 of
+//   every row lives in one contiguous column c64[R_COUNT] so a wave gathers it with two loads:
 //     xPow dPow dMinPow dInitMinPow sx sd se sde.re sde.im sxd.re sxd.im           (11 rows)
 //     xfBuf  re[12] im[12]   -- partition p at physical index p (circular, xfBufBlockPos on host)
 //     wfBuf  re[12] im[12]
@@ -21,7 +22,8 @@ constexpr int kPartLen = 64, kPartLen1 = 65, kPartLen2 = 128, kFrameLen = 80, kN
 constexpr int kFarSlots = 250;              // kBufSizePartitions, aec_core.c:37
 constexpr int kPreLen = 128 + 4 * 80;       // far_pre_buf, echo_cancellation.c:146-147
 constexpr int kFrBufLen = 80 + 64;          // nearFrBuf / outFrBuf, aec_core.c:1299-1305
-constexpr int kRow = 68;
+constexpr int kRow = 68;    // far-ring rows: 65 bins + pad
+constexpr int kRowS = 64;   // state rows: bins 0..63 (bin 64 in the c64 column)
 
 enum Row {
   R_XPOW = 0, R_DPOW, R_DMINPOW, R_DINITMINPOW, R_SX, R_SD, R_SE, R_SDE_RE, R_SDE_IM, R_SXD_RE,
@@ -35,14 +37,15 @@ enum Row {
 };
 
 constexpr int kOffRows = 0;
-constexpr int kOffDBuf = R_COUNT * kRow;          // 5644
+constexpr int kOffC64 = R_COUNT * kRowS;          // bin 64 of every row: 84 dwords
+constexpr int kOffDBuf = kOffC64 + 84 + 12;       // keeps the sample buffers 256-byte aligned
 constexpr int kOffEBuf = kOffDBuf + 128;
 constexpr int kOffOutBuf = kOffEBuf + 128;
 constexpr int kOffScalars = kOffOutBuf + 64;
 constexpr int kOffPre = kOffScalars + 32;
 constexpr int kOffNearFr = kOffPre + kPreLen;
 constexpr int kOffOutFr = kOffNearFr + kFrBufLen;
-constexpr int kStateDwords = ((kOffOutFr + kFrBufLen + 63) / 64) * 64;  // 6784 dwords = 27 136 B
+constexpr int kStateDwords = ((kOffOutFr + kFrBufLen + 63) / 64) * 64;
 
 enum Scalar {
   S_HNLFBMIN = 0, S_HNLFBLOCALMIN, S_HNLXDAVGMIN, S_OVERDRIVE, S_OVERDRIVESM,  // float
