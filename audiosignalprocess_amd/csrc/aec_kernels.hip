@@ -421,6 +421,10 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   }
 
   for (int r = lane; r < R_COUNT; r += 64) c64[r] = st[kOffC64 + r];
+  // rows of the power / noise-floor update and the overlap-add tail: in flight during the first FFT
+  const float p_xpow = rows[R_XPOW * kRowS + lane], p_dpow = rows[R_DPOW * kRowS + lane];
+  const float p_dmin = rows[R_DMINPOW * kRowS + lane], p_dinit = rows[R_DINITMINPOW * kRowS + lane];
+  const float p_outbuf = st[kOffOutBuf + lane];
   wave_fence();
 
   AEC_STAMP(1)
@@ -460,12 +464,12 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     const float xr = XFR[bin], xi = XFI[bin];
     const float far_spectrum = (xr * xr) + (xi * xi);
     const float near_spectrum = DFR[bin] * DFR[bin] + DFI[bin] * DFI[bin];
-    const float xp = 0.9f * ROW_LD(R_XPOW) + 0.1f * kNumPart * far_spectrum;
-    const float dp = 0.9f * ROW_LD(R_DPOW) + 0.1f * near_spectrum;
+    const float xp = 0.9f * (t_ == 0 ? p_xpow : c64[R_XPOW]) + 0.1f * kNumPart * far_spectrum;
+    const float dp = 0.9f * (t_ == 0 ? p_dpow : c64[R_DPOW]) + 0.1f * near_spectrum;
     ROW_ST(R_XPOW, xp);
     ROW_ST(R_DPOW, dp);
     XPW[bin] = xp;
-    float dmin = ROW_LD(R_DMINPOW);
+    float dmin = t_ == 0 ? p_dmin : c64[R_DMINPOW];
     if (noise_track) {
       if (dp < dmin) {
         dmin = (dp + 0.1f * (dmin - dp)) * 1.0002f;
@@ -476,7 +480,7 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     }
     float npow = dmin;
     if (noise_init) {
-      float dinit = ROW_LD(R_DINITMINPOW);
+      float dinit = t_ == 0 ? p_dinit : c64[R_DINITMINPOW];
       if (dmin > dinit) {
         dinit = 0.999f * dinit + 0.001f * dmin;
       } else {
@@ -565,6 +569,11 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   wave_fence();
 
   AEC_STAMP(7)
+  // the PSD rows of the NLP: in flight during the six FFT rounds of the filter update
+  const float q_sd = rows[R_SD * kRowS + lane], q_se = rows[R_SE * kRowS + lane];
+  const float q_sx = rows[R_SX * kRowS + lane];
+  const float q_sde_r = rows[R_SDE_RE * kRowS + lane], q_sde_i = rows[R_SDE_IM * kRowS + lane];
+  const float q_sxd_r = rows[R_SXD_RE * kRowS + lane], q_sxd_i = rows[R_SXD_IM * kRowS + lane];
   // ---- FilterAdaptation (aec_core.c:221-269): four partitions per round
   for (int g = 0; g < kNumPart / 4; ++g) {
 #pragma unroll
@@ -635,6 +644,7 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     wave_fence();
     if (lane < kNumPart) {
       float wfEn = 0.f;
+#pragma unroll
       for (int j = 0; j < 65; ++j) wfEn += pe[lane * kLRow + j];
       misc[lane] = wfEn;
     }
@@ -663,14 +673,14 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     const float dr = DWR[bin], di = DWI[bin], er = EWR[bin], ei = EWI[bin];
     const float xr = delayIdx == 0 ? XWR[bin] : ROW_LD((R_XFW + 2 * pd));
     const float xi = delayIdx == 0 ? XWI[bin] : ROW_LD((R_XFW + 2 * pd + 1));
-    const float sd = g0 * ROW_LD(R_SD) + g1 * (dr * dr + di * di);
-    const float se = g0 * ROW_LD(R_SE) + g1 * (er * er + ei * ei);
+    const float sd = g0 * (t_ == 0 ? q_sd : c64[R_SD]) + g1 * (dr * dr + di * di);
+    const float se = g0 * (t_ == 0 ? q_se : c64[R_SE]) + g1 * (er * er + ei * ei);
     const float xx = xr * xr + xi * xi;
-    const float sx = g0 * ROW_LD(R_SX) + g1 * (xx > 15.f ? xx : 15.f);
-    const float sde_r = g0 * ROW_LD(R_SDE_RE) + g1 * (dr * er + di * ei);
-    const float sde_i = g0 * ROW_LD(R_SDE_IM) + g1 * (dr * ei - di * er);
-    const float sxd_r = g0 * ROW_LD(R_SXD_RE) + g1 * (dr * xr + di * xi);
-    const float sxd_i = g0 * ROW_LD(R_SXD_IM) + g1 * (dr * xi - di * xr);
+    const float sx = g0 * (t_ == 0 ? q_sx : c64[R_SX]) + g1 * (xx > 15.f ? xx : 15.f);
+    const float sde_r = g0 * (t_ == 0 ? q_sde_r : c64[R_SDE_RE]) + g1 * (dr * er + di * ei);
+    const float sde_i = g0 * (t_ == 0 ? q_sde_i : c64[R_SDE_IM]) + g1 * (dr * ei - di * er);
+    const float sxd_r = g0 * (t_ == 0 ? q_sxd_r : c64[R_SXD_RE]) + g1 * (dr * xr + di * xi);
+    const float sxd_i = g0 * (t_ == 0 ? q_sxd_i : c64[R_SXD_IM]) + g1 * (dr * xi - di * xr);
     ROW_ST(R_SD, sd);
     ROW_ST(R_SE, se);
     ROW_ST(R_SX, sx);
@@ -689,7 +699,11 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     const float* src = lane == 0 ? T0 : lane == 1 ? XPW : lane == 2 ? COHXD : COHDE;
     const int lo = lane < 2 ? 0 : minPrefBand, hi = lane < 2 ? 65 : prefBandSize + minPrefBand;
     float acc = 0.f;
-    for (int j = lo; j < hi; ++j) acc += src[j];
+#pragma unroll
+    for (int j = 0; j < 65; ++j) {  // fixed trip count: the LDS reads batch, the adds stay in order
+      const float v = src[j];
+      if (j >= lo && j < hi) acc += v;
+    }
     misc[lane] = acc;
   }
   wave_fence();
@@ -762,9 +776,10 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
     if (lane < prefBandSize) {
       const float v = HNL[minPrefBand + lane];
       int rank = 0;
-      for (int j = 0; j < prefBandSize; ++j) {
-        const float u = HNL[minPrefBand + j];
-        rank += (u < v) || (u == v && j < lane);
+#pragma unroll
+      for (int j = 0; j < 24; ++j) {
+        const float u = HNL[minPrefBand + j];  // j < 24 + 4 stays inside the row
+        rank += (j < prefBandSize) && ((u < v) || (u == v && j < lane));
       }
       if (rank == iFb) misc[4] = v;
       if (rank == iLow) misc[5] = v;
@@ -846,7 +861,7 @@ __device__ __attribute__((noinline)) void process_block(float* __restrict__ st, 
   {
     const float* tf = reinterpret_cast<const float*>(tile(wl, 0));
     float a = tf[lane] * scale;
-    a = a * T.hann[lane] + st[kOffOutBuf + lane];
+    a = a * T.hann[lane] + p_outbuf;
     const float b = tf[64 + lane] * scale;
     st[kOffOutBuf + lane] = b * T.hann[64 - lane];
     const float o = a > 32767.f ? 32767.f : (a < -32768.f ? -32768.f : a);
