@@ -353,7 +353,7 @@ __device__ __attribute__((noinline)) float cosf_via_f64(float x) { return (float
 __device__ __attribute__((noinline)) float sinf_via_f64(float x) { return (float)sin((double)x); }
 
 // One ProcessBlock + NonLinearProcessing for this wave's stream.
-__device__ __attribute__((noinline)) void process_block(float* __restrict__ st, float* __restrict__ wl,
+__device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
                                               const float* __restrict__ far_slot,
                                               const SharedTables& T, const BlockOp& op, int mult,
                                               int nlp_mode, float mu, float error_threshold,
