@@ -22,9 +22,10 @@ using namespace aspaec;
 namespace aspaec {
 hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, const float* farend,
                              int num_streams, const FarOps& ops, hipStream_t s);
-hipError_t launch_aec_process(float* state, const float* far_ring, const AecTables* T,
+hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
-                              const ProcOps& ops, hipStream_t s, unsigned long long* stamps = nullptr);
+                              const ProcOps& ops, const float* farend, const FarOps& fops,
+                              hipStream_t s, unsigned long long* stamps = nullptr);
 hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
                               hipStream_t s);
 }  // namespace aspaec
@@ -212,6 +213,10 @@ struct AspAecBatch {
   int xf_pos = 0, xfw_head = 0, blocks_processed = 0;
   RingPos pre_pos{}, far_pos{}, near_pos{}, out_pos{};
   unsigned long long* debug_stamps = nullptr;  // diagnostic only (AspAecBatch_DebugStamps)
+  // a BufferFarend whose device work is deferred into the next Process launch (Run / TimedSteps)
+  bool far_pending = false;
+  FarOps far_ops{};
+  const float* far_src = nullptr;
 };
 
 namespace {
@@ -374,7 +379,21 @@ void init_canonical(AspAecState* s) {  // WebRtcAec_InitAec float state, aec_cor
 }
 
 // WebRtcAec_BufferFarend control plane (echo_cancellation.c:278-339) -> launches on device data.
-int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n) {
+int flush_pending_farend(AspAecBatch* b) {
+  if (b->far_pending) {
+    b->far_pending = false;
+    AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, b->far_src, b->S, b->far_ops, b->stream));
+  }
+  return 0;
+}
+
+// defer = true: when the call needs one launch descriptor (the normal case) its device work is
+// kept for the following Process launch instead of being launched on its own.
+int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer = false) {
+  {
+    const int rc = flush_pending_farend(b);
+    if (rc != 0) return rc;
+  }
   b->farend_started = 1;
   b->system_delay += n;
   FarOps ops;
@@ -398,8 +417,15 @@ int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n) {
       pending = false;
     }
   }
-  if (pending || ops.nparts > 0)
-    AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
+  if (pending || ops.nparts > 0) {
+    if (defer && pending) {  // everything of this call fits one descriptor
+      b->far_pending = true;
+      b->far_ops = ops;
+      b->far_src = far_dev;
+    } else {
+      AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
+    }
+  }
   return 0;
 }
 
@@ -472,8 +498,16 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
     if (out_elements < kFrameLen) rp_move_read(&b->out_pos, out_elements - kFrameLen);
     rp_read(&b->out_pos, kFrameLen, &sf.out_rpos);
   }
-  AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, b->stream,
-                             b->debug_stamps));
+  const float* far_src = nullptr;
+  FarOps fops;
+  memset(&fops, 0, sizeof fops);
+  if (b->far_pending) {
+    b->far_pending = false;
+    far_src = b->far_src;
+    fops = b->far_ops;
+  }
+  AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
+                             b->stream, b->debug_stamps));
   return 0;
 }
 
@@ -485,6 +519,10 @@ int process_normal_device(AspAecBatch* b, const float* near_dev, float* out_dev,
   msInSndCardBuf += 10;
   b->msInSndCardBuf = msInSndCardBuf;
   if (b->startup_phase) {
+    {
+      const int rc = flush_pending_farend(b);
+      if (rc != 0) return rc;
+    }
     if (near_dev != out_dev)
       AEC_TRY(hipMemcpyAsync(out_dev, near_dev, (size_t)b->S * n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
     if (b->checkBuffSize) {
@@ -800,7 +838,7 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
       }
       for (int f = 0; f < nf && err == 0; ++f) {
         int rc = 0;
-        err = buffer_farend_device(b, dfar + per * f, nrOfSamples);
+        err = buffer_farend_device(b, dfar + per * f, nrOfSamples, true);
         if (err == 0) err = process_device(b, dnear + per * f, dout + per * f, nrOfSamples, msInSndCardBuf, &rc);
         rc_all |= rc;
       }
@@ -819,7 +857,7 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
   }
   for (int f = 0; f < num_frames; ++f) {
     int rc = 0;
-    int err = buffer_farend_device(b, farend + per * f, nrOfSamples);
+    int err = buffer_farend_device(b, farend + per * f, nrOfSamples, true);
     if (err == 0) err = process_device(b, nearend + per * f, out + per * f, nrOfSamples, msInSndCardBuf, &rc);
     if (err != 0) return err;
     rc_all |= rc;
@@ -838,7 +876,7 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
   for (int k = 0; k < steps; ++k) {
     const size_t off = per * (size_t)(k % frames_in_ring);
     int rc = 0;
-    int err = buffer_farend_device(b, farend + off, nrOfSamples);
+    int err = buffer_farend_device(b, farend + off, nrOfSamples, true);
     if (err == 0) err = process_device(b, nearend + off, out + off, nrOfSamples, 0, &rc);
     if (err != 0) return err;
   }

@@ -304,24 +304,15 @@ __device__ __forceinline__ int ring_idx(int pos, int i, int count) {
 }
 
 // ------------------------------------------------------------------ far end
-// WebRtcAec_BufferFarend for every stream: append to far_pre, then transform the partitions the
-// host scheduled (plain and sqrt-Hann windowed) into their far-ring slots.
-__global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ state,
-                                                         float* __restrict__ far_ring,
-                                                         const AecTables* __restrict__ G,
-                                                         const float* __restrict__ farend,
-                                                         int num_streams, FarOps ops) {
-  __shared__ SharedTables T;
-  __shared__ float lds[4 * kLdsWave];
-  stage_tables(T, G);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int stream = blockIdx.x * 4 + wave;
-  if (stream >= num_streams) return;
-  float* wl = lds + wave * kLdsWave;
-  float* st = state + (size_t)stream * kStateDwords;
+// The far-end work of one WebRtcAec_BufferFarend call for this wave's stream.
+__device__ __forceinline__ void farend_work(float* __restrict__ st, float* __restrict__ far_ring,
+                                            float* __restrict__ wl, const SharedTables& T,
+                                            const float* __restrict__ farend, int num_streams,
+                                            int stream, const FarOps& ops, int lane) {
   float* pre = st + kOffPre;
   for (int i = lane; i < ops.n; i += 64) pre[ring_idx(ops.wpos, i, kPreLen)] = farend[(size_t)stream * ops.n + i];
-  // the partitions below read samples other lanes of this wave just wrote: order them (same CU, same L1: workgroup scope; agent scope would flush the XCD L2)
+  // the partitions below read samples other lanes of this wave just wrote: order them (same CU,
+  // same L1: workgroup scope; agent scope would flush the XCD L2)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -343,6 +334,24 @@ __global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ sta
     unpack_tile(wl, 1, slot + 2 * kRow, slot + 3 * kRow, lane);
     wave_fence();
   }
+}
+
+// WebRtcAec_BufferFarend for every stream: append to far_pre, then transform the partitions the
+// host scheduled (plain and sqrt-Hann windowed) into their far-ring slots.
+__global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ state,
+                                                         float* __restrict__ far_ring,
+                                                         const AecTables* __restrict__ G,
+                                                         const float* __restrict__ farend,
+                                                         int num_streams, FarOps ops) {
+  __shared__ SharedTables T;
+  __shared__ float lds[4 * kLdsWave];
+  stage_tables(T, G);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  float* wl = lds + wave * kLdsWave;
+  float* st = state + (size_t)stream * kStateDwords;
+  farend_work(st, far_ring, wl, T, farend, num_streams, stream, ops, lane);
 }
 
 // --------------------------------------------------------------- transcendentals
@@ -898,11 +907,12 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 // WebRtcAec_ProcessFrames for every stream (running phase): per 80-sample sub-frame append the
 // near samples, run the scheduled blocks, emit 80 output samples.
 __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__ state,
-                                                          const float* __restrict__ far_ring,
+                                                          float* far_ring,
                                                           const AecTables* __restrict__ G,
                                                           const float* __restrict__ nearend,
                                                           float* __restrict__ out, int num_streams,
                                                           int nrOfSamples, ProcOps ops,
+                                                          const float* __restrict__ farend, FarOps fops,
                                                           unsigned long long* __restrict__ stamps) {
   __shared__ SharedTables T;
   __shared__ float lds[4 * kLdsWave];
@@ -914,6 +924,13 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
   float* st = state + (size_t)stream * kStateDwords;
   const float* nin = nearend + (size_t)stream * nrOfSamples;
   float* o = out + (size_t)stream * nrOfSamples;
+  if (farend != nullptr) {
+    // the WebRtcAec_BufferFarend call that preceded this Process call, fused into the launch
+    farend_work(st, far_ring, wl, T, farend, num_streams, stream, fops, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
   for (int s = 0; s < ops.nsub; ++s) {
     const SubFrame& sf = ops.sub[s];
     // near samples of this sub-frame are read into registers first: `out` may alias `nearend`
@@ -986,11 +1003,12 @@ hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, 
   return hipGetLastError();
 }
 
-hipError_t launch_aec_process(float* state, const float* far_ring, const AecTables* T,
+hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
-                              const ProcOps& ops, hipStream_t s, unsigned long long* stamps) {
+                              const ProcOps& ops, const float* farend, const FarOps& fops,
+                              hipStream_t s, unsigned long long* stamps) {
   hipLaunchKernelGGL(aec_process_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
-                     far_ring, T, nearend, out, num_streams, nrOfSamples, ops, stamps);
+                     far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, stamps);
   return hipGetLastError();
 }
 
