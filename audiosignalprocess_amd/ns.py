@@ -28,9 +28,14 @@ def load_library():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB):
-        raise AspError(
-            "HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
-            " (there is no CPU fallback)" % LIB)
+        # a fresh checkout: compile the library in-tree (hipcc); there is no CPU fallback
+        try:
+            from .build import build_library
+            build_library()
+        except Exception as e:  # noqa: BLE001
+            raise AspError(
+                "HIP library %s is missing and could not be built (%s): run `python -c 'import "
+                "__graft_entry__ as g; g.build()'` (there is no CPU fallback)" % (LIB, e))
     lib = C.CDLL(LIB)
     vp, ip, fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
     sig = {
