@@ -410,11 +410,22 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       c64[r] = (v);                          \
     }                                        \
   } while (0)
+  // loads return in order: the few the first FFT round waits for go first
+  const float c64_a = st[kOffC64 + lane];
+  const float c64_b = lane < R_COUNT - 64 ? st[kOffC64 + 64 + lane] : 0.f;
+  float fs_lane[4], fs_64[4];  // this block's far spectra (plain re/im, windowed re/im)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    fs_lane[k] = far_slot[k * kRow + lane];
+    fs_64[k] = far_slot[k * kRow + 64];
+  }
   // ---- near block (aec_core.c:1114-1124) and the far spectra of this block (:1137, 888-891)
   const float ne = st[kOffNearFr + ring_idx(op.near_rpos, lane, kFrBufLen)];
   dbuf[lane] = st[kOffDBuf + lane];
   dbuf[64 + lane] = ne;
   ebuf[lane] = st[kOffEBuf + lane];
+  c64[lane] = c64_a;
+  if (lane < R_COUNT - 64) c64[64 + lane] = c64_b;
   // issued after the few loads the first FFT needs, consumed much later
   // the lane's own bins of the far-spectrum history and of the filter stay in registers from
   // here to the end of the filter update (logical partition order)
@@ -429,7 +440,6 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     wi[i] = rows[(R_WF_IM + i) * kRowS + lane];
   }
 
-  for (int r = lane; r < R_COUNT; r += 64) c64[r] = st[kOffC64 + r];
   // rows of the power / noise-floor update and the overlap-add tail: in flight during the first FFT
   const float p_xpow = rows[R_XPOW * kRowS + lane], p_dpow = rows[R_DPOW * kRowS + lane];
   const float p_dmin = rows[R_DMINPOW * kRowS + lane], p_dinit = rows[R_DINITMINPOW * kRowS + lane];
@@ -451,12 +461,12 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   unpack_tile(wl, 0, DFR, DFI, lane);
   unpack_tile(wl, 1, DWR, DWI, lane);
   // the far spectra of this block (their loads were in flight during the transform)
-  xr[0] = far_slot[lane];
-  xi[0] = far_slot[kRow + lane];
+  xr[0] = fs_lane[0];
+  xi[0] = fs_lane[1];
   BINS_2TRIPS {
-    XFR[bin] = far_slot[bin];
-    XFI[bin] = far_slot[kRow + bin];
-    const float wr = far_slot[2 * kRow + bin], wi = far_slot[3 * kRow + bin];
+    XFR[bin] = t_ == 0 ? fs_lane[0] : fs_64[0];
+    XFI[bin] = t_ == 0 ? fs_lane[1] : fs_64[1];
+    const float wr = t_ == 0 ? fs_lane[2] : fs_64[2], wi = t_ == 0 ? fs_lane[3] : fs_64[3];
     XWR[bin] = wr;
     XWI[bin] = wi;
     ROW_ST((R_XFW + 2 * op.xfw_head), wr);
