@@ -217,6 +217,8 @@ struct AspAecBatch {
   bool far_pending = false;
   FarOps far_ops{};
   const float* far_src = nullptr;
+  // control-plane-only handle (AspAecBatch_CreateControlOnly): no device, nothing is launched
+  bool sim = false;
 };
 
 namespace {
@@ -382,7 +384,7 @@ void init_canonical(AspAecState* s) {  // WebRtcAec_InitAec float state, aec_cor
 int flush_pending_farend(AspAecBatch* b) {
   if (b->far_pending) {
     b->far_pending = false;
-    AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, b->far_src, b->S, b->far_ops, b->stream));
+    if (!b->sim) AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, b->far_src, b->S, b->far_ops, b->stream));
   }
   return 0;
 }
@@ -412,7 +414,7 @@ int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer
     ops.nparts++;
     rp_move_read(&b->pre_pos, -kPartLen);  // overlap, echo_cancellation.c:336
     if (ops.nparts == 3) {
-      AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
+      if (!b->sim) AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
       memset(&ops, 0, sizeof ops);
       pending = false;
     }
@@ -423,7 +425,7 @@ int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer
       b->far_ops = ops;
       b->far_src = far_dev;
     } else {
-      AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
+      if (!b->sim) AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
     }
   }
   return 0;
@@ -506,8 +508,9 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
     far_src = b->far_src;
     fops = b->far_ops;
   }
-  AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
-                             b->stream, b->debug_stamps));
+  if (!b->sim)
+    AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
+                               b->stream, b->debug_stamps));
   return 0;
 }
 
@@ -523,7 +526,7 @@ int process_normal_device(AspAecBatch* b, const float* near_dev, float* out_dev,
       const int rc = flush_pending_farend(b);
       if (rc != 0) return rc;
     }
-    if (near_dev != out_dev)
+    if (near_dev != out_dev && !b->sim)
       AEC_TRY(hipMemcpyAsync(out_dev, near_dev, (size_t)b->S * n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
     if (b->checkBuffSize) {
       b->checkBufSizeCtr++;
@@ -635,8 +638,24 @@ int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device) {
   return ASP_OK;
 }
 
+// The integer control plane alone (no device is touched, nothing is launched): BufferFarend /
+// Process / set_config / GetControl behave as on a real batch, so the host logic can be checked
+// against the oracle on a machine without a GPU.  Every data-touching entry point refuses it.
+int AspAecBatch_CreateControlOnly(AspAecBatch** out, int num_streams) {
+  if (!out || num_streams <= 0) return aec_fail(ASP_ERR_PARAM, "AspAecBatch_CreateControlOnly: bad argument");
+  AspAecBatch* b = new AspAecBatch();
+  b->S = num_streams;
+  b->sim = true;
+  *out = b;
+  return ASP_OK;
+}
+
 int AspAecBatch_Free(AspAecBatch* b) {
   if (!b) return -1;
+  if (b->sim) {
+    delete b;
+    return 0;
+  }
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->state) (void)hipFree(b->state);
@@ -721,8 +740,8 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
   b->xf_pos = 0;
   b->xfw_head = 0;
   b->blocks_processed = 0;
-  AEC_TRY(hipSetDevice(b->device));
-  {
+  if (!b->sim) {
+    AEC_TRY(hipSetDevice(b->device));
     AspAecState s0;
     init_canonical(&s0);
     std::vector<float> blk(kStateDwords);
@@ -766,6 +785,7 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
 int AspAecBatch_BufferFarend(AspAecBatch* b, const float* farend, int nrOfSamples, int mem) {
   const int chk = check_running(b, farend, nrOfSamples);
   if (chk != 0) return chk;
+  if (b->sim) return buffer_farend_device(b, farend, nrOfSamples);
   AEC_TRY(hipSetDevice(b->device));
   const float* dev = farend;
   if (mem == ASP_MEM_HOST) {
@@ -787,6 +807,11 @@ int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nr
   }
   const int chk = check_running(b, nearend, nrOfSamples);
   if (chk != 0) return chk;
+  if (b->sim) {
+    int rc_sim = 0;
+    const int err_sim = process_device(b, nearend, out, nrOfSamples, msInSndCardBuf, &rc_sim);
+    return err_sim != 0 ? err_sim : rc_sim;
+  }
   AEC_TRY(hipSetDevice(b->device));
   const size_t bytes = (size_t)b->S * nrOfSamples * sizeof(float);
   const float* nd = nearend;
@@ -808,6 +833,7 @@ int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nr
 
 int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, float* out,
                     int nrOfSamples, int num_frames, int msInSndCardBuf, int mem) {
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_Run: control-only handle");
   if (b && out == nullptr) {
     b->lastError = AEC_NULL_POINTER_ERROR;
     return -1;
@@ -867,6 +893,7 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
 
 int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nearend, float* out,
                            int nrOfSamples, int frames_in_ring, int steps, float* elapsed_ms) {
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_TimedSteps: control-only handle");
   if (!b || !farend || !nearend || !out || frames_in_ring <= 0 || steps < 0 || !elapsed_ms)
     return aec_fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
   if (check_running(b, farend, nrOfSamples) != 0) return -1;
@@ -887,6 +914,7 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
 }
 
 int AspAecBatch_Synchronize(AspAecBatch* b) {
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_Synchronize: control-only handle");
   if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
   AEC_TRY(hipSetDevice(b->device));
   AEC_TRY(hipStreamSynchronize(b->stream));
@@ -894,6 +922,7 @@ int AspAecBatch_Synchronize(AspAecBatch* b) {
 }
 
 int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out) {
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_ExportState: control-only handle");
   if (!b || !out || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ExportState: bad argument");
   AEC_TRY(hipSetDevice(b->device));
   AEC_TRY(hipStreamSynchronize(b->stream));
@@ -904,6 +933,7 @@ int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out) {
 }
 
 int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in) {
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_ImportState: control-only handle");
   if (!b || !in || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ImportState: bad argument");
   AEC_TRY(hipSetDevice(b->device));
   AEC_TRY(hipStreamSynchronize(b->stream));
@@ -948,6 +978,7 @@ int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* c) {
 }
 
 int AspAecBatch_get_echo_status(AspAecBatch* b, int* status) {
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_get_echo_status: control-only handle");
   if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
   if (status == nullptr) {
     b->lastError = AEC_NULL_POINTER_ERROR;

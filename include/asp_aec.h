@@ -134,6 +134,10 @@ typedef struct AspAecControl {
 
 int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device);
 int AspAecBatch_Free(AspAecBatch* b);
+/* The integer control plane alone: no device is touched and nothing is launched; Init / set_config /
+ * BufferFarend / Process / GetControl work (buffers are only checked for NULL), everything that
+ * touches data refuses the handle.  For checking the host logic on a machine without a GPU. */
+int AspAecBatch_CreateControlOnly(AspAecBatch** out, int num_streams);
 /* WebRtcAec_Init for every stream; sampFreq 8000 or 16000. */
 int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq);
 int AspAecBatch_set_config(AspAecBatch* b, AecConfig config);

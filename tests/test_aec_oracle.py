@@ -178,3 +178,48 @@ def test_oracle_threaded_runner_matches_single(aec_golden):
     far, near = aec_golden["far_i16"][:120].astype(np.float32), aec_golden["near_i16"][:120].astype(np.float32)
     out = oracle_lib.aec_oracle_run_mt(far, near, threads=2)
     assert np.array_equal(_bits(out), _bits(aec_golden["out_f32"][:120]))
+
+
+def test_host_control_plane_matches_oracle():
+    """The HIP library's host-side control plane (aec_api.hip: start-up phase, system-delay
+    bookkeeping, ring read/write positions, block scheduling) run WITHOUT a device
+    (AspAecBatch_CreateControlOnly) against the oracle's -- which the tests above pin to the
+    reference -- after every call of a sequence with delay jumps, both call sizes and both rates."""
+    import ctypes as C
+
+    from audiosignalprocess_amd import aec as aec_mod
+    from audiosignalprocess_amd._abi import AspAecControl
+
+    lib = aec_mod._lib()
+    lib.AspAecBatch_CreateControlOnly.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    for fs, n in [(16000, 160), (16000, 80), (8000, 80)]:
+        h = C.c_void_p()
+        assert lib.AspAecBatch_CreateControlOnly(C.byref(h), 7) == 0
+        assert lib.AspAecBatch_Init(h, fs, 48000) == 0
+        ora = oracle_lib.OracleAec(fs)
+        dummy = np.zeros(7 * 160, np.float32)
+        z = np.zeros(n, np.float32)
+        for f in range(900):
+            d = 0
+            if f in (120, 121):
+                d = 700
+            if f == 300:
+                d = -3
+            if 400 <= f < 520:
+                d = 90
+            if 600 <= f < 640:
+                d = 20
+            rc_o = ora.frame(z, z, d)[1]
+            rc_b = lib.AspAecBatch_BufferFarend(h, dummy.ctypes.data, n, 1)
+            rc_b |= lib.AspAecBatch_Process(h, dummy.ctypes.data, dummy.ctypes.data, n, d, 0, 1)
+            assert (rc_b != 0) == (rc_o != 0), (fs, n, f)
+            cb = AspAecControl()
+            assert lib.AspAecBatch_GetControl(h, C.byref(cb)) == 0
+            _, co = ora.export()
+            for name, _t in cb._fields_:
+                assert getattr(cb, name) == getattr(co, name), (fs, n, f, name)
+        assert lib.AspAecBatch_get_error_code(h) == ora.error_code()
+        # data-touching entry points refuse a control-only handle
+        lib.AspAecBatch_Synchronize.argtypes = [C.c_void_p]
+        assert lib.AspAecBatch_Synchronize(h) != 0
+        assert lib.AspAecBatch_Free(h) == 0
