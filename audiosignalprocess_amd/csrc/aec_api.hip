@@ -121,6 +121,7 @@ void build_tables(AecTables* T) {
     T->weight[k] = k == 0 ? 0.f : via_text(0.3 * sqrt((double)(k - 1) / 63.0) + 0.1, 4);
     T->odrive[k] = via_text(sqrt((double)k / 64.0) + 1.0, 4);
   }
+  for (int j = 0; j < 64; ++j) T->exp2_64[j] = exp2((double)j / 64.0);
   uint32_t a = 1, c = 0;  // WebRtcSpl_RandU jump-ahead (randomization_functions.c:93-100)
   for (int k = 0; k < 64; ++k) {
     c = c * 69069u + 1u;

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "aec_layout.h"
+#include "ns_device.h"  // lean fp64 pow / sincos shared with the NS kernels
 
 using namespace aspaec;
 
@@ -53,6 +54,7 @@ constexpr int kLdsWave = kLdsC64 + 84;                // 1940 floats = 7 760 B p
 static_assert(kNumPart * kLRow <= kLdsRows + 9 * kLRow, "partition-energy rows overlay");
 
 struct SharedTables {
+  double exp2_64[64];
   float w[64], wk3a[16], wk3b[16], hann[68], weight[68], odrive[68];
   uint32_t lcg_a[64], lcg_c[64];
 };
@@ -282,6 +284,7 @@ __device__ __forceinline__ void unpack_tile(float* wl, int f, float* re, float* 
 __device__ __forceinline__ void stage_tables(SharedTables& S, const AecTables* __restrict__ G) {
   for (int i = threadIdx.x; i < 64; i += blockDim.x) {
     S.w[i] = G->w[i];
+    S.exp2_64[i] = G->exp2_64[i];
     S.lcg_a[i] = G->lcg_a[i];
     S.lcg_c[i] = G->lcg_c[i];
   }
@@ -354,19 +357,27 @@ __global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ sta
   farend_work(st, far_ring, wl, T, farend, num_streams, stream, ops, lane);
 }
 
-// --------------------------------------------------------------- transcendentals
-// (float)pow / cos / sin evaluated in fp64: correctly rounded up to double rounding; glibc's powf /
-// cosf / sinf (<= 0.52 / 0.56 ulp) differ from that in rare last-place cases.
-__device__ __attribute__((noinline)) float powf_via_f64(float x, float y) { return (float)pow((double)x, (double)y); }
-__device__ __attribute__((noinline)) float cosf_via_f64(float x) { return (float)cos((double)x); }
-__device__ __attribute__((noinline)) float sinf_via_f64(float x) { return (float)sin((double)x); }
+// The NLP's powf / cosf / sinf are evaluated as (float)f((double)x) by the lean fp64 forms of
+// ns_device.h (identical to the plain ocml forms for every argument, tests/test_aec_gpu.py); glibc's
+// float versions (<= 0.52 / 0.56 ulp) differ from that in rare last-place cases.
+
+// Out of line on purpose: inlined, their fp64 polynomials push process_block into spilling.
+__device__ __attribute__((noinline)) float nlp_pow(float x, float y, const double* __restrict__ t64) {
+  return aspns_dev::pow_f32_via_f64(x, y, t64);
+}
+__device__ __attribute__((noinline)) float2 nlp_sincos(float x) {
+  float2 r;
+  aspns_dev::sincos_f32_via_f64(x, r.x, r.y);
+  return r;
+}
 
 // One ProcessBlock + NonLinearProcessing for this wave's stream.
 __device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
                                               const float* __restrict__ far_slot,
                                               const SharedTables& T, const BlockOp& op, int mult,
                                               int nlp_mode, float mu, float error_threshold,
-                                              int lane, unsigned long long* stamps) {
+                                              int lane, const double* __restrict__ exp2_global,
+                                              unsigned long long* stamps) {
   // diagnostic phase stamps (never enabled by the product entry points)
 #define AEC_STAMP(k) \
   if (stamps != nullptr) stamps[k] = __builtin_amdgcn_s_memtime();
@@ -843,7 +854,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   BINS_2TRIPS {
     float h = HNL[bin];
     if (h > hNlFb) h = T.weight[bin] * hNlFb + (1 - T.weight[bin]) * h;
-    h = powf_via_f64(h, overDriveSm * T.odrive[bin]);
+    h = nlp_pow(h, overDriveSm * T.odrive[bin], exp2_global);
     float er = EWR[bin] * h, ei = EWI[bin] * h;
     ei *= -1;
     float ur = 0.f, ui = 0.f;
@@ -853,8 +864,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       const float rnd = ((float)(int16_t)(s >> 16)) / 32768;
       const float tmp = 6.28318530717959f * rnd;
       const float noise = sqrtf(T1[bin]);
-      ur = noise * cosf_via_f64(tmp);
-      ui = -noise * sinf_via_f64(tmp);
+      const float2 sc2 = nlp_sincos(tmp);
+      ur = noise * sc2.y;
+      ui = -noise * sc2.x;
       if (bin == 64) ui = 0.f;
     }
     const float r = 1 - h * h;
@@ -955,7 +967,7 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
     for (int k = 0; k < sf.nblocks; ++k) {
       const BlockOp& op = sf.blk[k];
       const float* slot = far_ring + ((size_t)op.far_slot * num_streams + stream) * kFarSlotDwords;
-      process_block(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane,
+      process_block(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
                     (stamps != nullptr && stream == 0 && s == 0 && k == 0 && lane == 0) ? stamps : nullptr);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();

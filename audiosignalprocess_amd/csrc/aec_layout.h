@@ -65,6 +65,7 @@ struct AecTables {
   float odrive[68];    // WebRtcAec_overDriveCurve[65]
   uint32_t lcg_a[64];  // 69069^(k+1) mod 2^32
   uint32_t lcg_c[64];  // sum_{i<=k} 69069^i mod 2^32
+  double exp2_64[64];  // 2^(j/64) of the lean exp (ns_device.h)
 };
 
 // One WebRtcAec_BufferFarend call (echo_cancellation.c:278-339) as the device sees it.

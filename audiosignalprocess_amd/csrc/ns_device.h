@@ -228,6 +228,83 @@ __device__ __forceinline__ float log_f32_via_f64(float x) {
   return r;
 }
 
+// ---- lean fp64 forms of the echo canceller's float transcendentals (aec_core.c:280, 487-488) ----
+// Each returns exactly what its plain form `(float)f((double)x)` (ocml fp64, rounded) returns: the
+// lean evaluation is accurate to ~2^-46, the float rounding is taken from it only when the fp64
+// value sits more than 2^-44 (relative) away from a rounding boundary, everything else -- and every
+// argument outside the fast range -- goes to the plain form.  Compared with the plain forms over
+// whole float ranges on the device in tests/test_aec_gpu.py.
+
+// exp of a double argument with |x| <= 87 (float result normal): exp_lean_f64 for a double.
+__device__ __forceinline__ double exp_lean_f64d(double x, const double* __restrict__ t64) {
+  const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);
+  const int k = (int)kd;
+  double r = __builtin_fma(-kd, 0x1.62e42ff000000p-7, x);
+  r = __builtin_fma(-kd, -0x1.718432a1b0e26p-41, r);
+  double q = 1.0 / 120.0;
+  q = __builtin_fma(q, r, 1.0 / 24.0);
+  q = __builtin_fma(q, r, 1.0 / 6.0);
+  q = __builtin_fma(q, r, 0.5);
+  const double p = __builtin_fma(q, r * r, r);
+  const double T = t64[k & 63];
+  return __builtin_amdgcn_ldexp(__builtin_fma(T, p, T), k >> 6);
+}
+
+// (float)pow((double)x, (double)y).  Fast range: x a positive normal float, |y log x| <= 40.
+__device__ __forceinline__ float pow_f32_via_f64(float x, float y, const double* __restrict__ t64) {
+  const unsigned ax = __float_as_uint(x);
+  const bool normal_pos = (ax - 0x00800000u) < 0x7f000000u;
+  const double t = (double)y * log_lean_f64(normal_pos ? x : 1.0f);
+  const bool in_range = normal_pos && (__builtin_fabs(t) <= 40.0);  // false for NaN too
+  const double v = exp_lean_f64d(in_range ? t : 0.0, t64);
+  const bool ok = in_range && f64_rounds_safely_to_f32(v);
+  float r = (float)v;
+  if (__builtin_expect(!ok, 0)) r = (float)pow((double)x, (double)y);
+  return r;
+}
+
+// (float)cos((double)x) and (float)sin((double)x) for one argument.  Fast range: 0 <= x < 8:
+// k = rint(x 2/pi), r = x - k pi/2 in two exact-enough steps (33-bit head: x - k C1 is exact for a
+// float x, then one fused step with the next 53 bits), kernels of fdlibm (k_sin.c / k_cos.c).
+__device__ __forceinline__ void sincos_f32_via_f64(float x, float& s_out, float& c_out) {
+  const bool in_range = __float_as_uint(x) < 0x41000000u;  // [+0, 8): not -0, not NaN
+  const double xd = in_range ? (double)x : 0.0;
+  const double kd = __builtin_rint(xd * 0x1.45f306dc9c883p-1);  // 2/pi
+  const int k = (int)kd;
+  double r = __builtin_fma(-kd, 0x1.921fb54400000p+0, xd);       // pi/2, 33 significant bits: exact
+  r = __builtin_fma(-kd, 0x1.0b4611a626331p-34, r);              // next 53 bits
+  const double z = r * r;
+  // k_sin
+  double ps = 1.58969099521155010221e-10;                          // S6
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);          // S5
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);           // S4
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);          // S3
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);           // S2
+  const double v3 = z * r;
+  const double sn = __builtin_fma(v3, __builtin_fma(z, ps, -1.66666666666666324348e-01), r);  // S1
+  // k_cos
+  double pc = -1.13596475577881948265e-11;                         // C6
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);           // C5
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);          // C4
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);           // C3
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);          // C2
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);           // C1
+  const double hz = 0.5 * z;
+  const double a = 1.0 - hz;
+  const double cs = a + (((1.0 - a) - hz) + z * z * pc);
+  const int q = k & 3;
+  const double sv = (q & 1) ? cs : sn, cv = (q & 1) ? sn : cs;
+  const double sd = (q & 2) ? -sv : sv;
+  const double cd = ((q + 1) & 2) ? -cv : cv;
+  const bool ok = in_range && f64_rounds_safely_to_f32(sd) && f64_rounds_safely_to_f32(cd);
+  s_out = (float)sd;
+  c_out = (float)cd;
+  if (__builtin_expect(!ok, 0)) {
+    s_out = (float)sin((double)x);
+    c_out = (float)cos((double)x);
+  }
+}
+
 // --------------------------------------------------------------------------
 // Histogram window close: FeatureParameterExtraction(self, 1), ns_core.c:337-517.
 // Runs once per 500 frames per stream.  Zero bins cannot change any of the

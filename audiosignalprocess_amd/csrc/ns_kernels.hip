@@ -830,6 +830,12 @@ __device__ __forceinline__ float debug_fn(int fn, float x, float param,
     case 1: return (float)log((double)x);
     case 2: return (float)exp((double)x);
     case 3: return (float)tanh((double)x);
+    case 13: return (float)pow((double)x, (double)param);
+    case 14: return pow_f32_via_f64(x, param, t64);
+    case 15: return (float)cos((double)x);
+    case 16: { float sv, cv; sincos_f32_via_f64(x, sv, cv); return cv; }
+    case 17: return (float)sin((double)x);
+    case 18: { float sv, cv; sincos_f32_via_f64(x, sv, cv); return sv; }
     default: return x;
   }
 }

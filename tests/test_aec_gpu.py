@@ -259,3 +259,28 @@ def test_wav_driver_end_to_end(aec, aec_golden, tmp_path):
     want_i16 = np.clip(want_i16, -32768, 32767).astype(np.int32)
     d = np.abs(out[:F * 160].astype(np.int32) - want_i16)
     assert d.max() <= 1 and (d == 0).mean() >= 0.999
+
+
+def test_device_pow_sincos_lean_equal_plain_forms(aec):
+    """The NLP's lean fp64 pow / cos / sin (ns_device.h) return what the plain
+    (float)f((double)x) forms return: pow for EVERY float base (all 2^32 bit patterns: negative,
+    zero, denormal, > 1, inf, NaN included) at several exponents in the overdrive range, cos / sin
+    for every float in [0, 8] and a stretch beyond (fallback range)."""
+    from audiosignalprocess_amd import ns
+    from tests.test_ns_gpu import _sweep_all_floats
+
+    lib = ns.load_library()
+    step = 1 << 28
+    for y in (1.0, 1.1767766, 2.0, 3.3137085, 7.25, 15.0, 40.0):
+        total, examples = 0, []
+        for start in range(0, 1 << 32, step):
+            from tests.test_ns_gpu import _debug_compare
+            n, ex = _debug_compare(lib, 14, 13, start, step, param=y)
+            total += n
+            examples += ex
+        assert total == 0, (y, total, [hex(b) for b in examples[:8]])
+    for fa, fb, name in [(16, 15, "cos"), (18, 17, "sin")]:
+        bad, ex = _sweep_all_floats(lib, fa, fb, 0x00000000, 0x42000000)   # [0, 32)
+        assert bad == 0, (name, bad, [hex(b) for b in ex[:8]])
+        bad, ex = _sweep_all_floats(lib, fa, fb, 0x80000000, 0xc1000000)   # negatives: fallback
+        assert bad == 0, (name, bad, [hex(b) for b in ex[:8]])
