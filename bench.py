@@ -31,7 +31,10 @@ ALGO_BYTES_PER_FRAME = 15716  # frame-synchronous NS mod
 # WRITE_SIZE (separate rocprofv3 --pmc passes, tools/traffic_ns.sh), calibrated on the kernel's own
 # known byte count at 32768 streams as MI355X_MICROARCH.md prescribes for access widths it does not
 # cover; see profiles/README.md ("HBM traffic of the NS kernel").  Measured once per round, not live.
-PMC_TRAFFIC_BYTES_PER_FRAME = (4.832 * 1.638 + 9.158 / 1.09) * 1024
+PMC_TRAFFIC_BYTES_PER_FRAME = (4.832 * 1.638 + 9.158 / 1.09) * 1024      # ns_frame_kernel<true,true>
+# ns_frame2_kernel (default): FETCH_SIZE 4.0253 / WRITE_SIZE 7.9428 KB per stream at 4096 streams against
+# 3.9533 / 7.9705 KB at 32768 streams, where the kernel's known 7 856 B each way are all HBM traffic
+PMC_TRAFFIC_BYTES_PER_FRAME_DUAL = 7856 * (4.0253 / 3.9533 + 7.9428 / 7.9705)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -326,7 +329,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": PMC_TRAFFIC_BYTES_PER_FRAME * S / max(args.split, 1),
+                "traffic": (PMC_TRAFFIC_BYTES_PER_FRAME_DUAL if args.streams_per_wave == 2
+                            else PMC_TRAFFIC_BYTES_PER_FRAME) * S / max(args.split, 1),
                 "traffic_source": "profiles/README.md (PMC passes of round 1, per launch)",
                 "kernel": "ns_frame2_kernel<false>" if args.streams_per_wave == 2 else "ns_frame_kernel<true,true>",
                 # one frame step = `concurrent_launches` launches of this kernel side by side

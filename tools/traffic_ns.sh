@@ -16,6 +16,6 @@ import csv,glob
 for S in (4096,32768):
     for C in ('FETCH_SIZE','WRITE_SIZE'):
         for f in glob.glob('$OUT/%d_%s/*/*counter_collection.csv'%(S,C)):
-            v=[float(r['Counter_Value']) for r in csv.DictReader(open(f)) if 'ns_frame_kernel' in r['Kernel_Name'] and r['Counter_Name']==C]
+            v=[float(r['Counter_Value']) for r in csv.DictReader(open(f)) if ('ns_frame_kernel' in r['Kernel_Name'] or 'ns_frame2_kernel' in r['Kernel_Name']) and r['Counter_Name']==C]
             t=v[-30:]; print(S,C,'per-launch(raw KB units?) %.6g'%(sum(t)/len(t)), 'per-stream %.4f'%(sum(t)/len(t)/S))
 PY
