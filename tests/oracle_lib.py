@@ -448,3 +448,59 @@ def aec_oracle_run_mt(far, near, fs=16000, delay_ms=0, threads=1):
     rc = lib.asp_aec_oracle_run_mt(S, far, near, out, F, n, delay_ms, fs, threads)
     assert rc == 0
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# two-band QMF (oracle/qmf_oracle.c; reference: oracle/_ref/libspl_ref.so)
+SPL_REF_SO = os.path.join(ORACLE_DIR, "_ref", "libspl_ref.so")
+_i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_spl_ref = None
+
+
+def have_spl_ref():
+    return os.path.exists(SPL_REF_SO)
+
+
+class _Qmf:
+    """One channel: analysis / synthesis with caller-owned states, through `fa` / `fs`."""
+
+    def __init__(self, fa, fs):
+        self.fa, self.fs = fa, fs
+        self.a1, self.a2 = np.zeros(6, np.int32), np.zeros(6, np.int32)
+        self.s1, self.s2 = np.zeros(6, np.int32), np.zeros(6, np.int32)
+
+    def analysis(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        low, high = np.empty(x.size // 2, np.int16), np.empty(x.size // 2, np.int16)
+        self.fa(x, x.size, low, high, self.a1, self.a2)
+        return low, high
+
+    def synthesis(self, low, high):
+        low, high = np.ascontiguousarray(low, np.int16), np.ascontiguousarray(high, np.int16)
+        out = np.empty(2 * low.size, np.int16)
+        self.fs(low, high, low.size, out, self.s1, self.s2)
+        return out
+
+    def state(self):
+        return np.concatenate([self.a1, self.a2, self.s1, self.s2])
+
+
+def _qmf_sig(fa, fs):
+    fa.argtypes = [_i16p, C.c_int, _i16p, _i16p, _i32p, _i32p]
+    fs.argtypes = [_i16p, _i16p, C.c_int, _i16p, _i32p, _i32p]
+    fa.restype = None
+    fs.restype = None
+    return fa, fs
+
+
+def OracleQmf():
+    lib = oracle_lib()
+    return _Qmf(*_qmf_sig(lib.asp_qmf_oracle_analysis, lib.asp_qmf_oracle_synthesis))
+
+
+def RefQmf():
+    global _spl_ref
+    if _spl_ref is None:
+        _spl_ref = C.CDLL(SPL_REF_SO)
+    return _Qmf(*_qmf_sig(_spl_ref.WebRtcSpl_AnalysisQMF, _spl_ref.WebRtcSpl_SynthesisQMF))
