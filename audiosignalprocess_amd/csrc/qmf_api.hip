@@ -1,0 +1,208 @@
+// qmf_api.hip -- host side of include/asp_split.h: the batch handle (filter states in HBM) and
+// the reference's WebRtcSpl_AnalysisQMF / WebRtcSpl_SynthesisQMF as a batch of one channel with
+// caller-owned states.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "asp_ns.h"
+#include "asp_split.h"
+
+namespace aspqmf {
+hipError_t launch_analysis(int32_t* state, const int16_t* in, int16_t* low, int16_t* high,
+                           int num_channels, int band_length, hipStream_t s);
+hipError_t launch_synthesis(int32_t* state, const int16_t* low, const int16_t* high, int16_t* out,
+                            int num_channels, int band_length, hipStream_t s);
+}  // namespace aspqmf
+
+namespace {
+thread_local char g_qmf_err[512] = "";
+int qmf_fail(int code, const char* what, hipError_t e = hipSuccess) {
+  if (e != hipSuccess)
+    snprintf(g_qmf_err, sizeof g_qmf_err, "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(g_qmf_err, sizeof g_qmf_err, "%s", what);
+  fprintf(stderr, "asp_split: %s\n", g_qmf_err);
+  return code;
+}
+#define QMF_TRY(expr)                                             \
+  do {                                                            \
+    hipError_t e_ = (expr);                                       \
+    if (e_ != hipSuccess) return qmf_fail(ASP_ERR_HIP, #expr, e_); \
+  } while (0)
+}  // namespace
+
+struct AspQmfBatch {
+  int C = 0, device = 0;
+  hipStream_t stream = nullptr;
+  int32_t* state = nullptr;                  // [C][24]
+  int16_t *s_in = nullptr, *s_a = nullptr, *s_b = nullptr;  // staging [C][640], [C][320] x 2
+};
+
+extern "C" {
+
+int AspQmfBatch_Create(AspQmfBatch** out, int num_channels, int device) {
+  if (!out || num_channels <= 0) return qmf_fail(ASP_ERR_PARAM, "AspQmfBatch_Create: bad argument");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return qmf_fail(ASP_ERR_NO_DEVICE, "no HIP device: the band split has no CPU fallback");
+  if (device < 0 || device >= count) return qmf_fail(ASP_ERR_PARAM, "device ordinal out of range");
+  QMF_TRY(hipSetDevice(device));
+  AspQmfBatch* b = new AspQmfBatch();
+  b->C = num_channels;
+  b->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->state, (size_t)num_channels * 24 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->s_in, (size_t)num_channels * 2 * ASP_QMF_MAX_BAND * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->s_a, (size_t)num_channels * ASP_QMF_MAX_BAND * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->s_b, (size_t)num_channels * ASP_QMF_MAX_BAND * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMemset(b->state, 0, (size_t)num_channels * 24 * sizeof(int32_t));
+  if (e != hipSuccess) {
+    AspQmfBatch_Free(b);
+    return qmf_fail(ASP_ERR_HIP, "AspQmfBatch_Create", e);
+  }
+  *out = b;
+  return ASP_OK;
+}
+
+int AspQmfBatch_Free(AspQmfBatch* b) {
+  if (!b) return -1;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->state) (void)hipFree(b->state);
+  if (b->s_in) (void)hipFree(b->s_in);
+  if (b->s_a) (void)hipFree(b->s_a);
+  if (b->s_b) (void)hipFree(b->s_b);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return 0;
+}
+
+int AspQmfBatch_num_channels(const AspQmfBatch* b) { return b ? b->C : 0; }
+
+int AspQmfBatch_Reset(AspQmfBatch* b) {
+  if (!b) return qmf_fail(ASP_ERR_PARAM, "null batch handle");
+  QMF_TRY(hipSetDevice(b->device));
+  QMF_TRY(hipMemsetAsync(b->state, 0, (size_t)b->C * 24 * sizeof(int32_t), b->stream));
+  return ASP_OK;
+}
+
+int AspQmfBatch_Analysis(AspQmfBatch* b, const int16_t* in, int band_length, int16_t* low,
+                         int16_t* high, int mem) {
+  if (!b || !in || !low || !high || band_length <= 0 || band_length > ASP_QMF_MAX_BAND)
+    return qmf_fail(ASP_ERR_PARAM, "AspQmfBatch_Analysis: bad argument");
+  QMF_TRY(hipSetDevice(b->device));
+  const size_t nb = (size_t)b->C * band_length * sizeof(int16_t);
+  const int16_t* din = in;
+  int16_t *dl = low, *dh = high;
+  if (mem == ASP_MEM_HOST) {
+    QMF_TRY(hipMemcpyAsync(b->s_in, in, 2 * nb, hipMemcpyHostToDevice, b->stream));
+    din = b->s_in;
+    dl = b->s_a;
+    dh = b->s_b;
+  } else if (mem != ASP_MEM_DEVICE) {
+    return qmf_fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  }
+  QMF_TRY(aspqmf::launch_analysis(b->state, din, dl, dh, b->C, band_length, b->stream));
+  if (mem == ASP_MEM_HOST) {
+    QMF_TRY(hipMemcpyAsync(low, dl, nb, hipMemcpyDeviceToHost, b->stream));
+    QMF_TRY(hipMemcpyAsync(high, dh, nb, hipMemcpyDeviceToHost, b->stream));
+    QMF_TRY(hipStreamSynchronize(b->stream));
+  }
+  return ASP_OK;
+}
+
+int AspQmfBatch_Synthesis(AspQmfBatch* b, const int16_t* low, const int16_t* high,
+                          int band_length, int16_t* out, int mem) {
+  if (!b || !out || !low || !high || band_length <= 0 || band_length > ASP_QMF_MAX_BAND)
+    return qmf_fail(ASP_ERR_PARAM, "AspQmfBatch_Synthesis: bad argument");
+  QMF_TRY(hipSetDevice(b->device));
+  const size_t nb = (size_t)b->C * band_length * sizeof(int16_t);
+  const int16_t *dl = low, *dh = high;
+  int16_t* dout = out;
+  if (mem == ASP_MEM_HOST) {
+    QMF_TRY(hipMemcpyAsync(b->s_a, low, nb, hipMemcpyHostToDevice, b->stream));
+    QMF_TRY(hipMemcpyAsync(b->s_b, high, nb, hipMemcpyHostToDevice, b->stream));
+    dl = b->s_a;
+    dh = b->s_b;
+    dout = b->s_in;
+  } else if (mem != ASP_MEM_DEVICE) {
+    return qmf_fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  }
+  QMF_TRY(aspqmf::launch_synthesis(b->state, dl, dh, dout, b->C, band_length, b->stream));
+  if (mem == ASP_MEM_HOST) {
+    QMF_TRY(hipMemcpyAsync(out, dout, 2 * nb, hipMemcpyDeviceToHost, b->stream));
+    QMF_TRY(hipStreamSynchronize(b->stream));
+  }
+  return ASP_OK;
+}
+
+int AspQmfBatch_ExportState(AspQmfBatch* b, int channel, AspQmfState* out) {
+  if (!b || !out || channel < 0 || channel >= b->C) return qmf_fail(ASP_ERR_PARAM, "ExportState: bad argument");
+  QMF_TRY(hipSetDevice(b->device));
+  QMF_TRY(hipStreamSynchronize(b->stream));
+  QMF_TRY(hipMemcpy(out, b->state + (size_t)channel * 24, sizeof *out, hipMemcpyDeviceToHost));
+  return ASP_OK;
+}
+
+int AspQmfBatch_ImportState(AspQmfBatch* b, int channel, const AspQmfState* in) {
+  if (!b || !in || channel < 0 || channel >= b->C) return qmf_fail(ASP_ERR_PARAM, "ImportState: bad argument");
+  QMF_TRY(hipSetDevice(b->device));
+  QMF_TRY(hipStreamSynchronize(b->stream));
+  QMF_TRY(hipMemcpy(b->state + (size_t)channel * 24, in, sizeof *in, hipMemcpyHostToDevice));
+  return ASP_OK;
+}
+
+int AspQmfBatch_Synchronize(AspQmfBatch* b) {
+  if (!b) return qmf_fail(ASP_ERR_PARAM, "null batch handle");
+  QMF_TRY(hipSetDevice(b->device));
+  QMF_TRY(hipStreamSynchronize(b->stream));
+  return ASP_OK;
+}
+
+// ------------------------------------------------------------------ layer 1
+// The reference's functions: one channel, caller-owned states.  Errors (no device) abort loudly:
+// the reference functions return void.
+static AspQmfBatch* one_channel() {
+  static thread_local AspQmfBatch* b = nullptr;
+  if (!b && AspQmfBatch_Create(&b, 1, 0) != ASP_OK) {
+    fprintf(stderr, "asp_split: WebRtcSpl_*QMF needs a HIP device (no CPU fallback)\n");
+    abort();
+  }
+  return b;
+}
+
+void WebRtcSpl_AnalysisQMF(const int16_t* in_data, int in_data_length, int16_t* low_band,
+                           int16_t* high_band, int32_t* filter_state1, int32_t* filter_state2) {
+  AspQmfBatch* b = one_channel();
+  AspQmfState st;
+  memset(&st, 0, sizeof st);
+  memcpy(st.analysis_state1, filter_state1, sizeof st.analysis_state1);
+  memcpy(st.analysis_state2, filter_state2, sizeof st.analysis_state2);
+  if (AspQmfBatch_ImportState(b, 0, &st) != ASP_OK ||
+      AspQmfBatch_Analysis(b, in_data, in_data_length / 2, low_band, high_band, ASP_MEM_HOST) != ASP_OK ||
+      AspQmfBatch_ExportState(b, 0, &st) != ASP_OK)
+    abort();
+  memcpy(filter_state1, st.analysis_state1, sizeof st.analysis_state1);
+  memcpy(filter_state2, st.analysis_state2, sizeof st.analysis_state2);
+}
+
+void WebRtcSpl_SynthesisQMF(const int16_t* low_band, const int16_t* high_band, int band_length,
+                            int16_t* out_data, int32_t* filter_state1, int32_t* filter_state2) {
+  AspQmfBatch* b = one_channel();
+  AspQmfState st;
+  memset(&st, 0, sizeof st);
+  memcpy(st.synthesis_state1, filter_state1, sizeof st.synthesis_state1);
+  memcpy(st.synthesis_state2, filter_state2, sizeof st.synthesis_state2);
+  if (AspQmfBatch_ImportState(b, 0, &st) != ASP_OK ||
+      AspQmfBatch_Synthesis(b, low_band, high_band, band_length, out_data, ASP_MEM_HOST) != ASP_OK ||
+      AspQmfBatch_ExportState(b, 0, &st) != ASP_OK)
+    abort();
+  memcpy(filter_state1, st.synthesis_state1, sizeof st.synthesis_state1);
+  memcpy(filter_state2, st.synthesis_state2, sizeof st.synthesis_state2);
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+"""GPU parity tests of the batched two-band QMF (through the C-ABI, include/asp_split.h):
+integer arithmetic, so everything is bit-exact against oracle/qmf_oracle.c (pinned to the
+reference in tests/test_qmf_oracle.py) and against the committed reference outputs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib
+from tests.test_qmf_oracle import qmf_inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def qmf():
+    from audiosignalprocess_amd import ns
+    from audiosignalprocess_amd import qmf as mod
+
+    assert ns.device_count() >= 1, "GPU tests need a HIP device"
+    return mod
+
+
+@pytest.mark.parametrize("n", [320, 160, 640])
+def test_batch_equals_oracle_bitwise(qmf, n):
+    """37 channels (partial wave), 40 frames with saturating content, states carried; channel c
+    sees the frames rotated by c so every lane works on different data."""
+    Cn = 37
+    x = qmf_inputs(n=n)
+    F = x.shape[0]
+    g = qmf.QmfBatch(Cn)
+    oras = [oracle_lib.OracleQmf() for _ in range(Cn)]
+    for f in range(F):
+        frame = np.stack([x[(f + c) % F] for c in range(Cn)])
+        low, high = g.analysis(frame)
+        hb = (high.astype(np.int32) * 3 // 4).astype(np.int16)
+        out = g.synthesis(low, hb)
+        for c in range(0, Cn, 6):
+            lo, ho = oras[c].analysis(frame[c])
+            assert np.array_equal(low[c], lo) and np.array_equal(high[c], ho), (f, c)
+            assert np.array_equal(out[c], oras[c].synthesis(lo, (ho.astype(np.int32) * 3 // 4).astype(np.int16))), (f, c)
+    for c in range(0, Cn, 6):
+        assert np.array_equal(g.state(c), oras[c].state()), c
+
+
+def test_golden_reference_outputs(qmf):
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "qmf_golden.npz")))
+    g = qmf.QmfBatch(1)
+    for f in range(gold["x"].shape[0]):
+        low, high = g.analysis(gold["x"][f][None])
+        assert np.array_equal(low[0], gold["low"][f]) and np.array_equal(high[0], gold["high"][f]), f
+        assert np.array_equal(g.synthesis(low, high)[0], gold["merged"][f]), f
+    assert np.array_equal(g.state(0), gold["state"])
+
+
+def test_layer1_reference_api_and_scale(qmf):
+    """WebRtcSpl_AnalysisQMF / SynthesisQMF with caller-owned states, as splitting_filter.cc:63-88
+    calls them; and 8192 channels fed the same frame all produce the same bands."""
+    lib = qmf._lib()
+    i16p, i32p = C.POINTER(C.c_int16), C.POINTER(C.c_int32)
+    lib.WebRtcSpl_AnalysisQMF.argtypes = [i16p, C.c_int, i16p, i16p, i32p, i32p]
+    lib.WebRtcSpl_AnalysisQMF.restype = None
+    lib.WebRtcSpl_SynthesisQMF.argtypes = [i16p, i16p, C.c_int, i16p, i32p, i32p]
+    lib.WebRtcSpl_SynthesisQMF.restype = None
+    x = qmf_inputs(frames=12)
+    ora = oracle_lib.OracleQmf()
+    s = [np.zeros(6, np.int32) for _ in range(4)]
+    for fr in x:
+        low, high, out = np.empty(160, np.int16), np.empty(160, np.int16), np.empty(320, np.int16)
+        lib.WebRtcSpl_AnalysisQMF(fr.ctypes.data_as(i16p), 320, low.ctypes.data_as(i16p), high.ctypes.data_as(i16p),
+                                  s[0].ctypes.data_as(i32p), s[1].ctypes.data_as(i32p))
+        lib.WebRtcSpl_SynthesisQMF(low.ctypes.data_as(i16p), high.ctypes.data_as(i16p), 160, out.ctypes.data_as(i16p),
+                                   s[2].ctypes.data_as(i32p), s[3].ctypes.data_as(i32p))
+        lo, ho = ora.analysis(fr)
+        assert np.array_equal(low, lo) and np.array_equal(high, ho)
+        assert np.array_equal(out, ora.synthesis(lo, ho))
+    assert np.array_equal(np.concatenate(s), ora.state())
+    Cn = 8192
+    g = qmf.QmfBatch(Cn)
+    low, high = g.analysis(np.broadcast_to(x[3], (Cn, 320)))
+    assert (low == low[0]).all() and (high == high[0]).all()
