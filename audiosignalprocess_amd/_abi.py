@@ -82,6 +82,12 @@ class AspNsState(C.Structure):
 STATE_FIELDS = [n for n, _ in AspNsState._fields_]
 
 
+class AspNsHbState(C.Structure):
+    """include/asp_ns.h: AspNsHbState (high-band analysis buffers, ns_core.h:112)."""
+
+    _fields_ = [("dataBufHB", C.c_float * (2 * 256))]
+
+
 class AspBtState(C.Structure):
     """include/asp_bt.h: AspBtState (carried state between macroblocks)."""
 

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libasp_amd.so")
-SOURCES = ["ns_kernels.hip", "ns_kernels2.hip", "ns_api.hip", "bt_kernels.hip", "bt_api.hip",
+SOURCES = ["ns_kernels.hip", "ns_kernels2.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_api.hip",
            "aec_kernels.hip", "aec_api.hip", "qmf_kernels.hip", "qmf_api.hip"]
 C_SOURCES = ["wav_io.c"]  # host-only C (kept C, as in the reference)
 # -ffp-contract=off: parity with the reference depends on unfused mul/add.

@@ -26,6 +26,11 @@ hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTabl
                             const float* in, float* out, int num_streams, hipStream_t s,
                             unsigned long long* stamps = nullptr);
 hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
+hipError_t launch_ns_hb_live(const float* state, const NsTables* T, const float* in_low,
+                             int32_t* live, int num_streams, int hist_off, hipStream_t s);
+hipError_t launch_ns_hb_apply(const float* state, float* hb_tail, const int32_t* live,
+                              const NsTables* T, const float* in_high, float* out_high,
+                              int num_streams, int num_high, int paired, hipStream_t s);
 hipError_t launch_ns_set_policy(float* state, int num_streams, int mode, float overdrive,
                                 float denoiseBound, int gainmap, hipStream_t s);
 hipError_t launch_rdft256(float* data, int count, int isgn, const NsTables* T, hipStream_t s);
@@ -433,6 +438,12 @@ struct AspNsBatch {
   bool dual = true;  // fused paired step through the two-streams-per-wave kernel
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
+  // > 16 kHz: 1 or 2 high bands next to the low band (ns_core.c:1362-1414)
+  uint32_t fs = 16000;
+  int num_high = 0;
+  float* hb_tail = nullptr;    // [S][2][96]: dataBufHB[b][160..255]
+  int32_t* hb_live = nullptr;  // [S]: energy1 != 0 of the frame being processed
+  float* hb_stage = nullptr;   // host-memory callers: [2][num_high][S][160]
 };
 
 namespace {
@@ -522,6 +533,9 @@ int AspNsBatch_Free(AspNsBatch* b) {
   if (b->hist) (void)hipFree(b->hist);
   if (b->stage_in) (void)hipFree(b->stage_in);
   if (b->stage_out) (void)hipFree(b->stage_out);
+  if (b->hb_tail) (void)hipFree(b->hb_tail);
+  if (b->hb_live) (void)hipFree(b->hb_live);
+  if (b->hb_stage) (void)hipFree(b->hb_stage);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
@@ -538,9 +552,19 @@ int AspNsBatch_num_streams(const AspNsBatch* b) { return b ? b->S : ASP_ERR_PARA
 
 int AspNsBatch_Init(AspNsBatch* b, uint32_t fs) {
   if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
-  if (fs != 16000)  // ns_core.c:82-86 accepts 8/16/32/48 kHz; only 16 kHz is built
-    return fail(ASP_ERR_PARAM, "AspNsBatch_Init: only fs = 16000 is implemented");
+  // ns_core.c:82-86 accepts 8/16/32/48 kHz; the 160 / 256 / 129 geometry (16, 32, 48 kHz) is built
+  if (fs != 16000 && fs != 32000 && fs != 48000)
+    return fail(ASP_ERR_PARAM, "AspNsBatch_Init: fs must be 16000, 32000 or 48000");
   HIP_TRY(hipSetDevice(b->device));
+  b->fs = fs;
+  b->num_high = (int)(fs / 16000) - 1;
+  if (b->num_high > 0) {
+    if (!b->hb_tail) HIP_TRY(hipMalloc((void**)&b->hb_tail, (size_t)b->S * 2 * kCarry * sizeof(float)));
+    if (!b->hb_live) HIP_TRY(hipMalloc((void**)&b->hb_live, (size_t)b->S * sizeof(int32_t)));
+    if (!b->hb_stage)
+      HIP_TRY(hipMalloc((void**)&b->hb_stage, (size_t)2 * 2 * b->S * kBlockL * sizeof(float)));
+    HIP_TRY(hipMemset(b->hb_tail, 0, (size_t)b->S * 2 * kCarry * sizeof(float)));  // ns_core.c:110-112
+  }
   AspNsState* s0 = (AspNsState*)malloc(sizeof(AspNsState));
   init_state(s0, fs);
   const int chunk = b->S < 256 ? b->S : 256;
@@ -692,6 +716,100 @@ int AspNsBatch_AnalyzeProcess(AspNsBatch* b, const float* in, float* out, int nu
   return run_frames(b, 2, in, out, num_frames, mem);
 }
 
+// One frame of every stream with its high band(s): `fused` = Analyze + Process of the low band in
+// one step (paired state), otherwise Process alone (the caller ran Analyze).  Device pointers.
+static int bands_frame_device(AspNsBatch* b, bool fused, const float* low_in, const float* high_in,
+                              float* low_out, float* high_out) {
+  const int hist_off = b->paired ? kOffAnaHist : kOffDataHist;
+  HIP_TRY(launch_ns_hb_live(b->state, b->tables, low_in, b->hb_live, b->S, hist_off, b->stream));
+  if (fused && b->paired) {
+    HIP_TRY(fused_launch(b, false, low_in, low_out, 0, b->S, b->stream));
+  } else {
+    if (fused)  // unpaired streams: Analyze then Process as two launches
+      HIP_TRY(launch_ns_frame(0, b->state, b->hist, b->tables, low_in, low_out, b->S, b->stream));
+    HIP_TRY(launch_ns_frame(1, b->state, b->hist, b->tables, low_in, low_out, b->S, b->stream));
+  }
+  HIP_TRY(launch_ns_hb_apply(b->state, b->hb_tail, b->hb_live, b->tables, high_in, high_out, b->S,
+                             b->num_high, b->paired ? 1 : 0, b->stream));
+  return ASP_OK;
+}
+
+static int bands_run(AspNsBatch* b, bool fused, const float* low_in, const float* high_in,
+                     float* low_out, float* high_out, int num_frames, int mem) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (b->num_high < 1) return fail(ASP_ERR_STATE, "bands: the batch was initialised at 16 kHz (one band)");
+  if (!low_in || !high_in || !low_out || !high_out || num_frames < 0)
+    return fail(ASP_ERR_PARAM, "bands: bad argument");
+  const size_t lper = (size_t)b->S * kBlockL, hper = lper * b->num_high;
+  if (mem == ASP_MEM_DEVICE) {
+    for (int f = 0; f < num_frames; ++f) {
+      rc = bands_frame_device(b, fused, low_in + lper * f, high_in + hper * f, low_out + lper * f,
+                              high_out + hper * f);
+      if (rc) return rc;
+    }
+    return ASP_OK;
+  }
+  if (mem != ASP_MEM_HOST) return fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  rc = ensure_stage(b, 1);
+  if (rc) return rc;
+  float* hin = b->hb_stage;
+  float* hout = b->hb_stage + (size_t)2 * lper;
+  for (int f = 0; f < num_frames; ++f) {
+    HIP_TRY(hipMemcpyAsync(b->stage_in, low_in + lper * f, lper * 4, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(hin, high_in + hper * f, hper * 4, hipMemcpyHostToDevice, b->stream));
+    rc = bands_frame_device(b, fused, b->stage_in, hin, b->stage_out, hout);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(low_out + lper * f, b->stage_out, lper * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(high_out + hper * f, hout, hper * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return ASP_OK;
+}
+
+int AspNsBatch_AnalyzeProcessBands(AspNsBatch* b, const float* low_in, const float* high_in,
+                                   float* low_out, float* high_out, int num_frames, int mem) {
+  int rc = check(b);
+  if (rc) return rc;
+  return bands_run(b, true, low_in, high_in, low_out, high_out, num_frames, mem);
+}
+
+int AspNsBatch_ProcessBands(AspNsBatch* b, const float* low_in, const float* high_in, float* low_out,
+                            float* high_out, int mem) {
+  int rc = check(b);
+  if (rc) return rc;
+  rc = ensure_unpaired(b);
+  if (rc) return rc;
+  return bands_run(b, false, low_in, high_in, low_out, high_out, 1, mem);
+}
+
+int AspNsBatch_num_bands(const AspNsBatch* b) { return b ? 1 + b->num_high : ASP_ERR_PARAM; }
+
+int AspNsBatch_ExportHbState(AspNsBatch* b, int stream, AspNsHbState* out) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!out || stream < 0 || stream >= b->S || b->num_high < 1)
+    return fail(ASP_ERR_PARAM, "ExportHbState: bad argument");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  float tail[2 * kCarry];
+  HIP_TRY(hipMemcpy(tail, b->hb_tail + (size_t)stream * 2 * kCarry, sizeof tail, hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof *out);
+  for (int k = 0; k < 2; ++k) memcpy(out->dataBufHB[k] + kBlockL, tail + k * kCarry, kCarry * sizeof(float));
+  return ASP_OK;
+}
+
+int AspNsBatch_ImportHbState(AspNsBatch* b, int stream, const AspNsHbState* in) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!in || stream < 0 || stream >= b->S || b->num_high < 1)
+    return fail(ASP_ERR_PARAM, "ImportHbState: bad argument");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  float tail[2 * kCarry];
+  for (int k = 0; k < 2; ++k) memcpy(tail + k * kCarry, in->dataBufHB[k] + kBlockL, kCarry * sizeof(float));
+  HIP_TRY(hipMemcpy(b->hb_tail + (size_t)stream * 2 * kCarry, tail, sizeof tail, hipMemcpyHostToDevice));
+  return ASP_OK;
+}
+
 int AspNsBatch_AnalyzeProcessS16(AspNsBatch* b, const int16_t* in, int16_t* out, int num_frames,
                                  int mem) {
   int rc = check(b);
@@ -756,7 +874,8 @@ int AspNsBatch_ImportState(AspNsBatch* b, int stream, const AspNsState* in) {
   int rc = check(b);
   if (rc) return rc;
   if (!in || stream < 0 || stream >= b->S) return fail(ASP_ERR_PARAM, "ImportState: bad argument");
-  if (in->fs != 16000) return fail(ASP_ERR_PARAM, "ImportState: only fs = 16000 is implemented");
+  if (in->fs != 16000 && in->fs != 32000 && in->fs != 48000)
+    return fail(ASP_ERR_PARAM, "ImportState: fs must be 16000, 32000 or 48000");
   for (int i = kCarry; i < kAnal; ++i)
     if (in->syntBuf[i] != 0.f)
       return fail(ASP_ERR_PARAM, "ImportState: syntBuf[96..255] must be zero (between frames)");
@@ -987,9 +1106,20 @@ void WebRtcNs_Process(NsHandle* NS_inst, const float* const* spframe, int num_ba
     fprintf(stderr, "WebRtcNs_Process: handle not initialised\n");
     abort();
   }
-  if (num_bands != 1) {
-    fprintf(stderr, "WebRtcNs_Process: only num_bands = 1 (<= 16 kHz) is implemented\n");
+  if (num_bands != AspNsBatch_num_bands(NS_inst->batch)) {  // the reference trusts the caller here
+    fprintf(stderr, "WebRtcNs_Process: num_bands = %d does not match the rate given to WebRtcNs_Init\n",
+            num_bands);
     abort();
+  }
+  if (num_bands > 1) {
+    float hin[2 * kBlockL], hout[2 * kBlockL];
+    for (int k = 1; k < num_bands; ++k) memcpy(hin + (k - 1) * kBlockL, spframe[k], kBlockL * sizeof(float));
+    if (AspNsBatch_ProcessBands(NS_inst->batch, spframe[0], hin, outframe[0], hout, ASP_MEM_HOST) != ASP_OK) {
+      fprintf(stderr, "WebRtcNs_Process: %s\n", g_err);
+      abort();
+    }
+    for (int k = 1; k < num_bands; ++k) memcpy(outframe[k], hout + (k - 1) * kBlockL, kBlockL * sizeof(float));
+    return;
   }
   if (AspNsBatch_Process(NS_inst->batch, spframe[0], outframe[0], ASP_MEM_HOST) != ASP_OK) {
     fprintf(stderr, "WebRtcNs_Process: %s\n", g_err);

@@ -48,6 +48,11 @@ def load_library():
         "AspNsBatch_Process": [vp, vp, vp, ip],
         "AspNsBatch_AnalyzeProcess": [vp, vp, vp, ip, ip],
         "AspNsBatch_AnalyzeProcessS16": [vp, vp, vp, ip, ip],
+        "AspNsBatch_AnalyzeProcessBands": [vp, vp, vp, vp, vp, ip, ip],
+        "AspNsBatch_ProcessBands": [vp, vp, vp, vp, vp, ip],
+        "AspNsBatch_num_bands": [vp],
+        "AspNsBatch_ExportHbState": [vp, ip, vp],
+        "AspNsBatch_ImportHbState": [vp, ip, vp],
         "AspNsBatch_ExportState": [vp, ip, C.POINTER(AspNsState)],
         "AspNsBatch_ImportState": [vp, ip, C.POINTER(AspNsState)],
         "AspNsBatch_prior_speech_probability": [vp, vp],
@@ -166,6 +171,34 @@ class NsBatch:
         _check(self.lib.AspNsBatch_AnalyzeProcess(self.h, _ptr(frames), _ptr(out), F, MEM_HOST),
                "AspNsBatch_AnalyzeProcess")
         return out
+
+    def analyze_process_bands(self, low, high):
+        """low [F][S][160], high [F][nh][S][160] float32 -> (out_low, out_high): the fused step of the
+        low band plus the high-band gain (32 / 48 kHz batches)."""
+        low = np.ascontiguousarray(low, np.float32)
+        high = np.ascontiguousarray(high, np.float32)
+        F = low.shape[0]
+        assert low.shape == (F, self.S, BLOCKL) and high.shape[0] == F and high.shape[2:] == (self.S, BLOCKL)
+        ol, oh = np.empty_like(low), np.empty_like(high)
+        _check(self.lib.AspNsBatch_AnalyzeProcessBands(self.h, _ptr(low), _ptr(high), _ptr(ol), _ptr(oh), F,
+                                                       MEM_HOST), "AspNsBatch_AnalyzeProcessBands")
+        return ol, oh
+
+    def process_bands(self, low, high):
+        """One frame: WebRtcNs_Process with bands after a separate analyze(); low [S][160],
+        high [nh][S][160]."""
+        low = np.ascontiguousarray(low, np.float32)
+        high = np.ascontiguousarray(high, np.float32)
+        ol, oh = np.empty_like(low), np.empty_like(high)
+        _check(self.lib.AspNsBatch_ProcessBands(self.h, _ptr(low), _ptr(high), _ptr(ol), _ptr(oh), MEM_HOST),
+               "AspNsBatch_ProcessBands")
+        return ol, oh
+
+    def export_hb(self, stream):
+        from ._abi import AspNsHbState
+        hb = AspNsHbState()
+        _check(self.lib.AspNsBatch_ExportHbState(self.h, stream, C.byref(hb)), "AspNsBatch_ExportHbState")
+        return np.ctypeslib.as_array(hb.dataBufHB).reshape(2, 256).copy()
 
     def analyze_process_s16(self, pcm):
         """pcm [F][S][160] int16 -> denoised int16 of the same shape (fused step, PCM in/out)."""

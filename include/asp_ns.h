@@ -98,6 +98,13 @@ typedef struct AspNsState {
   int32_t histSpecDiff[ASP_NS_HIST];
 } AspNsState;
 
+/* High-band analysis buffers of one stream (dataBufHB, ns_core.h:112): only used above 16 kHz,
+ * where the band split hands WebRtcNs_Process one or two high bands (ns_core.c:1227-1235,
+ * 1362-1414).  Kept apart from AspNsState so that 16 kHz checkpoints do not carry them. */
+typedef struct AspNsHbState {
+  float dataBufHB[2][ASP_NS_ANAL];
+} AspNsHbState;
+
 typedef struct AspNsBatch AspNsBatch;
 
 /* Where the caller's frame buffers live. */
@@ -132,6 +139,20 @@ int AspNsBatch_Process(AspNsBatch* b, const float* in, float* out, int mem);
  * allowed (the driver aliases them, test_ns_module.cpp:98-99). */
 int AspNsBatch_AnalyzeProcess(AspNsBatch* b, const float* in, float* out,
                               int num_frames, int mem);
+
+/* 32 / 48 kHz (AspNsBatch_Init(b, 32000 | 48000)): the band split (asp_split.h) hands the suppressor
+ * the 0-8 kHz band plus num_bands - 1 high bands; the low band is processed as above, the high bands
+ * get the time-domain gain of ns_core.c:1362-1414.  low [num_frames][num_streams][160],
+ * high [num_frames][num_bands - 1][num_streams][160]; in-place (out == in) allowed.
+ * AnalyzeProcessBands = WebRtcNs_Analyze(low) + WebRtcNs_Process(bands) per frame
+ * (libapm/src/apm_ns.cpp:69-74); ProcessBands = WebRtcNs_Process(bands) after a separate Analyze. */
+int AspNsBatch_num_bands(const AspNsBatch* b);
+int AspNsBatch_AnalyzeProcessBands(AspNsBatch* b, const float* low_in, const float* high_in,
+                                   float* low_out, float* high_out, int num_frames, int mem);
+int AspNsBatch_ProcessBands(AspNsBatch* b, const float* low_in, const float* high_in, float* low_out,
+                            float* high_out, int mem);
+int AspNsBatch_ExportHbState(AspNsBatch* b, int stream, AspNsHbState* out);
+int AspNsBatch_ImportHbState(AspNsBatch* b, int stream, const AspNsHbState* in);
 
 /* The same fused step on int16 PCM frames, [num_frames][num_streams][160] int16: what the
  * WAV drivers move (test_ns_module.cpp:85-106).  int16 -> float-S16 on load is value

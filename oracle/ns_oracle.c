@@ -410,7 +410,7 @@ int asp_ns_oracle_set_policy(AspNsState* s, int mode) { /* ns_core.c:1013-1041 *
 int asp_ns_oracle_init(AspNsState* s, uint32_t fs) { /* ns_core.c:74-214 */
   int i;
   if (s == NULL) return -1;
-  if (fs != 16000) return -1; /* only the 160/256/129 geometry is restated */
+  if (fs != 16000 && fs != 32000 && fs != 48000) return -1; /* only the 160/256/129 geometry is restated */
   ensure_tables();
   memset(s, 0, sizeof *s);
   s->fs = (int32_t)fs;
@@ -853,7 +853,8 @@ static float sat16(float x) { /* WEBRTC_SPL_SAT(32767, x, -32768), ns_core.c:135
   return x > 32767 ? 32767 : (x < -32768 ? -32768 : x);
 }
 
-void asp_ns_oracle_process(AspNsState* s, const float* in, float* out, int mode) {
+/* returns 0 for the zero-energy early exit (ns_core.c:1239-1264), 1 otherwise */
+static int process_low(AspNsState* s, const float* in, float* out, int mode) {
   int i;
   float energy1, energy2, gain, factor, factor1, factor2;
   float fout[BLOCKL], win[ANAL], magn[BINS], theFilter[BINS], re[BINS], im[BINS];
@@ -865,7 +866,7 @@ void asp_ns_oracle_process(AspNsState* s, const float* in, float* out, int mode)
     for (i = 0; i < BLOCKL; i++) fout[i] = s->syntBuf[i];
     slide_and_window(s->syntBuf, NULL, NULL);
     for (i = 0; i < BLOCKL; ++i) out[i] = sat16(fout[i]);
-    return;
+    return 0;
   }
   forward_spectrum(win, re, im, magn); /* :1266 */
   if (s->blockInd < END_STARTUP_SHORT) /* :1268-1272 */
@@ -929,6 +930,53 @@ void asp_ns_oracle_process(AspNsState* s, const float* in, float* out, int mode)
   for (i = 0; i < BLOCKL; i++) fout[i] = s->syntBuf[i];
   slide_and_window(s->syntBuf, NULL, NULL); /* :1355 */
   for (i = 0; i < BLOCKL; ++i) out[i] = sat16(fout[i]);
+  return 1;
+}
+
+void asp_ns_oracle_process(AspNsState* s, const float* in, float* out, int mode) {
+  (void)process_low(s, in, out, mode);
+}
+
+void asp_ns_oracle_process_bands(AspNsState* s, AspNsHbState* hb, const float* in_low,
+                                 const float* in_high, int num_high, float* out_low,
+                                 float* out_high, int mode) {
+  int i, j, live;
+  const int deltaBweHB = BINS / 4, deltaGainHB = BINS / 4; /* :1221-1223 */
+  float avgProbSpeechHB, avgProbSpeechHBTmp, avgFilterGainHB, gainModHB, gainTimeDomainHB;
+  float sumMagnAnalyze, sumMagnProcess;
+  const float decayBweHB = 1.0, gainMapParHB = 1.0; /* :1202-1203 */
+  for (i = 0; i < num_high; ++i) /* UpdateBuffer of the high bands, :1227-1235 */
+    slide_and_window(hb->dataBufHB[i], in_high + (size_t)i * BLOCKL, NULL);
+  live = process_low(s, in_low, out_low, mode);
+  if (!live) { /* :1252-1261 */
+    for (i = 0; i < num_high; ++i)
+      for (j = 0; j < BLOCKL; ++j) out_high[(size_t)i * BLOCKL + j] = sat16(hb->dataBufHB[i][j]);
+    return;
+  }
+  /* :1362-1414 */
+  avgProbSpeechHB = 0.0;
+  for (i = BINS - deltaBweHB - 1; i < BINS - 1; i++) avgProbSpeechHB += s->speechProb[i];
+  avgProbSpeechHB = avgProbSpeechHB / ((float)deltaBweHB);
+  sumMagnAnalyze = 0;
+  sumMagnProcess = 0;
+  for (i = 0; i < BINS; ++i) {
+    sumMagnAnalyze += s->magnPrevAnalyze[i];
+    sumMagnProcess += s->magnPrevProcess[i];
+  }
+  avgProbSpeechHB *= sumMagnProcess / sumMagnAnalyze;
+  avgFilterGainHB = 0.0;
+  for (i = BINS - deltaGainHB - 1; i < BINS - 1; i++) avgFilterGainHB += s->smooth[i];
+  avgFilterGainHB = avgFilterGainHB / ((float)(deltaGainHB));
+  avgProbSpeechHBTmp = 2.f * avgProbSpeechHB - 1.f;
+  gainModHB = 0.5f * (1.f + (float)tanh(gainMapParHB * avgProbSpeechHBTmp));
+  gainTimeDomainHB = 0.5f * gainModHB + 0.5f * avgFilterGainHB;
+  if (avgProbSpeechHB >= 0.5f) gainTimeDomainHB = 0.25f * gainModHB + 0.75f * avgFilterGainHB;
+  gainTimeDomainHB = gainTimeDomainHB * decayBweHB;
+  if (gainTimeDomainHB < s->denoiseBound) gainTimeDomainHB = s->denoiseBound;
+  if (gainTimeDomainHB > 1.f) gainTimeDomainHB = 1.f;
+  for (i = 0; i < num_high; ++i)
+    for (j = 0; j < BLOCKL; j++)
+      out_high[(size_t)i * BLOCKL + j] = sat16(gainTimeDomainHB * hb->dataBufHB[i][j]);
 }
 
 /* ------------------------------------------------------------ batch helper */

@@ -42,6 +42,12 @@ void asp_ns_oracle_process(AspNsState* s, const float* in,    /* ns_core.c:1183-
 
 /* Batch helper: frames [num_frames][num_streams][160]; Analyze then Process on
  * the same frame per stream (test_ns_module.cpp:97-99). */
+/* WebRtcNs_ProcessCore with num_bands = 1 + num_high (ns_core.c:1183-1415): the low band as
+ * asp_ns_oracle_process, plus the time-domain gain of the high band(s) (:1227-1235, 1252-1261,
+ * 1362-1414).  in_high / out_high [num_high][160]. */
+void asp_ns_oracle_process_bands(AspNsState* s, AspNsHbState* hb, const float* in_low,
+                                 const float* in_high, int num_high, float* out_low,
+                                 float* out_high, int mode);
 void asp_ns_oracle_run(AspNsState* states, int num_streams, const float* in,
                        float* out, int num_frames, int reduce_mode);
 /* Same, with `threads` pthreads each owning a contiguous shard of streams. */

@@ -166,3 +166,27 @@ void ref_ns_run(NoiseSuppressionC* inst, int S, const float* in, float* out,
   free(th);
   free(sh);
 }
+
+/* ---- multi-band runs (32 / 48 kHz: one or two high bands next to the low band) ---- */
+/* One stream: frames low [F][160], high [F][num_high][160]; Analyze(low) then
+ * Process(bands, 1 + num_high) per frame, the order of libapm/src/apm_ns.cpp:69-74. */
+void ref_ns_run_bands(NoiseSuppressionC* inst, const float* low, const float* high, int num_high,
+                      float* out_low, float* out_high, int F) {
+  for (int f = 0; f < F; ++f) {
+    float lb[160], hb[2][160], ol[160], oh[2][160];
+    const float* in_b[3] = {lb, hb[0], hb[1]};
+    float* out_b[3] = {ol, oh[0], oh[1]};
+    memcpy(lb, low + (size_t)f * 160, sizeof lb);
+    for (int i = 0; i < num_high; ++i)
+      memcpy(hb[i], high + ((size_t)f * num_high + i) * 160, sizeof hb[i]);
+    WebRtcNs_AnalyzeCore(inst, lb);
+    WebRtcNs_ProcessCore(inst, in_b, 1 + num_high, out_b);
+    memcpy(out_low + (size_t)f * 160, ol, sizeof ol);
+    for (int i = 0; i < num_high; ++i)
+      memcpy(out_high + ((size_t)f * num_high + i) * 160, oh[i], sizeof oh[i]);
+  }
+}
+
+void ref_ns_export_hb(const NoiseSuppressionC* inst, AspNsHbState* out) {
+  memcpy(out->dataBufHB, inst->dataBufHB, sizeof out->dataBufHB);
+}
