@@ -13,8 +13,11 @@
  * planar int16 (FloatToS16 for the float overload) -> float-S16 ->
  * WebRtcNs_Analyze + WebRtcNs_Process -> FloatS16ToS16 -> interleaved.
  *
- * This build covers the 1-band rates the kernels cover: frequency 16000,
- * 160 samples per channel.  8/32/48 kHz make initNsModule return false.
+ * This build covers 16 kHz (one band, 160 samples per channel) and 32 kHz (320 samples per
+ * channel: AudioBuffer::SplitIntoFrequencyBands = the two-band QMF of asp_split.h, the suppressor
+ * with one high band, MergeFrequencyBands; audio_buffer.cc:455-463).  8 and 48 kHz make
+ * initNsModule return false (48 kHz needs the 48 <-> 64 kHz sinc resampler of the three-band
+ * split, splitting_filter.cc:91-170).
  */
 #ifndef ASP_APM_NS_H_
 #define ASP_APM_NS_H_
@@ -23,6 +26,7 @@
 #include <vector>
 
 #include "asp_ns.h"
+#include "asp_split.h"
 
 enum {
   NS_Mode_Mild = 0,
@@ -32,7 +36,7 @@ enum {
 
 class APM_NS {
  public:
-  APM_NS() : m_batch(nullptr), m_frequency(0), m_channels(0), m_ns_mode(0), m_device(0),
+  APM_NS() : m_batch(nullptr), m_qmf(nullptr), m_frequency(0), m_channels(0), m_ns_mode(0), m_device(0),
              init_flag(false) {}
   ~APM_NS() { release(); }
   APM_NS(const APM_NS&) = delete;
@@ -48,14 +52,27 @@ class APM_NS {
     m_channels = input_channels;
     m_ns_mode = ns_mode;
     if (m_channels <= 0) return false;
-    if (frequency != 16000 || input_frames != ASP_NS_BLOCKL) return false;
+    const bool two_bands = frequency == 32000;
+    if (!(frequency == 16000 && input_frames == ASP_NS_BLOCKL) &&
+        !(two_bands && input_frames == 2 * ASP_NS_BLOCKL))
+      return false;
     if (AspNsBatch_Create(&m_batch, m_channels, m_device) != ASP_OK) return false;
+    if (two_bands && AspQmfBatch_Create(&m_qmf, m_channels, m_device) != ASP_OK) {
+      release();
+      return false;
+    }
     if (AspNsBatch_Init(m_batch, frequency) != ASP_OK ||
         AspNsBatch_set_policy(m_batch, ns_mode) != ASP_OK) {
       release();
       return false;
     }
-    m_planar.assign((size_t)m_channels * ASP_NS_BLOCKL, 0);
+    m_planar.assign((size_t)m_channels * input_frames, 0);
+    if (two_bands) {
+      m_low.assign((size_t)m_channels * ASP_NS_BLOCKL, 0);
+      m_high.assign((size_t)m_channels * ASP_NS_BLOCKL, 0);
+      m_lowf.assign((size_t)m_channels * ASP_NS_BLOCKL, 0.f);
+      m_highf.assign((size_t)m_channels * ASP_NS_BLOCKL, 0.f);
+    }
     init_flag = true;
     return true;
   }
@@ -65,13 +82,11 @@ class APM_NS {
     if (!usable(samples_per_channel, input_channels)) return;
     for (int c = 0; c < input_channels; ++c)
       for (int j = 0; j < samples_per_channel; ++j)
-        m_planar[(size_t)c * ASP_NS_BLOCKL + j] = floatToS16(data[(size_t)j * input_channels + c]);
-    if (AspNsBatch_AnalyzeProcessS16(m_batch, m_planar.data(), m_planar.data(), 1,
-                                     ASP_MEM_HOST) != ASP_OK)
-      return;
+        m_planar[(size_t)c * samples_per_channel + j] = floatToS16(data[(size_t)j * input_channels + c]);
+    if (!denoisePlanar()) return;
     for (int c = 0; c < input_channels; ++c)
       for (int j = 0; j < samples_per_channel; ++j)
-        data[(size_t)j * input_channels + c] = s16ToFloat(m_planar[(size_t)c * ASP_NS_BLOCKL + j]);
+        data[(size_t)j * input_channels + c] = s16ToFloat(m_planar[(size_t)c * samples_per_channel + j]);
   }
 
   /* apm_ns.cpp:88-130: int16 PCM, interleaved, processed in place. */
@@ -79,13 +94,11 @@ class APM_NS {
     if (!usable(samples_per_channel, input_channels)) return;
     for (int c = 0; c < input_channels; ++c)
       for (int j = 0; j < samples_per_channel; ++j)
-        m_planar[(size_t)c * ASP_NS_BLOCKL + j] = data[(size_t)j * input_channels + c];
-    if (AspNsBatch_AnalyzeProcessS16(m_batch, m_planar.data(), m_planar.data(), 1,
-                                     ASP_MEM_HOST) != ASP_OK)
-      return;
+        m_planar[(size_t)c * samples_per_channel + j] = data[(size_t)j * input_channels + c];
+    if (!denoisePlanar()) return;
     for (int c = 0; c < input_channels; ++c)
       for (int j = 0; j < samples_per_channel; ++j)
-        data[(size_t)j * input_channels + c] = m_planar[(size_t)c * ASP_NS_BLOCKL + j];
+        data[(size_t)j * input_channels + c] = m_planar[(size_t)c * samples_per_channel + j];
   }
 
  private:
@@ -100,17 +113,50 @@ class APM_NS {
     const float kMinInt16Inverse = 1.f / -32768;
     return v * (v > 0 ? kMaxInt16Inverse : -kMinInt16Inverse);
   }
+  /* common_audio/include/audio_util.h:41-49 */
+  static int16_t floatS16ToS16(float v) {
+    const float kMaxRound = 32767 - 0.5f, kMinRound = -32768 + 0.5f;
+    if (v > 0) return v >= kMaxRound ? (int16_t)32767 : (int16_t)(v + 0.5f);
+    return v <= kMinRound ? (int16_t)-32768 : (int16_t)(v - 0.5f);
+  }
   bool usable(int samples_per_channel, int input_channels) const {
-    return init_flag && input_channels == m_channels && samples_per_channel == ASP_NS_BLOCKL;
+    return init_flag && input_channels == m_channels &&
+           samples_per_channel == (m_qmf ? 2 : 1) * ASP_NS_BLOCKL;
+  }
+  /* m_planar [channels][samples] int16, in place: apm_ns.cpp:66-77 */
+  bool denoisePlanar() {
+    if (!m_qmf)
+      return AspNsBatch_AnalyzeProcessS16(m_batch, m_planar.data(), m_planar.data(), 1, ASP_MEM_HOST) == ASP_OK;
+    const size_t n = (size_t)m_channels * ASP_NS_BLOCKL;
+    if (AspQmfBatch_Analysis(m_qmf, m_planar.data(), ASP_NS_BLOCKL, m_low.data(), m_high.data(),
+                             ASP_MEM_HOST) != ASP_OK)
+      return false;
+    for (size_t i = 0; i < n; ++i) {  // int16 -> float-S16 views of the bands (channel_buffer.cc:43-53)
+      m_lowf[i] = (float)m_low[i];
+      m_highf[i] = (float)m_high[i];
+    }
+    if (AspNsBatch_AnalyzeProcessBands(m_batch, m_lowf.data(), m_highf.data(), m_lowf.data(),
+                                       m_highf.data(), 1, ASP_MEM_HOST) != ASP_OK)
+      return false;
+    for (size_t i = 0; i < n; ++i) {  // back to the int16 bands (channel_buffer.cc:55-61)
+      m_low[i] = floatS16ToS16(m_lowf[i]);
+      m_high[i] = floatS16ToS16(m_highf[i]);
+    }
+    return AspQmfBatch_Synthesis(m_qmf, m_low.data(), m_high.data(), ASP_NS_BLOCKL, m_planar.data(),
+                                 ASP_MEM_HOST) == ASP_OK;
   }
   void release() {
     if (m_batch) AspNsBatch_Free(m_batch);
+    if (m_qmf) AspQmfBatch_Free(m_qmf);
     m_batch = nullptr;
+    m_qmf = nullptr;
     init_flag = false;
   }
 
   AspNsBatch* m_batch;
-  std::vector<int16_t> m_planar;
+  AspQmfBatch* m_qmf;
+  std::vector<int16_t> m_planar, m_low, m_high;
+  std::vector<float> m_lowf, m_highf;
   unsigned int m_frequency;
   int m_channels;
   int m_ns_mode;
