@@ -751,7 +751,9 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
     for (int s = 0; s < b->S; ++s) memcpy(all.data() + (size_t)s * kStateDwords, blk.data(), kStateDwords * sizeof(float));
     AEC_TRY(hipStreamSynchronize(b->stream));
     AEC_TRY(hipMemcpy(b->state, all.data(), state_bytes(b), hipMemcpyHostToDevice));
-    AEC_TRY(hipMemset(b->far_ring, 0, far_bytes(b)));  // WebRtc_InitBuffer zeroes the rings
+    // on the batch's own (non-blocking) stream: a null-stream memset is not ordered with its kernels
+    AEC_TRY(hipMemsetAsync(b->far_ring, 0, far_bytes(b), b->stream));  // WebRtc_InitBuffer zeroes the rings
+    AEC_TRY(hipStreamSynchronize(b->stream));
   }
   rp_init(&b->pre_pos, kPreLen);
   rp_move_read(&b->pre_pos, -kPartLen);  // start overlap, echo_cancellation.c:226

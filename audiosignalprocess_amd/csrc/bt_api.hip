@@ -163,7 +163,8 @@ int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int devic
   const size_t frame_bytes = (size_t)num_streams * b->macro * sizeof(float);
   hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&b->state, (size_t)num_streams * kStateFloats * 4);
-  if (e == hipSuccess) e = hipMemset(b->state, 0, (size_t)num_streams * kStateFloats * 4);
+  if (e == hipSuccess) e = hipMemsetAsync(b->state, 0, (size_t)num_streams * kStateFloats * 4, b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_in, frame_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out, frame_bytes);
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);

@@ -563,7 +563,8 @@ int AspNsBatch_Init(AspNsBatch* b, uint32_t fs) {
     if (!b->hb_live) HIP_TRY(hipMalloc((void**)&b->hb_live, (size_t)b->S * sizeof(int32_t)));
     if (!b->hb_stage)
       HIP_TRY(hipMalloc((void**)&b->hb_stage, (size_t)2 * 2 * b->S * kBlockL * sizeof(float)));
-    HIP_TRY(hipMemset(b->hb_tail, 0, (size_t)b->S * 2 * kCarry * sizeof(float)));  // ns_core.c:110-112
+    // on the batch's own (non-blocking) stream: a null-stream memset is not ordered with its kernels
+    HIP_TRY(hipMemsetAsync(b->hb_tail, 0, (size_t)b->S * 2 * kCarry * sizeof(float), b->stream));  // ns_core.c:110-112
   }
   AspNsState* s0 = (AspNsState*)malloc(sizeof(AspNsState));
   init_state(s0, fs);
@@ -580,7 +581,8 @@ int AspNsBatch_Init(AspNsBatch* b, uint32_t fs) {
     HIP_TRY(hipMemcpy(b->state + (size_t)s * kStreamDwords, blk.data(),
                       (size_t)n * kStreamDwords * 4, hipMemcpyHostToDevice));
   }
-  HIP_TRY(hipMemset(b->hist, 0, (size_t)b->S * kHistDwords * 4));
+  HIP_TRY(hipMemsetAsync(b->hist, 0, (size_t)b->S * kHistDwords * 4, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
   b->inited = true;
   b->paired = true;
   return ASP_OK;

@@ -59,7 +59,8 @@ int AspQmfBatch_Create(AspQmfBatch** out, int num_channels, int device) {
   if (e == hipSuccess) e = hipMalloc((void**)&b->s_in, (size_t)num_channels * 2 * ASP_QMF_MAX_BAND * sizeof(int16_t));
   if (e == hipSuccess) e = hipMalloc((void**)&b->s_a, (size_t)num_channels * ASP_QMF_MAX_BAND * sizeof(int16_t));
   if (e == hipSuccess) e = hipMalloc((void**)&b->s_b, (size_t)num_channels * ASP_QMF_MAX_BAND * sizeof(int16_t));
-  if (e == hipSuccess) e = hipMemset(b->state, 0, (size_t)num_channels * 24 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemsetAsync(b->state, 0, (size_t)num_channels * 24 * sizeof(int32_t), b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (e != hipSuccess) {
     AspQmfBatch_Free(b);
     return qmf_fail(ASP_ERR_HIP, "AspQmfBatch_Create", e);
