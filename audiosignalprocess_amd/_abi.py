@@ -120,6 +120,7 @@ class AspAecState(C.Structure):
         ("divergeState", C.c_int32),
         ("xfBufBlockPos", C.c_int32), ("noiseEstCtr", C.c_int32), ("delayEstCtr", C.c_int32),
         ("seed", C.c_uint32),
+        ("dBufH", C.c_float * 128),
     ]
 
 

@@ -11,7 +11,8 @@
  * the call sequence and the reported delays, so one host copy serves every stream of a
  * batch; the per-stream float state and the four ring buffers live in HBM.
  *
- * Built configuration = what test_aec_module.cpp:60-88 runs: 8 or 16 kHz (one band),
+ * Built configuration = what test_aec_module.cpp:60-88 runs: 8 or 16 kHz (one band), plus 32 kHz
+ * (two bands),
  * 12 partitions, reported-delay mode, no skew compensation, no delay logging, metrics
  * off.  Anything else is refused with the reference's own error codes.
  */
@@ -117,6 +118,7 @@ typedef struct AspAecState {
   int32_t delayIdx, stNearState, echoState, divergeState;
   int32_t xfBufBlockPos, noiseEstCtr, delayEstCtr;
   uint32_t seed;
+  float dBufH[128]; /* first high band (32 kHz), aec_core_internal.h:67 */
 } AspAecState;
 
 /* Integer control plane shared by all streams of a batch (one Aec + the integer part of
@@ -150,6 +152,16 @@ int AspAecBatch_BufferFarend(AspAecBatch* b, const float* farend, int nrOfSample
  * processes, echo_cancellation.c:367-375). */
 int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nrOfSamples,
                         int msInSndCardBuf, int32_t skew, int mem);
+/* 32 kHz (AspAecBatch_Init(b, 32000, ...)): WebRtcAec_Process with num_bands = 2: the 0-8 kHz band
+ * is cancelled as above, the high band is delayed alongside and scaled by the average NLP gain
+ * of the upper half of the low band plus comfort noise (aec_core.c:501-545, 1032-1067).
+ * near_high / out_high [num_streams][nrOfSamples].  (48 kHz: the reference's own InitAec breaks
+ * there -- (short)48000 / 16000 = -1, aec_core.c:1541-1543 -- and is refused.) */
+int AspAecBatch_ProcessBands(AspAecBatch* b, const float* near_low, const float* near_high,
+                             float* out_low, float* out_high, int nrOfSamples, int msInSndCardBuf,
+                             int32_t skew, int mem);
+int AspAecBatch_num_bands(const AspAecBatch* b);
+
 /* num_frames x (BufferFarend + Process) on [num_frames][num_streams][n] buffers: the loop of
  * test_aec_module.cpp:75-88 in one call (amortises launches; device or host memory). */
 int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, float* out,

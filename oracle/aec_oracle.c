@@ -388,6 +388,10 @@ struct AspAecOracle {
   float farw[FAR_SLOTS][2 * PART_LEN1];
   float nearfr[FRBUF_LEN];
   float outfr[FRBUF_LEN];
+  /* 32 kHz: one high band next to the low band (its rings move in lock-step with the low band's) */
+  int num_bands;
+  float nearfrH[FRBUF_LEN];
+  float outfrH[FRBUF_LEN];
 };
 
 static const int kInitCheck = 42;      /* ec:59 */
@@ -427,12 +431,15 @@ static void init_core(AspAecOracle* o, int sampFreq) { /* WebRtcAec_InitAec, cor
   rp_init(&o->far_pos, FAR_SLOTS);
   memset(o->nearfr, 0, sizeof o->nearfr);
   memset(o->outfr, 0, sizeof o->outfr);
+  memset(o->nearfrH, 0, sizeof o->nearfrH);
+  memset(o->outfrH, 0, sizeof o->outfrH);
   memset(o->far, 0, sizeof o->far);
   memset(o->farw, 0, sizeof o->farw);
   o->system_delay = 0;
   o->delay_logging = 0;
   o->nlp_mode = 1;
-  o->mult = sampFreq / 8000; /* one band: core:1553-1557 */
+  o->num_bands = sampFreq > 16000 ? sampFreq / 16000 : 1; /* core:1466-1473 */
+  o->mult = o->num_bands > 1 ? (short)sampFreq / 16000 : (short)sampFreq / 8000; /* core:1541-1545 */
   o->core_knownDelay = 0;
   memset(s, 0, sizeof *s);
   for (int i = 0; i < PART_LEN1; i++) s->dMinPow[i] = 1.0e6f;
@@ -495,7 +502,7 @@ int asp_aec_oracle_init(AspAecOracle* o, int32_t sampFreq, int32_t scSampFreq) {
     o->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
   }
-  if (sampFreq > 16000) { /* multi-band: outside the covered configuration */
+  if (sampFreq > 32000) { /* the reference's own mult is broken at 48 kHz (core:1541-1543) */
     o->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
     return -1;
   }
@@ -510,7 +517,7 @@ int asp_aec_oracle_init(AspAecOracle* o, int32_t sampFreq, int32_t scSampFreq) {
   memset(o->pre, 0, sizeof o->pre);
   rp_move_read(&o->pre_pos, -PART_LEN); /* start overlap, ec:226 */
   o->initFlag = kInitCheck;
-  o->splitSampFreq = sampFreq;
+  o->splitSampFreq = sampFreq == 32000 ? 16000 : sampFreq; /* ec:231-235 */
   o->rate_factor = o->splitSampFreq / 8000;
   o->sum = 0;
   o->counter = 0;
@@ -601,7 +608,8 @@ static void sort_floats(float* v, int n) { /* qsort + CmpFloat, core:140-145,956
   }
 }
 
-static void nonlinear_processing(AspAecOracle* o, float* output, const float* noisePow) { /* core:852-1082 */
+static void nonlinear_processing(AspAecOracle* o, float* output, float* outputH,
+                                 const float* noisePow) { /* core:852-1082 */
   AspAecState* s = &o->st;
   float efw[2][PART_LEN1], xfw[2][PART_LEN1], dfw[2][PART_LEN1];
   float fft[PART_LEN2];
@@ -755,7 +763,9 @@ static void nonlinear_processing(AspAecOracle* o, float* output, const float* no
     efw[1][i] *= -1;
   }
 
-  /* ComfortNoise (one band), core:461-500 */
+  /* ComfortNoise, core:461-545 */
+  float cnH[PART_LEN1][2];
+  memset(cnH, 0, sizeof cnH);
   {
     float rnd[PART_LEN];
     float u[PART_LEN1][2];
@@ -778,6 +788,34 @@ static void nonlinear_processing(AspAecOracle* o, float* output, const float* no
       const float tmp = sqrtf(r > 0 ? r : 0);
       efw[0][i] += tmp * u[i][0];
       efw[1][i] += tmp * u[i][1];
+    }
+    if (o->num_bands > 1) { /* H band comfort noise, core:501-545 */
+      float noiseAvg = 0.0, tmpAvg = 0.0;
+      int num = 0;
+      for (i = PART_LEN1 >> 1; i < PART_LEN1; i++) {
+        num++;
+        noiseAvg += sqrtf(noisePow[i]);
+      }
+      noiseAvg /= (float)num;
+      num = 0;
+      for (i = PART_LEN1 >> 1; i < PART_LEN1; i++) {
+        const float r = 1 - hNl[i] * hNl[i];
+        num++;
+        tmpAvg += sqrtf(r > 0 ? r : 0);
+      }
+      tmpAvg /= (float)num;
+      u[0][0] = 0;
+      u[0][1] = 0;
+      for (i = 1; i < PART_LEN1; i++) {
+        const float tmp = pi2 * rnd[i - 1];
+        u[i][0] = noiseAvg * (float)cos(tmp);
+        u[i][1] = -noiseAvg * (float)sin(tmp);
+      }
+      u[PART_LEN][1] = 0;
+      for (i = 0; i < PART_LEN1; i++) {
+        cnH[i][0] = tmpAvg * u[i][0];
+        cnH[i][1] = tmpAvg * u[i][1];
+      }
     }
   }
 
@@ -802,6 +840,29 @@ static void nonlinear_processing(AspAecOracle* o, float* output, const float* no
     }
   }
 
+  if (o->num_bands > 1) { /* core:1032-1067 */
+    float nlpGainHband = (float)0.0;
+    for (i = PART_LEN / 2; i < PART_LEN1 - 1; i++) nlpGainHband += hNl[i]; /* GetHighbandGain, core:451-459 */
+    nlpGainHband /= (float)(PART_LEN1 - 1 - PART_LEN / 2);
+    fft[0] = cnH[0][0];
+    fft[1] = cnH[PART_LEN][0];
+    for (i = 1; i < PART_LEN; i++) {
+      fft[2 * i] = cnH[i][0];
+      fft[2 * i + 1] = cnH[i][1];
+    }
+    asp_aec_oracle_rdft128(fft, -1);
+    {
+      const float scale = 2.0f / PART_LEN2;
+      for (i = 0; i < PART_LEN; i++) {
+        float dtmp = s->dBufH[i];
+        dtmp = dtmp * nlpGainHband;
+        fft[i] *= scale;
+        dtmp += (float)0.4 * fft[i]; /* cnScaleHband, core:45-46 */
+        outputH[i] = dtmp > 32767 ? 32767 : (dtmp < -32768 ? -32768 : dtmp);
+      }
+    }
+    memcpy(s->dBufH, s->dBufH + PART_LEN, sizeof(float) * PART_LEN); /* core:1075-1077 */
+  }
   /* core:1069-1081 */
   memcpy(s->dBuf, s->dBuf + PART_LEN, sizeof(float) * PART_LEN);
   memcpy(s->eBuf, s->eBuf + PART_LEN, sizeof(float) * PART_LEN);
@@ -820,6 +881,12 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
   const float* noisePow = s->dMinPow;
   int i;
 
+  if (o->num_bands > 1) { /* core:1117-1123: the high band's ring moves with the low band's */
+    RingPos keep = o->near_pos;
+    float nearH[PART_LEN];
+    ring_read(&keep, o->nearfrH, 1, nearH, PART_LEN);
+    memcpy(s->dBufH + PART_LEN, nearH, sizeof nearH);
+  }
   ring_read(&o->near_pos, o->nearfr, 1, nearend, PART_LEN);
   memcpy(s->dBuf + PART_LEN, nearend, sizeof nearend);
 
@@ -947,16 +1014,28 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
     }
   }
 
-  nonlinear_processing(o, output, noisePow);
+  {
+    float outputH[PART_LEN];
+    nonlinear_processing(o, output, outputH, noisePow);
+    if (o->num_bands > 1) { /* core:1280-1282 */
+      RingPos keep = o->out_pos;
+      ring_write(&keep, o->outfrH, 1, outputH, PART_LEN);
+    }
+  }
   ring_write(&o->out_pos, o->outfr, 1, output, PART_LEN); /* core:1276 */
   o->blocks_processed++;
 }
 
 /* ------------------------------------------------------------ frame plumbing */
-static void process_frames(AspAecOracle* o, const float* nearend, int num_samples, int knownDelay,
-                           float* out) { /* WebRtcAec_ProcessFrames, core:1647-1778 */
+static void process_frames(AspAecOracle* o, const float* nearend, const float* nearendH,
+                           int num_samples, int knownDelay, float* out,
+                           float* outH) { /* WebRtcAec_ProcessFrames, core:1647-1778 */
   for (int j = 0; j < num_samples; j += FRAME_LEN) {
     int out_elements;
+    if (o->num_bands > 1) { /* core:1691-1693 */
+      RingPos keep = o->near_pos;
+      ring_write(&keep, o->nearfrH, 1, nearendH + j, FRAME_LEN);
+    }
     ring_write(&o->near_pos, o->nearfr, 1, nearend + j, FRAME_LEN);
     if (o->system_delay < FRAME_LEN) far_move_read(o, -(o->mult + 1));
     {
@@ -968,6 +1047,10 @@ static void process_frames(AspAecOracle* o, const float* nearend, int num_sample
     o->system_delay -= FRAME_LEN;
     out_elements = rp_avail_read(&o->out_pos);
     if (out_elements < FRAME_LEN) rp_move_read(&o->out_pos, out_elements - FRAME_LEN);
+    if (o->num_bands > 1) { /* core:1767-1776 */
+      RingPos keep = o->out_pos;
+      ring_read(&keep, o->outfrH, 1, outH + j, FRAME_LEN);
+    }
     ring_read(&o->out_pos, o->outfr, 1, out + j, FRAME_LEN);
   }
 }
@@ -1031,7 +1114,8 @@ int asp_aec_oracle_buffer_farend(AspAecOracle* o, const float* farend, int nrOfS
   return 0;
 }
 
-static int process_normal(AspAecOracle* o, const float* nearend, float* out, int nrOfSamples,
+static int process_normal(AspAecOracle* o, const float* nearend, const float* nearendH, float* out,
+                          float* outH, int nrOfSamples,
                           int16_t msInSndCardBuf) { /* ProcessNormal, ec:594-742 */
   const int nBlocks10ms = nrOfSamples / (FRAME_LEN * o->rate_factor);
   msInSndCardBuf = msInSndCardBuf > kMaxTrustedDelayMs ? kMaxTrustedDelayMs : msInSndCardBuf;
@@ -1039,6 +1123,7 @@ static int process_normal(AspAecOracle* o, const float* nearend, float* out, int
   o->msInSndCardBuf = msInSndCardBuf;
   if (o->startup_phase) {
     if (nearend != out) memcpy(out, nearend, sizeof(float) * nrOfSamples);
+    if (o->num_bands > 1 && nearendH != outH) memcpy(outH, nearendH, sizeof(float) * nrOfSamples);
     if (o->checkBuffSize) {
       double lim;
       o->checkBufSizeCtr++;
@@ -1076,13 +1161,19 @@ static int process_normal(AspAecOracle* o, const float* nearend, float* out, int
     }
   } else {
     est_buf_delay_normal(o);
-    process_frames(o, nearend, nrOfSamples, o->knownDelay, out);
+    process_frames(o, nearend, nearendH, nrOfSamples, o->knownDelay, out, outH);
   }
   return 0;
 }
 
 int asp_aec_oracle_process(AspAecOracle* o, const float* nearend, float* out, int nrOfSamples,
-                           int msInSndCardBuf, int32_t skew) { /* WebRtcAec_Process, ec:341-408 */
+                           int msInSndCardBuf, int32_t skew) {
+  return asp_aec_oracle_process_bands(o, nearend, NULL, out, NULL, nrOfSamples, msInSndCardBuf, skew);
+}
+
+int asp_aec_oracle_process_bands(AspAecOracle* o, const float* nearend, const float* nearendH,
+                                 float* out, float* outH, int nrOfSamples, int msInSndCardBuf,
+                                 int32_t skew) { /* WebRtcAec_Process, ec:341-408 */
   int retVal = 0;
   (void)skew;
   if (out == NULL) {
@@ -1105,7 +1196,11 @@ int asp_aec_oracle_process(AspAecOracle* o, const float* nearend, float* out, in
     o->lastError = AEC_BAD_PARAMETER_WARNING;
     retVal = -1;
   }
-  if (process_normal(o, nearend, out, nrOfSamples, (int16_t)msInSndCardBuf) != 0) retVal = -1;
+  if (o->num_bands > 1 && (nearendH == NULL || outH == NULL)) {
+    o->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (process_normal(o, nearend, nearendH, out, outH, nrOfSamples, (int16_t)msInSndCardBuf) != 0) retVal = -1;
   return retVal;
 }
 

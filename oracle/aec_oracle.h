@@ -27,6 +27,10 @@ int asp_aec_oracle_set_config(AspAecOracle* o, AecConfig config);
 int asp_aec_oracle_buffer_farend(AspAecOracle* o, const float* farend, int nrOfSamples);
 int asp_aec_oracle_process(AspAecOracle* o, const float* nearend, float* out, int nrOfSamples,
                            int msInSndCardBuf, int32_t skew);
+/* WebRtcAec_Process with two bands (32 kHz): nearendH / outH are the 8-16 kHz band. */
+int asp_aec_oracle_process_bands(AspAecOracle* o, const float* nearend, const float* nearendH,
+                                 float* out, float* outH, int nrOfSamples, int msInSndCardBuf,
+                                 int32_t skew);
 int asp_aec_oracle_echo_status(const AspAecOracle* o);
 int asp_aec_oracle_error_code(const AspAecOracle* o);
 void asp_aec_oracle_export(const AspAecOracle* o, AspAecState* st, AspAecControl* ctl);

@@ -107,6 +107,7 @@ void ref_aec_export(void* h, AspAecState* st, AspAecControl* c) {
   st->noiseEstCtr = k->noiseEstCtr;
   st->delayEstCtr = k->delayEstCtr;
   st->seed = k->seed;
+  memcpy(st->dBufH, k->dBufH[0], sizeof st->dBufH);
   if (c) {
     memset(c, 0, sizeof *c);
     c->startup_phase = a->startup_phase;
@@ -128,4 +129,25 @@ void ref_aec_export(void* h, AspAecState* st, AspAecControl* c) {
     c->near_read = (int32_t)WebRtc_available_read(k->nearFrBuf);
     c->out_read = (int32_t)WebRtc_available_read(k->outFrBuf);
   }
+}
+
+/* two bands (32 kHz): near / out low and high band of one 10 ms frame */
+int ref_aec_frame_bands(void* h, const float* far, const float* near_low, const float* near_high,
+                        float* out_low, float* out_high, int n, int16_t delay_ms) {
+  float nl[160], nh[160], ol[160], oh[160];
+  const float* np[2] = {nl, nh};
+  float* op[2] = {ol, oh};
+  int rc;
+  memcpy(nl, near_low, sizeof(float) * n);
+  memcpy(nh, near_high, sizeof(float) * n);
+  rc = WebRtcAec_BufferFarend(h, far, (int16_t)n);
+  rc |= WebRtcAec_Process(h, np, 2, op, (int16_t)n, delay_ms, 0);
+  memcpy(out_low, ol, sizeof(float) * n);
+  memcpy(out_high, oh, sizeof(float) * n);
+  return rc;
+}
+
+void ref_aec_export_dbufh(void* h, float* out128) {
+  const Aec* a = (const Aec*)h;
+  memcpy(out128, a->aec->dBufH[0], sizeof(float) * 128);
 }

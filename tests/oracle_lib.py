@@ -373,6 +373,21 @@ class RefAec:
     def set_nlp(self, mode):
         return self.lib.ref_aec_set_nlp(self.h, mode)
 
+    def frame_bands(self, far, near_low, near_high, delay_ms=0):
+        far = np.ascontiguousarray(far, np.float32)
+        nl, nh = np.ascontiguousarray(near_low, np.float32), np.ascontiguousarray(near_high, np.float32)
+        ol, oh = np.empty_like(nl), np.empty_like(nh)
+        fn = self.lib.ref_aec_frame_bands
+        fn.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int16]
+        rc = fn(self.h, far, nl, nh, ol, oh, far.size, delay_ms)
+        return ol, oh, rc
+
+    def dbufh(self):
+        out = np.zeros(128, np.float32)
+        self.lib.ref_aec_export_dbufh.argtypes = [C.c_void_p, _f32p]
+        self.lib.ref_aec_export_dbufh(self.h, out)
+        return out
+
     def export(self):
         from audiosignalprocess_amd._abi import AspAecControl, AspAecState
         st, ctl = AspAecState(), AspAecControl()
@@ -456,6 +471,16 @@ class OracleAec:
         rc = self.lib.asp_aec_oracle_buffer_farend(self.h, far, far.size)
         rc |= self.lib.asp_aec_oracle_process(self.h, near, out, near.size, delay_ms, 0)
         return out, rc
+
+    def frame_bands(self, far, near_low, near_high, delay_ms=0):
+        far = np.ascontiguousarray(far, np.float32)
+        nl, nh = np.ascontiguousarray(near_low, np.float32), np.ascontiguousarray(near_high, np.float32)
+        ol, oh = np.empty_like(nl), np.empty_like(nh)
+        fn = self.lib.asp_aec_oracle_process_bands
+        fn.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int32]
+        rc = self.lib.asp_aec_oracle_buffer_farend(self.h, far, far.size)
+        rc |= fn(self.h, nl, nh, ol, oh, nl.size, delay_ms, 0)
+        return ol, oh, rc
 
     def export(self):
         from audiosignalprocess_amd._abi import AspAecControl, AspAecState

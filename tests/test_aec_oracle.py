@@ -223,3 +223,40 @@ def test_host_control_plane_matches_oracle():
         lib.AspAecBatch_Synchronize.argtypes = [C.c_void_p]
         assert lib.AspAecBatch_Synchronize(h) != 0
         assert lib.AspAecBatch_Free(h) == 0
+
+
+def _aec_band_frames(F, seed=5):
+    """Far / near low band as the 16 kHz generator, plus a high band that carries echo-like and
+    independent content (int16-range floats)."""
+    far, near = aec_frames(2, F)
+    rng = np.random.default_rng(seed)
+    high = (0.3 * near[:, 1] + rng.standard_normal((F, 160)).astype(np.float32) * 200).astype(np.float32)
+    high[120, :4] = 40000.0    # saturation of the scaled high band
+    return far[:, 0].copy(), near[:, 0].copy(), high
+
+
+@needs_ref
+def test_oracle_two_bands_equals_reference_live():
+    """32 kHz: the high band (delay line, average NLP gain of the upper half of the low band,
+    H-band comfort noise: aec_core.c:501-545, 1032-1067) bit-equal to the reference, with the low
+    band, the float state and the control plane, frame by frame."""
+    F = 420
+    far, nl, nh = _aec_band_frames(F)
+    ref, ora = oracle_lib.RefAec(32000), oracle_lib.OracleAec(32000)
+    rhs = np.empty_like(nh)
+    for f in range(F):
+        d = 40 if 250 <= f < 330 else 0
+        rl, rh, rc_r = ref.frame_bands(far[f], nl[f], nh[f], d)
+        rhs[f] = rh
+        ol, oh, rc_o = ora.frame_bands(far[f], nl[f], nh[f], d)
+        assert rc_r == rc_o, f
+        assert np.array_equal(_bits(rl), _bits(ol)), f
+        assert np.array_equal(_bits(rh), _bits(oh)), f
+        if f % 60 == 0 or f == F - 1:
+            _compare_states(ref, ora)
+            st, _ = ora.export()
+            # the reference keeps [previous | current] 64-sample halves; the first half is the carried one
+            assert np.array_equal(_bits(ref.dbufh()[:64]), _bits(np.ctypeslib.as_array(st.dBufH)[:64])), f
+    # the high band is attenuated while the far end is loud and the near end silent of speech
+    assert np.abs(rhs[170:240]).mean() < 0.9 * np.abs(nh[170:240]).mean()
+    assert oracle_lib.OracleAec(48000).init_rc == -1
