@@ -23,6 +23,8 @@ def _lib():
             "AspAecBatch_num_streams": [vp],
             "AspAecBatch_BufferFarend": [vp, vp, ip, ip],
             "AspAecBatch_Process": [vp, vp, vp, ip, ip, C.c_int32, ip],
+            "AspAecBatch_ProcessBands": [vp, vp, vp, vp, vp, ip, ip, C.c_int32, ip],
+            "AspAecBatch_num_bands": [vp],
             "AspAecBatch_Run": [vp, vp, vp, vp, ip, ip, ip, ip],
             "AspAecBatch_get_echo_status": [vp, C.POINTER(ip)],
             "AspAecBatch_get_error_code": [vp],
@@ -79,6 +81,19 @@ class AecBatch:
         rc = self.lib.AspAecBatch_Process(self.h, near.ctypes.data, out.ctypes.data, near.shape[-1],
                                           delay_ms, skew, MEM_HOST)
         return out, rc
+
+    def process_bands(self, near_low, near_high, delay_ms=0, skew=0):
+        """32 kHz: near_low / near_high [S][n] -> (out_low, out_high, rc)."""
+        nl, nh = np.ascontiguousarray(near_low, np.float32), np.ascontiguousarray(near_high, np.float32)
+        ol, oh = np.empty_like(nl), np.empty_like(nh)
+        rc = self.lib.AspAecBatch_ProcessBands(self.h, nl.ctypes.data, nh.ctypes.data, ol.ctypes.data,
+                                               oh.ctypes.data, nl.shape[-1], delay_ms, skew, MEM_HOST)
+        return ol, oh, rc
+
+    def frame_bands(self, far, near_low, near_high, delay_ms=0):
+        rc = self.buffer_farend(far)
+        ol, oh, rc2 = self.process_bands(near_low, near_high, delay_ms)
+        return ol, oh, rc | rc2
 
     def frame(self, far, near, delay_ms=0):
         rc = self.buffer_farend(far)

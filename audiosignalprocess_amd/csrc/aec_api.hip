@@ -25,7 +25,8 @@ hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, 
 hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
-                              hipStream_t s, unsigned long long* stamps = nullptr);
+                              const float* near_high, float* out_high, hipStream_t s,
+                              unsigned long long* stamps = nullptr);
 hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
                               hipStream_t s);
 }  // namespace aspaec
@@ -220,6 +221,11 @@ struct AspAecBatch {
   const float* far_src = nullptr;
   // control-plane-only handle (AspAecBatch_CreateControlOnly): no device, nothing is launched
   bool sim = false;
+  // 32 kHz: one high band (aec_core.c:1032-1067)
+  int num_high = 0;
+  float *stage_near_h = nullptr, *stage_out_h = nullptr;  // [S][160]
+  const float* cur_near_high = nullptr;  // device pointers of the Process call in flight
+  float* cur_out_high = nullptr;
 };
 
 namespace {
@@ -285,6 +291,7 @@ void pack_stream(const AspAecBatch* b, const AspAecState* s, float* blk) {
   memcpy(blk + kOffDBuf, s->dBuf, 64 * sizeof(float));
   memcpy(blk + kOffEBuf, s->eBuf, 64 * sizeof(float));
   memcpy(blk + kOffOutBuf, s->outBuf, 64 * sizeof(float));
+  memcpy(blk + kOffDBufH, s->dBufH, 64 * sizeof(float));
   float* sc = blk + kOffScalars;
   int32_t* sci = reinterpret_cast<int32_t*>(sc);
   sc[S_HNLFBMIN] = s->hNlFbMin;
@@ -350,6 +357,8 @@ void unpack_stream(const AspAecBatch* b, const float* blk, AspAecState* s) {
   memcpy(s->eBuf, blk + kOffEBuf, 64 * sizeof(float));
   memcpy(s->eBuf + 64, blk + kOffEBuf, 64 * sizeof(float));
   memcpy(s->outBuf, blk + kOffOutBuf, 64 * sizeof(float));
+  memcpy(s->dBufH, blk + kOffDBufH, 64 * sizeof(float));
+  memcpy(s->dBufH + 64, blk + kOffDBufH, 64 * sizeof(float));  // the copy left by aec_core.c:1076
   const float* sc = blk + kOffScalars;
   const int32_t* sci = reinterpret_cast<const int32_t*>(sc);
   s->hNlFbMin = sc[S_HNLFBMIN];
@@ -471,6 +480,7 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
   memset(&ops, 0, sizeof ops);
   ops.mult = b->mult;
   ops.nlp_mode = b->nlp_mode;
+  ops.num_high = b->num_high;
   ops.mu = b->normal_mu;
   ops.error_threshold = b->normal_error_threshold;
   for (int j = 0; j < n; j += kFrameLen) {
@@ -511,7 +521,7 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
   }
   if (!b->sim)
     AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
-                               b->stream, b->debug_stamps));
+                               b->cur_near_high, b->cur_out_high, b->stream, b->debug_stamps));
   return 0;
 }
 
@@ -529,6 +539,9 @@ int process_normal_device(AspAecBatch* b, const float* near_dev, float* out_dev,
     }
     if (near_dev != out_dev && !b->sim)
       AEC_TRY(hipMemcpyAsync(out_dev, near_dev, (size_t)b->S * n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    if (b->num_high > 0 && b->cur_near_high != b->cur_out_high && !b->sim)
+      AEC_TRY(hipMemcpyAsync(b->cur_out_high, b->cur_near_high, (size_t)b->S * n * sizeof(float),
+                             hipMemcpyDeviceToDevice, b->stream));
     if (b->checkBuffSize) {
       b->checkBufSizeCtr++;
       if (b->counter == 0) {
@@ -624,6 +637,8 @@ int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device) {
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_far, (size_t)num_streams * 160 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_near, (size_t)num_streams * 160 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out, (size_t)num_streams * 160 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->stage_near_h, (size_t)num_streams * 160 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out_h, (size_t)num_streams * 160 * sizeof(float));
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev1);
   if (e == hipSuccess) {
@@ -665,6 +680,8 @@ int AspAecBatch_Free(AspAecBatch* b) {
   if (b->stage_far) (void)hipFree(b->stage_far);
   if (b->stage_near) (void)hipFree(b->stage_near);
   if (b->stage_out) (void)hipFree(b->stage_out);
+  if (b->stage_near_h) (void)hipFree(b->stage_near_h);
+  if (b->stage_out_h) (void)hipFree(b->stage_out_h);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream && b->own_stream) (void)hipStreamDestroy(b->stream);
@@ -713,7 +730,7 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
     b->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
   }
-  if (sampFreq > 16000) {  // band-split rates are not built (asp_aec.h)
+  if (sampFreq > 32000) {  // 48 kHz: the reference's own mult breaks there (aec_core.c:1541-1543)
     b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
     return -1;
   }
@@ -736,7 +753,8 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
   rp_init(&b->far_pos, kFarSlots);
   b->system_delay = 0;
   b->nlp_mode = 1;
-  b->mult = sampFreq / 8000;
+  b->num_high = sampFreq == 32000 ? 1 : 0;             // aec_core.c:1466-1473
+  b->mult = sampFreq == 32000 ? 2 : sampFreq / 8000;    // aec_core.c:1541-1545
   b->core_knownDelay = 0;
   b->xf_pos = 0;
   b->xfw_head = 0;
@@ -758,7 +776,7 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
   rp_init(&b->pre_pos, kPreLen);
   rp_move_read(&b->pre_pos, -kPartLen);  // start overlap, echo_cancellation.c:226
   b->initFlag = kInitCheck;
-  b->splitSampFreq = sampFreq;
+  b->splitSampFreq = sampFreq == 32000 ? 16000 : sampFreq;  // echo_cancellation.c:231-235
   b->rate_factor = b->splitSampFreq / 8000;
   b->sum = 0;
   b->counter = 0;
@@ -801,9 +819,34 @@ int AspAecBatch_BufferFarend(AspAecBatch* b, const float* farend, int nrOfSample
   return 0;
 }
 
+static int process_impl(AspAecBatch* b, const float* nearend, const float* near_high, float* out,
+                        float* out_high, int nrOfSamples, int msInSndCardBuf, int mem);
+
 int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nrOfSamples,
                         int msInSndCardBuf, int32_t skew, int mem) {
   (void)skew;
+  if (b && b->num_high > 0) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;  // a 32 kHz batch needs both bands (ProcessBands)
+    return -1;
+  }
+  return process_impl(b, nearend, nullptr, out, nullptr, nrOfSamples, msInSndCardBuf, mem);
+}
+
+int AspAecBatch_ProcessBands(AspAecBatch* b, const float* near_low, const float* near_high,
+                             float* out_low, float* out_high, int nrOfSamples, int msInSndCardBuf,
+                             int32_t skew, int mem) {
+  (void)skew;
+  if (b && (b->num_high < 1 || near_high == nullptr || out_high == nullptr)) {
+    b->lastError = b->num_high < 1 ? AEC_BAD_PARAMETER_ERROR : AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  return process_impl(b, near_low, near_high, out_low, out_high, nrOfSamples, msInSndCardBuf, mem);
+}
+
+int AspAecBatch_num_bands(const AspAecBatch* b) { return b ? 1 + b->num_high : 0; }
+
+static int process_impl(AspAecBatch* b, const float* nearend, const float* near_high, float* out,
+                        float* out_high, int nrOfSamples, int msInSndCardBuf, int mem) {
   if (b && out == nullptr) {
     b->lastError = AEC_NULL_POINTER_ERROR;
     return -1;
@@ -812,6 +855,8 @@ int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nr
   if (chk != 0) return chk;
   if (b->sim) {
     int rc_sim = 0;
+    b->cur_near_high = near_high;
+    b->cur_out_high = out_high;
     const int err_sim = process_device(b, nearend, out, nrOfSamples, msInSndCardBuf, &rc_sim);
     return err_sim != 0 ? err_sim : rc_sim;
   }
@@ -819,16 +864,25 @@ int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nr
   const size_t bytes = (size_t)b->S * nrOfSamples * sizeof(float);
   const float* nd = nearend;
   float* od = out;
+  b->cur_near_high = near_high;
+  b->cur_out_high = out_high;
   if (mem == ASP_MEM_HOST) {
     AEC_TRY(hipMemcpyAsync(b->stage_near, nearend, bytes, hipMemcpyHostToDevice, b->stream));
     nd = b->stage_near;
     od = b->stage_out;
+    if (b->num_high > 0) {
+      AEC_TRY(hipMemcpyAsync(b->stage_near_h, near_high, bytes, hipMemcpyHostToDevice, b->stream));
+      b->cur_near_high = b->stage_near_h;
+      b->cur_out_high = b->stage_out_h;
+    }
   }
   int rc = 0;
   const int err = process_device(b, nd, od, nrOfSamples, msInSndCardBuf, &rc);
   if (err != 0) return err;
   if (mem == ASP_MEM_HOST) {
     AEC_TRY(hipMemcpyAsync(out, od, bytes, hipMemcpyDeviceToHost, b->stream));
+    if (b->num_high > 0)
+      AEC_TRY(hipMemcpyAsync(out_high, b->stage_out_h, bytes, hipMemcpyDeviceToHost, b->stream));
     AEC_TRY(hipStreamSynchronize(b->stream));
   }
   return rc;
@@ -836,6 +890,7 @@ int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nr
 
 int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, float* out,
                     int nrOfSamples, int num_frames, int msInSndCardBuf, int mem) {
+  if (b && b->num_high > 0) return aec_fail(ASP_ERR_STATE, "AspAecBatch_Run: single-band batches only (use ProcessBands)");
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_Run: control-only handle");
   if (b && out == nullptr) {
     b->lastError = AEC_NULL_POINTER_ERROR;
@@ -896,6 +951,7 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
 
 int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nearend, float* out,
                            int nrOfSamples, int frames_in_ring, int steps, float* elapsed_ms) {
+  if (b && b->num_high > 0) return aec_fail(ASP_ERR_STATE, "AspAecBatch_TimedSteps: single-band batches only (use ProcessBands)");
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_TimedSteps: control-only handle");
   if (!b || !farend || !nearend || !out || frames_in_ring <= 0 || steps < 0 || !elapsed_ms)
     return aec_fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
@@ -1104,10 +1160,13 @@ int32_t WebRtcAec_Process(void* aecInst, const float* const* nearend, int num_ba
     b->lastError = AEC_NULL_POINTER_ERROR;
     return -1;
   }
-  if (num_bands != 1) {  // the reference asserts aec->num_bands == num_bands (aec_core.c:1677)
+  if (num_bands != 1 + b->num_high) {  // the reference asserts aec->num_bands == num_bands (aec_core.c:1683)
     b->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
   }
+  if (num_bands == 2)
+    return AspAecBatch_ProcessBands(b, nearend[0], nearend[1], out[0], out[1], nrOfSamples, msInSndCardBuf,
+                                    skew, ASP_MEM_HOST) == 0 ? 0 : -1;
   return AspAecBatch_Process(b, nearend[0], out[0], nrOfSamples, msInSndCardBuf, skew, ASP_MEM_HOST) == 0 ? 0 : -1;
 }
 

@@ -377,7 +377,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
                                               const SharedTables& T, const BlockOp& op, int mult,
                                               int nlp_mode, float mu, float error_threshold,
                                               int lane, const double* __restrict__ exp2_global,
-                                              unsigned long long* stamps) {
+                                              int num_high, unsigned long long* stamps) {
   // diagnostic phase stamps (never enabled by the product entry points)
 #define AEC_STAMP(k) \
   if (stamps != nullptr) stamps[k] = __builtin_amdgcn_s_memtime();
@@ -868,6 +868,11 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       ur = noise * sc2.y;
       ui = -noise * sc2.x;
       if (bin == 64) ui = 0.f;
+      if (num_high > 0) {  // kept for the high band's comfort noise (aec_core.c:501-545)
+        DFR[bin] = noise;
+        YFR[bin] = sc2.y;
+        YFI[bin] = sc2.x;
+      }
     }
     const float r = 1 - h * h;
     const float tmp2 = sqrtf(r > 0 ? r : 0);
@@ -875,6 +880,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     ei += tmp2 * ui;
     EWR[bin] = er;
     EWI[bin] = ei;
+    if (num_high > 0) {
+      HNL[bin] = h;
+      DFI[bin] = tmp2;
+    }
   }
   const uint32_t new_seed = (T.lcg_a[63] * seed + T.lcg_c[63]) & 0x7fffffffu;
   wave_fence();
@@ -897,6 +906,42 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     st[kOffOutBuf + lane] = b * T.hann[64 - lane];
     const float o = a > 32767.f ? 32767.f : (a < -32768.f ? -32768.f : a);
     st[kOffOutFr + ring_idx(op.out_wpos, lane, kFrBufLen)] = o;
+  }
+  if (num_high > 0) {
+    // ---- high band (aec_core.c:1032-1067, 501-545, 451-459): the three averages are summed by
+    // one lane each in the reference's order
+    wave_fence();
+    if (lane < 3) {
+      const float* src = lane == 0 ? HNL : lane == 1 ? DFR : DFI;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 32; j < 65; ++j)
+        if (j < 64 || lane > 0) acc += src[j];
+      misc[8 + lane] = acc;
+    }
+    wave_fence();
+    const float nlpGainHband = misc[8] / 32.0f;
+    const float noiseAvg = misc[9] / 33.0f, tmpAvg = misc[10] / 33.0f;
+    {
+      // comfortNoiseHband packed for the inverse transform: fft[0] = cn[0].re (0), fft[1] = cn[64].re
+      float2 v;
+      v.x = lane == 0 ? 0.f : tmpAvg * (noiseAvg * YFR[lane]);
+      v.y = lane == 0 ? tmpAvg * (noiseAvg * YFR[64]) : tmpAvg * (-noiseAvg * YFI[lane]);
+      tile(wl, 0)[lane] = v;
+    }
+    wave_fence();
+    rdft_inv_quad(wl, lane, T);
+    {
+      const float cn = reinterpret_cast<const float*>(tile(wl, 0))[lane] * scale;
+      const float nearH = st[kOffNearFrH + ring_idx(op.near_rpos, lane, kFrBufLen)];
+      float dtmp = st[kOffDBufH + lane];
+      dtmp = dtmp * nlpGainHband;
+      dtmp += 0.4f * cn;  // cnScaleHband, aec_core.c:45-46
+      st[kOffOutFrH + ring_idx(op.out_wpos, lane, kFrBufLen)] =
+          dtmp > 32767.f ? 32767.f : (dtmp < -32768.f ? -32768.f : dtmp);
+      st[kOffDBufH + lane] = nearH;
+    }
+    wave_fence();
   }
   AEC_STAMP(14)
   // ---- carry the block (aec_core.c:1069-1081; the xfwBuf shift is the host's circular head)
@@ -935,6 +980,7 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
                                                           float* __restrict__ out, int num_streams,
                                                           int nrOfSamples, ProcOps ops,
                                                           const float* __restrict__ farend, FarOps fops,
+                                                          const float* near_high, float* out_high,
                                                           unsigned long long* __restrict__ stamps) {
   __shared__ SharedTables T;
   __shared__ float lds[4 * kLdsWave];
@@ -960,6 +1006,13 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
     const float n1 = lane < 16 ? nin[80 * s + 64 + lane] : 0.f;
     st[kOffNearFr + ring_idx(sf.near_wpos, lane, kFrBufLen)] = n0;
     if (lane < 16) st[kOffNearFr + ring_idx(sf.near_wpos, 64 + lane, kFrBufLen)] = n1;
+    if (ops.num_high > 0) {  // the high band's frame into its ring (aec_core.c:1691-1693)
+      const float* hin = near_high + (size_t)stream * nrOfSamples;
+      const float h0 = hin[80 * s + lane];
+      const float h1 = lane < 16 ? hin[80 * s + 64 + lane] : 0.f;
+      st[kOffNearFrH + ring_idx(sf.near_wpos, lane, kFrBufLen)] = h0;
+      if (lane < 16) st[kOffNearFrH + ring_idx(sf.near_wpos, 64 + lane, kFrBufLen)] = h1;
+    }
     // ring traffic between lanes of this wave goes through L2: order it at workgroup scope (same CU and L1; agent scope would flush the XCD L2)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -968,6 +1021,7 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
       const BlockOp& op = sf.blk[k];
       const float* slot = far_ring + ((size_t)op.far_slot * num_streams + stream) * kFarSlotDwords;
       process_block(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
+                    ops.num_high,
                     (stamps != nullptr && stream == 0 && s == 0 && k == 0 && lane == 0) ? stamps : nullptr);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -975,6 +1029,11 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
     }
     o[80 * s + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, lane, kFrBufLen)];
     if (lane < 16) o[80 * s + 64 + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, 64 + lane, kFrBufLen)];
+    if (ops.num_high > 0) {  // aec_core.c:1774-1776
+      float* ho = out_high + (size_t)stream * nrOfSamples;
+      ho[80 * s + lane] = st[kOffOutFrH + ring_idx(sf.out_rpos, lane, kFrBufLen)];
+      if (lane < 16) ho[80 * s + 64 + lane] = st[kOffOutFrH + ring_idx(sf.out_rpos, 64 + lane, kFrBufLen)];
+    }
   }
 }
 
@@ -1028,9 +1087,11 @@ hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, 
 hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
-                              hipStream_t s, unsigned long long* stamps) {
+                              const float* near_high, float* out_high, hipStream_t s,
+                              unsigned long long* stamps) {
   hipLaunchKernelGGL(aec_process_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
-                     far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, stamps);
+                     far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,
+                     out_high, stamps);
   return hipGetLastError();
 }
 

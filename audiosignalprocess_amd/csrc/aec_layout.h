@@ -45,7 +45,11 @@ constexpr int kOffScalars = kOffOutBuf + 64;
 constexpr int kOffPre = kOffScalars + 32;
 constexpr int kOffNearFr = kOffPre + kPreLen;
 constexpr int kOffOutFr = kOffNearFr + kFrBufLen;
-constexpr int kStateDwords = ((kOffOutFr + kFrBufLen + 63) / 64) * 64;
+// 32 kHz: the high band's delay line and its two rings (positions shared with the low band's)
+constexpr int kOffDBufH = kOffOutFr + kFrBufLen;   // dBufH[0][0..63]
+constexpr int kOffNearFrH = kOffDBufH + 64;
+constexpr int kOffOutFrH = kOffNearFrH + kFrBufLen;
+constexpr int kStateDwords = ((kOffOutFrH + kFrBufLen + 63) / 64) * 64;
 
 enum Scalar {
   S_HNLFBMIN = 0, S_HNLFBLOCALMIN, S_HNLXDAVGMIN, S_OVERDRIVE, S_OVERDRIVESM,  // float
@@ -97,6 +101,7 @@ struct ProcOps {
   int32_t nsub;      // 1 or 2 sub-frames of 80 samples
   int32_t mult;      // sampFreq / 8000
   int32_t nlp_mode;
+  int32_t num_high;  // 0, or 1 at 32 kHz
   float mu, error_threshold;
   SubFrame sub[2];
 };

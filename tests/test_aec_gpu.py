@@ -284,3 +284,42 @@ def test_device_pow_sincos_lean_equal_plain_forms(aec):
         assert bad == 0, (name, bad, [hex(b) for b in ex[:8]])
         bad, ex = _sweep_all_floats(lib, fa, fb, 0x80000000, 0xc1000000)   # negatives: fallback
         assert bad == 0, (name, bad, [hex(b) for b in ex[:8]])
+
+
+def test_two_bands_32khz_vs_oracle(aec):
+    """32 kHz: low band as at 16 kHz; the high band (delay line x average NLP gain + H-band comfort
+    noise) against the oracle: the device evaluates this branch's (float)cos / (float)sin exactly as
+    the reference does, so the high band inherits only the low band's powf last places.  Linear
+    state bit-exact, both outputs within 1e-5 per-stream rel-L2, layer-1 entry point included."""
+    from tests.test_aec_oracle import _aec_band_frames
+
+    S, F = 5, 420
+    far1, nl1, nh1 = _aec_band_frames(F)
+    rng = np.random.default_rng(9)
+    scale = (0.5 + rng.random(S)).astype(np.float32)
+    far = far1[:, None, :] * scale[None, :, None]
+    nl = nl1[:, None, :] * scale[None, :, None]
+    nh = nh1[:, None, :] * scale[None, :, None]
+    g = aec.AecBatch(S, 32000)
+    oras = [OracleAec(32000) for _ in range(S)]
+    gl, gh = np.empty_like(nl), np.empty_like(nh)
+    ol, oh = np.empty_like(nl), np.empty_like(nh)
+    for f in range(F):
+        d = 40 if 250 <= f < 330 else 0
+        gl[f], gh[f], rc_g = g.frame_bands(far[f], nl[f], nh[f], d)
+        for s in range(S):
+            ol[f, s], oh[f, s], rc_o = oras[s].frame_bands(far[f, s], nl[f, s], nh[f, s], d)
+        assert rc_g == rc_o, f
+    for s in range(S):
+        st_o, _ = oras[s].export()
+        rep = _state_report(g.export_state(s), st_o)
+        bad = [k for k in LINEAR_FIELDS + ["dBufH"] if not rep[k][0]]
+        assert bad == [], (s, {k: rep[k] for k in bad})
+        assert _rel_l2(gl[:, s], ol[:, s]) <= 1e-5 and _rel_l2(gh[:, s], oh[:, s]) <= 1e-5, s
+    print("AEC 32 kHz: low %.4f / high %.4f of output samples bit-equal to the oracle"
+          % ((_bits(gl) == _bits(ol)).mean(), (_bits(gh) == _bits(oh)).mean()))
+    assert np.abs(gh[170:240]).mean() < 0.9 * np.abs(nh[170:240]).mean()
+    # a 32 kHz batch refuses the one-band entry point, 48 kHz is refused at Init
+    out, rc = g.process(nl[0])
+    assert rc == -1 and g.error_code() == 12004
+    assert aec.AecBatch(2, 48000).init_rc == -1
