@@ -579,3 +579,67 @@ def RefQmf():
     if _spl_ref is None:
         _spl_ref = C.CDLL(SPL_REF_SO)
     return _Qmf(*_qmf_sig(_spl_ref.WebRtcSpl_AnalysisQMF, _spl_ref.WebRtcSpl_SynthesisQMF))
+
+
+# ------------------------------------------------------------------------------------------
+# push sinc resampler (oracle/sinc_oracle.c; reference: oracle/_ref/libsinc_ref.so)
+SINC_REF_SO = os.path.join(ORACLE_DIR, "_ref", "libsinc_ref.so")
+_sinc_ref = None
+
+
+def have_sinc_ref():
+    return os.path.exists(SINC_REF_SO)
+
+
+class OracleSinc:
+    def __init__(self, src, dst):
+        lib = oracle_lib()
+        lib.asp_sinc_oracle_create.restype = C.c_void_p
+        lib.asp_sinc_oracle_create.argtypes = [C.c_int, C.c_int]
+        lib.asp_sinc_oracle_free.argtypes = [C.c_void_p]
+        lib.asp_sinc_oracle_resample_i16.argtypes = [C.c_void_p, _i16p, _i16p]
+        lib.asp_sinc_oracle_resample_i16.restype = None
+        lib.asp_sinc_oracle_kernel.restype = C.POINTER(C.c_float)
+        lib.asp_sinc_oracle_kernel.argtypes = [C.c_void_p]
+        self.lib, self.src, self.dst = lib, src, dst
+        self.h = lib.asp_sinc_oracle_create(src, dst)
+
+    def resample(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        assert x.size == self.src
+        out = np.empty(self.dst, np.int16)
+        self.lib.asp_sinc_oracle_resample_i16(self.h, x, out)
+        return out
+
+    def kernel(self):
+        return np.ctypeslib.as_array(self.lib.asp_sinc_oracle_kernel(self.h), shape=(33 * 32,)).copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.asp_sinc_oracle_free(self.h)
+            self.h = None
+
+
+class RefSinc:
+    def __init__(self, src, dst):
+        global _sinc_ref
+        if _sinc_ref is None:
+            lib = C.CDLL(SINC_REF_SO)
+            lib.ref_sinc_create.restype = C.c_void_p
+            lib.ref_sinc_create.argtypes = [C.c_int, C.c_int]
+            lib.ref_sinc_free.argtypes = [C.c_void_p]
+            lib.ref_sinc_resample_i16.argtypes = [C.c_void_p, _i16p, C.c_int, _i16p, C.c_int]
+            _sinc_ref = lib
+        self.lib, self.src, self.dst = _sinc_ref, src, dst
+        self.h = self.lib.ref_sinc_create(src, dst)
+
+    def resample(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        out = np.empty(self.dst, np.int16)
+        assert self.lib.ref_sinc_resample_i16(self.h, x, self.src, out, self.dst) == self.dst
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_sinc_free(self.h)
+            self.h = None
