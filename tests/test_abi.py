@@ -18,7 +18,7 @@ def declared_functions(header):
     return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", txt)))
 
 
-@pytest.mark.parametrize("header", ["asp_ns.h", "wav_io.h", "asp_bt.h", "asp_aec.h", "asp_split.h"])
+@pytest.mark.parametrize("header", ["asp_ns.h", "wav_io.h", "asp_bt.h", "asp_aec.h", "asp_split.h", "asp_resample.h"])
 def test_every_declared_symbol_is_exported(built_lib, header):
     lib = C.CDLL(built_lib)
     names = declared_functions(header)
