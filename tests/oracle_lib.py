@@ -643,3 +643,76 @@ class RefSinc:
         if getattr(self, "h", None):
             self.lib.ref_sinc_free(self.h)
             self.h = None
+
+
+# ------------------------------------------------------------------------------------------
+# SplittingFilter (oracle/split_oracle.c; reference: oracle/_ref/libsplit_ref.so)
+SPLIT_REF_SO = os.path.join(ORACLE_DIR, "_ref", "libsplit_ref.so")
+_split_ref = None
+
+
+def have_split_ref():
+    return os.path.exists(SPLIT_REF_SO)
+
+
+class OracleSplit:
+    def __init__(self, num_bands):
+        lib = oracle_lib()
+        lib.asp_split_oracle_create.restype = C.c_void_p
+        lib.asp_split_oracle_create.argtypes = [C.c_int]
+        lib.asp_split_oracle_free.argtypes = [C.c_void_p]
+        lib.asp_split_oracle_analysis.argtypes = [C.c_void_p, _i16p, _i16p]
+        lib.asp_split_oracle_synthesis.argtypes = [C.c_void_p, _i16p, _i16p]
+        lib.asp_split_oracle_analysis.restype = None
+        lib.asp_split_oracle_synthesis.restype = None
+        self.lib, self.nb = lib, num_bands
+        self.h = lib.asp_split_oracle_create(num_bands)
+
+    def analysis(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        bands = np.empty((self.nb, 160), np.int16)
+        self.lib.asp_split_oracle_analysis(self.h, x, bands)
+        return bands
+
+    def synthesis(self, bands):
+        bands = np.ascontiguousarray(bands, np.int16)
+        out = np.empty(160 * self.nb, np.int16)
+        self.lib.asp_split_oracle_synthesis(self.h, bands, out)
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.asp_split_oracle_free(self.h)
+            self.h = None
+
+
+class RefSplit:
+    def __init__(self, num_bands):
+        global _split_ref
+        if _split_ref is None:
+            lib = C.CDLL(SPLIT_REF_SO)
+            lib.ref_split_create.restype = C.c_void_p
+            lib.ref_split_create.argtypes = [C.c_int, C.c_int]
+            lib.ref_split_free.argtypes = [C.c_void_p]
+            lib.ref_split_analysis.argtypes = [C.c_void_p, _i16p, C.c_int, C.c_int, _i16p]
+            lib.ref_split_synthesis.argtypes = [C.c_void_p, _i16p, C.c_int, C.c_int, _i16p]
+            _split_ref = lib
+        self.lib, self.nb = _split_ref, num_bands
+        self.h = self.lib.ref_split_create(160 * num_bands, num_bands)
+
+    def analysis(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        bands = np.empty((self.nb, 160), np.int16)
+        self.lib.ref_split_analysis(self.h, x, 160 * self.nb, self.nb, bands)
+        return bands
+
+    def synthesis(self, bands):
+        bands = np.ascontiguousarray(bands, np.int16)
+        out = np.empty(160 * self.nb, np.int16)
+        self.lib.ref_split_synthesis(self.h, bands, 160 * self.nb, self.nb, out)
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_split_free(self.h)
+            self.h = None
