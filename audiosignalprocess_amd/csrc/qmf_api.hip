@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "asp_ns.h"
+#include "asp_resample.h"
 #include "asp_split.h"
 
 namespace aspqmf {
@@ -204,6 +205,139 @@ void WebRtcSpl_SynthesisQMF(const int16_t* low_band, const int16_t* high_band, i
     abort();
   memcpy(filter_state1, st.synthesis_state1, sizeof st.synthesis_state1);
   memcpy(filter_state2, st.synthesis_state2, sizeof st.synthesis_state2);
+}
+
+// ------------------------------------------------------------------ SplittingFilter
+}  // extern "C"
+
+struct AspSplitBatch {
+  int C = 0, nb = 0, device = 0;
+  hipStream_t stream = nullptr;
+  int32_t* st = nullptr;       // [3][C][24]: two_bands_states_, band1_states_, band2_states_
+  int16_t *buf640 = nullptr, *low320 = nullptr, *high320 = nullptr, *zeros160 = nullptr;
+  int16_t *s_in = nullptr, *s_bands = nullptr;   // staging for host-memory callers
+  AspSincBatch *up = nullptr, *down = nullptr;   // analysis / synthesis resamplers (48 <-> 64 kHz)
+};
+
+extern "C" {
+
+int AspSplitBatch_Create(AspSplitBatch** out, int num_channels, int num_bands, int device) {
+  if (!out || num_channels <= 0 || (num_bands != 2 && num_bands != 3))
+    return qmf_fail(ASP_ERR_PARAM, "AspSplitBatch_Create: bad argument");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return qmf_fail(ASP_ERR_NO_DEVICE, "no HIP device: the band split has no CPU fallback");
+  if (device < 0 || device >= count) return qmf_fail(ASP_ERR_PARAM, "device ordinal out of range");
+  QMF_TRY(hipSetDevice(device));
+  AspSplitBatch* b = new AspSplitBatch();
+  b->C = num_channels;
+  b->nb = num_bands;
+  b->device = device;
+  const size_t c = (size_t)num_channels;
+  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->st, 3 * c * 24 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->buf640, c * 640 * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->low320, c * 320 * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->high320, c * 320 * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->zeros160, c * 160 * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->s_in, c * 160 * num_bands * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->s_bands, c * 160 * num_bands * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMemsetAsync(b->st, 0, 3 * c * 24 * sizeof(int32_t), b->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(b->zeros160, 0, c * 160 * sizeof(int16_t), b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  int rc = e == hipSuccess ? ASP_OK : qmf_fail(ASP_ERR_HIP, "AspSplitBatch_Create", e);
+  if (rc == ASP_OK && num_bands == 3) {
+    rc = AspSincBatch_Create(&b->up, num_channels, 480, 640, device);
+    if (rc == ASP_OK) rc = AspSincBatch_Create(&b->down, num_channels, 640, 480, device);
+    if (rc == ASP_OK) rc = AspSincBatch_SetStream(b->up, b->stream);
+    if (rc == ASP_OK) rc = AspSincBatch_SetStream(b->down, b->stream);
+  }
+  if (rc != ASP_OK) {
+    AspSplitBatch_Free(b);
+    return rc;
+  }
+  *out = b;
+  return ASP_OK;
+}
+
+int AspSplitBatch_Free(AspSplitBatch* b) {
+  if (!b) return -1;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->up) AspSincBatch_Free(b->up);
+  if (b->down) AspSincBatch_Free(b->down);
+  if (b->st) (void)hipFree(b->st);
+  if (b->buf640) (void)hipFree(b->buf640);
+  if (b->low320) (void)hipFree(b->low320);
+  if (b->high320) (void)hipFree(b->high320);
+  if (b->zeros160) (void)hipFree(b->zeros160);
+  if (b->s_in) (void)hipFree(b->s_in);
+  if (b->s_bands) (void)hipFree(b->s_bands);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return 0;
+}
+
+int AspSplitBatch_Analysis(AspSplitBatch* b, const int16_t* in, int16_t* bands, int mem) {
+  if (!b || !in || !bands) return qmf_fail(ASP_ERR_PARAM, "AspSplitBatch_Analysis: bad argument");
+  QMF_TRY(hipSetDevice(b->device));
+  const size_t c = (size_t)b->C, total = c * 160 * b->nb * sizeof(int16_t);
+  const int16_t* din = in;
+  int16_t* dbands = bands;
+  if (mem == ASP_MEM_HOST) {
+    QMF_TRY(hipMemcpyAsync(b->s_in, in, total, hipMemcpyHostToDevice, b->stream));
+    din = b->s_in;
+    dbands = b->s_bands;
+  } else if (mem != ASP_MEM_DEVICE) {
+    return qmf_fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  }
+  int32_t *stA = b->st, *stB = b->st + c * 24, *stC = b->st + 2 * c * 24;
+  if (b->nb == 2) {  // TwoBandsAnalysis, splitting_filter.cc:63-75
+    QMF_TRY(aspqmf::launch_analysis(stA, din, dbands, dbands + c * 160, b->C, 160, b->stream));
+  } else {  // ThreeBandsAnalysis, splitting_filter.cc:96-131
+    const int rc = AspSincBatch_Resample(b->up, din, b->buf640, ASP_MEM_DEVICE);
+    if (rc != ASP_OK) return rc;
+    QMF_TRY(aspqmf::launch_analysis(stA, b->buf640, b->low320, b->high320, b->C, 320, b->stream));
+    QMF_TRY(aspqmf::launch_analysis(stB, b->low320, dbands, dbands + c * 160, b->C, 160, b->stream));
+    // the lower output of the upper half is the empty 24-32 kHz band: written to scratch, dropped
+    QMF_TRY(aspqmf::launch_analysis(stC, b->high320, b->low320, dbands + 2 * c * 160, b->C, 160, b->stream));
+  }
+  if (mem == ASP_MEM_HOST) {
+    QMF_TRY(hipMemcpyAsync(bands, dbands, total, hipMemcpyDeviceToHost, b->stream));
+    QMF_TRY(hipStreamSynchronize(b->stream));
+  }
+  return ASP_OK;
+}
+
+int AspSplitBatch_Synthesis(AspSplitBatch* b, const int16_t* bands, int16_t* out, int mem) {
+  if (!b || !out || !bands) return qmf_fail(ASP_ERR_PARAM, "AspSplitBatch_Synthesis: bad argument");
+  QMF_TRY(hipSetDevice(b->device));
+  const size_t c = (size_t)b->C, total = c * 160 * b->nb * sizeof(int16_t);
+  const int16_t* dbands = bands;
+  int16_t* dout = out;
+  if (mem == ASP_MEM_HOST) {
+    QMF_TRY(hipMemcpyAsync(b->s_bands, bands, total, hipMemcpyHostToDevice, b->stream));
+    dbands = b->s_bands;
+    dout = b->s_in;
+  } else if (mem != ASP_MEM_DEVICE) {
+    return qmf_fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  }
+  int32_t *stA = b->st, *stB = b->st + c * 24, *stC = b->st + 2 * c * 24;
+  if (b->nb == 2) {  // TwoBandsSynthesis, splitting_filter.cc:77-88
+    QMF_TRY(aspqmf::launch_synthesis(stA, dbands, dbands + c * 160, dout, b->C, 160, b->stream));
+  } else {  // ThreeBandsSynthesis, splitting_filter.cc:137-169 (the uppermost band is empty)
+    QMF_TRY(aspqmf::launch_synthesis(stB, dbands, dbands + c * 160, b->low320, b->C, 160, b->stream));
+    QMF_TRY(aspqmf::launch_synthesis(stC, b->zeros160, dbands + 2 * c * 160, b->high320, b->C, 160, b->stream));
+    QMF_TRY(aspqmf::launch_synthesis(stA, b->low320, b->high320, b->buf640, b->C, 320, b->stream));
+    const int rc = AspSincBatch_Resample(b->down, b->buf640, dout, ASP_MEM_DEVICE);
+    if (rc != ASP_OK) return rc;
+  }
+  if (mem == ASP_MEM_HOST) {
+    QMF_TRY(hipMemcpyAsync(out, dout, total, hipMemcpyDeviceToHost, b->stream));
+    QMF_TRY(hipStreamSynchronize(b->stream));
+  }
+  return ASP_OK;
 }
 
 }  // extern "C"

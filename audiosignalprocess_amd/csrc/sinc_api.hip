@@ -40,7 +40,7 @@ int sinc_fail(int code, const char* what, hipError_t e = hipSuccess) {
 
 struct AspSincBatch {
   int C = 0, device = 0, src = 0, dst = 0, buf_len = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, own_stream = nullptr;
   float* state = nullptr;   // [C][buf_len]
   float* ktable = nullptr;  // [33 * 32]
   OutDesc* desc = nullptr;  // [max outputs per call]
@@ -164,7 +164,8 @@ int AspSincBatch_Create(AspSincBatch** out, int num_channels, int source_frames,
   update_regions(b, false);
   init_kernel(b);
   const size_t max_out = (size_t)destination_frames * 2 + 64;
-  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  hipError_t e = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
+  b->stream = b->own_stream;
   if (e == hipSuccess) e = hipMalloc((void**)&b->state, (size_t)num_channels * b->buf_len * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->ktable, b->kernel_host.size() * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->desc, max_out * sizeof(OutDesc));
@@ -192,9 +193,17 @@ int AspSincBatch_Free(AspSincBatch* b) {
   if (b->desc) (void)hipFree(b->desc);
   if (b->s_in) (void)hipFree(b->s_in);
   if (b->s_out) (void)hipFree(b->s_out);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
   return 0;
+}
+
+int AspSincBatch_SetStream(AspSincBatch* b, void* hip_stream) {
+  if (!b) return sinc_fail(ASP_ERR_PARAM, "null batch handle");
+  SINC_TRY(hipSetDevice(b->device));
+  SINC_TRY(hipStreamSynchronize(b->stream));
+  b->stream = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+  return ASP_OK;
 }
 
 int AspSincBatch_num_channels(const AspSincBatch* b) { return b ? b->C : 0; }

@@ -90,3 +90,44 @@ class QmfBatch:
 
     def __del__(self):
         self.close()
+
+
+class SplitBatch:
+    """N independent channels of the reference's SplittingFilter (2 bands at 32 kHz, 3 at 48 kHz)."""
+
+    def __init__(self, num_channels, num_bands, device=0):
+        self.lib = _lib()
+        vp, ip = C.c_void_p, C.c_int
+        self.lib.AspSplitBatch_Create.argtypes = [C.POINTER(vp), ip, ip, ip]
+        self.lib.AspSplitBatch_Free.argtypes = [vp]
+        self.lib.AspSplitBatch_Analysis.argtypes = [vp, vp, vp, ip]
+        self.lib.AspSplitBatch_Synthesis.argtypes = [vp, vp, vp, ip]
+        self.C, self.nb = int(num_channels), int(num_bands)
+        h = C.c_void_p()
+        _check(self.lib.AspSplitBatch_Create(C.byref(h), self.C, self.nb, device), "AspSplitBatch_Create")
+        self.h = h
+
+    def analysis(self, x):
+        """x [C][160 nb] int16 -> bands [nb][C][160]."""
+        x = np.ascontiguousarray(x, np.int16)
+        assert x.shape == (self.C, 160 * self.nb)
+        bands = np.empty((self.nb, self.C, 160), np.int16)
+        _check(self.lib.AspSplitBatch_Analysis(self.h, x.ctypes.data, bands.ctypes.data, MEM_HOST),
+               "AspSplitBatch_Analysis")
+        return bands
+
+    def synthesis(self, bands):
+        bands = np.ascontiguousarray(bands, np.int16)
+        assert bands.shape == (self.nb, self.C, 160)
+        out = np.empty((self.C, 160 * self.nb), np.int16)
+        _check(self.lib.AspSplitBatch_Synthesis(self.h, bands.ctypes.data, out.ctypes.data, MEM_HOST),
+               "AspSplitBatch_Synthesis")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.AspSplitBatch_Free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

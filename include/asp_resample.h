@@ -32,6 +32,8 @@ int AspSincBatch_num_channels(const AspSincBatch* b);
  * out [num_channels][destination_frames].  mem: 0 host, 1 device (asp_ns.h ASP_MEM_*). */
 int AspSincBatch_Resample(AspSincBatch* b, const int16_t* in, int16_t* out, int mem);
 int AspSincBatch_Synchronize(AspSincBatch* b);
+/* Run the batch on the caller's HIP stream (hipStream_t as void*) instead of its own. */
+int AspSincBatch_SetStream(AspSincBatch* b, void* hip_stream);
 /* The 33 x 32 kernel table built on the host (SincResampler::InitializeKernel), for the parity
  * tests.  Returns the number of floats written (1056). */
 int AspSincBatch_kernel_table(const AspSincBatch* b, float* out, int capacity);

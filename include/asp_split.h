@@ -56,6 +56,16 @@ int AspQmfBatch_ExportState(AspQmfBatch* b, int channel, AspQmfState* out);
 int AspQmfBatch_ImportState(AspQmfBatch* b, int channel, const AspQmfState* in);
 int AspQmfBatch_Synchronize(AspQmfBatch* b);
 
+/* ---- SplittingFilter: the band split / merge of AudioBuffer (splitting_filter.cc:28-170) ----
+ * num_bands 2: 32 kHz <-> two 16 kHz bands (one QMF); num_bands 3: 48 kHz <-> three 16 kHz bands
+ * (48 -> 64 kHz sinc resampler, QMF twice, empty top band dropped; the reverse on the way back). */
+typedef struct AspSplitBatch AspSplitBatch;
+int AspSplitBatch_Create(AspSplitBatch** out, int num_channels, int num_bands, int device);
+int AspSplitBatch_Free(AspSplitBatch* b);
+/* in [num_channels][160 * num_bands] int16 -> bands [num_bands][num_channels][160]. */
+int AspSplitBatch_Analysis(AspSplitBatch* b, const int16_t* in, int16_t* bands, int mem);
+int AspSplitBatch_Synthesis(AspSplitBatch* b, const int16_t* bands, int16_t* out, int mem);
+
 #ifdef __cplusplus
 }
 #endif
