@@ -2,7 +2,7 @@
 // interleaved capture file, 10 ms at a time, the way a libapm client calls it
 // (WebRtc_AMP_Port/libapm/src/apm_ns.cpp:47-130).
 //
-//   apm_ns_raw <in.raw> <out.raw> <channels> <mode 0|1|2> <s16|f32> [frequency = 16000 | 32000]
+//   apm_ns_raw <in.raw> <out.raw> <channels> <mode 0|1|2> <s16|f32> [frequency = 16000 | 32000 | 48000]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
   short probe[4] = {1, 2, 3, 4};
   ns.processCaptureStream(probe, 2, 2);
   if (probe[0] != 1 || probe[3] != 4) return 3;
-  if (ns.initNsModule(48000, mode, 480, channels)) return 4;  // not covered by this build
+  if (ns.initNsModule(8000, mode, 80, channels)) return 4;  // not covered by this build
   if (!ns.initNsModule(frequency, mode, spc, channels)) {
     fprintf(stderr, "initNsModule failed: %s\n", AspNs_last_error());
     return 1;

@@ -13,11 +13,10 @@
  * planar int16 (FloatToS16 for the float overload) -> float-S16 ->
  * WebRtcNs_Analyze + WebRtcNs_Process -> FloatS16ToS16 -> interleaved.
  *
- * This build covers 16 kHz (one band, 160 samples per channel) and 32 kHz (320 samples per
- * channel: AudioBuffer::SplitIntoFrequencyBands = the two-band QMF of asp_split.h, the suppressor
- * with one high band, MergeFrequencyBands; audio_buffer.cc:455-463).  8 and 48 kHz make
- * initNsModule return false (48 kHz needs the 48 <-> 64 kHz sinc resampler of the three-band
- * split, splitting_filter.cc:91-170).
+ * This build covers 16 kHz (one band, 160 samples per channel), 32 kHz (320 per channel, two
+ * bands) and 48 kHz (480 per channel, three bands): AudioBuffer::SplitIntoFrequencyBands /
+ * MergeFrequencyBands (audio_buffer.cc:455-463) are the SplittingFilter of asp_split.h, the
+ * suppressor runs with one or two high bands.  8 kHz makes initNsModule return false.
  */
 #ifndef ASP_APM_NS_H_
 #define ASP_APM_NS_H_
@@ -36,7 +35,7 @@ enum {
 
 class APM_NS {
  public:
-  APM_NS() : m_batch(nullptr), m_qmf(nullptr), m_frequency(0), m_channels(0), m_ns_mode(0), m_device(0),
+  APM_NS() : m_batch(nullptr), m_qmf(nullptr), m_bands(1), m_frequency(0), m_channels(0), m_ns_mode(0), m_device(0),
              init_flag(false) {}
   ~APM_NS() { release(); }
   APM_NS(const APM_NS&) = delete;
@@ -52,12 +51,12 @@ class APM_NS {
     m_channels = input_channels;
     m_ns_mode = ns_mode;
     if (m_channels <= 0) return false;
-    const bool two_bands = frequency == 32000;
-    if (!(frequency == 16000 && input_frames == ASP_NS_BLOCKL) &&
-        !(two_bands && input_frames == 2 * ASP_NS_BLOCKL))
-      return false;
+    if (frequency != 16000 && frequency != 32000 && frequency != 48000) return false;
+    m_bands = (int)(frequency / 16000);
+    if (input_frames != m_bands * ASP_NS_BLOCKL) return false;
+    const bool two_bands = m_bands > 1;
     if (AspNsBatch_Create(&m_batch, m_channels, m_device) != ASP_OK) return false;
-    if (two_bands && AspQmfBatch_Create(&m_qmf, m_channels, m_device) != ASP_OK) {
+    if (two_bands && AspSplitBatch_Create(&m_qmf, m_channels, m_bands, m_device) != ASP_OK) {
       release();
       return false;
     }
@@ -68,10 +67,8 @@ class APM_NS {
     }
     m_planar.assign((size_t)m_channels * input_frames, 0);
     if (two_bands) {
-      m_low.assign((size_t)m_channels * ASP_NS_BLOCKL, 0);
-      m_high.assign((size_t)m_channels * ASP_NS_BLOCKL, 0);
-      m_lowf.assign((size_t)m_channels * ASP_NS_BLOCKL, 0.f);
-      m_highf.assign((size_t)m_channels * ASP_NS_BLOCKL, 0.f);
+      m_low.assign((size_t)m_bands * m_channels * ASP_NS_BLOCKL, 0);      // [band][channel][160]
+      m_lowf.assign((size_t)m_bands * m_channels * ASP_NS_BLOCKL, 0.f);
     }
     init_flag = true;
     return true;
@@ -121,42 +118,36 @@ class APM_NS {
   }
   bool usable(int samples_per_channel, int input_channels) const {
     return init_flag && input_channels == m_channels &&
-           samples_per_channel == (m_qmf ? 2 : 1) * ASP_NS_BLOCKL;
+           samples_per_channel == m_bands * ASP_NS_BLOCKL;
   }
   /* m_planar [channels][samples] int16, in place: apm_ns.cpp:66-77 */
   bool denoisePlanar() {
     if (!m_qmf)
       return AspNsBatch_AnalyzeProcessS16(m_batch, m_planar.data(), m_planar.data(), 1, ASP_MEM_HOST) == ASP_OK;
-    const size_t n = (size_t)m_channels * ASP_NS_BLOCKL;
-    if (AspQmfBatch_Analysis(m_qmf, m_planar.data(), ASP_NS_BLOCKL, m_low.data(), m_high.data(),
-                             ASP_MEM_HOST) != ASP_OK)
+    const size_t n = (size_t)m_channels * ASP_NS_BLOCKL;  // one band of every channel
+    if (AspSplitBatch_Analysis(m_qmf, m_planar.data(), m_low.data(), ASP_MEM_HOST) != ASP_OK) return false;
+    // int16 -> float-S16 views of the bands (channel_buffer.cc:43-53)
+    for (size_t i = 0; i < n * m_bands; ++i) m_lowf[i] = (float)m_low[i];
+    if (AspNsBatch_AnalyzeProcessBands(m_batch, m_lowf.data(), m_lowf.data() + n, m_lowf.data(),
+                                       m_lowf.data() + n, 1, ASP_MEM_HOST) != ASP_OK)
       return false;
-    for (size_t i = 0; i < n; ++i) {  // int16 -> float-S16 views of the bands (channel_buffer.cc:43-53)
-      m_lowf[i] = (float)m_low[i];
-      m_highf[i] = (float)m_high[i];
-    }
-    if (AspNsBatch_AnalyzeProcessBands(m_batch, m_lowf.data(), m_highf.data(), m_lowf.data(),
-                                       m_highf.data(), 1, ASP_MEM_HOST) != ASP_OK)
-      return false;
-    for (size_t i = 0; i < n; ++i) {  // back to the int16 bands (channel_buffer.cc:55-61)
-      m_low[i] = floatS16ToS16(m_lowf[i]);
-      m_high[i] = floatS16ToS16(m_highf[i]);
-    }
-    return AspQmfBatch_Synthesis(m_qmf, m_low.data(), m_high.data(), ASP_NS_BLOCKL, m_planar.data(),
-                                 ASP_MEM_HOST) == ASP_OK;
+    // back to the int16 bands (channel_buffer.cc:55-61)
+    for (size_t i = 0; i < n * m_bands; ++i) m_low[i] = floatS16ToS16(m_lowf[i]);
+    return AspSplitBatch_Synthesis(m_qmf, m_low.data(), m_planar.data(), ASP_MEM_HOST) == ASP_OK;
   }
   void release() {
     if (m_batch) AspNsBatch_Free(m_batch);
-    if (m_qmf) AspQmfBatch_Free(m_qmf);
+    if (m_qmf) AspSplitBatch_Free(m_qmf);
     m_batch = nullptr;
     m_qmf = nullptr;
     init_flag = false;
   }
 
   AspNsBatch* m_batch;
-  AspQmfBatch* m_qmf;
-  std::vector<int16_t> m_planar, m_low, m_high;
-  std::vector<float> m_lowf, m_highf;
+  AspSplitBatch* m_qmf;
+  int m_bands;
+  std::vector<int16_t> m_planar, m_low;
+  std::vector<float> m_lowf;
   unsigned int m_frequency;
   int m_channels;
   int m_ns_mode;
