@@ -716,3 +716,41 @@ class RefSplit:
         if getattr(self, "h", None):
             self.lib.ref_split_free(self.h)
             self.h = None
+
+
+# ------------------------------------------------------------------------------------------
+# libapm APM_NS class end to end (reference: oracle/_ref/libapm_ref.so)
+APM_REF_SO = os.path.join(ORACLE_DIR, "_ref", "libapm_ref.so")
+
+
+def have_apm_ref():
+    return os.path.exists(APM_REF_SO)
+
+
+class RefApm:
+    def __init__(self, freq, mode, channels):
+        lib = C.CDLL(APM_REF_SO)
+        lib.ref_apm_create.restype = C.c_void_p
+        lib.ref_apm_create.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_int]
+        lib.ref_apm_free.argtypes = [C.c_void_p]
+        lib.ref_apm_process_s16.argtypes = [C.c_void_p, _i16p, C.c_int, C.c_int]
+        lib.ref_apm_process_f32.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int]
+        self.lib, self.ch, self.spc = lib, channels, freq // 100
+        self.h = lib.ref_apm_create(freq, mode, self.spc, channels)
+        assert self.h
+
+    def process_f32(self, frame):
+        """frame [spc][channels] float32 interleaved in [-1, 1]; returns the processed copy."""
+        x = np.array(frame, np.float32, copy=True)
+        self.lib.ref_apm_process_f32(self.h, x.reshape(-1), self.spc, self.ch)
+        return x
+
+    def process_s16(self, frame):
+        x = np.array(frame, np.int16, copy=True)
+        self.lib.ref_apm_process_s16(self.h, x.reshape(-1), self.spc, self.ch)
+        return x
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_apm_free(self.h)
+            self.h = None
