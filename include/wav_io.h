@@ -14,46 +14,57 @@
 #ifndef ASP_WAV_IO_H_
 #define ASP_WAV_IO_H_
 
+#include <stdint.h>
 #include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define BUFFER_SIZE 256
-#define ID_LEN 4
+enum { BUFFER_SIZE = 256, ID_LEN = 4 }; /* bytes scanned for chunk IDs; length of a chunk ID */
 
-typedef struct {
-  char ID[ID_LEN];
-  int size;
-  char type[ID_LEN];
+/* The three chunks of a canonical 44-byte header.  Field names are the reference's (its drivers
+ * read header.format.sample_per_sec, .channels, .bits_per_sample ...); widths are spelled out. */
+typedef struct RiffChunk {   /* bytes  0..11 */
+  char ID[ID_LEN];           /* "RIFF"                 */
+  int32_t size;              /* file size - 8          */
+  char type[ID_LEN];         /* "WAVE"                 */
 } RIFF_CHUNK;
 
-typedef struct {
-  char ID[ID_LEN];
-  int size;
-  short format;
-  short channels;
-  int sample_per_sec;
-  int avg_bytes_per_sec;
-  short blockAlign;
-  short bits_per_sample;
+typedef struct FormatChunk { /* bytes 12..35 */
+  char ID[ID_LEN];           /* "fmt "                 */
+  int32_t size;              /* 16 for PCM             */
+  int16_t format;            /* 1 = PCM                */
+  int16_t channels;
+  int32_t sample_per_sec;
+  int32_t avg_bytes_per_sec;
+  int16_t blockAlign;
+  int16_t bits_per_sample;
 } FORMAT_CHUNK;
 
-typedef struct {
-  char ID[ID_LEN];
-  int size;
+typedef struct DataChunk {   /* bytes 36..43 */
+  char ID[ID_LEN];           /* "data"                 */
+  int32_t size;              /* payload bytes          */
 } DATA_CHUNK;
 
-typedef struct {
+typedef struct WavHeader {
   RIFF_CHUNK riff;
   FORMAT_CHUNK format;
   DATA_CHUNK data;
 } WAV_HEADER;
 
+#ifndef __cplusplus
+_Static_assert(sizeof(RIFF_CHUNK) == 12 && sizeof(FORMAT_CHUNK) == 24 && sizeof(DATA_CHUNK) == 8 &&
+                   sizeof(WAV_HEADER) == 44,
+               "the header structs are copied from the file image byte for byte");
+#endif
+
+/* chunk search inside a memory image of the file's first BUFFER_SIZE bytes */
 int search_ID(const char* ID, char* buf, int buf_size, int* loc);
+/* header in / out; both return 0 on success */
 int read_header(WAV_HEADER* header, FILE* file);
 int write_header(WAV_HEADER* header, FILE* file);
+/* raw int16 samples; the return value is the fread / fwrite element count */
 int read_samples(short* buf, int num_samples, WAV_HEADER* header, FILE* file);
 int write_samples(short* buf, int num_samples, WAV_HEADER* header, FILE* file);
 void print_header(WAV_HEADER* header);

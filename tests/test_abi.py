@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", txt)))
+    names = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", txt))
+    return sorted(names - {"_Static_assert"})
 
 
 @pytest.mark.parametrize("header", ["asp_ns.h", "wav_io.h", "asp_bt.h", "asp_aec.h", "asp_split.h", "asp_resample.h"])
