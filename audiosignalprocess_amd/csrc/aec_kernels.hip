@@ -371,6 +371,55 @@ __device__ __attribute__((noinline)) float2 nlp_sincos(float x) {
   return r;
 }
 
+// The high band of a 32 kHz stream (aec_core.c:1032-1067, 501-545, 451-459).  Out of line on
+// purpose: it keeps the one-band path's register allocation untouched (its LDS accesses become
+// generic here, which only the two-band path pays for).
+__device__ __attribute__((noinline)) void high_band_block(float* __restrict__ st, float* __restrict__ wl,
+                                                          const SharedTables& T, int near_rpos,
+                                                          int out_wpos, int lane) {
+  float* misc = wl + kLdsMisc;
+  float* HNL = lrow(wl, L_HNL);
+  float* DFR = lrow(wl, L_DFR);
+  float* DFI = lrow(wl, L_DFI);
+  float* YFR = lrow(wl, L_YFR);
+  float* YFI = lrow(wl, L_YFI);
+  const float scale = 2.0f / 128;
+    // ---- high band (aec_core.c:1032-1067, 501-545, 451-459): the three averages are summed by
+    // one lane each in the reference's order
+    wave_fence();
+    if (lane < 3) {
+      const float* src = lane == 0 ? HNL : lane == 1 ? DFR : DFI;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 32; j < 65; ++j)
+        if (j < 64 || lane > 0) acc += src[j];
+      misc[8 + lane] = acc;
+    }
+    wave_fence();
+    const float nlpGainHband = misc[8] / 32.0f;
+    const float noiseAvg = misc[9] / 33.0f, tmpAvg = misc[10] / 33.0f;
+    {
+      // comfortNoiseHband packed for the inverse transform: fft[0] = cn[0].re (0), fft[1] = cn[64].re
+      float2 v;
+      v.x = lane == 0 ? 0.f : tmpAvg * (noiseAvg * YFR[lane]);
+      v.y = lane == 0 ? tmpAvg * (noiseAvg * YFR[64]) : tmpAvg * (-noiseAvg * YFI[lane]);
+      tile(wl, 0)[lane] = v;
+    }
+    wave_fence();
+    rdft_inv_quad(wl, lane, T);
+    {
+      const float cn = reinterpret_cast<const float*>(tile(wl, 0))[lane] * scale;
+      const float nearH = st[kOffNearFrH + ring_idx(near_rpos, lane, kFrBufLen)];
+      float dtmp = st[kOffDBufH + lane];
+      dtmp = dtmp * nlpGainHband;
+      dtmp += 0.4f * cn;  // cnScaleHband, aec_core.c:45-46
+      st[kOffOutFrH + ring_idx(out_wpos, lane, kFrBufLen)] =
+          dtmp > 32767.f ? 32767.f : (dtmp < -32768.f ? -32768.f : dtmp);
+      st[kOffDBufH + lane] = nearH;
+    }
+    wave_fence();
+}
+
 // One ProcessBlock + NonLinearProcessing for this wave's stream.
 __device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
                                               const float* __restrict__ far_slot,
@@ -907,42 +956,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     const float o = a > 32767.f ? 32767.f : (a < -32768.f ? -32768.f : a);
     st[kOffOutFr + ring_idx(op.out_wpos, lane, kFrBufLen)] = o;
   }
-  if (num_high > 0) {
-    // ---- high band (aec_core.c:1032-1067, 501-545, 451-459): the three averages are summed by
-    // one lane each in the reference's order
-    wave_fence();
-    if (lane < 3) {
-      const float* src = lane == 0 ? HNL : lane == 1 ? DFR : DFI;
-      float acc = 0.f;
-#pragma unroll
-      for (int j = 32; j < 65; ++j)
-        if (j < 64 || lane > 0) acc += src[j];
-      misc[8 + lane] = acc;
-    }
-    wave_fence();
-    const float nlpGainHband = misc[8] / 32.0f;
-    const float noiseAvg = misc[9] / 33.0f, tmpAvg = misc[10] / 33.0f;
-    {
-      // comfortNoiseHband packed for the inverse transform: fft[0] = cn[0].re (0), fft[1] = cn[64].re
-      float2 v;
-      v.x = lane == 0 ? 0.f : tmpAvg * (noiseAvg * YFR[lane]);
-      v.y = lane == 0 ? tmpAvg * (noiseAvg * YFR[64]) : tmpAvg * (-noiseAvg * YFI[lane]);
-      tile(wl, 0)[lane] = v;
-    }
-    wave_fence();
-    rdft_inv_quad(wl, lane, T);
-    {
-      const float cn = reinterpret_cast<const float*>(tile(wl, 0))[lane] * scale;
-      const float nearH = st[kOffNearFrH + ring_idx(op.near_rpos, lane, kFrBufLen)];
-      float dtmp = st[kOffDBufH + lane];
-      dtmp = dtmp * nlpGainHband;
-      dtmp += 0.4f * cn;  // cnScaleHband, aec_core.c:45-46
-      st[kOffOutFrH + ring_idx(op.out_wpos, lane, kFrBufLen)] =
-          dtmp > 32767.f ? 32767.f : (dtmp < -32768.f ? -32768.f : dtmp);
-      st[kOffDBufH + lane] = nearH;
-    }
-    wave_fence();
-  }
+  if (num_high > 0) high_band_block(st, wl, T, op.near_rpos, op.out_wpos, lane);
   AEC_STAMP(14)
   // ---- carry the block (aec_core.c:1069-1081; the xfwBuf shift is the host's circular head)
   st[kOffDBuf + lane] = ne;
