@@ -124,6 +124,40 @@ class AspAecState(C.Structure):
     ]
 
 
+class AspAecPowerLevel(C.Structure):
+    _fields_ = [("sfrsum", C.c_float), ("sfrcounter", C.c_int32), ("framelevel", C.c_float), ("frsum", C.c_float),
+                ("frcounter", C.c_int32), ("minlevel", C.c_float), ("averagelevel", C.c_float)]
+
+
+class AspAecStats(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("instant", "average", "min", "max", "sum", "hisum", "himean")] + \
+               [("counter", C.c_int32), ("hicounter", C.c_int32)]
+
+
+class AspAecMetricsState(C.Structure):
+    """include/asp_aec.h: AspAecMetricsState."""
+
+    _fields_ = [("farlevel", AspAecPowerLevel), ("nearlevel", AspAecPowerLevel), ("linoutlevel", AspAecPowerLevel),
+                ("nlpoutlevel", AspAecPowerLevel), ("erl", AspAecStats), ("erle", AspAecStats), ("aNlp", AspAecStats),
+                ("rerl", AspAecStats), ("stateCounter", C.c_int32)]
+
+    def to_array(self):
+        import numpy as np
+        return np.frombuffer(bytes(self), dtype=np.uint32).copy()
+
+
+class AecLevel(C.Structure):
+    _fields_ = [("instant", C.c_int), ("average", C.c_int), ("max", C.c_int), ("min", C.c_int)]
+
+
+class AecMetrics(C.Structure):
+    _fields_ = [("rerl", AecLevel), ("erl", AecLevel), ("erle", AecLevel), ("aNlp", AecLevel)]
+
+    def to_tuple(self):
+        return tuple(getattr(getattr(self, a), f) for a in ("rerl", "erl", "erle", "aNlp")
+                     for f in ("instant", "average", "max", "min"))
+
+
 class AspAecControl(C.Structure):
     """include/asp_aec.h: AspAecControl (integer control plane shared by a batch)."""
 

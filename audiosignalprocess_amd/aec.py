@@ -28,6 +28,8 @@ def _lib():
             "AspAecBatch_Run": [vp, vp, vp, vp, ip, ip, ip, ip],
             "AspAecBatch_get_echo_status": [vp, C.POINTER(ip)],
             "AspAecBatch_get_error_code": [vp],
+            "AspAecBatch_GetMetrics": [vp, vp],
+            "AspAecBatch_ExportMetricsState": [vp, ip, vp],
             "AspAecBatch_ExportState": [vp, ip, C.POINTER(AspAecState)],
             "AspAecBatch_ImportState": [vp, ip, C.POINTER(AspAecState)],
             "AspAecBatch_GetControl": [vp, C.POINTER(AspAecControl)],
@@ -132,6 +134,21 @@ class AecBatch:
         st = AspAecState()
         _check(self.lib.AspAecBatch_ExportState(self.h, stream, C.byref(st)), "AspAecBatch_ExportState")
         return st
+
+    def metrics_state(self, stream):
+        from ._abi import AspAecMetricsState
+        m = AspAecMetricsState()
+        _check(self.lib.AspAecBatch_ExportMetricsState(self.h, stream, C.byref(m)), "AspAecBatch_ExportMetricsState")
+        return m
+
+    def get_metrics(self):
+        """WebRtcAec_GetMetrics of every stream: int32 [S][16] = rerl, erl, erle, aNlp x (instant, average, max, min)."""
+        from ._abi import AecMetrics
+        arr = (AecMetrics * self.S)()
+        rc = self.lib.AspAecBatch_GetMetrics(self.h, arr)
+        if rc != 0:
+            raise AspError("AspAecBatch_GetMetrics failed (%d)" % rc)
+        return np.array([m.to_tuple() for m in arr], np.int32)
 
     def import_state(self, stream, st):
         _check(self.lib.AspAecBatch_ImportState(self.h, stream, C.byref(st)), "AspAecBatch_ImportState")

@@ -25,8 +25,8 @@ hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, 
 hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
-                              const float* near_high, float* out_high, hipStream_t s,
-                              unsigned long long* stamps = nullptr);
+                              const float* near_high, float* out_high, float* metrics,
+                              hipStream_t s, unsigned long long* stamps = nullptr);
 hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
                               hipStream_t s);
 }  // namespace aspaec
@@ -226,6 +226,9 @@ struct AspAecBatch {
   float *stage_near_h = nullptr, *stage_out_h = nullptr;  // [S][160]
   const float* cur_near_high = nullptr;  // device pointers of the Process call in flight
   float* cur_out_high = nullptr;
+  // echo metrics (aec_core.c:548-770): [S][kMetDwords], updated by the kernel when metricsMode is on
+  int metricsMode = 0;
+  float* metrics = nullptr;
 };
 
 namespace {
@@ -234,6 +237,26 @@ int far_move_read(AspAecBatch* b, int elements) {  // WebRtcAec_MoveFarReadPtr, 
   const int moved = rp_move_read(&b->far_pos, elements);
   b->system_delay -= moved * kPartLen;
   return moved;
+}
+
+// InitMetrics (aec_core.c:548-583) for every stream, ordered on the batch's stream.
+int init_metrics_device(AspAecBatch* b) {
+  AspAecMetricsState m;
+  memset(&m, 0, sizeof m);
+  AspAecPowerLevel* lv[4] = {&m.farlevel, &m.nearlevel, &m.linoutlevel, &m.nlpoutlevel};
+  for (AspAecPowerLevel* l : lv) l->minlevel = 1E17f;
+  AspAecStats* st[4] = {&m.erl, &m.erle, &m.aNlp, &m.rerl};
+  for (AspAecStats* s : st) {
+    s->instant = s->average = s->max = s->himean = -100;  // kOffsetLevel
+    s->min = 100;
+  }
+  static_assert(sizeof(AspAecMetricsState) == 65 * 4 && sizeof(AspAecMetricsState) <= kMetDwords * 4, "metrics image");
+  std::vector<float> all((size_t)b->S * kMetDwords, 0.f);
+  for (int s = 0; s < b->S; ++s) memcpy(all.data() + (size_t)s * kMetDwords, &m, sizeof m);
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  AEC_TRY(hipMemcpy(b->metrics, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
 }
 
 size_t state_bytes(const AspAecBatch* b) { return (size_t)b->S * kStateDwords * sizeof(float); }
@@ -521,7 +544,8 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
   }
   if (!b->sim)
     AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
-                               b->cur_near_high, b->cur_out_high, b->stream, b->debug_stamps));
+                               b->cur_near_high, b->cur_out_high, b->metricsMode ? b->metrics : nullptr, b->stream,
+                               b->debug_stamps));
   return 0;
 }
 
@@ -639,6 +663,7 @@ int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device) {
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out, (size_t)num_streams * 160 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_near_h, (size_t)num_streams * 160 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out_h, (size_t)num_streams * 160 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->metrics, (size_t)num_streams * kMetDwords * sizeof(float));
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev1);
   if (e == hipSuccess) {
@@ -682,6 +707,7 @@ int AspAecBatch_Free(AspAecBatch* b) {
   if (b->stage_out) (void)hipFree(b->stage_out);
   if (b->stage_near_h) (void)hipFree(b->stage_near_h);
   if (b->stage_out_h) (void)hipFree(b->stage_out_h);
+  if (b->metrics) (void)hipFree(b->metrics);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream && b->own_stream) (void)hipStreamDestroy(b->stream);
@@ -716,11 +742,16 @@ int AspAecBatch_set_config(AspAecBatch* b, AecConfig config) {  // echo_cancella
     b->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
   }
-  if (config.skewMode || config.metricsMode || config.delay_logging) {
+  if (config.skewMode || config.delay_logging) {
     b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;  // outside the built configuration (asp_aec.h)
     return -1;
   }
-  b->nlp_mode = config.nlpMode;  // WebRtcAec_SetConfigCore, aec_core.c:1844-1858
+  b->nlp_mode = config.nlpMode;  // WebRtcAec_SetConfigCore, aec_core.c:1844-1862
+  b->metricsMode = config.metricsMode;
+  if (b->metricsMode && !b->sim) {
+    const int err = init_metrics_device(b);
+    if (err) return err;
+  }
   return 0;
 }
 
@@ -772,6 +803,8 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
     // on the batch's own (non-blocking) stream: a null-stream memset is not ordered with its kernels
     AEC_TRY(hipMemsetAsync(b->far_ring, 0, far_bytes(b), b->stream));  // WebRtc_InitBuffer zeroes the rings
     AEC_TRY(hipStreamSynchronize(b->stream));
+    const int err = init_metrics_device(b);  // aec_core.c:1612-1613
+    if (err) return err;
   }
   rp_init(&b->pre_pos, kPreLen);
   rp_move_read(&b->pre_pos, -kPartLen);  // start overlap, echo_cancellation.c:226
@@ -1057,6 +1090,61 @@ int AspAecBatch_get_echo_status(AspAecBatch* b, int* status) {
   return 0;
 }
 
+namespace {
+void level_of(const AspAecStats& s, AecLevel* out) {  // echo_cancellation.c:484-499 (and the erle / aNlp copies)
+  const float kUpWeight = 0.7f;
+  out->instant = (int)s.instant;
+  if ((s.himean > -100) && (s.average > -100)) {
+    const float dtmp = kUpWeight * s.himean + (1 - kUpWeight) * s.average;
+    out->average = (int)dtmp;
+  } else {
+    out->average = -100;
+  }
+  out->max = (int)s.max;
+  out->min = s.min < 100 ? (int)s.min : -100;
+}
+}  // namespace
+
+int AspAecBatch_GetMetrics(AspAecBatch* b, AecMetrics* out) {  // WebRtcAec_GetMetrics, echo_cancellation.c:456-548
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_GetMetrics: control-only handle");
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  if (out == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (b->initFlag != kInitCheck) {
+    b->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  std::vector<float> all((size_t)b->S * kMetDwords);
+  AEC_TRY(hipMemcpy(all.data(), b->metrics, all.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (int s = 0; s < b->S; ++s) {
+    AspAecMetricsState m;
+    memcpy(&m, all.data() + (size_t)s * kMetDwords, sizeof m);
+    AecMetrics* o = out + s;
+    level_of(m.erl, &o->erl);
+    level_of(m.erle, &o->erle);
+    const int stmp = (o->erl.average > -100 && o->erle.average > -100) ? o->erl.average + o->erle.average : -100;
+    o->rerl.average = stmp;
+    o->rerl.instant = stmp;
+    o->rerl.max = stmp;
+    o->rerl.min = stmp;
+    level_of(m.aNlp, &o->aNlp);
+  }
+  return 0;
+}
+
+int AspAecBatch_ExportMetricsState(AspAecBatch* b, int stream, AspAecMetricsState* out) {
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_ExportMetricsState: control-only handle");
+  if (!b || !out || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ExportMetricsState: bad argument");
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  AEC_TRY(hipMemcpy(out, b->metrics + (size_t)stream * kMetDwords, sizeof *out, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // Diagnostic: one BufferFarend + Process on device frames with phase time stamps (s_memtime
 // ticks) of stream 0's first block.
 int AspAecBatch_DebugStamps(AspAecBatch* b, const float* far_dev, const float* near_dev, float* out_dev,
@@ -1189,14 +1277,7 @@ int WebRtcAec_GetMetrics(void* handle, AecMetrics* metrics) {  // echo_cancellat
     b->lastError = AEC_UNINITIALIZED_ERROR;
     return -1;
   }
-  // metrics are off: the statistics stay at InitStats' values (aec_core.c:560-583), which the
-  // reference reports as instant = max = min = average = kOffsetLevel (-100)
-  const AecLevel init = {-100, -100, -100, -100};
-  metrics->rerl = init;
-  metrics->erl = init;
-  metrics->erle = init;
-  metrics->aNlp = init;
-  return 0;
+  return AspAecBatch_GetMetrics(b, metrics) == 0 ? 0 : -1;
 }
 
 int WebRtcAec_GetDelayMetrics(void* handle, int* median, int* std) {  // echo_cancellation.c:550-571

@@ -44,13 +44,15 @@ constexpr int kTileStride = 66;                 // float2 per transform tile (64
 constexpr int kLdsTile = 0;                     // 4 tiles: 4 * 66 float2 = 528 floats
 constexpr int kLdsRows = 4 * kTileStride * 2;   // per-bin rows of 66 floats
 enum LRow { L_XFR = 0, L_XFI, L_DFR, L_DFI, L_YFR, L_YFI, L_EFR, L_EFI, L_XPOW, L_XWR, L_XWI,
-            L_COHDE, L_COHXD, L_HNL, L_T0, L_T1, L_DWR, L_DWI, L_EWR, L_EWI, L_NROWS };
+            L_COHDE, L_COHXD, L_HNL, L_T0, L_T1, L_DWR, L_DWI, L_EWR, L_EWI,
+            L_MET,  // 4 rows: per-bin energy terms of far / near / linear-out / NLP-out (metrics mode)
+            L_NROWS = L_MET + 4 };
 constexpr int kLRow = 66;
 constexpr int kLdsDbuf = kLdsRows + L_NROWS * kLRow;  // 128
 constexpr int kLdsEbuf = kLdsDbuf + 128;              // 128
 constexpr int kLdsMisc = kLdsEbuf + 128;              // 16
 constexpr int kLdsC64 = kLdsMisc + 16;                // bin 64 of every state row (84)
-constexpr int kLdsWave = kLdsC64 + 84;                // 1940 floats = 7 760 B per wave
+constexpr int kLdsWave = kLdsC64 + 84;                // 2204 floats = 8 816 B per wave
 static_assert(kNumPart * kLRow <= kLdsRows + 9 * kLRow, "partition-energy rows overlay");
 
 struct SharedTables {
@@ -420,13 +422,118 @@ __device__ __attribute__((noinline)) void high_band_block(float* __restrict__ st
     wave_fence();
 }
 
-// One ProcessBlock + NonLinearProcessing for this wave's stream.
+// UpdateLevel x 4 + UpdateMetrics (aec_core.c:585-770) from the per-bin energy terms the block
+// left in the L_MET rows: lanes 0..3 each sum one level in the reference's order (bin 0, bin 64,
+// bins 1..63) and update its PowerLevel; lane 0 then updates the ERL / A_NLP / ERLE statistics.
+// `met` is this stream's AspAecMetricsState image (include/asp_aec.h).
+__device__ __attribute__((noinline)) void metrics_block(float* __restrict__ met, float* __restrict__ wl,
+                                                        int lane, int echoState) {
+  constexpr int subCountLen = 4, countLen = 50;  // aec_core.c:47-48
+  int32_t* meti = reinterpret_cast<int32_t*>(met);
+  wave_fence();
+  float minlevel = 0.f, averagelevel = 0.f;
+  int frcounter = 0, sfrcounter = 0;
+  if (lane < 4) {
+    const float* src = lrow(wl, L_MET + lane);
+    float energy = src[0];
+    energy += src[64];
+#pragma unroll
+    for (int k = 1; k < 64; ++k) energy += src[k];
+    energy /= 128;
+    float* L = met + kMetLevel * lane;  // sfrsum sfrcounter framelevel frsum frcounter minlevel averagelevel
+    int32_t* Li = meti + kMetLevel * lane;
+    float sfrsum = L[0] + energy;
+    sfrcounter = Li[1] + 1;
+    frcounter = Li[4];
+    minlevel = L[5];
+    averagelevel = L[6];
+    if (sfrcounter > subCountLen) {
+      const float framelevel = sfrsum / (subCountLen * kPartLen);
+      L[2] = framelevel;
+      sfrsum = 0;
+      sfrcounter = 0;
+      if (framelevel > 0) {
+        if (framelevel < minlevel) {
+          minlevel = framelevel;
+        } else {
+          minlevel *= (1 + 0.001f);
+        }
+      }
+      frcounter++;
+      float frsum = L[3] + framelevel;
+      if (frcounter > countLen) {
+        averagelevel = frsum / countLen;
+        frsum = 0;
+        frcounter = 0;
+      }
+      L[3] = frsum;
+      Li[4] = frcounter;
+      L[5] = minlevel;
+      L[6] = averagelevel;
+    }
+    L[0] = sfrsum;
+    Li[1] = sfrcounter;
+  }
+  const float near_avg = __shfl(averagelevel, 1), near_min = __shfl(minlevel, 1);
+  const float lin_avg = __shfl(averagelevel, 2), lin_min = __shfl(minlevel, 2);
+  const float nlp_avg = __shfl(averagelevel, 3), nlp_min = __shfl(minlevel, 3);
+  if (lane == 0) {  // UpdateMetrics, aec_core.c:644-770 (lane 0 holds the far level)
+    int stateCounter = meti[kMetStateCounter];
+    if (echoState) stateCounter++;
+    if (frcounter == 0) {
+      const float actThreshold = minlevel < 300000.0f ? 40.0f : 8.0f;
+      if ((stateCounter > (0.5f * countLen * subCountLen)) && (sfrcounter == 0) &&
+          (averagelevel > (actThreshold * minlevel))) {
+        const float safety = 0.99995f;
+        const float echo = near_avg - safety * near_min;
+        auto add = [&](int which, float instant, float dtmp) {
+          float* S = met + kMetStats + kMetStat * which;  // instant average min max sum hisum himean counter hicounter
+          int32_t* Si = meti + kMetStats + kMetStat * which;
+          S[0] = instant;
+          if (dtmp > S[3]) S[3] = dtmp;
+          if (dtmp < S[2]) S[2] = dtmp;
+          const int counter = Si[7] + 1;
+          Si[7] = counter;
+          const float sum = S[4] + dtmp;
+          S[4] = sum;
+          const float average = sum / counter;
+          S[1] = average;
+          if (dtmp > average) {
+            const int hicounter = Si[8] + 1;
+            Si[8] = hicounter;
+            const float hisum = S[5] + dtmp;
+            S[5] = hisum;
+            S[6] = hisum / hicounter;
+          }
+        };
+        float dtmp = 10 * (float)log10((double)(averagelevel / near_avg + 1e-10f));
+        add(0, dtmp, dtmp);  // ERL
+        dtmp = 10 * (float)log10((double)(near_avg / (2 * lin_avg) + 1e-10f));
+        float suppressedEcho = 2 * (lin_avg - safety * lin_min);
+        float dtmp2 = 10 * (float)log10((double)(echo / suppressedEcho + 1e-10f));
+        add(2, dtmp2, dtmp);  // A_NLP
+        suppressedEcho = 2 * (nlp_avg - safety * nlp_min);
+        dtmp2 = 10 * (float)log10((double)(echo / suppressedEcho + 1e-10f));
+        add(1, dtmp2, dtmp2);  // ERLE
+      }
+      stateCounter = 0;
+    }
+    meti[kMetStateCounter] = stateCounter;
+  }
+  wave_fence();
+}
+
+// One ProcessBlock + NonLinearProcessing for this wave's stream.  kMetrics: metricsMode builds of
+// the kernel also gather the echo metrics (a separate instantiation keeps the plain one's
+// register allocation).
+template <bool kMetrics>
 __device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
                                               const float* __restrict__ far_slot,
                                               const SharedTables& T, const BlockOp& op, int mult,
                                               int nlp_mode, float mu, float error_threshold,
                                               int lane, const double* __restrict__ exp2_global,
-                                              int num_high, unsigned long long* stamps) {
+                                              int num_high, float* __restrict__ met,
+                                              unsigned long long* stamps) {
   // diagnostic phase stamps (never enabled by the product entry points)
 #define AEC_STAMP(k) \
   if (stamps != nullptr) stamps[k] = __builtin_amdgcn_s_memtime();
@@ -457,6 +564,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   float* DWI = lrow(wl, L_DWI);
   float* EWR = lrow(wl, L_EWR);  // windowed error spectrum (NLP)
   float* EWI = lrow(wl, L_EWI);
+  [[maybe_unused]] float* MET = lrow(wl, L_MET);  // [4][kLRow], metrics mode only
   const float scale = 2.0f / 128;
   // State rows: trip 0 (bin = lane) goes to HBM, trip 1 (bin 64) to a per-wave LDS copy of the
   // bin-64 column that is gathered once per block and scattered back at its end.
@@ -548,6 +656,11 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     ROW_ST(R_XPOW, xp);
     ROW_ST(R_DPOW, dp);
     XPW[bin] = xp;
+    if constexpr (kMetrics) {  // UpdateLevel terms of farlevel / nearlevel (aec_core.c:612-618, 1270-1274)
+      const bool edge = bin == 0 || bin == 64;
+      MET[bin] = edge ? far_spectrum / 2 : far_spectrum;
+      MET[kLRow + bin] = edge ? near_spectrum / 2 : near_spectrum;
+    }
     float dmin = t_ == 0 ? p_dmin : c64[R_DMINPOW];
     if (noise_track) {
       if (dp < dmin) {
@@ -631,6 +744,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   // ---- ScaleErrorSignal (aec_core.c:171-193)
   BINS_2TRIPS {
     float er = EFR[bin], ei = EFI[bin];
+    if constexpr (kMetrics) {  // linoutlevel (aec_core.c:1258-1263)
+      const float t = er * er + ei * ei;
+      MET[2 * kLRow + bin] = (bin == 0 || bin == 64) ? t / 2 : t;
+    }
     const float den = XPW[bin] + 1e-10f;
     er /= den;
     ei /= den;
@@ -929,6 +1046,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     ei += tmp2 * ui;
     EWR[bin] = er;
     EWI[bin] = ei;
+    if constexpr (kMetrics) {  // nlpoutlevel (aec_core.c:1000-1006)
+      const float t = er * er + ei * ei;
+      MET[3 * kLRow + bin] = (bin == 0 || bin == 64) ? t / 2 : t;
+    }
     if (num_high > 0) {
       HNL[bin] = h;
       DFI[bin] = tmp2;
@@ -957,6 +1078,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     st[kOffOutFr + ring_idx(op.out_wpos, lane, kFrBufLen)] = o;
   }
   if (num_high > 0) high_band_block(st, wl, T, op.near_rpos, op.out_wpos, lane);
+  if constexpr (kMetrics) metrics_block(met, wl, lane, echoState);
   AEC_STAMP(14)
   // ---- carry the block (aec_core.c:1069-1081; the xfwBuf shift is the host's circular head)
   st[kOffDBuf + lane] = ne;
@@ -987,6 +1109,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 
 // WebRtcAec_ProcessFrames for every stream (running phase): per 80-sample sub-frame append the
 // near samples, run the scheduled blocks, emit 80 output samples.
+template <bool kMetrics>
 __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__ state,
                                                           float* far_ring,
                                                           const AecTables* __restrict__ G,
@@ -995,6 +1118,7 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
                                                           int nrOfSamples, ProcOps ops,
                                                           const float* __restrict__ farend, FarOps fops,
                                                           const float* near_high, float* out_high,
+                                                          float* metrics,
                                                           unsigned long long* __restrict__ stamps) {
   __shared__ SharedTables T;
   __shared__ float lds[4 * kLdsWave];
@@ -1006,6 +1130,7 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
   float* st = state + (size_t)stream * kStateDwords;
   const float* nin = nearend + (size_t)stream * nrOfSamples;
   float* o = out + (size_t)stream * nrOfSamples;
+  float* met = kMetrics ? metrics + (size_t)stream * kMetDwords : nullptr;
   if (farend != nullptr) {
     // the WebRtcAec_BufferFarend call that preceded this Process call, fused into the launch
     farend_work(st, far_ring, wl, T, farend, num_streams, stream, fops, lane);
@@ -1034,8 +1159,8 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
     for (int k = 0; k < sf.nblocks; ++k) {
       const BlockOp& op = sf.blk[k];
       const float* slot = far_ring + ((size_t)op.far_slot * num_streams + stream) * kFarSlotDwords;
-      process_block(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
-                    ops.num_high,
+      process_block<kMetrics>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
+                    ops.num_high, met,
                     (stamps != nullptr && stream == 0 && s == 0 && k == 0 && lane == 0) ? stamps : nullptr);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -1101,11 +1226,17 @@ hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, 
 hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
-                              const float* near_high, float* out_high, hipStream_t s,
-                              unsigned long long* stamps) {
-  hipLaunchKernelGGL(aec_process_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
-                     far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,
-                     out_high, stamps);
+                              const float* near_high, float* out_high, float* metrics,
+                              hipStream_t s, unsigned long long* stamps) {
+  if (metrics != nullptr) {
+    hipLaunchKernelGGL(aec_process_kernel<true>, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
+                       far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,
+                       out_high, metrics, stamps);
+  } else {
+    hipLaunchKernelGGL(aec_process_kernel<false>, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
+                       far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,
+                       out_high, metrics, stamps);
+  }
   return hipGetLastError();
 }
 

@@ -59,6 +59,12 @@ enum Scalar {
 
 constexpr int kFarSlotDwords = 4 * kRow;  // per stream per slot
 
+// Echo metrics (metricsMode): a separate allocation [stream][kMetDwords] whose first 65 dwords are
+// the AspAecMetricsState image: 4 PowerLevel x 7, 4 Stats x 9 (erl, erle, aNlp, rerl), stateCounter.
+constexpr int kMetLevel = 7, kMetStat = 9, kMetStats = 4 * kMetLevel;
+constexpr int kMetStateCounter = kMetStats + 4 * kMetStat;  // 64
+constexpr int kMetDwords = 80;
+
 // Constant tables (host-built, aec_api.hip; the kernels stage them in LDS).
 struct AecTables {
   float w[64];         // rdft_w, aec_rdft.c:32-49

@@ -13,8 +13,8 @@
  *
  * Built configuration = what test_aec_module.cpp:60-88 runs: 8 or 16 kHz (one band), plus 32 kHz
  * (two bands),
- * 12 partitions, reported-delay mode, no skew compensation, no delay logging, metrics
- * off.  Anything else is refused with the reference's own error codes.
+ * 12 partitions, reported-delay mode, no skew compensation, no delay logging; echo metrics
+ * (ERL / ERLE / A_NLP) optional.  Anything else is refused with the reference's own error codes.
  */
 #ifndef ASP_AEC_H_
 #define ASP_AEC_H_
@@ -73,8 +73,8 @@ int32_t WebRtcAec_Process(void* aecInst, const float* const* nearend, int num_ba
                           int32_t skew);                                        /* .h:153 */
 int WebRtcAec_set_config(void* handle, AecConfig config);                       /* .h:175 */
 int WebRtcAec_get_echo_status(void* handle, int* status);                       /* .h:191 */
-/* Metrics are off in this build (metricsMode must stay kAecFalse): GetMetrics reports the
- * reference's initial values (kOffsetLevel = -100), GetDelayMetrics fails with
+/* GetMetrics: echo_cancellation.c:456-548 (the values stay at kOffsetLevel = -100 until
+ * set_config enables metricsMode).  Delay logging is not built: GetDelayMetrics fails with
  * AEC_UNSUPPORTED_FUNCTION_ERROR exactly as the reference does with logging disabled. */
 int WebRtcAec_GetMetrics(void* handle, AecMetrics* metrics);                    /* .h:207 */
 int WebRtcAec_GetDelayMetrics(void* handle, int* median, int* std);             /* .h:224 */
@@ -120,6 +120,25 @@ typedef struct AspAecState {
   uint32_t seed;
   float dBufH[128]; /* first high band (32 kHz), aec_core_internal.h:67 */
 } AspAecState;
+
+/* Echo metrics state of one stream (metricsMode = kAecTrue): PowerLevel x 4 and Stats x 4 of
+ * AecCore (aec_core_internal.h:39-47,126-135, aec_core.h:30-40) and stateCounter. */
+typedef struct AspAecPowerLevel {
+  float sfrsum;
+  int32_t sfrcounter;
+  float framelevel, frsum;
+  int32_t frcounter;
+  float minlevel, averagelevel;
+} AspAecPowerLevel;
+typedef struct AspAecStats {
+  float instant, average, min, max, sum, hisum, himean;
+  int32_t counter, hicounter;
+} AspAecStats;
+typedef struct AspAecMetricsState {
+  AspAecPowerLevel farlevel, nearlevel, linoutlevel, nlpoutlevel;
+  AspAecStats erl, erle, aNlp, rerl;
+  int32_t stateCounter;
+} AspAecMetricsState;
 
 /* Integer control plane shared by all streams of a batch (one Aec + the integer part of
  * AecCore), exposed for the parity tests. */
@@ -167,6 +186,10 @@ int AspAecBatch_num_bands(const AspAecBatch* b);
 int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, float* out,
                     int nrOfSamples, int num_frames, int msInSndCardBuf, int mem);
 int AspAecBatch_get_echo_status(AspAecBatch* b, int* status /* [num_streams] */);
+/* WebRtcAec_GetMetrics for every stream (echo_cancellation.c:456-548), out[num_streams]; metrics
+ * are gathered when set_config enabled metricsMode. */
+int AspAecBatch_GetMetrics(AspAecBatch* b, AecMetrics* out);
+int AspAecBatch_ExportMetricsState(AspAecBatch* b, int stream, AspAecMetricsState* out);
 int AspAecBatch_get_error_code(const AspAecBatch* b);
 int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out);
 int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in);

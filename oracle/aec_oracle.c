@@ -388,6 +388,7 @@ struct AspAecOracle {
   float farw[FAR_SLOTS][2 * PART_LEN1];
   float nearfr[FRBUF_LEN];
   float outfr[FRBUF_LEN];
+  AspAecMetricsState met; /* metricsMode = 1: core:548-770 */
   /* 32 kHz: one high band next to the low band (its rings move in lock-step with the low band's) */
   int num_bands;
   float nearfrH[FRBUF_LEN];
@@ -415,6 +416,110 @@ static int far_move_read(AspAecOracle* o, int elements) { /* WebRtcAec_MoveFarRe
   const int moved = rp_move_read(&o->far_pos, elements);
   o->system_delay -= moved * PART_LEN;
   return moved;
+}
+
+static void init_level(AspAecPowerLevel* l) { /* InitLevel, core:548-558 */
+  l->averagelevel = 0;
+  l->framelevel = 0;
+  l->minlevel = 1E17f;
+  l->frsum = 0;
+  l->sfrsum = 0;
+  l->frcounter = 0;
+  l->sfrcounter = 0;
+}
+static void init_stats(AspAecStats* s) { /* InitStats, core:560-570 */
+  s->instant = -100;
+  s->average = -100;
+  s->max = -100;
+  s->min = 100;
+  s->sum = 0;
+  s->hisum = 0;
+  s->himean = -100;
+  s->counter = 0;
+  s->hicounter = 0;
+}
+static void init_metrics(AspAecMetricsState* m) { /* InitMetrics, core:572-583 */
+  m->stateCounter = 0;
+  init_level(&m->farlevel);
+  init_level(&m->nearlevel);
+  init_level(&m->linoutlevel);
+  init_level(&m->nlpoutlevel);
+  init_stats(&m->erl);
+  init_stats(&m->erle);
+  init_stats(&m->aNlp);
+  init_stats(&m->rerl);
+}
+
+static void update_level(AspAecPowerLevel* level, float in[2][PART_LEN1]) { /* core:585-642 */
+  const int subCountLen = 4, countLen = 50;
+  float energy = (in[0][0] * in[0][0]) / 2;
+  energy += (in[0][PART_LEN] * in[0][PART_LEN]) / 2;
+  for (int k = 1; k < PART_LEN; k++) energy += (in[0][k] * in[0][k] + in[1][k] * in[1][k]);
+  energy /= PART_LEN2;
+  level->sfrsum += energy;
+  level->sfrcounter++;
+  if (level->sfrcounter > subCountLen) {
+    level->framelevel = level->sfrsum / (subCountLen * PART_LEN);
+    level->sfrsum = 0;
+    level->sfrcounter = 0;
+    if (level->framelevel > 0) {
+      if (level->framelevel < level->minlevel) {
+        level->minlevel = level->framelevel;
+      } else {
+        level->minlevel *= (1 + 0.001f);
+      }
+    }
+    level->frcounter++;
+    level->frsum += level->framelevel;
+    if (level->frcounter > countLen) {
+      level->averagelevel = level->frsum / countLen;
+      level->frsum = 0;
+      level->frcounter = 0;
+    }
+  }
+}
+
+static void stats_add(AspAecStats* st, float instant, float dtmp) { /* the repeated block of core:689-705 */
+  st->instant = instant;
+  if (dtmp > st->max) st->max = dtmp;
+  if (dtmp < st->min) st->min = dtmp;
+  st->counter++;
+  st->sum += dtmp;
+  st->average = st->sum / st->counter;
+  if (dtmp > st->average) {
+    st->hicounter++;
+    st->hisum += dtmp;
+    st->himean = st->hisum / st->hicounter;
+  }
+}
+
+static void update_metrics(AspAecMetricsState* m, int echoState) { /* core:644-770 */
+  const int subCountLen = 4, countLen = 50;
+  const float actThresholdNoisy = 8.0f, actThresholdClean = 40.0f, safety = 0.99995f;
+  const float noisyPower = 300000.0f;
+  float dtmp, dtmp2, actThreshold, echo, suppressedEcho;
+  if (echoState) m->stateCounter++;
+  if (m->farlevel.frcounter == 0) {
+    actThreshold = m->farlevel.minlevel < noisyPower ? actThresholdClean : actThresholdNoisy;
+    if ((m->stateCounter > (0.5f * countLen * subCountLen)) && (m->farlevel.sfrcounter == 0) &&
+        (m->farlevel.averagelevel > (actThreshold * m->farlevel.minlevel))) {
+      echo = m->nearlevel.averagelevel - safety * m->nearlevel.minlevel;
+      dtmp = 10 * (float)log10(m->farlevel.averagelevel / m->nearlevel.averagelevel + 1e-10f);
+      dtmp2 = 10 * (float)log10(m->farlevel.averagelevel / echo + 1e-10f);
+      (void)dtmp2;
+      stats_add(&m->erl, dtmp, dtmp); /* ERL */
+      dtmp = 10 * (float)log10(m->nearlevel.averagelevel / (2 * m->linoutlevel.averagelevel) + 1e-10f);
+      suppressedEcho = 2 * (m->linoutlevel.averagelevel - safety * m->linoutlevel.minlevel);
+      dtmp2 = 10 * (float)log10(echo / suppressedEcho + 1e-10f);
+      stats_add(&m->aNlp, dtmp2, dtmp); /* A_NLP: instant takes dtmp2, the statistics dtmp (core:714-729) */
+      suppressedEcho = 2 * (m->nlpoutlevel.averagelevel - safety * m->nlpoutlevel.minlevel);
+      dtmp = 10 * (float)log10(m->nearlevel.averagelevel / (2 * m->nlpoutlevel.averagelevel) + 1e-10f);
+      dtmp2 = 10 * (float)log10(echo / suppressedEcho + 1e-10f);
+      dtmp = dtmp2;
+      stats_add(&m->erle, dtmp, dtmp); /* ERLE */
+    }
+    m->stateCounter = 0;
+  }
 }
 
 static void init_core(AspAecOracle* o, int sampFreq) { /* WebRtcAec_InitAec, core:1460-1615 */
@@ -461,6 +566,7 @@ static void init_core(AspAecOracle* o, int sampFreq) { /* WebRtcAec_InitAec, cor
   s->xfBufBlockPos = 0;
   s->noiseEstCtr = 0;
   o->metricsMode = 0;
+  init_metrics(&o->met);
   o->blocks_processed = 0;
 }
 
@@ -487,12 +593,14 @@ int asp_aec_oracle_set_config(AspAecOracle* o, AecConfig config) { /* ec:410-438
     o->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
   }
-  if (config.skewMode || config.metricsMode || config.delay_logging) {
+  if (config.skewMode || config.delay_logging) {
     /* outside the covered configuration (header) */
     o->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
     return -1;
   }
-  o->nlp_mode = config.nlpMode; /* WebRtcAec_SetConfigCore, core:1844-1858 */
+  o->nlp_mode = config.nlpMode; /* WebRtcAec_SetConfigCore, core:1844-1862 */
+  o->metricsMode = config.metricsMode;
+  if (o->metricsMode) init_metrics(&o->met);
   return 0;
 }
 
@@ -819,6 +927,8 @@ static void nonlinear_processing(AspAecOracle* o, float* output, float* outputH,
     }
   }
 
+  if (o->metricsMode == 1) update_level(&o->met.nlpoutlevel, efw); /* core:1000-1006 */
+
   /* inverse error fft, overlap-add, saturate: core:1006-1030 */
   fft[0] = efw[0][0];
   fft[1] = efw[0][PART_LEN];
@@ -968,6 +1078,8 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
   asp_aec_oracle_rdft128(fft, 1);
   unpack_spectrum(fft, ef);
 
+  if (o->metricsMode == 1) update_level(&o->met.linoutlevel, ef); /* core:1258-1263 */
+
   { /* ScaleErrorSignal, core:171-193 */
     const float mu = o->normal_mu, error_threshold = o->normal_error_threshold;
     for (i = 0; i < PART_LEN1; i++) {
@@ -1017,6 +1129,11 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
   {
     float outputH[PART_LEN];
     nonlinear_processing(o, output, outputH, noisePow);
+    if (o->metricsMode == 1) { /* core:1270-1275 */
+      update_level(&o->met.farlevel, xf);
+      update_level(&o->met.nearlevel, df);
+      update_metrics(&o->met, s->echoState);
+    }
     if (o->num_bands > 1) { /* core:1280-1282 */
       RingPos keep = o->out_pos;
       ring_write(&keep, o->outfrH, 1, outputH, PART_LEN);
@@ -1205,6 +1322,35 @@ int asp_aec_oracle_process_bands(AspAecOracle* o, const float* nearend, const fl
 }
 
 int asp_aec_oracle_echo_status(const AspAecOracle* o) { return o->st.echoState; }
+void asp_aec_oracle_export_metrics(const AspAecOracle* o, AspAecMetricsState* m) { *m = o->met; }
+
+static void level_of(const AspAecStats* s, AecLevel* out) { /* ec:479-494 */
+  const float kUpWeight = 0.7f;
+  out->instant = (int)s->instant;
+  if ((s->himean > -100) && (s->average > -100)) {
+    const float dtmp = kUpWeight * s->himean + (1 - kUpWeight) * s->average;
+    out->average = (int)dtmp;
+  } else {
+    out->average = -100;
+  }
+  out->max = (int)s->max;
+  out->min = s->min < 100 ? (int)s->min : -100;
+}
+
+int asp_aec_oracle_get_metrics(const AspAecOracle* o, AecMetrics* metrics) { /* WebRtcAec_GetMetrics, ec:456-548 */
+  int stmp;
+  level_of(&o->met.erl, &metrics->erl);
+  level_of(&o->met.erle, &metrics->erle);
+  stmp = (metrics->erl.average > -100 && metrics->erle.average > -100)
+             ? metrics->erl.average + metrics->erle.average
+             : -100;
+  metrics->rerl.average = stmp;
+  metrics->rerl.instant = stmp;
+  metrics->rerl.max = stmp;
+  metrics->rerl.min = stmp;
+  level_of(&o->met.aNlp, &metrics->aNlp);
+  return 0;
+}
 int asp_aec_oracle_error_code(const AspAecOracle* o) { return o->lastError; }
 
 void asp_aec_oracle_export(const AspAecOracle* o, AspAecState* st, AspAecControl* c) {

@@ -33,6 +33,8 @@ int asp_aec_oracle_process_bands(AspAecOracle* o, const float* nearend, const fl
                                  int32_t skew);
 int asp_aec_oracle_echo_status(const AspAecOracle* o);
 int asp_aec_oracle_error_code(const AspAecOracle* o);
+void asp_aec_oracle_export_metrics(const AspAecOracle* o, AspAecMetricsState* m);
+int asp_aec_oracle_get_metrics(const AspAecOracle* o, AecMetrics* metrics); /* ec:456-548 */
 void asp_aec_oracle_export(const AspAecOracle* o, AspAecState* st, AspAecControl* ctl);
 void asp_aec_oracle_import(AspAecOracle* o, const AspAecState* st);
 /* test_aec_module.cpp:75-88 for one stream: F x (BufferFarend(far, n) + Process(near, n, delay)).

@@ -62,6 +62,49 @@ int ref_aec_frame(void* h, const float* far, const float* near, float* out, int 
   return rc;
 }
 
+int ref_aec_set_config(void* h, int mode, int metrics) {
+  AecConfig c;
+  c.nlpMode = (int16_t)mode;
+  c.skewMode = kAecFalse;
+  c.metricsMode = (int16_t)metrics;
+  c.delay_logging = kAecFalse;
+  return WebRtcAec_set_config(h, c);
+}
+
+static void copy_level(AspAecPowerLevel* d, const PowerLevel* s) {
+  d->sfrsum = s->sfrsum;
+  d->sfrcounter = s->sfrcounter;
+  d->framelevel = s->framelevel;
+  d->frsum = s->frsum;
+  d->frcounter = s->frcounter;
+  d->minlevel = s->minlevel;
+  d->averagelevel = s->averagelevel;
+}
+static void copy_stats(AspAecStats* d, const Stats* s) {
+  d->instant = s->instant;
+  d->average = s->average;
+  d->min = s->min;
+  d->max = s->max;
+  d->sum = s->sum;
+  d->hisum = s->hisum;
+  d->himean = s->himean;
+  d->counter = s->counter;
+  d->hicounter = s->hicounter;
+}
+void ref_aec_export_metrics(void* h, AspAecMetricsState* m) {
+  const AecCore* k = ((const Aec*)h)->aec;
+  copy_level(&m->farlevel, &k->farlevel);
+  copy_level(&m->nearlevel, &k->nearlevel);
+  copy_level(&m->linoutlevel, &k->linoutlevel);
+  copy_level(&m->nlpoutlevel, &k->nlpoutlevel);
+  copy_stats(&m->erl, &k->erl);
+  copy_stats(&m->erle, &k->erle);
+  copy_stats(&m->aNlp, &k->aNlp);
+  copy_stats(&m->rerl, &k->rerl);
+  m->stateCounter = k->stateCounter;
+}
+int ref_aec_get_metrics(void* h, AecMetrics* m) { return WebRtcAec_GetMetrics(h, m); }
+
 int ref_aec_set_nlp(void* h, int mode) {
   AecConfig c;
   c.nlpMode = (int16_t)mode;

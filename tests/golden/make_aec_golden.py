@@ -7,6 +7,11 @@ plain-C path forced).  Build-container only.  The reference ships no vectors for
   far_i16, near_i16 [F][S][160] int16   synthetic far / near-end PCM (SURVEY 8(d) generator)
   out_f32           [F][S][160] float32 WebRtcAec_BufferFarend + WebRtcAec_Process output
                                         (msInSndCardBuf = 0, skew = 0, test_aec_module.cpp:67-88)
+  met_state_u32     [2][S][65] uint32   AecCore's PowerLevel x 4 / Stats x 4 / stateCounter image
+                                        (include/asp_aec.h: AspAecMetricsState) after frames 350 and
+                                        700 of the same run repeated with metricsMode = kAecTrue
+  met_levels_i32    [2][S][16] int32    WebRtcAec_GetMetrics at the same two points: rerl, erl, erle,
+                                        aNlp x (instant, average, max, min)
 """
 import ctypes as C
 import os
@@ -31,8 +36,22 @@ def main():
     for s in range(S):
         r = RefAec()
         out[:, s] = r.run(far[:, s].astype(np.float32), near[:, s].astype(np.float32))
+    met_state = np.zeros((2, S, 65), np.uint32)
+    met_levels = np.zeros((2, S, 16), np.int32)
+    for s in range(S):
+        r = RefAec()
+        assert r.set_nlp(1, metrics=1) == 0
+        for f in range(F):
+            o, rc = r.frame(far[f, s].astype(np.float32), near[f, s].astype(np.float32))
+            assert rc == 0 and np.array_equal(o.view(np.uint32), out[f, s].view(np.uint32))
+            if f + 1 in (F // 2, F):
+                k = 0 if f + 1 == F // 2 else 1
+                met_state[k, s] = r.metrics_state().to_array()
+                met_levels[k, s] = r.get_metrics().to_tuple()
     path = os.path.join(ROOT, "tests", "golden", "aec_golden.npz")
-    np.savez_compressed(path, far_i16=far, near_i16=near, out_f32=out)
+    np.savez_compressed(path, far_i16=far, near_i16=near, out_f32=out, met_state_u32=met_state,
+                        met_levels_i32=met_levels)
+    print("metrics after %d frames:" % F, met_levels[1].tolist())
     # echo return loss enhancement over the double-talk-free loud far-end stretch, for the record
     seg = slice(160, 290)
     e_in = (near[seg].astype(np.float64) ** 2).mean()

@@ -170,8 +170,55 @@ def test_oracle_error_behaviour():
     assert oracle_lib.OracleAec(44100).init_rc == -1
     assert oracle_lib.OracleAec(16000, sc_fs=0).init_rc == -1
     assert o.set_nlp(3) == -1 and o.error_code() == 12004
-    assert o.set_nlp(1, metrics=1) == -1 and o.error_code() == 12001   # outside the built configuration
+    assert o.set_nlp(1, skew=1) == -1 and o.error_code() == 12001      # outside the built configuration
+    assert o.set_nlp(1, delay_logging=1) == -1 and o.error_code() == 12001
+    assert o.set_nlp(1, metrics=2) == -1 and o.error_code() == 12004
+    assert o.set_nlp(1, metrics=1) == 0
     assert o.set_nlp(2) == 0
+
+
+def test_oracle_metrics_reproduce_golden(aec_golden):
+    """metricsMode = kAecTrue: UpdateLevel / UpdateMetrics / WebRtcAec_GetMetrics (aec_core.c:585-770,
+    echo_cancellation.c:456-548) against the reference's own values in the fixture, bit for bit."""
+    far, near = aec_golden["far_i16"].astype(np.float32), aec_golden["near_i16"].astype(np.float32)
+    F, S = far.shape[:2]
+    for s in range(S):
+        o = oracle_lib.OracleAec(16000)
+        assert o.set_nlp(1, metrics=1) == 0
+        for f in range(F):
+            out, rc = o.frame(far[f, s], near[f, s])
+            assert rc == 0
+            if f + 1 in (F // 2, F):
+                k = 0 if f + 1 == F // 2 else 1
+                assert np.array_equal(o.metrics_state().to_array(), aec_golden["met_state_u32"][k, s])
+                assert o.get_metrics().to_tuple() == tuple(aec_golden["met_levels_i32"][k, s])
+        assert np.array_equal(_bits(out), _bits(aec_golden["out_f32"][F - 1, s]))   # metrics do not touch the audio
+    assert aec_golden["met_levels_i32"][1, :, 8].min() > 5                        # the fixture's ERLE is a real one
+
+
+@needs_ref
+def test_oracle_metrics_equal_reference_live():
+    """Every frame of a bursty far end with a synthetic echo path: the metrics image never differs."""
+    rng = np.random.default_rng(5)
+    F = 900
+    far = (rng.standard_normal((F, 160)) * 3000).astype(np.float32)
+    far *= np.repeat((rng.random(F // 20) > 0.3).astype(np.float32), 20)[:, None] * 0.98 + 0.02
+    h = (rng.standard_normal(200) * np.exp(-np.arange(200) / 40)).astype(np.float32) * 0.3
+    near = np.convolve(far.reshape(-1), h)[:F * 160].astype(np.float32)
+    near = (near + rng.standard_normal(F * 160).astype(np.float32) * 30).reshape(F, 160)
+    r, o = oracle_lib.RefAec(16000), oracle_lib.OracleAec(16000)
+    assert r.set_nlp(2, metrics=1) == 0 and o.set_nlp(2, metrics=1) == 0
+    for f in range(F):
+        a, _ = r.frame(far[f], near[f], 40)
+        b, _ = o.frame(far[f], near[f], 40)
+        assert np.array_equal(_bits(a), _bits(b))
+        assert np.array_equal(r.metrics_state().to_array(), o.metrics_state().to_array()), f
+    assert r.get_metrics().to_tuple() == o.get_metrics().to_tuple()
+    assert o.metrics_state().erle.counter > 3
+    # a second set_config restarts the statistics (aec_core.c:1858-1861)
+    assert r.set_nlp(2, metrics=1) == 0 and o.set_nlp(2, metrics=1) == 0
+    assert np.array_equal(r.metrics_state().to_array(), o.metrics_state().to_array())
+    assert o.metrics_state().erle.counter == 0
 
 
 def test_oracle_threaded_runner_matches_single(aec_golden):
