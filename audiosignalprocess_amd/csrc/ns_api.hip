@@ -181,6 +181,20 @@ void build_tables(NsTables* T) {
   T->sum_log_i = sli;
   T->sum_log_i_square = slis;
   for (int j = 0; j < 64; ++j) T->exp2_64[j] = exp2((double)j / 64.0);
+  // log table: sub-interval i covers the float bit patterns [kLogOff + i 2^16, kLogOff + (i+1) 2^16);
+  // c is its centre (exactly 1 for the interval around 1.0), invc = 1/c rounded to double and
+  // log c = -log(invc) of that rounded value, both through long double
+  for (int i = 0; i < 128; ++i) {
+    const uint32_t b0 = 0x3f328000u + ((uint32_t)i << 16), b1 = b0 + (1u << 16);
+    float f0, f1;
+    memcpy(&f0, &b0, 4);
+    memcpy(&f1, &b1, 4);
+    long double c = ((long double)f0 + (long double)f1) / 2;
+    if (f0 < 1.0f && f1 > 1.0f) c = 1.0L;
+    const double invc = (double)(1.0L / c);
+    T->logtab[i][0] = invc;
+    T->logtab[i][1] = c == 1.0L ? 0.0 : (double)(-logl((long double)invc));
+  }
   // full-butterfly twiddles of the two-streams-per-wave kernel: block index B of pass 0/1/2 is
   // lane, lane >> 2, lane >> 4 (same twiddle cases as above, fft4g.c:1008-1102 / 1114-1229)
   for (int pass = 0; pass < 3; ++pass)

@@ -228,6 +228,42 @@ __device__ __forceinline__ float log_f32_via_f64(float x) {
   return r;
 }
 
+// Table-driven (float)log((double)x), same contract as log_f32_via_f64 (identical to the ocml form
+// for every float, tests/test_ns_gpu.py) at about half the instructions:
+//   x = 2^k z with z's bit pattern in [kLogOff, kLogOff + 2^23) (z in [0.697, 1.394));
+//   the top 7 pattern bits pick c = 1 / invc (centre of the sub-interval; exactly 1 for the one
+//   around 1.0), r = z invc - 1 in one fused step (|r| <= 2^-8), and
+//   log x = k ln2 + log c + (r - r^2/2 + ... - r^6/6), truncation < 2^-50 of the result.
+// tab[i] = {invc, log c} is built on the host in long double (ns_api.hip).
+constexpr unsigned kLogOff = 0x3f328000u;
+__device__ __forceinline__ double log_tab_f64(float x, const double2* __restrict__ tab) {
+  const unsigned ix = __float_as_uint(x);
+  const unsigned tmp = ix - kLogOff;
+  const int i = (tmp >> 16) & 127;
+  const int k = (int)tmp >> 23;  // arithmetic
+  const double z = (double)__uint_as_float(ix - (tmp & 0xff800000u));
+  const double2 t = tab[i];
+  const double r = __builtin_fma(z, t.x, -1.0);
+  const double kd = (double)k;
+  double p = -1.0 / 6.0;
+  p = __builtin_fma(p, r, 1.0 / 5.0);
+  p = __builtin_fma(p, r, -1.0 / 4.0);
+  p = __builtin_fma(p, r, 1.0 / 3.0);
+  p = __builtin_fma(p, r, -0.5);
+  const double hi = __builtin_fma(kd, 0x1.62e42fefa38p-1, t.y);   // 41-bit ln2 head: k ln2_hi exact
+  const double lo = __builtin_fma(kd, 0x1.ef35793c7673p-45, __builtin_fma(r * r, p, r));
+  return hi + lo;
+}
+__device__ __forceinline__ float log_f32_via_tab(float x, const double2* __restrict__ tab) {
+  const unsigned ax = __float_as_uint(x);
+  const bool normal_pos = (ax - 0x00800000u) < 0x7f000000u;  // [2^-126, inf)
+  const double y = log_tab_f64(normal_pos ? x : 1.0f, tab);
+  const bool ok = normal_pos && f64_rounds_safely_to_f32(y);
+  float r = (float)y;
+  if (__builtin_expect(!ok, 0)) r = (float)log((double)x);
+  return r;
+}
+
 // ---- lean fp64 forms of the echo canceller's float transcendentals (aec_core.c:280, 487-488) ----
 // Each returns exactly what its plain form `(float)f((double)x)` (ocml fp64, rounded) returns: the
 // lean evaluation is accurate to ~2^-46, the float rounding is taken from it only when the fp64

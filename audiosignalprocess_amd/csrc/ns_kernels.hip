@@ -815,8 +815,10 @@ __global__ void ns_set_policy_kernel(float* __restrict__ state, int num_streams,
 // 1 = (float)log((double)x), 2 = (float)exp((double)x), 3 = (float)tanh((double)x),
 // 4..8 division forms, 9/10 sqrtf / fsqrt, 11/12 the kernels' exp / tanh.
 __device__ __forceinline__ float debug_fn(int fn, float x, float param,
-                                          const double* __restrict__ t64) {
+                                          const double* __restrict__ t64,
+                                          const double2* __restrict__ logtab) {
   switch (fn) {
+    case 19: return log_f32_via_tab(x, logtab);
     case 9: return sqrtf(x);
     case 10: return fsqrt(x);
     case 11: return exp_f32_via_f64(x, t64);
@@ -842,7 +844,7 @@ __device__ __forceinline__ float debug_fn(int fn, float x, float param,
 __global__ void debug_eval_kernel(int fn, float* data, size_t n,
                                   const NsTables* __restrict__ T) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) data[i] = debug_fn(fn, data[i], 1.0f, T->exp2_64);
+  if (i < n) data[i] = debug_fn(fn, data[i], 1.0f, T->exp2_64, reinterpret_cast<const double2*>(T->logtab));
 }
 // Compares fn_a and fn_b on every float whose bit pattern is in [start, start+count).
 __global__ void debug_compare_kernel(int fn_a, int fn_b, unsigned start, unsigned count,
@@ -851,7 +853,8 @@ __global__ void debug_compare_kernel(int fn_a, int fn_b, unsigned start, unsigne
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const float x = __uint_as_float(start + i);
-  const float a = debug_fn(fn_a, x, param, T->exp2_64), b = debug_fn(fn_b, x, param, T->exp2_64);
+  const double2* lt = reinterpret_cast<const double2*>(T->logtab);
+  const float a = debug_fn(fn_a, x, param, T->exp2_64, lt), b = debug_fn(fn_b, x, param, T->exp2_64, lt);
   const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
   if (!same) {
     const unsigned k = atomicAdd(n_bad, 1u);

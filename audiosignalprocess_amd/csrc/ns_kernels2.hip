@@ -202,10 +202,12 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   // per workgroup: the passes would otherwise stall on a table load from L2 each
   __shared__ __align__(16) float tabs[3 * 32 * 8 + 32 * 4 * 2];
   __shared__ __align__(16) double exp2s[64];  // 2^(j/64) of the lean exp / tanh
+  __shared__ __align__(16) double2 logts[128];  // {1/c, log c} of the table-driven log
   {
     const float4* src = reinterpret_cast<const float4*>(&T->tw2[0][0][0]);
     reinterpret_cast<float4*>(tabs)[threadIdx.x] = src[threadIdx.x];  // 256 x 16 B = the 4 KB
     if (threadIdx.x < 64) exp2s[threadIdx.x] = T->exp2_64[threadIdx.x];
+    if (threadIdx.x >= 128) logts[threadIdx.x - 128] = reinterpret_cast<const double2*>(T->logtab)[threadIdx.x - 128];
   }
   __syncthreads();
   const float* tw2s = tabs;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
 
   float lmagn[NS5];
 #pragma unroll
-  for (int k = 0; k < NS5; ++k) lmagn[k] = log_f32_via_f64(magn[k]);
+  for (int k = 0; k < NS5; ++k) lmagn[k] = log_f32_via_tab(magn[k], logts);
 
   NS_STAMP(3)
   float signalEnergy, sumMagn;
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
     const float t1 = 1.f + 2.f * snrLocPrior[k];
     const float t2 = fdiv(2.f * snrLocPrior[k], t1 + 0.0001f);
     const float besselTmp = (snrLocPost[k] + 1.f) * t2;
-    logLrt[k] += NS_LRT_TAVG * (besselTmp - log_f32_via_f64(t1) - logLrt[k]);
+    logLrt[k] += NS_LRT_TAVG * (besselTmp - log_f32_via_tab(t1, logts) - logLrt[k]);
   }
   float logLrtTimeAvgKsum = half_sum(PART5(logLrt));
   logLrtTimeAvgKsum = DIV129(logLrtTimeAvgKsum);

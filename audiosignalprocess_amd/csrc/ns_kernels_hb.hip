@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void ns_hb_apply_kernel(const float* __restric
                                                           const float* __restrict__ in_high,
                                                           float* __restrict__ out_high,
                                                           int num_streams, int num_high, int paired) {
-  __shared__ float lds[4][2 * 132 + 64];
+  // per wave: speechProb[32] | smooth[32] | magnPrevAnalyze[132] | magnPrevProcess[132] | 4 sums
+  constexpr int kSums = 64 + 2 * 132;
+  __shared__ float lds[4][kSums + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int stream = blockIdx.x * 4 + wave;
   if (stream >= num_streams) return;
@@ -89,15 +91,15 @@ __global__ __launch_bounds__(256) void ns_hb_apply_kernel(const float* __restric
 #pragma unroll 8
         for (int j = 0; j < kBins; ++j) acc += src[j];
       }
-      l[64 + 2 * 132 + lane] = acc;
+      l[kSums + lane] = acc;
     }
     wave_lds_fence();
-    float avgProbSpeechHB = l[64 + 2 * 132 + 0] / 32.0f;                // ns_core.c:1367-1371
+    float avgProbSpeechHB = l[kSums + 0] / 32.0f;                // ns_core.c:1367-1371
     if (!paired) {
       // paired state: magnPrevProcess is magnPrevAnalyze, the ratio is exactly 1
-      avgProbSpeechHB *= l[64 + 2 * 132 + 3] / l[64 + 2 * 132 + 2];     // :1375-1381
+      avgProbSpeechHB *= l[kSums + 3] / l[kSums + 2];     // :1375-1381
     }
-    const float avgFilterGainHB = l[64 + 2 * 132 + 1] / 32.0f;          // :1384-1388
+    const float avgFilterGainHB = l[kSums + 1] / 32.0f;          // :1384-1388
     const float tmp = 2.f * avgProbSpeechHB - 1.f;
     const float gainModHB = 0.5f * (1.f + tanh_f32_via_f64(1.0f * tmp, T->exp2_64));  // :1391
     gain = 0.5f * gainModHB + 0.5f * avgFilterGainHB;

@@ -78,6 +78,9 @@ struct NsTables {
   // two-streams-per-wave kernel (ns_kernels2.hip): one full butterfly per lane and pass
   float tw2[3][32][8];        // (w1r, w1i, w2r, w2i, w3r, w3i, diag, 0)
   float spl[32][4][2];        // real-split (wkr, wki) of element (lane & 15) + 16 t + 64 (lane >> 4)
+  double logtab[128][2];      // {1/c, log c} of the table-driven log (ns_device.h: log_tab_f64)
 };
+
+static_assert(__builtin_offsetof(NsTables, logtab) % 16 == 0, "logtab is read as double2");
 
 }  // namespace aspns

@@ -306,15 +306,18 @@ def _debug_compare(lib, fn_a, fn_b, start, count, param=1.0):
     return n_bad.value, [bad[i] for i in range(min(n_bad.value, 64))]
 
 
-def test_device_log_exhaustive_vs_libm_form(ns):
-    """The kernels' lean (float)log((double)x) equals the libm-based form for EVERY positive
-    float bit pattern (normal, denormal, inf) -- 2^31 inputs, checked on the device."""
+@pytest.mark.parametrize("form", [0, 19])
+def test_device_log_exhaustive_vs_libm_form(ns, form):
+    """The kernels' lean (float)log((double)x) -- form 0: the series form (ns_device.h:
+    log_f32_via_f64, also inside the AEC's pow), form 19: the table-driven form of the NS frame
+    kernel (log_f32_via_tab) -- equals the libm-based form for EVERY positive float bit pattern
+    (normal, denormal, inf): 2^31 inputs, checked on the device."""
     lib = ns.load_library()
     total_bad, examples = 0, []
     step = 1 << 28
     for start in range(0x00000000, 0x7f800001, step):
         count = min(step, 0x7f800001 - start)
-        n, ex = _debug_compare(lib, 0, 1, start, count)
+        n, ex = _debug_compare(lib, form, 1, start, count)
         total_bad += n
         examples += ex
     assert total_bad == 0, [hex(b) for b in examples[:8]]
