@@ -17,6 +17,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
          "-Wall", "-Wno-unused-function"]
 
 
+# per-file extras; ASP_HIPCC_EXTRA="file.hip:-flag -flag;other.hip:-flag" adds more (experiments)
+# kernarg preload (gfx950): the dispatch arrives with its arguments in SGPRs instead of fetching them
+# with dependent scalar loads before the first vector load can issue (-0.5 us per NS step, measured);
+# the object carries a prologue for firmware without the feature
+_PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=8"]
+EXTRA = {"ns_kernels2.hip": list(_PRELOAD), "ns_kernels.hip": list(_PRELOAD)}
+for _item in filter(None, os.environ.get("ASP_HIPCC_EXTRA", "").split(";")):
+    _f, _, _fl = _item.partition(":")
+    EXTRA.setdefault(_f.strip(), []).extend(_fl.split())
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -42,7 +53,7 @@ def build_library(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
         if force or _stale(o, deps):
-            cmd = [hipcc()] + FLAGS + inc + ["-c", s, "-o", o]
+            cmd = [hipcc()] + FLAGS + EXTRA.get(os.path.basename(s), []) + inc + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)

@@ -43,7 +43,12 @@ __device__ __forceinline__ float half_sum(float v) {
   v = v + dpp_move<0x4E>(v);
   v = v + dpp_move<0x141>(v);
   v = v + dpp_move<0x140>(v);
-  return v + swz_xor16(v);
+  // xor 16: v_permlane16_swap (gfx950) trades rows 1 <-> 0 and 3 <-> 2 of two copies, so one copy
+  // ends up holding the even row's value on both rows of a pair and the other the odd row's; their
+  // sum is own + partner on every lane (the addition commutes) without a trip through the LDS pipe
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 __device__ __forceinline__ void lds_sync() {
@@ -203,21 +208,23 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   __shared__ __align__(16) float tabs[3 * 32 * 8 + 32 * 4 * 2];
   __shared__ __align__(16) double exp2s[64];  // 2^(j/64) of the lean exp / tanh
   __shared__ __align__(16) double2 logts[128];  // {1/c, log c} of the table-driven log
-  {
-    const float4* src = reinterpret_cast<const float4*>(&T->tw2[0][0][0]);
-    reinterpret_cast<float4*>(tabs)[threadIdx.x] = src[threadIdx.x];  // 256 x 16 B = the 4 KB
-    if (threadIdx.x < 64) exp2s[threadIdx.x] = T->exp2_64[threadIdx.x];
-    if (threadIdx.x >= 128) logts[threadIdx.x - 128] = reinterpret_cast<const double2*>(T->logtab)[threadIdx.x - 128];
-  }
-  __syncthreads();
-  const float* tw2s = tabs;
-  const float* spls = tabs + 3 * 32 * 8;
+  __shared__ __align__(16) float wins[kAnal];    // the window, for the synthesis side (ns_core.c:1344-1349)
+  // Prologue: every load of the step's first phase is issued before the first wait -- the three
+  // table pieces first (loads return in order, so the LDS staging waits for them only), then the
+  // stream's scalars, samples and first group of state rows, which stay in flight across the
+  // staging barrier.  Waves past the last stream load from the last pair's addresses and exit
+  // after the barrier.
+  const float4 tab_v = reinterpret_cast<const float4*>(&T->tw2[0][0][0])[threadIdx.x];  // 256 x 16 B
+  const double exp2_v = T->exp2_64[threadIdx.x & 63];
+  const double2 logt_v = reinterpret_cast<const double2*>(T->logtab)[threadIdx.x & 127];
+  const float4 win_v = reinterpret_cast<const float4*>(T->window)[threadIdx.x & 63];
   const int lane = threadIdx.x & 63;
   const int lam = lane & 31, hb = lane & 32;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.x * 4 + wv;
-  if (2 * pair >= num_streams) return;
-  const int stream = 2 * pair + (lane >> 5);
+  const bool pair_live = 2 * pair < num_streams;
+  const int stream_raw = 2 * pair + (lane >> 5);
+  const int stream = stream_raw < num_streams ? stream_raw : num_streams - 1;  // clamped for the loads
   float* __restrict__ st = state + (size_t)stream * kStreamDwords;
   float* __restrict__ vec = st + kOffVec;
   int32_t* __restrict__ hist = hist_all + (size_t)stream * kHistDwords;
@@ -239,26 +246,29 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   // ---- sliding analysis buffer [96 carried | 160 new]: lane L owns samples 8L .. 8L+7
   float* hbuf = st + kOffAnaHist;
   float s8[8];
-  if (lam < 12 || !IO16) {
+  if (!IO16) {
     const float* src = lam < 12 ? hbuf + 8 * lam : in + (size_t)stream * kBlockL + (8 * lam - 96);
     const float4 a = *reinterpret_cast<const float4*>(src);
     const float4 b = *reinterpret_cast<const float4*>(src + 4);
     s8[0] = a.x; s8[1] = a.y; s8[2] = a.z; s8[3] = a.w;
     s8[4] = b.x; s8[5] = b.y; s8[6] = b.z; s8[7] = b.w;
   } else {
-    const short* in16 = reinterpret_cast<const short*>(in) + (size_t)stream * kBlockL + (8 * lam - 96);
+    // both sources are read by every lane (clamped), the lane keeps its own: no branch, no wait
+    const int lh = lam < 12 ? lam : 11, li = lam < 12 ? 12 : lam;
+    const float4 ha = *reinterpret_cast<const float4*>(hbuf + 8 * lh);
+    const float4 hb4 = *reinterpret_cast<const float4*>(hbuf + 8 * lh + 4);
+    const short* in16 = reinterpret_cast<const short*>(in) + (size_t)stream * kBlockL + (8 * li - 96);
     const short4 a = *reinterpret_cast<const short4*>(in16);
     const short4 b = *reinterpret_cast<const short4*>(in16 + 4);
-    s8[0] = (float)a.x; s8[1] = (float)a.y; s8[2] = (float)a.z; s8[3] = (float)a.w;
-    s8[4] = (float)b.x; s8[5] = (float)b.y; s8[6] = (float)b.z; s8[7] = (float)b.w;
+    const bool hsel = lam < 12;
+    s8[0] = hsel ? ha.x : (float)a.x; s8[1] = hsel ? ha.y : (float)a.y;
+    s8[2] = hsel ? ha.z : (float)a.z; s8[3] = hsel ? ha.w : (float)a.w;
+    s8[4] = hsel ? hb4.x : (float)b.x; s8[5] = hsel ? hb4.y : (float)b.y;
+    s8[6] = hsel ? hb4.z : (float)b.z; s8[7] = hsel ? hb4.w : (float)b.w;
   }
-  float wx[8];
-  {
-    const float4 wa = *reinterpret_cast<const float4*>(T->window + 8 * lam);
-    const float4 wb = *reinterpret_cast<const float4*>(T->window + 8 * lam + 4);
-    wx[0] = wa.x * s8[0]; wx[1] = wa.y * s8[1]; wx[2] = wa.z * s8[2]; wx[3] = wa.w * s8[3];
-    wx[4] = wb.x * s8[4]; wx[5] = wb.y * s8[5]; wx[6] = wb.z * s8[6]; wx[7] = wb.w * s8[7];
-  }
+  const float4 wa = *reinterpret_cast<const float4*>(T->window + 8 * lam);
+  const float4 wb = *reinterpret_cast<const float4*>(T->window + 8 * lam + 4);
+  // (pinning these ahead of the state rows below with a scheduling barrier measured 5 % slower)
 
 #define LOAD5(dst, f)                                                        \
   {                                                                          \
@@ -275,12 +285,25 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   LOAD5(LQ[0], V_LQ0) LOAD5(LQ[1], V_LQ1) LOAD5(LQ[2], V_LQ2)
   LOAD5(DEN[0], V_DEN0) LOAD5(DEN[1], V_DEN1) LOAD5(DEN[2], V_DEN2)
   LOAD5(quant, V_QUANT)
-  // syntBuf[0..95]: lanes < 16 own samples 2q + 32 t (t = 0..2)
+  // syntBuf[0..95]: lanes < 16 own samples 2q + 32 t (t = 0..2); every lane loads (no branch, no
+  // wait here), the overlap-add uses the owners' values only
   float2 carry[3];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
-    carry[t] = g == 0 ? *reinterpret_cast<const float2*>(st + kOffSynt + 2 * q + 32 * t)
-                      : make_float2(0.f, 0.f);
+  for (int t = 0; t < 3; ++t) carry[t] = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * q + 32 * t);
+
+  // ---- table staging (the loads above are in flight behind it)
+  reinterpret_cast<float4*>(tabs)[threadIdx.x] = tab_v;
+  if (threadIdx.x < 64) exp2s[threadIdx.x] = exp2_v;
+  if (threadIdx.x < 128) logts[threadIdx.x] = logt_v;
+  if (threadIdx.x >= 192) reinterpret_cast<float4*>(wins)[threadIdx.x - 192] = win_v;
+  __syncthreads();
+  if (!pair_live) return;
+  const float* tw2s = tabs;
+  const float* spls = tabs + 3 * 32 * 8;
+
+  float wx[8];
+  wx[0] = wa.x * s8[0]; wx[1] = wa.y * s8[1]; wx[2] = wa.z * s8[2]; wx[3] = wa.w * s8[3];
+  wx[4] = wb.x * s8[4]; wx[5] = wb.y * s8[5]; wx[6] = wb.z * s8[6]; wx[7] = wb.w * s8[7];
 
   // Windowing + Energy (ns_core.c:969-978, 951-960)
   float epart = wx[0] * wx[0];
@@ -751,7 +774,7 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int n = 2 * q + 32 * t + 128 * g;  // sample index of td[2t]
-      const float2 w = *reinterpret_cast<const float2*>(T->window + n);
+      const float2 w = *reinterpret_cast<const float2*>(wins + n);
       const float c0 = (g == 0 && t < 3) ? carry[t < 3 ? t : 0].x : 0.f;
       const float c1 = (g == 0 && t < 3) ? carry[t < 3 ? t : 0].y : 0.f;
       float o0 = c0 + factor * (w.x * td[2 * t]);

@@ -78,7 +78,7 @@ void run(const char* name, int waves_per_simd) {
 }
 
 int main() {
-  for (int w = 1; w <= 2; ++w) {
+  for (int w : {1, 2, 3, 4, 8}) {
     run<0>("v_fma_f32 independent", w);
     run<1>("v_fma_f32 dependent chain", w);
     run<2>("v_pk_fma_f32 independent", w);
