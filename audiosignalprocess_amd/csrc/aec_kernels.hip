@@ -44,15 +44,16 @@ constexpr int kTileStride = 66;                 // float2 per transform tile (64
 constexpr int kLdsTile = 0;                     // 4 tiles: 4 * 66 float2 = 528 floats
 constexpr int kLdsRows = 4 * kTileStride * 2;   // per-bin rows of 66 floats
 enum LRow { L_XFR = 0, L_XFI, L_DFR, L_DFI, L_YFR, L_YFI, L_EFR, L_EFI, L_XPOW, L_XWR, L_XWI,
-            L_COHDE, L_COHXD, L_HNL, L_T0, L_T1, L_DWR, L_DWI, L_EWR, L_EWI,
-            L_MET,  // 4 rows: per-bin energy terms of far / near / linear-out / NLP-out (metrics mode)
-            L_NROWS = L_MET + 4 };
+            L_COHDE, L_COHXD, L_HNL, L_T0, L_T1, L_DWR, L_DWI, L_EWR, L_EWI, L_NROWS };
 constexpr int kLRow = 66;
 constexpr int kLdsDbuf = kLdsRows + L_NROWS * kLRow;  // 128
 constexpr int kLdsEbuf = kLdsDbuf + 128;              // 128
 constexpr int kLdsMisc = kLdsEbuf + 128;              // 16
 constexpr int kLdsC64 = kLdsMisc + 16;                // bin 64 of every state row (84)
-constexpr int kLdsWave = kLdsC64 + 84;                // 2204 floats = 8 816 B per wave
+constexpr int kLdsWave = kLdsC64 + 84;                // 1940 floats = 7 760 B per wave
+// metrics mode appends 4 rows of per-bin energy terms (far / near / linear-out / NLP-out) to each wave's region
+constexpr int kLdsMet = kLdsWave;
+constexpr int kLdsWaveMet = kLdsWave + 4 * kLRow;
 static_assert(kNumPart * kLRow <= kLdsRows + 9 * kLRow, "partition-energy rows overlay");
 
 struct SharedTables {
@@ -423,7 +424,7 @@ __device__ __attribute__((noinline)) void high_band_block(float* __restrict__ st
 }
 
 // UpdateLevel x 4 + UpdateMetrics (aec_core.c:585-770) from the per-bin energy terms the block
-// left in the L_MET rows: lanes 0..3 each sum one level in the reference's order (bin 0, bin 64,
+// left in the wave's kLdsMet rows: lanes 0..3 each sum one level in the reference's order (bin 0, bin 64,
 // bins 1..63) and update its PowerLevel; lane 0 then updates the ERL / A_NLP / ERLE statistics.
 // `met` is this stream's AspAecMetricsState image (include/asp_aec.h).
 __device__ __attribute__((noinline)) void metrics_block(float* __restrict__ met, float* __restrict__ wl,
@@ -434,7 +435,7 @@ __device__ __attribute__((noinline)) void metrics_block(float* __restrict__ met,
   float minlevel = 0.f, averagelevel = 0.f;
   int frcounter = 0, sfrcounter = 0;
   if (lane < 4) {
-    const float* src = lrow(wl, L_MET + lane);
+    const float* src = wl + kLdsMet + lane * kLRow;
     float energy = src[0];
     energy += src[64];
 #pragma unroll
@@ -564,7 +565,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   float* DWI = lrow(wl, L_DWI);
   float* EWR = lrow(wl, L_EWR);  // windowed error spectrum (NLP)
   float* EWI = lrow(wl, L_EWI);
-  [[maybe_unused]] float* MET = lrow(wl, L_MET);  // [4][kLRow], metrics mode only
+  [[maybe_unused]] float* MET = wl + kLdsMet;  // [4][kLRow], metrics mode only
   const float scale = 2.0f / 128;
   // State rows: trip 0 (bin = lane) goes to HBM, trip 1 (bin 64) to a per-wave LDS copy of the
   // bin-64 column that is gathered once per block and scattered back at its end.
@@ -1121,12 +1122,13 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
                                                           float* metrics,
                                                           unsigned long long* __restrict__ stamps) {
   __shared__ SharedTables T;
-  __shared__ float lds[4 * kLdsWave];
+  constexpr int kWaveLds = kMetrics ? kLdsWaveMet : kLdsWave;
+  __shared__ float lds[4 * kWaveLds];
   stage_tables(T, G);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int stream = blockIdx.x * 4 + wave;
   if (stream >= num_streams) return;
-  float* wl = lds + wave * kLdsWave;
+  float* wl = lds + wave * kWaveLds;
   float* st = state + (size_t)stream * kStateDwords;
   const float* nin = nearend + (size_t)stream * nrOfSamples;
   float* o = out + (size_t)stream * nrOfSamples;

@@ -275,10 +275,13 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
     _Pragma("unroll") for (int k = 0; k < 4; ++k) dst[k] = vec[(f)*kVecStride + bin0 + 16 * k]; \
     dst[4] = vec[(f)*kVecStride + 128];                                      \
   }
+// bin 128 is computed identically by every lane of the half-wave: all of them store it (same
+// address, same value) instead of branching around a one-lane store for every row
+#define NS_TAIL_IF
 #define STORE5(f, srcv)                                                      \
   if (live) {                                                                \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) vec[(f)*kVecStride + bin0 + 16 * k] = srcv[k]; \
-    if (lam == 0) vec[(f)*kVecStride + 128] = srcv[4];                       \
+    NS_TAIL_IF vec[(f)*kVecStride + 128] = srcv[4];                          \
   }
 
   float LQ[3][NS5], DEN[3][NS5], quant[NS5];

@@ -1,13 +1,8 @@
 set -e
-run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$TAG', 'step_us %.2f' % (1000*d['ms_per_step']), 'Mfps %.1f' % (d['value']/1e6), 'frac %.3f' % d['roofline']['frac'])"; }
-variant() {
-  TAG="$1"; export ASP_HIPCC_EXTRA="ns_kernels2.hip:$2"
-  touch audiosignalprocess_amd/csrc/ns_kernels2.hip
-  python -c "from audiosignalprocess_amd import build; build.build_library()"
-  run; run; run
-}
-variant "perm0 order0" "-DNS_EXP_PERMLANE=0 -DNS_EXP_ORDER=0"
-variant "perm1 order0" "-DNS_EXP_PERMLANE=1 -DNS_EXP_ORDER=0"
-variant "perm0 order1" "-DNS_EXP_PERMLANE=0 -DNS_EXP_ORDER=1"
-variant "perm1 order1" "-DNS_EXP_PERMLANE=1 -DNS_EXP_ORDER=1"
-variant "perm0 order0 again" "-DNS_EXP_PERMLANE=0 -DNS_EXP_ORDER=0"
+export TMPDIR=/tmp
+python -m pytest tests -q -m gpu 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py > gpurun_out/r01_v5_bench.json 2> gpurun_out/r01_v5_bench.err; cat gpurun_out/r01_v5_bench.json
+python bench.py --workload aec > gpurun_out/r01_aec_v3_bench.json 2>/dev/null; cat gpurun_out/r01_aec_v3_bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v5 -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_v5.json 2> gpurun_out/prof_v5.err
+ls gpurun_out/prof_v5/*/ | head
