@@ -264,6 +264,76 @@ __device__ __forceinline__ float log_f32_via_tab(float x, const double2* __restr
   return r;
 }
 
+// ---- batched forms for the frame kernels -------------------------------------------------------
+// N independent arguments per lane: the fast paths run straight-line (no branch between them, so
+// the N fp64 chains and their table reads interleave), the per-argument "not decided by the lean
+// value" flags are OR-ed and ONE rarely taken branch redoes the lane's arguments through libm (out
+// of line).  Results equal the one-argument forms above.
+// libm forms out of line: the rarely taken branches call them instead of carrying N inlined copies
+__device__ __attribute__((noinline)) float log_f32_slow(float x) { return (float)log((double)x); }
+__device__ __attribute__((noinline)) float exp_f32_slow(float x) { return (float)exp((double)x); }
+__device__ __attribute__((noinline)) float sqrt_f32_slow(float x) { return sqrtf(x); }
+
+template <int N>
+__device__ __forceinline__ void log_f32_via_tab_n(const float (&x)[N], float (&out)[N],
+                                                  const double2* __restrict__ tab) {
+  unsigned bad = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const unsigned ax = __float_as_uint(x[k]);
+    const unsigned normal_pos = (ax - 0x00800000u) < 0x7f000000u ? 1u : 0u;  // [2^-126, inf)
+    const double y = log_tab_f64(normal_pos ? x[k] : 1.0f, tab);
+    bad |= (normal_pos ^ 1u) | (f64_rounds_safely_to_f32(y) ? 0u : 1u);
+    out[k] = (float)y;
+  }
+  if (__builtin_expect(bad != 0, 0)) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = log_f32_slow(x[k]);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void exp_f32_via_f64_n(const float (&x)[N], float (&out)[N],
+                                                  const double* __restrict__ t64) {
+  unsigned bad = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const unsigned in_range = fabsf(x[k]) <= 87.0f ? 1u : 0u;  // false for NaN too
+    const double y = exp_lean_f64(in_range ? x[k] : 0.0f, t64);
+    bad |= (in_range ^ 1u) | (f64_rounds_safely_to_f32(y) ? 0u : 1u);
+    out[k] = (float)y;
+  }
+  if (__builtin_expect(bad != 0, 0)) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = exp_f32_slow(x[k]);
+  }
+}
+
+// fsqrt for N arguments, one merged check for the tiny-argument case
+template <int N>
+__device__ __forceinline__ void fsqrt_n(const float (&x)[N], float (&out)[N]) {
+  unsigned bad = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float xv = x[k];
+    const float r = __builtin_amdgcn_rsqf(xv);
+    float g = xv * r;
+    float h = 0.5f * r;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, e, g);
+    h = __builtin_fmaf(h, e, h);
+    const float d = __builtin_fmaf(-g, g, xv);
+    g = __builtin_fmaf(d, h, g);
+    out[k] = (xv == 0.0f || xv == __builtin_inff()) ? xv : g;
+    bad |= (xv < 0x1p-100f && xv > 0.0f) ? 1u : 0u;
+  }
+  if (__builtin_expect(bad != 0, 0)) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (x[k] < 0x1p-100f && x[k] > 0.0f) out[k] = sqrt_f32_slow(x[k]);
+  }
+}
+
 // ---- lean fp64 forms of the echo canceller's float transcendentals (aec_core.c:280, 487-488) ----
 // Each returns exactly what its plain form `(float)f((double)x)` (ocml fp64, rounded) returns: the
 // lean evaluation is accurate to ~2^-46, the float rounding is taken from it only when the fp64

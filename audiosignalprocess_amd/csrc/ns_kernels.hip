@@ -819,6 +819,26 @@ __device__ __forceinline__ float debug_fn(int fn, float x, float param,
                                           const double2* __restrict__ logtab) {
   switch (fn) {
     case 19: return log_f32_via_tab(x, logtab);
+    // batched forms (two arguments: x and the fixed `param`, whose result must equal the
+    // one-argument form's; a wrong second result poisons the first)
+    case 20: {
+      const float in[2] = {x, param};
+      float o[2];
+      log_f32_via_tab_n<2>(in, o, logtab);
+      return __float_as_uint(o[1]) == __float_as_uint(log_f32_via_tab(param, logtab)) ? o[0] : __builtin_nanf("");
+    }
+    case 21: {
+      const float in[2] = {x, param};
+      float o[2];
+      exp_f32_via_f64_n<2>(in, o, t64);
+      return __float_as_uint(o[1]) == __float_as_uint(exp_f32_via_f64(param, t64)) ? o[0] : __builtin_nanf("");
+    }
+    case 22: {
+      const float in[2] = {x, param};
+      float o[2];
+      fsqrt_n<2>(in, o);
+      return __float_as_uint(o[1]) == __float_as_uint(fsqrt(param)) ? o[0] : __builtin_nanf("");
+    }
     case 9: return sqrtf(x);
     case 10: return fsqrt(x);
     case 11: return exp_f32_via_f64(x, t64);

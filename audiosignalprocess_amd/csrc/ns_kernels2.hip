@@ -195,8 +195,11 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
                                                         int num_streams,
                                                         unsigned long long* __restrict__ stamps) {
   // diagnostic phase stamps (never passed by the product entry points): wave 0, lane 0
+#ifndef NS_STAMP_BLOCK
+#define NS_STAMP_BLOCK 0
+#endif
 #define NS_STAMP(k)                                                                \
-  if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {                  \
+  if (stamps != nullptr && blockIdx.x == NS_STAMP_BLOCK && threadIdx.x == 0) {     \
     __builtin_amdgcn_sched_barrier(0);                                             \
     stamps[k] = __builtin_amdgcn_s_memtime();                                      \
     __builtin_amdgcn_sched_barrier(0);                                             \
@@ -209,10 +212,9 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   __shared__ __align__(16) double exp2s[64];  // 2^(j/64) of the lean exp / tanh
   __shared__ __align__(16) double2 logts[128];  // {1/c, log c} of the table-driven log
   __shared__ __align__(16) float wins[kAnal];    // the window, for the synthesis side (ns_core.c:1344-1349)
-  // Prologue: every load of the step's first phase is issued before the first wait -- the three
-  // table pieces first (loads return in order, so the LDS staging waits for them only), then the
-  // stream's scalars, samples and first group of state rows, which stay in flight across the
-  // staging barrier.  Waves past the last stream load from the last pair's addresses and exit
+  // Prologue: every load of the step's first phase is issued before the first wait -- the table
+  // pieces first (loads return in order, so the LDS staging waits for them only), then the stream's
+  // scalars and samples, which stay in flight across the staging barrier.  Waves past the last stream load from the last pair's addresses and exit
   // after the barrier.
   const float4 tab_v = reinterpret_cast<const float4*>(&T->tw2[0][0][0])[threadIdx.x];  // 256 x 16 B
   const double exp2_v = T->exp2_64[threadIdx.x & 63];
@@ -284,10 +286,7 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
     NS_TAIL_IF vec[(f)*kVecStride + 128] = srcv[4];                          \
   }
 
-  float LQ[3][NS5], DEN[3][NS5], quant[NS5];
-  LOAD5(LQ[0], V_LQ0) LOAD5(LQ[1], V_LQ1) LOAD5(LQ[2], V_LQ2)
-  LOAD5(DEN[0], V_DEN0) LOAD5(DEN[1], V_DEN1) LOAD5(DEN[2], V_DEN2)
-  LOAD5(quant, V_QUANT)
+  float LQ[3][NS5], DEN[3][NS5], quant[NS5];  // requested once the samples are in, below
   // syntBuf[0..95]: lanes < 16 own samples 2q + 32 t (t = 0..2); every lane loads (no branch, no
   // wait here), the overlap-add uses the owners' values only
   float2 carry[3];
@@ -321,6 +320,12 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
     *reinterpret_cast<float4*>(hbuf + 8 * lam - 156) = make_float4(s8[4], s8[5], s8[6], s8[7]);
   }
 
+  // the tracker rows are requested once the frame's samples are in (a shorter start-of-kernel burst:
+  // every wave of the launch starts at once, and under that load a request takes 1.5 us and more);
+  // they are used after the transform, the magnitudes and the logarithms
+  LOAD5(LQ[0], V_LQ0) LOAD5(LQ[1], V_LQ1) LOAD5(LQ[2], V_LQ2)
+  LOAD5(DEN[0], V_DEN0) LOAD5(DEN[1], V_DEN1) LOAD5(DEN[2], V_DEN2)
+  LOAD5(quant, V_QUANT)
   NS_STAMP(1)
   // ---- forward FFT (ns_core.c:886-911)
   *reinterpret_cast<float4*>(&tile[4 * lam]) = make_float4(wx[0], wx[1], wx[2], wx[3]);
@@ -332,7 +337,8 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   real_split2(tile, spls, lam, el, false);
 
   NS_STAMP(2)
-  // second group of state rows (latency hides under magnitude / log / trackers)
+  // second group of state rows (latency hides under magnitude / log / trackers; requesting them
+  // in the prologue as well made the start-of-kernel burst longer and the step 0.6 us slower)
   float smooth[NS5], noisePrev[NS5], magnPrevA[NS5], logLrt[NS5], avgPause[NS5];
   LOAD5(magnPrevA, V_MAGNPREV_A) LOAD5(logLrt, V_LOGLRT) LOAD5(avgPause, V_AVGPAUSE)
   LOAD5(smooth, V_SMOOTH) LOAD5(noisePrev, V_NOISEPREV)
@@ -347,7 +353,13 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   im[4] = 0.f;
   if (lam == 0) im[0] = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) magn[k] = fsqrt(re[k] * re[k] + im[k] * im[k]) + 1.f;
+  for (int k = 0; k < 4; ++k) magn[k] = re[k] * re[k] + im[k] * im[k];
+  {
+    float m2[4] = {magn[0], magn[1], magn[2], magn[3]}, rt[4];
+    fsqrt_n<4>(m2, rt);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) magn[k] = rt[k] + 1.f;
+  }
   if (lam == 0) magn[0] = fabsf(re[0]) + 1.f;
   magn[4] = fabsf(re[4]) + 1.f;
 
@@ -368,8 +380,7 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   int counter[3] = {SCI(S_COUNTER0), SCI(S_COUNTER1), SCI(S_COUNTER2)};
 
   float lmagn[NS5];
-#pragma unroll
-  for (int k = 0; k < NS5; ++k) lmagn[k] = log_f32_via_tab(magn[k], logts);
+  log_f32_via_tab_n<NS5>(magn, lmagn, logts);
 
   NS_STAMP(3)
   float signalEnergy, sumMagn;
@@ -599,12 +610,17 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
 
   NS_STAMP(9)
   // ---- SpeechNoiseProb (ns_core.c:642-749)
+  {
+    float t1[NS5], lt1[NS5];
 #pragma unroll
-  for (int k = 0; k < NS5; ++k) {
-    const float t1 = 1.f + 2.f * snrLocPrior[k];
-    const float t2 = fdiv(2.f * snrLocPrior[k], t1 + 0.0001f);
-    const float besselTmp = (snrLocPost[k] + 1.f) * t2;
-    logLrt[k] += NS_LRT_TAVG * (besselTmp - log_f32_via_tab(t1, logts) - logLrt[k]);
+    for (int k = 0; k < NS5; ++k) t1[k] = 1.f + 2.f * snrLocPrior[k];
+    log_f32_via_tab_n<NS5>(t1, lt1, logts);
+#pragma unroll
+    for (int k = 0; k < NS5; ++k) {
+      const float t2 = fdiv(2.f * snrLocPrior[k], t1[k] + 0.0001f);
+      const float besselTmp = (snrLocPost[k] + 1.f) * t2;
+      logLrt[k] += NS_LRT_TAVG * (besselTmp - lt1[k] - logLrt[k]);
+    }
   }
   float logLrtTimeAvgKsum = half_sum(PART5(logLrt));
   logLrtTimeAvgKsum = DIV129(logLrtTimeAvgKsum);
@@ -637,9 +653,13 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   float probSpeech[NS5];
   {
     const float gainPrior = fdiv(1.f - priorSpeechProb, priorSpeechProb + 0.0001f);
+    float nl[NS5], ev[NS5];
+#pragma unroll
+    for (int k = 0; k < NS5; ++k) nl[k] = -logLrt[k];
+    exp_f32_via_f64_n<NS5>(nl, ev, exp2s);
 #pragma unroll
     for (int k = 0; k < NS5; ++k) {
-      float invLrt = exp_f32_via_f64(-logLrt[k], exp2s);
+      float invLrt = ev[k];
       invLrt = (float)gainPrior * invLrt;
       probSpeech[k] = fdiv(1.f, 1.f + invLrt);
     }

@@ -400,6 +400,25 @@ def test_device_exp_tanh_sqrt_exhaustive(ns):
         assert bad == 0, (name, bad, [hex(b) for b in ex[:8]])
 
 
+def test_device_batched_forms_exhaustive(ns):
+    """The N-argument forms the frame kernels use (straight-line fast paths, one merged fallback
+    branch; ns_device.h: log_f32_via_tab_n / exp_f32_via_f64_n / fsqrt_n) against the libm forms for
+    EVERY float in the first slot, with a second argument on the fast path and one that forces the
+    fallback loop on every call (its result is checked inside the kernel)."""
+    lib = ns.load_library()
+    step = 1 << 28
+    for fa, fb, lo, hi, params, name in [(20, 1, 0, 0x7f800001, (0.75, 1e-40), "log"),
+                                         (21, 2, 0, 1 << 32, (-0.3, 100.0), "exp"),
+                                         (22, 9, 0, 0x7f800001, (2.0, 1e-35), "sqrt")]:
+        for prm in params:
+            total, examples = 0, []
+            for start in range(lo, hi, step):
+                n, ex = _debug_compare(lib, fa, fb, start, min(step, hi - start), prm)
+                total += n
+                examples += ex
+            assert total == 0, (name, prm, total, [hex(b) for b in examples[:8]])
+
+
 def test_split_launch_is_identical(ns):
     """The fused step issued as 2..4 sub-launches on separate HIP streams gives the same bits."""
     S, F = 256, 30

@@ -1,8 +1,4 @@
 set -e
-export TMPDIR=/tmp
-python -m pytest tests -q -m gpu 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python bench.py > gpurun_out/r01_v5_bench.json 2> gpurun_out/r01_v5_bench.err; cat gpurun_out/r01_v5_bench.json
-python bench.py --workload aec > gpurun_out/r01_aec_v3_bench.json 2>/dev/null; cat gpurun_out/r01_aec_v3_bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v5 -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_v5.json 2> gpurun_out/prof_v5.err
-ls gpurun_out/prof_v5/*/ | head
+run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$TAG', 'step_us %.2f' % (1000*d['ms_per_step']), '%.2f M/s' % (d['value']/1e6), 'frac %.3f' % d['roofline']['frac'])"; }
+python -m pytest tests/test_ns_gpu.py -q -x -k "not exhaustive" 2>&1 | tail -1
+TAG=final; run; run; run
