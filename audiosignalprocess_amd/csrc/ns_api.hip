@@ -288,11 +288,12 @@ inline int32_t f2i(float f) {
 
 void vec_put(float* blk, int f, const float* src) {
   float* d = blk + kOffVec + f * kVecStride;
-  memcpy(d, src, sizeof(float) * kBins);
+  for (int i = 0; i < kBins; ++i) d[row_pos(i)] = src[i];
   for (int i = kBins; i < kVecStride; ++i) d[i] = 0.f;
 }
 void vec_get(const float* blk, int f, float* dst) {
-  memcpy(dst, blk + kOffVec + f * kVecStride, sizeof(float) * kBins);
+  const float* r = blk + kOffVec + f * kVecStride;
+  for (int i = 0; i < kBins; ++i) dst[i] = r[row_pos(i)];
 }
 
 void pack_stream(const AspNsState* s, float* blk, int32_t* hist) {

@@ -243,19 +243,21 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
   }
   const float4 w4 = *reinterpret_cast<const float4*>(T->window + 4 * lane);
 
-  // ---- state rows (issued early; consumed after the FFT)
+  // ---- state rows (issued early; consumed after the FFT); bins lane and 64 + lane sit at
+  // row_pos(lane) and 64 + row_pos(lane) (ns_layout.h)
+  const int rpos = 4 * (lane & 15) + (lane >> 4);
   float LQ[3][3], DEN[3][3], quant[3], smooth[3], noisePrev[3], magnPrevA[3], logLrt[3],
       avgPause[3], noiseSt[3], magnPrevP[3];
 #define LOAD_ROW(dst, f)                          \
   {                                               \
-    dst[0] = vec[(f)*kVecStride + lane];          \
-    dst[1] = vec[(f)*kVecStride + 64 + lane];     \
+    dst[0] = vec[(f)*kVecStride + rpos];          \
+    dst[1] = vec[(f)*kVecStride + 64 + rpos];     \
     dst[2] = vec[(f)*kVecStride + 128];           \
   }
 #define STORE_ROW(f, srcv)                                  \
   {                                                         \
-    vec[(f)*kVecStride + lane] = srcv[0];                   \
-    vec[(f)*kVecStride + 64 + lane] = srcv[1];              \
+    vec[(f)*kVecStride + rpos] = srcv[0];                   \
+    vec[(f)*kVecStride + 64 + rpos] = srcv[1];              \
     if (lane == 0) vec[(f)*kVecStride + 128] = srcv[2];     \
   }
   if (DO_A) {

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
 
 #define LOAD5(dst, f)                                                        \
   {                                                                          \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) dst[k] = vec[(f)*kVecStride + bin0 + 16 * k]; \
+    const float4 v4_ = *reinterpret_cast<const float4*>(vec + (f)*kVecStride + 4 * lam);   \
+    dst[0] = v4_.x; dst[1] = v4_.y; dst[2] = v4_.z; dst[3] = v4_.w;           \
     dst[4] = vec[(f)*kVecStride + 128];                                      \
   }
 // bin 128 is computed identically by every lane of the half-wave: all of them store it (same
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
 #define NS_TAIL_IF
 #define STORE5(f, srcv)                                                      \
   if (live) {                                                                \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) vec[(f)*kVecStride + bin0 + 16 * k] = srcv[k]; \
+    *reinterpret_cast<float4*>(vec + (f)*kVecStride + 4 * lam) =              \
+        make_float4(srcv[0], srcv[1], srcv[2], srcv[3]);                       \
     NS_TAIL_IF vec[(f)*kVecStride + 128] = srcv[4];                          \
   }
 

@@ -69,15 +69,15 @@ __global__ __launch_bounds__(256) void ns_hb_apply_kernel(const float* __restric
     if (lane < 32) {
       const int i = 96 + lane;
       const float gainPrior = (1.f - prior) / (prior + 0.0001f);        // ns_core.c:743
-      float invLrt = exp_f32_via_f64(-vec[V_LOGLRT * kVecStride + i], T->exp2_64);
+      float invLrt = exp_f32_via_f64(-vec[V_LOGLRT * kVecStride + row_pos(i)], T->exp2_64);
       invLrt = gainPrior * invLrt;
       l[lane] = 1.f / (1.f + invLrt);                                   // speechProb[i]
-      l[32 + lane] = vec[V_SMOOTH * kVecStride + i];
+      l[32 + lane] = vec[V_SMOOTH * kVecStride + row_pos(i)];
     }
     if (!paired) {
       for (int i = lane; i < kBins; i += 64) {
-        l[64 + i] = vec[V_MAGNPREV_A * kVecStride + i];
-        l[64 + 132 + i] = vec[V_MAGNPREV_P * kVecStride + i];
+        l[64 + i] = vec[V_MAGNPREV_A * kVecStride + row_pos(i)];
+        l[64 + 132 + i] = vec[V_MAGNPREV_P * kVecStride + row_pos(i)];
       }
     }
     wave_lds_fence();

@@ -18,6 +18,13 @@ constexpr int kAnal = 256;     // ns/defines.h:15
 constexpr int kBins = 129;     // ns/defines.h:16
 constexpr int kHist = 1000;    // ns/defines.h:45
 constexpr int kVecStride = 132;
+// Position of bin b inside a state row.  The four bins a lane of the two-streams-per-wave kernel
+// owns (q + 16 k + 64 g, k = 0..3, lane = q + 16 g) sit next to each other, so a row moves as one
+// 16-byte access per lane instead of four 4-byte ones (a quarter of the vector-memory
+// instructions; the per-CU address unit was the busiest part of the step); bin 128 stays last.
+constexpr int row_pos(int b) {
+  return b >= 128 ? b : 4 * ((b & 15) + 16 * (b >> 6)) + ((b >> 4) & 3);
+}
 constexpr int kCarry = kAnal - kBlockL;  // 96 live samples of each sliding buffer
 
 // 129-bin arrays, in block order.  "hot" = touched by the fused lock-step step.
