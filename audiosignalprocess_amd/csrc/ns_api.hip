@@ -288,12 +288,11 @@ inline int32_t f2i(float f) {
 
 void vec_put(float* blk, int f, const float* src) {
   float* d = blk + kOffVec + f * kVecStride;
-  for (int i = 0; i < kBins; ++i) d[row_pos(i)] = src[i];
-  for (int i = kBins; i < kVecStride; ++i) d[i] = 0.f;
+  for (int i = 128; i < kVecStride; ++i) d[i] = 0.f;
+  for (int i = 0; i < kBins; ++i) blk[row_dword(f, i)] = src[i];
 }
 void vec_get(const float* blk, int f, float* dst) {
-  const float* r = blk + kOffVec + f * kVecStride;
-  for (int i = 0; i < kBins; ++i) dst[i] = r[row_pos(i)];
+  for (int i = 0; i < kBins; ++i) dst[i] = blk[row_dword(f, i)];
 }
 
 void pack_stream(const AspNsState* s, float* blk, int32_t* hist) {

@@ -252,13 +252,13 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
   {                                               \
     dst[0] = vec[(f)*kVecStride + rpos];          \
     dst[1] = vec[(f)*kVecStride + 64 + rpos];     \
-    dst[2] = vec[(f)*kVecStride + 128];           \
+    dst[2] = SC_F(S_TAIL0 + (f));                 \
   }
 #define STORE_ROW(f, srcv)                                  \
   {                                                         \
     vec[(f)*kVecStride + rpos] = srcv[0];                   \
     vec[(f)*kVecStride + 64 + rpos] = srcv[1];              \
-    if (lane == 0) vec[(f)*kVecStride + 128] = srcv[2];     \
+    SC_SET_F(S_TAIL0 + (f), srcv[2]);                       \
   }
   if (DO_A) {
     LOAD_ROW(LQ[0], V_LQ0) LOAD_ROW(LQ[1], V_LQ1) LOAD_ROW(LQ[2], V_LQ2)
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     }
   }
 
-  if (DO_A) st[kOffScalars + lane] = sv;
+  st[kOffScalars + lane] = sv;  // Process alone changes no scalar but the rows' bin-128 slots
 #undef SC_I
 #undef SC_F
 #undef SC_SET_I
@@ -798,6 +798,10 @@ __global__ __launch_bounds__(256) void ns_unpair_kernel(float* __restrict__ stat
   for (int i = lane; i < kVecStride; i += 64) {
     vec[V_MAGNPREV_P * kVecStride + i] = vec[V_MAGNPREV_A * kVecStride + i];
     vec[V_NOISE * kVecStride + i] = vec[V_NOISEPREV * kVecStride + i];
+  }
+  if (lane == 0) {  // bin 128 of the two rows (kept with the scalars)
+    st[kOffScalars + S_TAIL0 + V_MAGNPREV_P] = st[kOffScalars + S_TAIL0 + V_MAGNPREV_A];
+    st[kOffScalars + S_TAIL0 + V_NOISE] = st[kOffScalars + S_TAIL0 + V_NOISEPREV];
   }
 }
 

@@ -276,16 +276,15 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   {                                                                          \
     const float4 v4_ = *reinterpret_cast<const float4*>(vec + (f)*kVecStride + 4 * lam);   \
     dst[0] = v4_.x; dst[1] = v4_.y; dst[2] = v4_.z; dst[3] = v4_.w;           \
-    dst[4] = vec[(f)*kVecStride + 128];                                      \
+    dst[4] = SCF(S_TAIL0 + (f));                                             \
   }
-// bin 128 is computed identically by every lane of the half-wave: all of them store it (same
-// address, same value) instead of branching around a one-lane store for every row
-#define NS_TAIL_IF
+// bin 128 of a row lives in scalar slot S_TAIL0 + f (ns_layout.h): read by a broadcast from the
+// scalar registers, written back into them
 #define STORE5(f, srcv)                                                      \
   if (live) {                                                                \
     *reinterpret_cast<float4*>(vec + (f)*kVecStride + 4 * lam) =              \
         make_float4(srcv[0], srcv[1], srcv[2], srcv[3]);                       \
-    NS_TAIL_IF vec[(f)*kVecStride + 128] = srcv[4];                          \
+    SET_F(S_TAIL0 + (f), srcv[4])                                            \
   }
 
   float LQ[3][NS5], DEN[3][NS5], quant[NS5];  // requested once the samples are in, below

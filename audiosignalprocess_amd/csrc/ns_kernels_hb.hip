@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void ns_hb_apply_kernel(const float* __restric
     }
     if (!paired) {
       for (int i = lane; i < kBins; i += 64) {
-        l[64 + i] = vec[V_MAGNPREV_A * kVecStride + row_pos(i)];
-        l[64 + 132 + i] = vec[V_MAGNPREV_P * kVecStride + row_pos(i)];
+        l[64 + i] = st[row_dword(V_MAGNPREV_A, i)];
+        l[64 + 132 + i] = st[row_dword(V_MAGNPREV_P, i)];
       }
     }
     wave_lds_fence();

@@ -21,10 +21,8 @@ constexpr int kVecStride = 132;
 // Position of bin b inside a state row.  The four bins a lane of the two-streams-per-wave kernel
 // owns (q + 16 k + 64 g, k = 0..3, lane = q + 16 g) sit next to each other, so a row moves as one
 // 16-byte access per lane instead of four 4-byte ones (a quarter of the vector-memory
-// instructions; the per-CU address unit was the busiest part of the step); bin 128 stays last.
-constexpr int row_pos(int b) {
-  return b >= 128 ? b : 4 * ((b & 15) + 16 * (b >> 6)) + ((b >> 4) & 3);
-}
+// instructions; the per-CU address unit was the busiest part of the step).  b < 128.
+constexpr int row_pos(int b) { return 4 * ((b & 15) + 16 * (b >> 6)) + ((b >> 4) & 3); }
 constexpr int kCarry = kAnal - kBlockL;  // 96 live samples of each sliding buffer
 
 // 129-bin arrays, in block order.  "hot" = touched by the fused lock-step step.
@@ -57,6 +55,12 @@ enum Scalar : int {
   S_COUNT
 };
 
+// Bin 128 of state row f is kept with the scalars, in slot S_TAIL0 + f: it arrives with the two
+// scalar loads of a step and leaves with the two scalar stores instead of costing every row a
+// one-dword load and a one-dword store of its own.
+constexpr int S_TAIL0 = 48;
+static_assert(S_COUNT <= S_TAIL0 && S_TAIL0 + V_COUNT <= 64, "row tails share the 64 scalar slots");
+
 // dword offsets inside one stream block
 constexpr int kOffScalars = 0;                               // 64 dwords
 constexpr int kOffAnaHist = 64;                              // analyzeBuf[160..255]
@@ -64,6 +68,10 @@ constexpr int kOffSynt = kOffAnaHist + kCarry;               // syntBuf[0..95]
 constexpr int kOffVec = kOffSynt + kCarry;                   // 256
 constexpr int kOffDataHist = kOffVec + V_COUNT * kVecStride; // dataBuf[160..255] (cold)
 constexpr int kStreamDwordsRaw = kOffDataHist + kCarry;
+// dword offset of bin `bin` of state row f inside the stream block
+constexpr int row_dword(int f, int bin) {
+  return bin < 128 ? kOffVec + f * kVecStride + row_pos(bin) : kOffScalars + S_TAIL0 + f;
+}
 constexpr int kStreamDwords = (kStreamDwordsRaw + 63) / 64 * 64;  // 256-byte multiple
 
 // histograms: [stream][3][kHistStride] int32 (histLrt, histSpecFlat, histSpecDiff)
