@@ -268,9 +268,7 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
     s8[4] = hsel ? hb4.x : (float)b.x; s8[5] = hsel ? hb4.y : (float)b.y;
     s8[6] = hsel ? hb4.z : (float)b.z; s8[7] = hsel ? hb4.w : (float)b.w;
   }
-  const float4 wa = *reinterpret_cast<const float4*>(T->window + 8 * lam);
-  const float4 wb = *reinterpret_cast<const float4*>(T->window + 8 * lam + 4);
-  // (pinning these ahead of the state rows below with a scheduling barrier measured 5 % slower)
+  // (pinning the sample loads ahead of the state rows below with a scheduling barrier measured 5 % slower)
 
 #define LOAD5(dst, f)                                                        \
   {                                                                          \
@@ -304,6 +302,10 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   const float* tw2s = tabs;
   const float* spls = tabs + 3 * 32 * 8;
 
+  // the analysis window comes from the staged copy as well (it used to be 8 KB of L2 reads per
+  // workgroup inside the start-of-kernel burst)
+  const float4 wa = *reinterpret_cast<const float4*>(wins + 8 * lam);
+  const float4 wb = *reinterpret_cast<const float4*>(wins + 8 * lam + 4);
   float wx[8];
   wx[0] = wa.x * s8[0]; wx[1] = wa.y * s8[1]; wx[2] = wa.z * s8[2]; wx[3] = wa.w * s8[3];
   wx[4] = wb.x * s8[4]; wx[5] = wb.y * s8[5]; wx[6] = wb.z * s8[6]; wx[7] = wb.w * s8[7];
