@@ -6,6 +6,8 @@
 // and fails with ASP_ERR_NO_DEVICE / -1 otherwise.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -863,8 +865,12 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
     return fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
   if (!b->paired) return fail(ASP_ERR_STATE, "TimedSteps needs the fused (paired) representation");
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
+  const auto h0 = std::chrono::steady_clock::now();
   rc = fused_steps(b, in, out, frames_in_ring, steps);
   if (rc) return rc;
+  if (getenv("ASP_NS_DEBUG_TIMING"))
+    fprintf(stderr, "TimedSteps: host enqueue of %d steps took %.1f us per step\n", steps,
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count() / (steps > 0 ? steps : 1));
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
   HIP_TRY(hipEventSynchronize(b->ev1));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));

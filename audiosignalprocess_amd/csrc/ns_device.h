@@ -92,6 +92,28 @@ __device__ __forceinline__ float fdiv(float n, float d) {
   const float e2 = __builtin_fmaf(-d, q1, n);
   return __builtin_fmaf(e2, r1, q1);
 }
+// Two / five correctly rounded divisions at a time: the same arithmetic as fdiv with the seven
+// multiply-add steps issued as packed-f32 instructions (one issue slot for two quotients).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fdiv2(f32x2 n, f32x2 d) {
+  f32x2 r0;
+  r0.x = __builtin_amdgcn_rcpf(d.x);
+  r0.y = __builtin_amdgcn_rcpf(d.y);
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 e0 = __builtin_elementwise_fma(-d, r0, one);
+  const f32x2 r1 = __builtin_elementwise_fma(e0, r0, r0);
+  const f32x2 q0 = n * r1;
+  const f32x2 e1 = __builtin_elementwise_fma(-d, q0, n);
+  const f32x2 q1 = __builtin_elementwise_fma(e1, r1, q0);
+  const f32x2 e2 = __builtin_elementwise_fma(-d, q1, n);
+  return __builtin_elementwise_fma(e2, r1, q1);
+}
+__device__ __forceinline__ void fdiv5(const float (&n)[5], const float (&d)[5], float (&q)[5]) {
+  const f32x2 a = fdiv2(f32x2{n[0], n[1]}, f32x2{d[0], d[1]});
+  const f32x2 b = fdiv2(f32x2{n[2], n[3]}, f32x2{d[2], d[3]});
+  q[0] = a.x; q[1] = a.y; q[2] = b.x; q[3] = b.y;
+  q[4] = fdiv(n[4], d[4]);
+}
 #define DIV129(a) div_by_uniform((a), 129.0f, 1.0f / 129.0f)
 
 // (float)log((double)x), the reference's idiom (ns_core.c:228,540,681,1096), for

@@ -406,10 +406,15 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
     const float cnt = (float)counter[s];
     const float cnt1 = (float)(counter[s] + 1);
     const float rcnt1 = 1.f / cnt1;
+    float dq[NS5];  // FACTOR / density for the five bins, packed (used where density > 1)
+    {
+      const float forty[NS5] = {NS_FACTOR * 1.f, NS_FACTOR * 1.f, NS_FACTOR * 1.f, NS_FACTOR * 1.f, NS_FACTOR * 1.f};
+      fdiv5(forty, DEN[s], dq);
+    }
 #pragma unroll
     for (int k = 0; k < NS5; ++k) {
       float den = DEN[s][k], lq = LQ[s][k];
-      const float delta = den > 1.0f ? fdiv(NS_FACTOR * 1.f, den) : NS_FACTOR;
+      const float delta = den > 1.0f ? dq[k] : NS_FACTOR;
       const bool up = lmagn[k] > lq;
       const float step =
           div_by_uniform(up ? NS_QUANTILE * delta : (1.f - NS_QUANTILE) * delta, cnt1, rcnt1);
@@ -502,13 +507,23 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   NS_STAMP(6)
   // ---- ComputeSnr (ns_core.c:566-588)
   float snrLocPost[NS5], snrLocPrior[NS5];
+  {
+    float dn1[NS5], dn2[NS5], q1[NS5], q2[NS5];
 #pragma unroll
-  for (int k = 0; k < NS5; ++k) {
-    const float previousEstimateStsa = fdiv(magnPrevA[k], noisePrev[k] + 0.0001f) * smooth[k];
-    prevStsa[k] = previousEstimateStsa;
-    snrLocPost[k] = 0.f;
-    if (magn[k] > noise[k]) snrLocPost[k] = fdiv(magn[k], noise[k] + 0.0001f) - 1.f;
-    snrLocPrior[k] = NS_DD_PR_SNR * previousEstimateStsa + (1.f - NS_DD_PR_SNR) * snrLocPost[k];
+    for (int k = 0; k < NS5; ++k) {
+      dn1[k] = noisePrev[k] + 0.0001f;
+      dn2[k] = noise[k] + 0.0001f;
+    }
+    fdiv5(magnPrevA, dn1, q1);
+    fdiv5(magn, dn2, q2);  // used where magn > noise
+#pragma unroll
+    for (int k = 0; k < NS5; ++k) {
+      const float previousEstimateStsa = q1[k] * smooth[k];
+      prevStsa[k] = previousEstimateStsa;
+      snrLocPost[k] = 0.f;
+      if (magn[k] > noise[k]) snrLocPost[k] = q2[k] - 1.f;
+      snrLocPrior[k] = NS_DD_PR_SNR * previousEstimateStsa + (1.f - NS_DD_PR_SNR) * snrLocPost[k];
+    }
   }
 
   NS_STAMP(7)
@@ -618,9 +633,16 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
 #pragma unroll
     for (int k = 0; k < NS5; ++k) t1[k] = 1.f + 2.f * snrLocPrior[k];
     log_f32_via_tab_n<NS5>(t1, lt1, logts);
+    float tn[NS5], td5[NS5], t2v[NS5];
 #pragma unroll
     for (int k = 0; k < NS5; ++k) {
-      const float t2 = fdiv(2.f * snrLocPrior[k], t1[k] + 0.0001f);
+      tn[k] = 2.f * snrLocPrior[k];
+      td5[k] = t1[k] + 0.0001f;
+    }
+    fdiv5(tn, td5, t2v);
+#pragma unroll
+    for (int k = 0; k < NS5; ++k) {
+      const float t2 = t2v[k];
       const float besselTmp = (snrLocPost[k] + 1.f) * t2;
       logLrt[k] += NS_LRT_TAVG * (besselTmp - lt1[k] - logLrt[k]);
     }
@@ -660,11 +682,16 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
 #pragma unroll
     for (int k = 0; k < NS5; ++k) nl[k] = -logLrt[k];
     exp_f32_via_f64_n<NS5>(nl, ev, exp2s);
+    {
+      float pd[NS5];
+      const float ones[NS5] = {1.f, 1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-    for (int k = 0; k < NS5; ++k) {
-      float invLrt = ev[k];
-      invLrt = (float)gainPrior * invLrt;
-      probSpeech[k] = fdiv(1.f, 1.f + invLrt);
+      for (int k = 0; k < NS5; ++k) {
+        float invLrt = ev[k];
+        invLrt = (float)gainPrior * invLrt;
+        pd[k] = 1.f + invLrt;
+      }
+      fdiv5(ones, pd, probSpeech);
     }
   }
 
@@ -722,13 +749,24 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
     STORE5(V_INITMAGN, initMagn)
   }
   float gainv[NS5];
+  float gq1[NS5], gq2[NS5], snrP[NS5];
+  {
+    float gd1[NS5], gd2[NS5];
+#pragma unroll
+    for (int k = 0; k < NS5; ++k) gd1[k] = noise[k] + 0.0001f;
+    fdiv5(magn, gd1, gq1);  // used where magn > noise
+#pragma unroll
+    for (int k = 0; k < NS5; ++k) {
+      float currentEstimateStsa = 0.f;
+      if (magn[k] > noise[k]) currentEstimateStsa = gq1[k] - 1.f;
+      snrP[k] = NS_DD_PR_SNR * prevStsa[k] + (1.f - NS_DD_PR_SNR) * currentEstimateStsa;
+      gd2[k] = overdrive + snrP[k];
+    }
+    fdiv5(snrP, gd2, gq2);
+  }
 #pragma unroll
   for (int k = 0; k < NS5; ++k) {
-    float currentEstimateStsa = 0.f;
-    if (magn[k] > noise[k]) currentEstimateStsa = fdiv(magn[k], noise[k] + 0.0001f) - 1.f;
-    const float snrPrior =
-        NS_DD_PR_SNR * prevStsa[k] + (1.f - NS_DD_PR_SNR) * currentEstimateStsa;
-    float gg = fdiv(snrPrior, overdrive + snrPrior);
+    float gg = gq2[k];
     if (gg < denoiseBound) gg = denoiseBound;
     if (gg > 1.f) gg = 1.f;
     if (startup) {
