@@ -406,23 +406,19 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
     const float cnt = (float)counter[s];
     const float cnt1 = (float)(counter[s] + 1);
     const float rcnt1 = 1.f / cnt1;
-    float dq[NS5];  // FACTOR / density for the five bins, packed (used where density > 1)
     {
-      const float forty[NS5] = {NS_FACTOR * 1.f, NS_FACTOR * 1.f, NS_FACTOR * 1.f, NS_FACTOR * 1.f, NS_FACTOR * 1.f};
-      fdiv5(forty, DEN[s], dq);
-    }
-#pragma unroll
-    for (int k = 0; k < NS5; ++k) {
-      float den = DEN[s][k], lq = LQ[s][k];
-      const float delta = den > 1.0f ? dq[k] : NS_FACTOR;
-      const bool up = lmagn[k] > lq;
-      const float step =
-          div_by_uniform(up ? NS_QUANTILE * delta : (1.f - NS_QUANTILE) * delta, cnt1, rcnt1);
-      lq = up ? lq + step : lq - step;
-      const float nd = div_by_uniform(cnt * den + 1.f / (2.f * NS_WIDTH), cnt1, rcnt1);
-      den = fabsf(lmagn[k] - lq) < NS_WIDTH ? nd : den;
-      DEN[s][k] = den;
-      LQ[s][k] = lq;
+      // the five bins of the lane as packed pairs (ns_device.h: F5); same operations as per bin
+      F5 den(DEN[s]), lq(LQ[s]);
+      const F5 lm(lmagn);
+      const F5 dq = fdiv5v(F5(NS_FACTOR * 1.f), den);  // used where density > 1
+      const F5 delta = sel5(gt5(den, F5(1.0f)), dq, F5(NS_FACTOR));
+      const B5 up = gt5(lm, lq);
+      const F5 step = div_by_uniform5(sel5(up, NS_QUANTILE * delta, (1.f - NS_QUANTILE) * delta), cnt1, rcnt1);
+      lq = sel5(up, lq + step, lq - step);
+      const F5 nd = div_by_uniform5(cnt * den + 1.f / (2.f * NS_WIDTH), cnt1, rcnt1);
+      den = sel5(lt5(abs5(lm - lq), F5(NS_WIDTH)), nd, den);
+      den.store(DEN[s]);
+      lq.store(LQ[s]);
     }
     if (counter[s] >= NS_END_STARTUP_LONG) {
       counter[s] = 0;

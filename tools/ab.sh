@@ -1,7 +1,4 @@
 set -e
-export TMPDIR=/tmp
-python -m pytest tests -q -m gpu 2>&1 | tail -2
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > gpurun_out/r01_v7_bench.json 2> gpurun_out/r01_v7_bench.err; cat gpurun_out/r01_v7_bench.json | cut -c1-260
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v7 -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_v7.json 2> gpurun_out/prof_v7.err
-bash tools/quick_pmc.sh v7 > gpurun_out/qpmc_v7.txt 2>&1; grep -c per-wave gpurun_out/qpmc_v7.txt
+run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$TAG $*', 'step_us %.2f' % (1000*d['ms_per_step']), '%.2f M/s' % (d['value']/1e6), 'frac %.3f' % d['roofline']['frac'])"; }
+python -m pytest tests/test_ns_gpu.py -q -x -k "not exhaustive" 2>&1 | tail -1
+TAG=f5; run; run; run; run --streams-per-gpu 8192; run --streams-per-gpu 16384
