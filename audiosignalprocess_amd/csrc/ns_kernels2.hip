@@ -592,9 +592,10 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   {
     // the window close needs the whole wave for one stream: do it stream by stream
     const bool closing = updateParsFlag >= 1 && mup3 == 0 && live;
+    const unsigned long long closing_mask = __ballot(closing);  // per-stream flag: bits 0 and 32
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const bool c_h = __shfl((int)closing, 32 * h, 64) != 0;  // wave-uniform
+      const bool c_h = ((closing_mask >> (32 * h)) & 1ull) != 0;  // wave-uniform
       if (c_h) {
         PriorModel pin;
         pin.p0 = __shfl(pm.p0, 32 * h, 64);
@@ -696,20 +697,15 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   // one bin i-1 selected.  Bin i-1 lives on the previous lane of the 16-lane row, same slot;
   // at a row start it is lane 15 / 31 of the half, previous slot (bin 63 for bin 64).
   {
-    float prevProb[NS5];
+    // row_ror:1 hands lane q the value of lane q - 1 of its 16-lane row and lane 0 that of lane 15:
+    // slot k of the rotated values is the predecessor for q > 0, slot k - 1 for q == 0
+    float prevProb[NS5], ror[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) prevProb[k] = dpp_move<0x111>(probSpeech[k]);  // row_shr:1
-    const float l15_3 = half_lane(probSpeech[3], hb, 15);
-    const float l15_0 = half_lane(probSpeech[0], hb, 15), l15_1 = half_lane(probSpeech[1], hb, 15),
-                l15_2 = half_lane(probSpeech[2], hb, 15);
-    const float l31_0 = half_lane(probSpeech[0], hb, 31), l31_1 = half_lane(probSpeech[1], hb, 31),
-                l31_2 = half_lane(probSpeech[2], hb, 31), l31_3 = half_lane(probSpeech[3], hb, 31);
-    if (q == 0) {
-      prevProb[0] = g == 0 ? 0.0f : l15_3;  // bin 0 has no predecessor; bin 64 <- bin 63
-      prevProb[1] = g == 0 ? l15_0 : l31_0;
-      prevProb[2] = g == 0 ? l15_1 : l31_1;
-      prevProb[3] = g == 0 ? l15_2 : l31_2;
-    }
+    for (int k = 0; k < 4; ++k) ror[k] = dpp_move<0x121>(probSpeech[k]);  // row_ror:1
+    const float l15_3 = half_lane(probSpeech[3], hb, 15), l31_3 = half_lane(probSpeech[3], hb, 31);
+    prevProb[0] = q == 0 ? (g == 0 ? 0.0f : l15_3) : ror[0];  // bin 0 has no predecessor; bin 64 <- bin 63
+#pragma unroll
+    for (int k = 1; k < 4; ++k) prevProb[k] = q == 0 ? ror[k - 1] : ror[k];
     prevProb[4] = l31_3;  // bin 128 <- bin 127
 #pragma unroll
     for (int k = 0; k < NS5; ++k) {
