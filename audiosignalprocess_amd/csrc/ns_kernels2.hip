@@ -578,15 +578,14 @@ __global__ __launch_bounds__(256) void ns_frame2_kernel(float* __restrict__ stat
   bool window_closed = false;
   if (updateParsFlag >= 1) {
     mup3--;
-    if (mup3 > 0 && lam == 0 && live) {  // FeatureParameterExtraction(self, 0), ns_core.c:309-334
-      // one writer per stream: a no-return atomic add is the same increment without the
-      // load -> add -> store round trip
-      if ((fd3 < kHist * 0.1f) && (fd3 >= 0.0f))
-        atomicAdd(&hist[(int)div_by_uniform(fd3, 0.1f, 1.0f / 0.1f)], 1);
-      if ((fd0 < kHist * 0.05f) && (fd0 >= 0.0f))
-        atomicAdd(&hist[kHistStride + (int)div_by_uniform(fd0, 0.05f, 1.0f / 0.05f)], 1);
-      if ((fd4 < kHist * 0.1f) && (fd4 >= 0.0f))
-        atomicAdd(&hist[2 * kHistStride + (int)div_by_uniform(fd4, 0.1f, 1.0f / 0.1f)], 1);
+    {  // FeatureParameterExtraction(self, 0), ns_core.c:309-334: lanes 0..2 of a half take one
+       // histogram each (LRT, spectral flatness, spectral difference); one writer per bin and stream,
+       // so a no-return atomic add is the increment without the load -> add -> store round trip
+      const float fv = lam == 0 ? fd3 : (lam == 1 ? fd0 : fd4);
+      const float bw = lam == 1 ? 0.05f : 0.1f, rbw = lam == 1 ? 1.0f / 0.05f : 1.0f / 0.1f;
+      const float lim = lam == 1 ? kHist * 0.05f : kHist * 0.1f;
+      if (mup3 > 0 && lam < 3 && live && (fv < lim) && (fv >= 0.0f))
+        atomicAdd(&hist[lam * kHistStride + (int)div_by_uniform(fv, bw, rbw)], 1);
     }
   }
   {
