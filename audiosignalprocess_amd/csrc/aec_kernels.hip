@@ -71,65 +71,44 @@ struct Tw {
 // B = 0 no twiddles, B = 1 the w[2] block, B = 2u / 2u + 1 general.
 __device__ __forceinline__ void bfly(float2& e0, float2& e1, float2& e2, float2& e3, int B,
                                      const SharedTables& T) {
-  float x0r = e0.x + e1.x, x0i = e0.y + e1.y;
+  // Branch-free: the lanes of a pass hold different blocks B, so the three forms of the reference
+  // (no twiddles, the w[2] block, general) would otherwise run one after the other under divergent
+  // branches.  The general form is evaluated for every lane (B = 0 reads w[0..1] = (1, 0): harmless),
+  // the plain form is its own intermediate values, the w[2] form costs ten more operations; the lane
+  // then keeps the form of its block.  Every kept value comes from the reference's own operations.
+  const float x0r = e0.x + e1.x, x0i = e0.y + e1.y;
   const float x1r = e0.x - e1.x, x1i = e0.y - e1.y;
   const float x2r = e2.x + e3.x, x2i = e2.y + e3.y;
   const float x3r = e2.x - e3.x, x3i = e2.y - e3.y;
   e0.x = x0r + x2r;
   e0.y = x0i + x2i;
-  if (B == 0) {
-    e2.x = x0r - x2r;
-    e2.y = x0i - x2i;
-    e1.x = x1r - x3i;
-    e1.y = x1i + x3r;
-    e3.x = x1r + x3i;
-    e3.y = x1i - x3r;
-  } else if (B == 1) {
-    const float ws = T.w[2];
-    float yr, yi;
-    e2.x = x2i - x0i;
-    e2.y = x0r - x2r;
-    yr = x1r - x3i;
-    yi = x1i + x3r;
-    e1.x = ws * (yr - yi);
-    e1.y = ws * (yr + yi);
-    yr = x3i + x1r;
-    yi = x3r - x1i;
-    e3.x = ws * (yi - yr);
-    e3.y = ws * (yi + yr);
-  } else {
-    const int k1 = 2 * (B >> 1), k2 = 2 * k1;
-    const float wk2r = T.w[k1], wk2i = T.w[k1 + 1];
-    Tw t;
-    if ((B & 1) == 0) {
-      t.w1r = T.w[k2];
-      t.w1i = T.w[k2 + 1];
-      t.w3r = T.wk3a[k1];
-      t.w3i = T.wk3a[k1 + 1];
-      t.w2r = wk2r;
-      t.w2i = wk2i;
-    } else {
-      t.w1r = T.w[k2 + 2];
-      t.w1i = T.w[k2 + 3];
-      t.w3r = T.wk3b[k1];
-      t.w3i = T.wk3b[k1 + 1];
-      t.w2r = -wk2i;
-      t.w2i = wk2r;
-    }
-    float yr, yi;
-    x0r -= x2r;
-    x0i -= x2i;
-    e2.x = t.w2r * x0r - t.w2i * x0i;
-    e2.y = t.w2r * x0i + t.w2i * x0r;
-    yr = x1r - x3i;
-    yi = x1i + x3r;
-    e1.x = t.w1r * yr - t.w1i * yi;
-    e1.y = t.w1r * yi + t.w1i * yr;
-    yr = x1r + x3i;
-    yi = x1i - x3r;
-    e3.x = t.w3r * yr - t.w3i * yi;
-    e3.y = t.w3r * yi + t.w3i * yr;
-  }
+  const int odd = B & 1;
+  const int k1 = 2 * (B >> 1), k2 = 2 * k1;
+  const float wk2r = T.w[k1], wk2i = T.w[k1 + 1];
+  const float w1r = T.w[k2 + 2 * odd], w1i = T.w[k2 + 2 * odd + 1];
+  const float w3r = T.wk3a[k1 + 16 * odd], w3i = T.wk3a[k1 + 16 * odd + 1];  // wk3b follows wk3a
+  const float w2r = odd ? -wk2i : wk2r, w2i = odd ? wk2r : wk2i;
+  // plain (B == 0) = the general form's operands
+  const float d0r = x0r - x2r, d0i = x0i - x2i;
+  const float y1r = x1r - x3i, y1i = x1i + x3r;
+  const float y3r = x1r + x3i, y3i = x1i - x3r;
+  // general
+  const float g2r = w2r * d0r - w2i * d0i, g2i = w2r * d0i + w2i * d0r;
+  const float g1r = w1r * y1r - w1i * y1i, g1i = w1r * y1i + w1i * y1r;
+  const float g3r = w3r * y3r - w3i * y3i, g3i = w3r * y3i + w3i * y3r;
+  // the w[2] block (B == 1)
+  const float ws = T.w[2];
+  const float s2r = x2i - x0i, s2i = d0r;
+  const float s1r = ws * (y1r - y1i), s1i = ws * (y1r + y1i);
+  const float zr = x3i + x1r, zi = x3r - x1i;
+  const float s3r = ws * (zi - zr), s3i = ws * (zi + zr);
+  const bool plain = B == 0, diag = B == 1;
+  e2.x = plain ? d0r : (diag ? s2r : g2r);
+  e2.y = plain ? d0i : (diag ? s2i : g2i);
+  e1.x = plain ? y1r : (diag ? s1r : g1r);
+  e1.y = plain ? y1i : (diag ? s1i : g1i);
+  e3.x = plain ? y3r : (diag ? s3r : g3r);
+  e3.y = plain ? y3i : (diag ? s3i : g3i);
 }
 
 // Last pass of cftfsub_128 / cftbsub_128 (aec_rdft.c:446-507).
