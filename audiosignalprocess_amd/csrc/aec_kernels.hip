@@ -765,7 +765,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
         const float cr = i == 0 ? XFR[64] : c64[R_XF_RE + px];
         const float ci = -(i == 0 ? XFI[64] : c64[R_XF_IM + px]);
         const float p64 = cr * EFR[64] - ci * EFI[64];
-        if (lane == 0) v.y = p64;
+        v.y = lane == 0 ? p64 : v.y;
       }
       tile(wl, k)[lane] = v;
     }
@@ -774,13 +774,8 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float2 v = tile(wl, k)[lane];
-      if (lane < 32) {
-        v.x *= scale;
-        v.y *= scale;
-      } else {
-        v.x = 0.f;
-        v.y = 0.f;
-      }
+      v.x = lane < 32 ? v.x * scale : 0.f;
+      v.y = lane < 32 ? v.y * scale : 0.f;
       tile(wl, k)[lane] = v;
     }
     wave_fence();
@@ -791,11 +786,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       const float2 v = tile(wl, k)[lane];
       // lane 0 carries (fft[0], fft[1]) = updates of the real parts of bins 0 and 64
       wr[i] += v.x;
-      if (lane == 0) {
-        c64[R_WF_RE + i] += v.y;
-      } else {
-        wi[i] += v.y;
-      }
+      const float wi_new = wi[i] + v.y;
+      wi[i] = lane == 0 ? wi[i] : wi_new;
+      if (lane == 0) c64[R_WF_RE + i] += v.y;
     }
     wave_fence();
   }
@@ -955,7 +948,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #pragma unroll
       for (int j = 0; j < 24; ++j) {
         const float u = HNL[minPrefBand + j];  // j < 24 + 4 stays inside the row
-        rank += (j < prefBandSize) && ((u < v) || (u == v && j < lane));
+        rank += (int)(j < prefBandSize) & ((int)(u < v) | ((int)(u == v) & (int)(j < lane)));  // no short-circuit branches
       }
       if (rank == iFb) misc[4] = v;
       if (rank == iLow) misc[5] = v;
