@@ -237,29 +237,44 @@ class RefNs:
 from audiosignalprocess_amd._abi import AspBtState  # noqa: E402
 
 
+_bt_ready = False
+_bt_lock = __import__("threading").Lock()
+
+
+def _bt_lib():
+    """Prototypes are declared once, under a lock: bench.py builds one OracleBt per worker thread, and
+    re-assigning argtypes while another thread is inside a call makes ctypes reject that call."""
+    global _bt_ready
+    lib = oracle_lib()
+    with _bt_lock:
+        if not _bt_ready:
+            lib.bt_oracle_create.restype = C.c_void_p
+            lib.bt_oracle_create.argtypes = [C.c_int]
+            for n in ("bt_oracle_free", "bt_oracle_reset"):
+                getattr(lib, n).argtypes = [C.c_void_p]
+            lib.bt_oracle_denoise_float.argtypes = [C.c_void_p, _f32p, C.c_int]
+            lib.bt_oracle_output_float.argtypes = [C.c_void_p, _f32p, C.c_int]
+            lib.bt_oracle_flush_float.argtypes = [C.c_void_p, _f32p, C.c_int]
+            lib.bt_oracle_macroblock.argtypes = [C.c_void_p, _f32p, _f32p, C.c_void_p]
+            lib.bt_oracle_export.argtypes = [C.c_void_p, C.POINTER(AspBtState)]
+            lib.bt_oracle_import.argtypes = [C.c_void_p, C.POINTER(AspBtState)]
+            lib.bt_oracle_kiss_fftr.argtypes = [C.c_void_p, _f32p, _f32p]
+            lib.bt_oracle_kiss_fftri.argtypes = [C.c_void_p, _f32p, _f32p]
+            lib.bt_oracle_hann.restype = C.POINTER(C.c_float)
+            lib.bt_oracle_hann.argtypes = [C.c_void_p]
+            lib.bt_oracle_s16_to_float.restype = C.c_float
+            lib.bt_oracle_s16_to_float.argtypes = [C.c_int16]
+            lib.bt_oracle_float_to_s16.restype = C.c_int16
+            lib.bt_oracle_float_to_s16.argtypes = [C.c_float]
+            _bt_ready = True
+    return lib
+
+
 class OracleBt:
     """One stream through the CPU restatement of Denoise/BlockThresholding."""
 
     def __init__(self, win_size):
-        lib = oracle_lib()
-        lib.bt_oracle_create.restype = C.c_void_p
-        lib.bt_oracle_create.argtypes = [C.c_int]
-        for n in ("bt_oracle_free", "bt_oracle_reset"):
-            getattr(lib, n).argtypes = [C.c_void_p]
-        lib.bt_oracle_denoise_float.argtypes = [C.c_void_p, _f32p, C.c_int]
-        lib.bt_oracle_output_float.argtypes = [C.c_void_p, _f32p, C.c_int]
-        lib.bt_oracle_flush_float.argtypes = [C.c_void_p, _f32p, C.c_int]
-        lib.bt_oracle_macroblock.argtypes = [C.c_void_p, _f32p, _f32p, C.c_void_p]
-        lib.bt_oracle_export.argtypes = [C.c_void_p, C.POINTER(AspBtState)]
-        lib.bt_oracle_import.argtypes = [C.c_void_p, C.POINTER(AspBtState)]
-        lib.bt_oracle_kiss_fftr.argtypes = [C.c_void_p, _f32p, _f32p]
-        lib.bt_oracle_kiss_fftri.argtypes = [C.c_void_p, _f32p, _f32p]
-        lib.bt_oracle_hann.restype = C.POINTER(C.c_float)
-        lib.bt_oracle_hann.argtypes = [C.c_void_p]
-        lib.bt_oracle_s16_to_float.restype = C.c_float
-        lib.bt_oracle_s16_to_float.argtypes = [C.c_int16]
-        lib.bt_oracle_float_to_s16.restype = C.c_int16
-        lib.bt_oracle_float_to_s16.argtypes = [C.c_float]
+        lib = _bt_lib()
         self.lib = lib
         self.h = lib.bt_oracle_create(win_size)
         if not self.h:
