@@ -186,24 +186,28 @@ __device__ __forceinline__ void rdft_fwd_quad(float* wl, int lane, const SharedT
   cft64_quad(t, b, false, T);
 #pragma unroll
   for (int r = 0; r < 2; ++r) {  // rftfsub_128 (aec_rdft.c:509-527), pairs (j1, 64 - j1)
+    // lane 15 of the second trip (j1 = 32) has no pair: it does the a[0], a[1] step of
+    // aec_rdft.c:544-546 instead.  Both forms are evaluated by every lane (clamped index), only the
+    // stores differ, so the trip is one straight line with two small masked stores.
     const int j1 = b + 1 + 16 * r;
-    if (j1 < 32) {
-      const int k = 64 - j1;
-      const float wkr = 0.5f - c[32 - j1], wki = c[j1];
-      float2 aj = t[j1], ak = t[k];
-      const float xr = aj.x - ak.x, xi = aj.y + ak.y;
-      const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
-      aj.x -= yr;
-      aj.y -= yi;
-      ak.x += yr;
-      ak.y -= yi;
-      t[j1] = aj;
+    const bool pair = j1 < 32;
+    const int jc = pair ? j1 : 31, k = 64 - jc;
+    const float wkr = 0.5f - c[32 - jc], wki = c[jc];
+    float2 aj = t[jc], ak = t[k];
+    float2 a0 = t[0];
+    const float xr = aj.x - ak.x, xi = aj.y + ak.y;
+    const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
+    aj.x -= yr;
+    aj.y -= yi;
+    ak.x += yr;
+    ak.y -= yi;
+    const float x0 = a0.x - a0.y;
+    a0.x += a0.y;
+    a0.y = x0;
+    if (pair) {
+      t[jc] = aj;
       t[k] = ak;
-    } else {  // a[0], a[1] (aec_rdft.c:544-546)
-      float2 a0 = t[0];
-      const float xi = a0.x - a0.y;
-      a0.x += a0.y;
-      a0.y = xi;
+    } else {
       t[0] = a0;
     }
   }
@@ -216,26 +220,27 @@ __device__ __forceinline__ void rdft_inv_quad(float* wl, int lane, const SharedT
   const int b = lane & 15;
   const float* c = T.w + 32;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {  // rftbsub_128 (aec_rdft.c:529-537)
+  for (int r = 0; r < 2; ++r) {  // rftbsub_128 (aec_rdft.c:529-537); lane 15 of the second trip: a[0], a[1], a[65]
     const int j1 = b + 1 + 16 * r;
-    if (j1 < 32) {
-      const int k = 64 - j1;
-      const float wkr = 0.5f - c[32 - j1], wki = c[j1];
-      float2 aj = t[j1], ak = t[k];
-      const float xr = aj.x - ak.x, xi = aj.y + ak.y;
-      const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
-      aj.x = aj.x - yr;
-      aj.y = yi - aj.y;
-      ak.x = yr + ak.x;
-      ak.y = yi - ak.y;
-      t[j1] = aj;
+    const bool pair = j1 < 32;
+    const int jc = pair ? j1 : 31, k = 64 - jc;
+    const float wkr = 0.5f - c[32 - jc], wki = c[jc];
+    float2 aj = t[jc], ak = t[k];
+    float2 a0 = t[0], am = t[32];
+    const float xr = aj.x - ak.x, xi = aj.y + ak.y;
+    const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
+    aj.x = aj.x - yr;
+    aj.y = yi - aj.y;
+    ak.x = yr + ak.x;
+    ak.y = yi - ak.y;
+    a0.y = 0.5f * (a0.x - a0.y);
+    a0.x -= a0.y;
+    a0.y = -a0.y;
+    am.y = -am.y;  // a[65] = -a[65]
+    if (pair) {
+      t[jc] = aj;
       t[k] = ak;
     } else {
-      float2 a0 = t[0], am = t[32];
-      a0.y = 0.5f * (a0.x - a0.y);
-      a0.x -= a0.y;
-      a0.y = -a0.y;
-      am.y = -am.y;  // a[65] = -a[65]
       t[0] = a0;
       t[32] = am;
     }
