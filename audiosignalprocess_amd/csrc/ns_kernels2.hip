@@ -186,10 +186,13 @@ __device__ __forceinline__ float sat16f(float x) {
 }
 
 // --------------------------------------------------------------------------
+#ifndef NS_MIN_WG_PER_CU
+#define NS_MIN_WG_PER_CU 3
+#endif
 // launch bounds (256, 3): at most 168 VGPRs, so three waves fit a SIMD (it matters from 8192 streams
 // per GPU on; at 4096 there are two per SIMD to run)
 template <bool IO16>
-__global__ __launch_bounds__(256, 3) void ns_frame2_kernel(float* __restrict__ state,
+__global__ __launch_bounds__(256, NS_MIN_WG_PER_CU) void ns_frame2_kernel(float* __restrict__ state,
                                                         int32_t* __restrict__ hist_all,
                                                         const NsTables* __restrict__ T,
                                                         const float* __restrict__ in,
