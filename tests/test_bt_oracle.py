@@ -86,3 +86,91 @@ def test_s16_conversions():
     g = o.lib.bt_oracle_float_to_s16
     assert f(32767) == 1.0 and f(-32768) == -1.0 and f(0) == 0.0
     assert g(1.5) == 32767 and g(-1.5) == -32768 and g(0.5) == 16384 and g(-0.5) == -16384
+
+
+def _bt_float64(x, n):
+    """Denoise/BlockThresholding restated independently in numpy float64 from the reference source
+    (audioDenoiseBlockTreshold.c:273-539; numpy's rfft / irfft stand in for kiss_fftr / kiss_fftri): a
+    second reading of the algorithm to hold the C oracle against, not a bit-exact model."""
+    half, macro, nb = n // 2, 4 * n, n // 2 + 1
+    i = np.arange(n)
+    hann = (0.5 - 0.5 * np.cos(2 * np.pi * np.minimum(i, n - 1 - i) / (n - 1))).astype(np.float32).astype(np.float64)
+    sigma = float(np.float32(np.float32(0.047) * np.sqrt(0.375)))            # .c:111-112
+    lam = np.array([[1.5, 1.8, 2, 2.5, 2.5], [1.8, 2, 2.5, 3.5, 3.5], [2, 2.5, 3.5, 4.7, 4.7]],
+                   np.float32).astype(np.float64)                           # .c:11-13
+    in_tail, out_tail = np.zeros(half), np.zeros(half)
+    out, segs, sures = [], [], []
+    for blk in x.astype(np.float64).reshape(-1, macro):
+        b = np.concatenate([in_tail, blk])
+        in_tail = blk[-half:]
+        coef = np.stack([np.fft.rfft(b[half * t:half * t + n] * hann) for t in range(8)])   # .c:273-282
+        thre = np.zeros_like(coef)
+
+        def per_bin(col):                                                   # .c:501-506, 518-532
+            a = 1 - (2.5 * 8.0 * sigma ** 2 * n) / (np.abs(coef[:, col]) ** 2).sum()
+            thre[:, col] = coef[:, col] * max(a, 0.0)
+        per_bin(0)
+        ncol = (n - 1) // 2 // 16
+        norm = np.sqrt(2.0) / (np.sqrt(n) * sigma)
+        seg = np.zeros((ncol, 2), np.int32)
+        sure_all = np.zeros((ncol, 3, 5))
+        for m in range(ncol):
+            tile = coef[:, 1 + 16 * m:17 + 16 * m]
+            e2 = (tile.real * norm) ** 2                                    # energy_real_STFT: real parts only
+            best = None
+            for T in range(3):
+                for F in range(5):
+                    TT, FF = 8 >> T, 16 >> F
+                    size, l = float(TT * FF), lam[T, F]
+                    temp = l * l * size * size - 2 * l * size * (size - 2)
+                    E = e2.reshape(1 << T, TT, 1 << F, FF).sum(axis=(1, 3))
+                    sure = (size + np.where(E > l * size, temp / E, 0.0) + np.where(E <= l * size, E - 2 * size, 0.0)).sum()
+                    sure_all[m, T, F] = sure
+                    if best is None or sure < best[0]:                      # first minimum wins (.c:404-416)
+                        best = (sure, T, F)
+            _, T, F = best
+            seg[m] = (T, F)
+            TT, FF = 8 >> T, 16 >> F
+            P = (np.abs(tile) ** 2).reshape(1 << T, TT, 1 << F, FF).sum(axis=(1, 3))
+            a = 1.0 - lam[T, F] * TT * FF * sigma ** 2 * n / P               # .c:421-454
+            a = np.where(a > 0, a, 0.0)
+            thre[:, 1 + 16 * m:17 + 16 * m] = tile * np.repeat(np.repeat(a, TT, axis=0), FF, axis=1)
+        for col in range(1 + 16 * ncol, nb):
+            per_bin(col)
+        p = np.abs(thre[:, :n // 2]) ** 2                                   # .c:469-486, Nyquist untouched
+        coef[:, :n // 2] *= p / (p + n * sigma ** 2)
+        buf = np.concatenate([out_tail, np.zeros(macro)])                   # .c:284-300
+        for t in range(8):
+            buf[half * t:half * t + n] += np.fft.irfft(coef[t], n)
+        out.append(buf[:macro])
+        out_tail = buf[macro:]
+        segs.append(seg)
+        sures.append(sure_all)
+    return np.concatenate(out), np.stack(segs), np.stack(sures)
+
+
+@pytest.mark.parametrize("n", [256, 1024])
+def test_oracle_against_an_independent_float64_restatement(n):
+    """The reference cannot be built here (its kiss_fft internals header is not in the tree), so the C
+    oracle is at least held against a second, independent reading of the reference source in numpy
+    float64: outputs within 1e-5 relative L2 (float32 vs float64 arithmetic), the adaptive
+    segmentation a minimiser of the float64 SURE values."""
+    o = OracleBt(n)
+    x = bt_samples(1, 4 * o.macro, stream0=5)[0]
+    k = np.arange(x.size)
+    x = (x + 0.08 * np.sin(2 * np.pi * (0.002 + 0.22 * k / x.size) * k)).astype(np.float32)   # a sweep through every macro-column
+    want, want_seg, sure = _bt_float64(x, n)
+    got, got_seg = [], []
+    for blk in x.reshape(-1, o.macro):
+        y, s = o.macroblock(blk, want_seg=True)
+        got.append(y)
+        got_seg.append(s)
+    got, got_seg = np.concatenate(got), np.stack(got_seg)
+    # the oracle's segmentation must be a minimiser of the float64 SURE matrix up to float32 rounding
+    # (noise-only columns tie exactly: every block is under its threshold and SURE = sum(E) - size)
+    chosen = np.take_along_axis(sure.reshape(*sure.shape[:2], 15), (got_seg[..., 0] * 5 + got_seg[..., 1])[..., None], axis=2)[..., 0]
+    best = sure.min(axis=(2, 3))
+    assert (chosen - best <= 2e-4 * np.maximum(1.0, np.abs(best))).all()
+    assert (got_seg == want_seg).all(axis=2).mean() > 0.3          # and it is not ties only: distinct minima agree
+    err = np.sqrt(((got - want) ** 2).sum() / (want ** 2).sum())
+    assert err <= 1e-5, err
