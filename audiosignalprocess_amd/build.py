@@ -23,6 +23,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 # the object carries a prologue for firmware without the feature
 _PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=8"]
 EXTRA = {"ns_kernels2.hip": list(_PRELOAD), "ns_kernels.hip": list(_PRELOAD)}
+# second builds of a source under another object name: (source, object, extra flags).  The NS frame
+# kernel exists as the 168-VGPR / three-waves-per-SIMD build (large batches) and as an ILP-scheduled
+# build (ns_kernels2.hip explains; the library picks by batch size)
+VARIANTS = [("ns_kernels2.hip", "ns_kernels2_ilp.hip.o",
+             ["-DNS_VARIANT_ILP", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"])]
 for _item in filter(None, os.environ.get("ASP_HIPCC_EXTRA", "").split(";")):
     _f, _, _fl = _item.partition(":")
     EXTRA.setdefault(_f.strip(), []).extend(_fl.split())
@@ -54,6 +59,15 @@ def build_library(force=False, verbose=False):
         o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
         if force or _stale(o, deps):
             cmd = [hipcc()] + FLAGS + EXTRA.get(os.path.basename(s), []) + inc + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        objs.append(o)
+    for src_name, obj_name, flags in VARIANTS:
+        s = os.path.join(CSRC, src_name)
+        o = os.path.join(LIBDIR, obj_name)
+        if force or _stale(o, deps):
+            cmd = [hipcc()] + FLAGS + EXTRA.get(src_name, []) + flags + inc + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)

@@ -24,6 +24,9 @@ using namespace aspns;
 namespace aspns {
 hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables* T,
                            const float* in, float* out, int num_streams, hipStream_t s);
+hipError_t launch_ns_frame2_ilp(bool io16, float* state, int32_t* hist, const NsTables* T,
+                                const float* in, float* out, int num_streams, hipStream_t s,
+                                unsigned long long* stamps = nullptr);
 hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
                             unsigned long long* stamps = nullptr);
@@ -617,6 +620,8 @@ int AspNsBatch_set_policy(AspNsBatch* b, int mode) {
   return ASP_OK;
 }
 
+constexpr int kIlpMaxStreams = 6144;  // streams per GPU up to which the ILP build of the frame kernel is used
+
 // One fused paired frame step over streams [s0, s0 + n) of the batch.
 static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float* dout, int s0, int n,
                                hipStream_t st) {
@@ -627,7 +632,10 @@ static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float
   float* out = dout + (size_t)s0 * sper;
   if (!b->dual || n < 2) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
   const int even = n & ~1;
-  hipError_t e = launch_ns_frame2(io16, state, hist, b->tables, in, out, even, st);
+  // two builds of the same kernel (ns_kernels2.hip): the ILP-scheduled one while the batch gives a
+  // SIMD at most two waves to run, the 168-VGPR one (three resident waves) for larger batches
+  hipError_t e = b->S <= kIlpMaxStreams ? launch_ns_frame2_ilp(io16, state, hist, b->tables, in, out, even, st)
+                                        : launch_ns_frame2(io16, state, hist, b->tables, in, out, even, st);
   if (e == hipSuccess && even != n)  // the odd last stream: one-stream-per-wave kernel
     e = launch_ns_frame(io16 ? 3 : 2, state + (size_t)even * kStreamDwords,
                         hist + (size_t)even * kHistDwords, b->tables, in + (size_t)even * sper,

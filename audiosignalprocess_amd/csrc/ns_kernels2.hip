@@ -186,11 +186,20 @@ __device__ __forceinline__ float sat16f(float x) {
 }
 
 // --------------------------------------------------------------------------
-#ifndef NS_MIN_WG_PER_CU
+// This file is compiled twice (audiosignalprocess_amd/build.py):
+//   as is                   -> ns_frame2_kernel, launch bounds (256, 3): at most 168 VGPRs, three waves
+//                              per SIMD -- the build for large batches (from about 6000 streams per GPU);
+//   with -DNS_VARIANT_ILP   -> ns_frame2_kernel_ilp, launch bounds (256, 2) and the compiler's
+//                              ILP-first scheduling (-mllvm -amdgpu-sched-strategy=iterative-ilp): at
+//                              4096 streams there are only two waves per SIMD to run, so a shorter
+//                              path per wave beats residency (+3 %; -3 .. -8 % at 8192 / 16384).
+#ifdef NS_VARIANT_ILP
+#define ns_frame2_kernel ns_frame2_kernel_ilp
+#define launch_ns_frame2 launch_ns_frame2_ilp
+#define NS_MIN_WG_PER_CU 2
+#else
 #define NS_MIN_WG_PER_CU 3
 #endif
-// launch bounds (256, 3): at most 168 VGPRs, so three waves fit a SIMD (it matters from 8192 streams
-// per GPU on; at 4096 there are two per SIMD to run)
 template <bool IO16>
 __global__ __launch_bounds__(256, NS_MIN_WG_PER_CU) void ns_frame2_kernel(float* __restrict__ state,
                                                         int32_t* __restrict__ hist_all,

@@ -344,7 +344,10 @@ def main():
                 "traffic": (PMC_TRAFFIC_BYTES_PER_FRAME_DUAL if args.streams_per_wave == 2
                             else PMC_TRAFFIC_BYTES_PER_FRAME) * S / max(args.split, 1),
                 "traffic_source": "profiles/README.md (PMC passes of round 1, per launch)",
-                "kernel": "ns_frame2_kernel<false>" if args.streams_per_wave == 2 else "ns_frame_kernel<true,true>",
+                # two builds of the two-streams-per-wave kernel: the ILP-scheduled one up to 6144 streams per
+                # GPU, the three-waves-per-SIMD one above (csrc/ns_kernels2.hip, ns_api.hip: kIlpMaxStreams)
+                "kernel": ("ns_frame2_kernel_ilp<false>" if S <= 6144 else "ns_frame2_kernel<false>")
+                          if args.streams_per_wave == 2 else "ns_frame_kernel<true,true>",
                 # one frame step = `concurrent_launches` launches of this kernel side by side
                 # (one per HIP stream, S / concurrent_launches streams each); each lasts about
                 # one step, so achieved = concurrent_launches * bytes_per_launch / avg_launch
