@@ -958,7 +958,9 @@ int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
   HIP_TRY(hipMalloc((void**)&d, 16 * sizeof(unsigned long long)));
   hipError_t e = hipMemset(d, 0, 16 * sizeof(unsigned long long));
   if (e == hipSuccess)
-    e = launch_ns_frame2(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d);
+    e = b->S <= kIlpMaxStreams  // the build the product path uses for this batch size
+            ? launch_ns_frame2_ilp(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d)
+            : launch_ns_frame2(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (e == hipSuccess) e = hipMemcpy(stamps16, d, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d);
