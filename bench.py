@@ -165,6 +165,51 @@ def bench_bt(args):
     print(json.dumps(line), flush=True)
 
 
+def bench_split(args):
+    """Secondary line: the three-band SplittingFilter of a 48 kHz channel, 10 ms frames
+    through Analysis (48 -> 64 kHz sinc resampler + two QMF stages) and Synthesis (the inverse), 1 GPU."""
+    import torch
+
+    from audiosignalprocess_amd.qmf import MEM_DEVICE, SplitBatch, _check
+
+    Cn = args.streams_per_gpu
+    ring = 8
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((ring, Cn, 480)) * 3000).astype(np.int16)
+    d_in = torch.from_numpy(x).cuda()
+    d_bands = torch.empty((3, Cn, 160), dtype=torch.int16, device="cuda")
+    d_out = torch.empty_like(d_in)
+    g = SplitBatch(Cn, 3)
+
+    def step(k):
+        _check(g.lib.AspSplitBatch_Analysis(g.h, d_in[k % ring].data_ptr(), d_bands.data_ptr(), MEM_DEVICE), "Analysis")
+        _check(g.lib.AspSplitBatch_Synthesis(g.h, d_bands.data_ptr(), d_out[k % ring].data_ptr(), MEM_DEVICE), "Synthesis")
+    steps, warm = max(args.steps // 4, 10), max(args.warmup // 10, 10)
+    for k in range(warm):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    algo = 2 * (480 * 2 + 3 * 160 * 2)      # samples in / bands out and back, int16; filter state is a few hundred bytes more
+    achieved = algo * Cn * steps / wall / 1e9
+    line = {
+        "metric": "48 kHz three-band split + merge, 10 ms channel-frames/sec (secondary)", "value": Cn * steps / wall,
+        "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * wall / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "s16", "data": "synthetic",
+        "config": {"workload": "SplittingFilter (splitting_filter.cc:28-170): %d channels at 48 kHz, Analysis + "
+                               "Synthesis per 10 ms frame, 1 MI355X" % Cn},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "sinc_resample_kernel + qmf_analysis_kernel / qmf_synthesis_kernel (several launches per step; "
+                               "wall-clock figure, launch-bound)",
+                     "algorithmic_bytes_per_launch": algo * Cn, "avg_launch_us": None},
+    }
+    print(json.dumps(line), flush=True)
+
+
 def bench_aec(args):
     """Secondary line (BASELINE config 4): 10 ms / 16 kHz frames per second through the echo
     canceller (WebRtcAec_BufferFarend + WebRtcAec_Process per frame), 1 GPU."""
@@ -231,11 +276,13 @@ def main():
     ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
     ap.add_argument("--streams-per-wave", type=int, default=2, choices=[1, 2],
                     help="fused-step kernel: 2 = two streams per wave64 (default), 1 = one")
-    ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256", "aec"],
-                    help="ns = the headline metric (default); bt* / aec = secondary lines")
+    ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256", "aec", "split48"],
+                    help="ns = the headline metric (default); bt* / aec / split48 = secondary lines")
     args = ap.parse_args()
     if args.workload == "aec":
         return bench_aec(args)
+    if args.workload == "split48":
+        return bench_split(args)
     if args.workload != "ns":
         return bench_bt(args)
 
