@@ -13,15 +13,9 @@
 
 namespace {
 
-__device__ __forceinline__ int32_t sub_sat(int32_t a, int32_t b) {  // WebRtcSpl_SubSatW32
-  int32_t d = (int32_t)((uint32_t)a - (uint32_t)b);
-  if (a < 0) {
-    if (b > 0 && d > 0) d = (int32_t)0x80000000;
-  } else {
-    if (b < 0 && d < 0) d = 0x7FFFFFFF;
-  }
-  return d;
-}
+// WebRtcSpl_SubSatW32 (spl_inl.h): signed subtraction saturated to [INT32_MIN, INT32_MAX] -- exactly
+// llvm.ssub.sat, one v_sub_i32 with the clamp bit instead of a compare-and-select ladder
+__device__ __forceinline__ int32_t sub_sat(int32_t a, int32_t b) { return __builtin_elementwise_sub_sat(a, b); }
 
 // WEBRTC_SPL_SCALEDIFF32 (signal_processing_library.h:77-79), summed in unsigned arithmetic
 __device__ __forceinline__ int32_t scale_diff(uint32_t a, int32_t b, int32_t c) {
