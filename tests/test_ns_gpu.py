@@ -555,6 +555,28 @@ def test_dual_kernel_golden_int16_split_and_scale(ns, golden):
     big.close()
 
 
+def test_large_batch_build_of_the_frame_kernel(ns):
+    """Batches above 6144 streams per GPU run the second build of the two-streams-per-wave kernel
+    (168 VGPRs, three waves per SIMD; csrc/ns_kernels2.hip, ns_api.hip: kIlpMaxStreams).  BASELINE
+    config 5 size (8192 streams): spot-checked bit for bit against the oracle through the start-up
+    phases, and equal to the small-batch build on the same streams."""
+    S, F = 8192, 230
+    base = ns_frames(16, F, stream0=40)
+    idx = np.arange(S) % 16
+    x = np.ascontiguousarray(base[:, idx])
+    big = ns.NsBatch(S, policy=2, streams_per_wave=2)
+    yb = big.analyze_process(x)
+    assert np.isfinite(yb).all()
+    yo = OracleNs(16, policy=2, reduce_mode=REDUCE_TREE32).run(base)
+    for k in (0, 5, 4095, 6143, 6144, 8190, 8191):
+        assert np.array_equal(yb[:, k], yo[:, idx[k]]), k
+    small = ns.NsBatch(16, policy=2, streams_per_wave=2)
+    assert np.array_equal(small.analyze_process(base), yo)
+    assert state_diff(big.export_state(8191), small.export_state(15)) == {}
+    big.close()
+    small.close()
+
+
 def test_dual_then_unfused_continues(ns):
     """Fused two-per-wave steps, then the reference's two-call protocol on the same batch."""
     S, F = 6, 130
