@@ -17,7 +17,7 @@ constexpr int kBlockL = 160;   // ns/defines.h:14
 constexpr int kAnal = 256;     // ns/defines.h:15
 constexpr int kBins = 129;     // ns/defines.h:16
 constexpr int kHist = 1000;    // ns/defines.h:45
-constexpr int kVecStride = 132;
+constexpr int kVecStride = 128;  // one state row = bins 0..127 (bin 128 lives with the scalars): 512 B, cache-line aligned
 // Position of bin b inside a state row.  The four bins a lane of the two-streams-per-wave kernel
 // owns (q + 16 k + 64 g, k = 0..3, lane = q + 16 g) sit next to each other, so a row moves as one
 // 16-byte access per lane instead of four 4-byte ones (a quarter of the vector-memory
@@ -85,7 +85,7 @@ struct NsTables {
   int32_t diag[64];           // bit s set: pass s uses the w[2] "diagonal" form on this lane
   float cq[64];               // makect table c[q]      (fft4g.c:671-690)
   float cr[64];               // makect table c[64 - q] (lane 0: unused)
-  float logi[kVecStride];     // (float)log((float)i), ns_core.c:1093
+  float logi[132];            // (float)log((float)i) for i = 0..128, ns_core.c:1093
   float sum_log_i;            // sequential sums over i = 5..128, ns_core.c:1094-1095
   float sum_log_i_square;
   float pad[2];
