@@ -32,10 +32,10 @@ ALGO_BYTES_PER_FRAME = 15716  # frame-synchronous NS mod
 # known byte count at 32768 streams as MI355X_MICROARCH.md prescribes for access widths it does not
 # cover; see profiles/README.md ("HBM traffic of the NS kernel").  Measured once per round, not live.
 PMC_TRAFFIC_BYTES_PER_FRAME = (4.832 * 1.638 + 9.158 / 1.09) * 1024      # ns_frame_kernel<true,true>
-# ns_frame2_kernel (default, v6 of round 1): FETCH_SIZE 4.0010 / WRITE_SIZE 7.9211 KB per stream at 4096
-# streams against 3.9500 / 7.9650 KB at 32768 streams, where the kernel's known 7 856 B each way are all
-# HBM traffic (v4 read 4.0253 / 7.9428 and 3.9533 / 7.9705, v5 4.0355 / 7.9553 and 3.9546 / 7.9783)
-PMC_TRAFFIC_BYTES_PER_FRAME_DUAL = 7856 * (4.0010 / 3.9500 + 7.9211 / 7.9650)
+# ns_frame2_kernel[_ilp] (default, end of round 1): FETCH_SIZE 3.8785 / WRITE_SIZE 7.7188 KB per stream at 4096
+# streams against 3.8269 / 7.7188 KB at 32768 streams, where the kernel's known 7 808 B each way (12 rows of
+# 512 B, two 384-B sliding buffers, 256 B of scalars, 640 B of samples) are all HBM traffic
+PMC_TRAFFIC_BYTES_PER_FRAME_DUAL = 7808 * (3.8785 / 3.8269 + 7.7188 / 7.7188)
 NS_PRIME_FRAMES = 250  # untimed set-up frames + warm-up >= this (start-up phase of ns_core.c is 200)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
