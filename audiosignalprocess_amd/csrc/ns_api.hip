@@ -27,6 +27,9 @@ hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables
 hipError_t launch_ns_frame2_ilp(bool io16, float* state, int32_t* hist, const NsTables* T,
                                 const float* in, float* out, int num_streams, hipStream_t s,
                                 unsigned long long* stamps = nullptr);
+hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
+                            const float* in, float* out, int num_streams, hipStream_t s,
+                            unsigned long long* stamps = nullptr);
 hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
                             unsigned long long* stamps = nullptr);
@@ -455,8 +458,22 @@ struct AspNsBatch {
   // overlap another part's arithmetic (streams never interact).
   int split = 1;
   bool dual = true;  // fused paired step through the two-streams-per-wave kernel
+  // fused step kernel: 1 = ns_frame_kernel (one stream per wave, bins q / q + 64), 2 = ns_frame2_kernel
+  // (two streams per wave), 3 = ns_frame1_kernel (one stream per wave, pair layout: ns_kernels1.hip)
+  int kernel = 2;
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
+  // A captured K-step replay (hipGraph): the launches of `g_steps` fused steps over the ring
+  // (g_in, g_out, g_ring), still one launch per frame step and sub-launch; replayed while the
+  // key is unchanged, so the host pays one graph launch instead of 2 K kernel launches.
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  const float* g_in = nullptr;
+  float* g_out = nullptr;
+  int g_ring = 0, g_steps = 0, g_split = 0;
+  bool g_io16 = false, g_dual = false;
+  int g_kernel = 0;
+  bool use_graph = true;
   // > 16 kHz: 1 or 2 high bands next to the low band (ns_core.c:1362-1414)
   uint32_t fs = 16000;
   int num_high = 0;
@@ -557,6 +574,8 @@ int AspNsBatch_Free(AspNsBatch* b) {
   if (b->hb_stage) (void)hipFree(b->hb_stage);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
+  if (b->graph) (void)hipGraphDestroy(b->graph);
   if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
   for (int i = 0; i < 3; ++i) {
     if (b->join_ev[i]) (void)hipEventDestroy(b->join_ev[i]);
@@ -630,6 +649,7 @@ static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float
   int32_t* hist = b->hist + (size_t)s0 * kHistDwords;
   const float* in = din + (size_t)s0 * sper;
   float* out = dout + (size_t)s0 * sper;
+  if (b->kernel == 3) return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st);
   if (!b->dual || n < 2) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
   const int even = n & ~1;
   // two builds of the same kernel (ns_kernels2.hip): the ILP-scheduled one while the batch gives a
@@ -675,6 +695,49 @@ static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, i
     HIP_TRY(hipEventRecord(b->join_ev[p - 1], b->side[p - 1]));
     HIP_TRY(hipStreamWaitEvent(b->stream, b->join_ev[p - 1], 0));
   }
+  return ASP_OK;
+}
+
+static void drop_graph(AspNsBatch* b) {
+  if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
+  if (b->graph) (void)hipGraphDestroy(b->graph);
+  b->gexec = nullptr;
+  b->graph = nullptr;
+  b->g_steps = 0;
+}
+
+// The same `steps` fused frame steps as fused_steps(), captured into a hipGraph (kernel nodes only:
+// one per frame step and sub-launch, the sub-launch chains as parallel branches).  The capture is
+// kept while (buffers, ring, steps, split, kernel) stay the same.
+static int ensure_graph(AspNsBatch* b, const float* din, float* dout, int ring, int steps, bool io16) {
+  const bool hit = b->gexec && b->g_in == din && b->g_out == dout && b->g_ring == ring &&
+                   b->g_steps == steps && b->g_split == b->split && b->g_io16 == io16 &&
+                   b->g_dual == b->dual && b->g_kernel == b->kernel;
+  if (hit) return ASP_OK;
+  drop_graph(b);
+  HIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = fused_steps(b, din, dout, ring, steps, io16);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(b->stream, &g);
+  if (rc) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "hipStreamEndCapture", e);
+  b->graph = g;
+  e = hipGraphInstantiate(&b->gexec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    drop_graph(b);
+    return fail(ASP_ERR_HIP, "hipGraphInstantiate", e);
+  }
+  b->g_in = din;
+  b->g_out = dout;
+  b->g_ring = ring;
+  b->g_steps = steps;
+  b->g_split = b->split;
+  b->g_io16 = io16;
+  b->g_dual = b->dual;
+  b->g_kernel = b->kernel;
   return ASP_OK;
 }
 
@@ -865,6 +928,22 @@ int AspNsBatch_AnalyzeProcessS16(AspNsBatch* b, const int16_t* in, int16_t* out,
   return ASP_OK;
 }
 
+int AspNsBatch_AnalyzeProcessReplay(AspNsBatch* b, const float* in, float* out, int frames_in_ring,
+                                    int steps) {
+  int rc = check(b);
+  if (rc) return rc;
+  if (!in || !out || frames_in_ring <= 0 || steps < 0)
+    return fail(ASP_ERR_PARAM, "AnalyzeProcessReplay: bad argument");
+  if (!b->paired) return fail(ASP_ERR_STATE, "AnalyzeProcessReplay needs the fused (paired) representation");
+  if (b->num_high > 0) return fail(ASP_ERR_STATE, "AnalyzeProcessReplay: one-band entry point on a multi-band batch");
+  if (steps == 0) return ASP_OK;
+  if (!b->use_graph || b->stream == nullptr) return fused_steps(b, in, out, frames_in_ring, steps);
+  rc = ensure_graph(b, in, out, frames_in_ring, steps, false);
+  if (rc) return rc;
+  HIP_TRY(hipGraphLaunch(b->gexec, b->stream));
+  return ASP_OK;
+}
+
 int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames_in_ring,
                           int steps, float* elapsed_ms) {
   int rc = check(b);
@@ -872,10 +951,20 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
   if (!in || !out || frames_in_ring <= 0 || steps < 0 || !elapsed_ms)
     return fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
   if (!b->paired) return fail(ASP_ERR_STATE, "TimedSteps needs the fused (paired) representation");
+  // graph replay: capture + instantiate outside the timed region (the legacy null stream cannot capture)
+  const bool graph = b->use_graph && b->stream != nullptr && steps > 0;
+  if (graph) {
+    rc = ensure_graph(b, in, out, frames_in_ring, steps, false);
+    if (rc) return rc;
+  }
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   const auto h0 = std::chrono::steady_clock::now();
-  rc = fused_steps(b, in, out, frames_in_ring, steps);
-  if (rc) return rc;
+  if (graph) {
+    HIP_TRY(hipGraphLaunch(b->gexec, b->stream));
+  } else {
+    rc = fused_steps(b, in, out, frames_in_ring, steps);
+    if (rc) return rc;
+  }
   if (getenv("ASP_NS_DEBUG_TIMING"))
     fprintf(stderr, "TimedSteps: host enqueue of %d steps took %.1f us per step\n", steps,
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count() / (steps > 0 ? steps : 1));
@@ -968,10 +1057,17 @@ int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
   return ASP_OK;
 }
 
+int AspNsBatch_SetGraph(AspNsBatch* b, int on) {
+  if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
+  b->use_graph = on != 0;
+  return ASP_OK;
+}
+
 int AspNsBatch_SetKernel(AspNsBatch* b, int streams_per_wave) {
-  if (!b || (streams_per_wave != 1 && streams_per_wave != 2))
-    return fail(ASP_ERR_PARAM, "SetKernel: streams_per_wave must be 1 or 2");
+  if (!b || streams_per_wave < 1 || streams_per_wave > 3)
+    return fail(ASP_ERR_PARAM, "SetKernel: 1 (one stream per wave, q / q + 64), 2 (two streams per wave) or 3 (one stream per wave, pair layout)");
   b->dual = streams_per_wave == 2;
+  b->kernel = streams_per_wave;
   return ASP_OK;
 }
 

@@ -171,6 +171,59 @@ __device__ __forceinline__ F5 div_by_uniform5(const F5& a, float d, float rd) {
 __device__ __forceinline__ F5 fdiv5v(const F5& n, const F5& d) {
   return F5(fdiv2(n.a, d.a), fdiv2(n.b, d.b), fdiv(n.t, d.t));
 }
+// Three bins of a lane of the one-stream-per-wave kernel (two owned + bin 128) as one packed pair
+// and a scalar; same contract as F5 (every operation is the IEEE single operation of its scalar spelling).
+struct B3 {
+  bool v[3];
+};
+struct F3 {
+  f32x2 p;
+  float t;
+  __device__ __forceinline__ F3() {}
+  __device__ __forceinline__ F3(f32x2 p_, float t_) : p(p_), t(t_) {}
+  __device__ __forceinline__ explicit F3(float c) : p(f32x2{c, c}), t(c) {}
+  __device__ __forceinline__ explicit F3(const float (&x)[3]) : p(f32x2{x[0], x[1]}), t(x[2]) {}
+  __device__ __forceinline__ void store(float (&x)[3]) const {
+    x[0] = p.x; x[1] = p.y; x[2] = t;
+  }
+};
+__device__ __forceinline__ F3 operator+(const F3& x, const F3& y) { return F3(x.p + y.p, x.t + y.t); }
+__device__ __forceinline__ F3 operator-(const F3& x, const F3& y) { return F3(x.p - y.p, x.t - y.t); }
+__device__ __forceinline__ F3 operator*(const F3& x, const F3& y) { return F3(x.p * y.p, x.t * y.t); }
+__device__ __forceinline__ F3 operator*(float c, const F3& y) { return F3(c) * y; }
+__device__ __forceinline__ F3 operator*(const F3& x, float c) { return x * F3(c); }
+__device__ __forceinline__ F3 operator+(const F3& x, float c) { return x + F3(c); }
+__device__ __forceinline__ F3 operator-(const F3& x, float c) { return x - F3(c); }
+__device__ __forceinline__ F3 operator-(float c, const F3& y) { return F3(c) - y; }
+__device__ __forceinline__ F3 fma3(const F3& x, const F3& y, const F3& z) {
+  return F3(__builtin_elementwise_fma(x.p, y.p, z.p), __builtin_fmaf(x.t, y.t, z.t));
+}
+__device__ __forceinline__ F3 abs3(const F3& x) {
+  return F3(f32x2{fabsf(x.p.x), fabsf(x.p.y)}, fabsf(x.t));
+}
+#define ASP_F3_CMP(name, op)                                                        \
+  __device__ __forceinline__ B3 name(const F3& x, const F3& y) {                    \
+    B3 r;                                                                           \
+    r.v[0] = x.p.x op y.p.x; r.v[1] = x.p.y op y.p.y; r.v[2] = x.t op y.t;          \
+    return r;                                                                       \
+  }
+ASP_F3_CMP(gt3, >)
+ASP_F3_CMP(lt3, <)
+#undef ASP_F3_CMP
+__device__ __forceinline__ F3 sel3(const B3& c, const F3& x, const F3& y) {  // c ? x : y
+  return F3(f32x2{c.v[0] ? x.p.x : y.p.x, c.v[1] ? x.p.y : y.p.y}, c.v[2] ? x.t : y.t);
+}
+__device__ __forceinline__ F3 div_by_uniform3(const F3& a, float d, float rd) {
+  const F3 q0 = a * rd;
+  const F3 r = fma3(F3(-d), q0, a);
+  return fma3(r, F3(rd), q0);
+}
+__device__ __forceinline__ F3 fdiv3v(const F3& n, const F3& d) { return F3(fdiv2(n.p, d.p), fdiv(n.t, d.t)); }
+__device__ __forceinline__ void fdiv3(const float (&n)[3], const float (&d)[3], float (&q)[3]) {
+  const f32x2 a = fdiv2(f32x2{n[0], n[1]}, f32x2{d[0], d[1]});
+  q[0] = a.x; q[1] = a.y;
+  q[2] = fdiv(n[2], d[2]);
+}
 #define DIV129(a) div_by_uniform((a), 129.0f, 1.0f / 129.0f)
 
 // (float)log((double)x), the reference's idiom (ns_core.c:228,540,681,1096), for

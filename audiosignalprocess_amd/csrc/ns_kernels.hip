@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
 
   // ---- state rows (issued early; consumed after the FFT); bins lane and 64 + lane sit at
   // row_pos(lane) and 64 + row_pos(lane) (ns_layout.h)
-  const int rpos = 4 * (lane & 15) + (lane >> 4);
+  const int rpos = 4 * (lane & 15) + 2 * ((lane >> 4) & 1) + (lane >> 5);  // row_pos(lane)
   float LQ[3][3], DEN[3][3], quant[3], smooth[3], noisePrev[3], magnPrevA[3], logLrt[3],
       avgPause[3], noiseSt[3], magnPrevP[3];
 #define LOAD_ROW(dst, f)                          \

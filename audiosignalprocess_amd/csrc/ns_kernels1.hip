@@ -1,0 +1,864 @@
+// ns_kernels1.hip -- the fused Analyze+Process frame step with ONE stream per wave64 and two
+// bins per lane: the low-latency build of the frame step.
+//
+// Same arithmetic as ns_frame2_kernel (ns_kernels2.hip) and ns_frame_kernel<true,true>
+// (ns_kernels.hip) -- every per-bin float operation of ns_core.c:1043-1359 in the reference's
+// order, Ooura-order FFT (fft4g.c), exact libm forms (ns_device.h) -- mapped so that a frame
+// step of 4096 streams is 4096 short waves (four per SIMD at <= 128 VGPRs) instead of 2048 long
+// ones: at that batch size a step is bound by the time ONE wave needs from its first load to its
+// last store (profiles/README.md, round 2), and a wave that carries one stream on 64 lanes has
+// about 0.6x the instructions of one that carries two streams on 32 lanes each, while four
+// resident waves per SIMD hide each other's LDS / memory / dependent-issue stalls.
+//
+//   * lane L = 2 lam + h (lam = q + 16 g: the "dual lane" of ns_layout.h's row order) owns the
+//     FFT elements / bins E = q + 64 g + 16 t for t = h and t = h + 2: exactly the two outputs
+//     of its half of a radix-4 butterfly (outputs 0, 2 on even lanes, 1, 3 on odd lanes), and,
+//     with ns_layout.h's row order (t = 0, 2, 1, 3 inside a dual lane), one 8-byte access per
+//     state row; bin 128 is computed on every lane (wave-uniform) and committed with the scalars;
+//   * per-stream scalars are wave-uniform: read from the scalar row with v_readlane, every
+//     data-independent branch of the reference is a scalar branch, written back with v_writelane;
+//   * the three radix-4 passes go through a 1 KB LDS tile per wave (each lane computes half a
+//     butterfly, no duplicated arithmetic), the radix-2 tail through v_permlane32_swap (element p
+//     on lane L, p + 64 on lane L ^ 32), the real split through one LDS gather;
+//   * cross-bin sums: lane-local (slot A + slot B, + bin 128 on lane 0), then the wave64 xor
+//     butterfly of ns_device.h's wave_sum; oracle/ns_oracle.c reproduces this association as
+//     ASP_NS_REDUCE_TREE64P and the tests compare bit for bit (outputs and every state array).
+#include <hip/hip_runtime.h>
+
+#include "ns_device.h"
+#include "ns_layout.h"
+
+namespace {
+using namespace aspns_dev;
+
+constexpr int NS3 = 3;  // 2 owned bins + the tail bin 128
+
+__device__ __forceinline__ void lds_sync1() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Half of one radix-4 butterfly of cft1st / cftmdl (fft4g.c:1002-1231): lane parity h = 0 produces
+// outputs 0 and 2, h = 1 outputs 1 and 3.  With s = (h ? -1 : +1):
+//   u = c0 + s c1, v = c2 + s c3, h: v <- i v, p = u + v, m = u - v, first = tA p, second = tB m
+// (tA, tB from the per-lane table: identity for twiddle-free blocks; `diag` selects the
+// reference's factored form of the w[2] block).  Same operations as ns_kernels.hip's cft_half_pass.
+__device__ __forceinline__ void half_bfly(float2 c0, float2 c1, float2 c2, float2 c3, bool h,
+                                          float4 tw, bool diag, float2& first, float2& second) {
+  const uint32_t sm = h ? 0x80000000u : 0u;
+  const float ur = c0.x + xorf(c1.x, sm), ui = c0.y + xorf(c1.y, sm);
+  const float vr = c2.x + xorf(c3.x, sm), vi = c2.y + xorf(c3.y, sm);
+  const float vr2 = h ? -vi : vr;
+  const float vi2 = h ? vr : vi;
+  const float pr = ur + vr2, pi = ui + vi2;
+  const float mr = ur - vr2, mi = ui - vi2;
+  const float g1r = tw.x * pr - tw.y * pi, g1i = tw.x * pi + tw.y * pr;
+  const float g2r = tw.z * mr - tw.w * mi, g2i = tw.z * mi + tw.w * mr;
+  const float d1r = tw.x * (pr - pi), d1i = tw.x * (pr + pi);
+  const float d2r = -(tw.x * (mr + mi)), d2i = tw.x * (mr - mi);
+  first = diag ? make_float2(d1r, d1i) : make_float2(g1r, g1i);
+  second = diag ? make_float2(d2r, d2i) : make_float2(g2r, g2i);
+}
+
+// Passes 1-3 of cftfsub / cftbsub for 128 complex points.  In: tile holds the inputs in natural
+// order (pass 1 reads bit-reversed = bitrv2).  Out: oA = element q + 64 g + 16 h, oB = oA's + 32.
+__device__ __forceinline__ void cft128_passes1(float2* tile, const float* tws, int diagbits,
+                                               int lane, float2& oA, float2& oB) {
+  const int b = lane >> 1;
+  const bool h = (lane & 1) != 0;
+  float2 f, s;
+  {
+    const int rb = (int)(__brev((unsigned)b) >> 27);
+    const float4 tw = *reinterpret_cast<const float4*>(tws + (0 * 64 + lane) * 4);
+    half_bfly(tile[rb], tile[rb + 64], tile[rb + 32], tile[rb + 96], h, tw, (diagbits & 1) != 0, f, s);
+    lds_sync1();
+    tile[4 * b + (h ? 1 : 0)] = f;
+    tile[4 * b + (h ? 3 : 2)] = s;
+  }
+  lds_sync1();
+  {
+    const int base = 16 * (b >> 2) + (b & 3);
+    const float4 tw = *reinterpret_cast<const float4*>(tws + (1 * 64 + lane) * 4);
+    half_bfly(tile[base], tile[base + 4], tile[base + 8], tile[base + 12], h, tw, (diagbits & 2) != 0, f, s);
+    lds_sync1();
+    tile[base + (h ? 4 : 0)] = f;
+    tile[base + (h ? 12 : 8)] = s;
+  }
+  lds_sync1();
+  {
+    const int base = 64 * (b >> 4) + (b & 15);
+    const float4 tw = *reinterpret_cast<const float4*>(tws + (2 * 64 + lane) * 4);
+    half_bfly(tile[base], tile[base + 16], tile[base + 32], tile[base + 48], h, tw, (diagbits & 4) != 0, oA, oB);
+  }
+}
+
+// radix-2 tail (fft4g.c:939-947 / 989-997): element p (lanes < 32) with p + 64 (lanes >= 32, same
+// lane & 31).  v_permlane32_swap on two copies leaves the low half's value on both halves of one
+// copy and the high half's on the other; p: a + c, p + 64: a - c, i.e. a + (+-c) on both.
+__device__ __forceinline__ float tail_combine(float v, uint32_t gmask) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + xorf(__uint_as_float(r[1]), gmask);
+}
+__device__ __forceinline__ void radix2_tail1(float2& a, float2& b, uint32_t gmask, bool backward) {
+  const float ar = tail_combine(a.x, gmask), ai = tail_combine(a.y, gmask);
+  const float br = tail_combine(b.x, gmask), bi = tail_combine(b.y, gmask);
+  a = make_float2(ar, backward ? -ai : ai);
+  b = make_float2(br, backward ? -bi : bi);
+}
+
+// rftfsub / rftbsub (fft4g.c:1234-1283) plus the a[0]/a[1] fix-ups of rdft (fft4g.c:347-352):
+// element E = q + 16 t + 64 g pairs with 128 - E; g = 0 lanes hold the j side, g = 1 the k side.
+__device__ __forceinline__ void real_split1(float2* tile, const float* spls, int lane, float2 e[2],
+                                            bool backward) {
+  const int b = lane >> 1, h = lane & 1;
+  const bool hi = b >= 16;
+  const int base = 64 * (b >> 4) + (b & 15) + 16 * h;
+  lds_sync1();
+  tile[base] = e[0];
+  tile[base + 32] = e[1];
+  lds_sync1();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int E = base + 32 * k;
+    const float2 pe = tile[(128 - E) & 127];
+    const float2 w = *reinterpret_cast<const float2*>(spls + (b * 4 + h + 2 * k) * 2);  // (wkr, wki)
+    const float2 J = hi ? pe : e[k], K = hi ? e[k] : pe;
+    const float xr = J.x - K.x, xi = J.y + K.y;
+    float2 r;
+    if (!backward) {
+      const float yr = w.x * xr - w.y * xi, yi = w.x * xi + w.y * xr;
+      r = hi ? make_float2(e[k].x + yr, e[k].y - yi) : make_float2(e[k].x - yr, e[k].y - yi);
+      if (E == 0) r = make_float2(e[k].x + e[k].y, e[k].x - e[k].y);
+      if (E == 64) r = e[k];
+    } else {
+      const float yr = w.x * xr + w.y * xi, yi = w.x * xi - w.y * xr;
+      r = hi ? make_float2(e[k].x + yr, yi - e[k].y) : make_float2(e[k].x - yr, yi - e[k].y);
+      if (E == 0) {
+        const float hh = 0.5f * (e[k].x - e[k].y);
+        r = make_float2(e[k].x - hh, -hh);
+      }
+      if (E == 64) r = make_float2(e[k].x, -e[k].y);
+    }
+    e[k] = r;
+  }
+}
+
+template <bool IO16>
+__device__ __forceinline__ void store2p(float* y, int idx, float a, float b) {
+  if (IO16) {
+    short2 v;
+    const float kMaxRound = 32767 - 0.5f, kMinRound = -32768 + 0.5f;
+    v.x = a > 0 ? (a >= kMaxRound ? (short)32767 : (short)(a + 0.5f))
+                : (a <= kMinRound ? (short)-32768 : (short)(a - 0.5f));
+    v.y = b > 0 ? (b >= kMaxRound ? (short)32767 : (short)(b + 0.5f))
+                : (b <= kMinRound ? (short)-32768 : (short)(b - 0.5f));
+    *reinterpret_cast<short2*>(reinterpret_cast<short*>(y) + idx) = v;
+  } else {
+    *reinterpret_cast<float2*>(y + idx) = make_float2(a, b);
+  }
+}
+
+__device__ __forceinline__ float sat16p(float x) {
+  return x > 32767 ? 32767 : (x < -32768 ? -32768 : x);
+}
+
+// v_writelane_b32: the (wave-uniform) value goes into lane K of the scalar row
+template <int K>
+__device__ __forceinline__ float writelane_bits(float row, int bits) {
+  int r = __float_as_int(row);
+  const int u = __builtin_amdgcn_readfirstlane(bits);
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(r) : "s"(u), "n"(K));
+  return __int_as_float(r);
+}
+
+#ifndef NS1_MIN_WAVES
+#define NS1_MIN_WAVES 4
+#endif
+
+template <bool IO16>
+__global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __restrict__ state,
+                                                           int32_t* __restrict__ hist_all,
+                                                           const NsTables* __restrict__ T,
+                                                           const float* __restrict__ in,
+                                                           float* __restrict__ out,
+                                                           int num_streams,
+                                                           unsigned long long* __restrict__ stamps) {
+#define NS_STAMP(k)                                                                \
+  if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {                  \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    stamps[k] = __builtin_amdgcn_s_memtime();                                      \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  }
+  NS_STAMP(0)
+  __shared__ float2 lds[4][128];
+  // per-lane twiddles of the three passes (3 x 64 x 4), real-split factors (32 x 4 x 2) and the
+  // window, staged in LDS once per workgroup behind the state loads
+  __shared__ __align__(16) float tabs[3 * 64 * 4 + 32 * 4 * 2];
+  __shared__ __align__(16) float wins[kAnal];
+  __shared__ __align__(16) double exp2s[64];     // 2^(j/64) of the lean exp / tanh
+  __shared__ __align__(16) double2 logts[128];   // {1/c, log c} of the table-driven log
+  const int tid = threadIdx.x;
+  // ---- prologue: every load of the first phase is issued before the first wait (table pieces
+  // first: loads return in order, the LDS staging waits for them only)
+  const float4* tab_src = tid < 192 ? reinterpret_cast<const float4*>(&T->tw[0][0][0]) + tid
+                                    : reinterpret_cast<const float4*>(&T->spl[0][0][0]) + (tid - 192);
+  const float4 tab_v = *tab_src;
+  const float4 win_v = reinterpret_cast<const float4*>(T->window)[tid & 63];
+  const double exp2_v = T->exp2_64[tid & 63];
+  const double2 logt_v = reinterpret_cast<const double2*>(T->logtab)[tid & 127];
+  const int lane = tid & 63;
+  const int diagbits = T->diag[lane];
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int stream_raw = blockIdx.x * 4 + wv;
+  const bool wave_live = stream_raw < num_streams;
+  const int stream = wave_live ? stream_raw : num_streams - 1;  // clamped for the loads
+  float* __restrict__ st = state + (size_t)stream * kStreamDwords;
+  float* __restrict__ vec = st + kOffVec;
+  int32_t* __restrict__ hist = hist_all + (size_t)stream * kHistDwords;
+  float2* tile = lds[wv];
+  const int lam = lane >> 1, h = lane & 1;
+  const int g = lam >> 4, q = lam & 15;
+  const int binA = q + 64 * g + 16 * h;  // slot 0; slot 1 = binA + 32; slot 2 = bin 128
+  const uint32_t gmask = g ? 0x80000000u : 0u;
+
+  // ---- scalars: lane k holds scalar k (wave-uniform values, read with v_readlane)
+  float sv = st[kOffScalars + lane];
+#define SC_I(k) __builtin_amdgcn_readlane(__float_as_int(sv), (k))
+#define SC_F(k) __int_as_float(SC_I(k))
+#define SC_SET_I(k, val) sv = writelane_bits<(k)>(sv, (int)(val))
+#define SC_SET_F(k, val) sv = writelane_bits<(k)>(sv, __float_as_int(val))
+
+  // ---- sliding analysis buffer [96 carried | 160 new]: lane L owns samples 4L .. 4L+3
+  float* hbuf = st + kOffAnaHist;
+  float4 s4;
+  if (!IO16) {
+    const float* src = lane < 24 ? hbuf + 4 * lane : in + (size_t)stream * kBlockL + 4 * (lane - 24);
+    s4 = *reinterpret_cast<const float4*>(src);
+  } else {
+    const int lh = lane < 24 ? lane : 23, li = lane < 24 ? 24 : lane;
+    const float4 ha = *reinterpret_cast<const float4*>(hbuf + 4 * lh);
+    const short* in16 = reinterpret_cast<const short*>(in) + (size_t)stream * kBlockL + 4 * (li - 24);
+    const short4 a = *reinterpret_cast<const short4*>(in16);
+    const bool hsel = lane < 24;
+    s4.x = hsel ? ha.x : (float)a.x;
+    s4.y = hsel ? ha.y : (float)a.y;
+    s4.z = hsel ? ha.z : (float)a.z;
+    s4.w = hsel ? ha.w : (float)a.w;
+  }
+
+#define LOAD3(dst, f)                                                                          \
+  {                                                                                            \
+    const float2 v2_ = *reinterpret_cast<const float2*>(vec + (f)*kVecStride + 2 * lane);      \
+    dst[0] = v2_.x; dst[1] = v2_.y;                                                            \
+    dst[2] = SC_F(S_TAIL0 + (f));                                                              \
+  }
+#define STORE3(f, srcv)                                                                        \
+  {                                                                                            \
+    *reinterpret_cast<float2*>(vec + (f)*kVecStride + 2 * lane) = make_float2(srcv[0], srcv[1]); \
+    SC_SET_F(S_TAIL0 + (f), srcv[2]);                                                          \
+  }
+
+  // syntBuf[0..95]: the lane's output samples 2E, 2E+1 that still carry overlap are those of
+  // slot 0 when g == 0 (2q + 32h) and of slot 1 when g == 0 and h == 0 (2q + 64); every lane
+  // loads (no branch), the overlap-add uses the owners' values only
+  const float2 carryA = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * q + 32 * h);
+  const float2 carryB = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * q + 64);
+
+  // ---- table staging (the loads above are in flight behind it)
+  reinterpret_cast<float4*>(tabs)[tid] = tab_v;
+  if (tid < 64) exp2s[tid] = exp2_v;
+  if (tid < 128) logts[tid] = logt_v;
+  if (tid >= 192) reinterpret_cast<float4*>(wins)[tid - 192] = win_v;
+  __syncthreads();
+  if (!wave_live) return;
+  const float* tws = tabs;
+  const float* spls = tabs + 3 * 64 * 4;
+
+  const float4 w4 = *reinterpret_cast<const float4*>(wins + 4 * lane);
+  const float wx0 = w4.x * s4.x, wx1 = w4.y * s4.y, wx2 = w4.z * s4.z, wx3 = w4.w * s4.w;
+  // Windowing + Energy (ns_core.c:969-978, 951-960)
+  float epart = wx0 * wx0;
+  epart += wx1 * wx1;
+  epart += wx2 * wx2;
+  epart += wx3 * wx3;
+  const float energy1 = wave_sum(epart);
+
+  // the carried 96 samples of the next frame are this frame's last 96
+  if (lane >= 40) *reinterpret_cast<float4*>(hbuf + 4 * (lane - 40)) = s4;
+
+  if (energy1 == 0.0f) {
+    // Analyze: nothing but the buffer slide (ns_core.c:1072-1082); Process: emit the synthesis
+    // tail and clear it (ns_core.c:1239-1264)
+    float* sy = st + kOffSynt;
+    float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * kBlockL)
+                    : out + (size_t)stream * kBlockL;
+    float2 o01 = make_float2(0.f, 0.f);
+    if (lane < 48) o01 = *reinterpret_cast<const float2*>(sy + 2 * lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    store2p<IO16>(y, 2 * lane, sat16p(o01.x), sat16p(o01.y));
+    if (lane < 16) store2p<IO16>(y, 128 + 2 * lane, 0.f, 0.f);
+    if (lane < 48) *reinterpret_cast<float2*>(sy + 2 * lane) = make_float2(0.f, 0.f);
+    return;
+  }
+
+  // the tracker rows are requested once the frame's samples are in; they are used after the
+  // transform, the magnitudes and the logarithms
+  float LQ[3][NS3], DEN[3][NS3], quant[NS3];
+  LOAD3(LQ[0], V_LQ0) LOAD3(LQ[1], V_LQ1) LOAD3(LQ[2], V_LQ2)
+  LOAD3(DEN[0], V_DEN0) LOAD3(DEN[1], V_DEN1) LOAD3(DEN[2], V_DEN2)
+  LOAD3(quant, V_QUANT)
+  NS_STAMP(1)
+  // ---- forward FFT (ns_core.c:886-911)
+  *reinterpret_cast<float4*>(&tile[2 * lane]) = make_float4(wx0, wx1, wx2, wx3);
+  lds_sync1();
+  float2 el[2];
+  cft128_passes1(tile, tws, diagbits, lane, el[0], el[1]);
+  radix2_tail1(el[0], el[1], gmask, false);
+  real_split1(tile, spls, lane, el, false);
+
+  NS_STAMP(2)
+  // second group of state rows (latency hides under magnitude / log / trackers)
+  float smooth[NS3], noisePrev[NS3], magnPrevA[NS3], logLrt[NS3], avgPause[NS3];
+  LOAD3(magnPrevA, V_MAGNPREV_A) LOAD3(logLrt, V_LOGLRT) LOAD3(avgPause, V_AVGPAUSE)
+  LOAD3(smooth, V_SMOOTH) LOAD3(noisePrev, V_NOISEPREV)
+
+  float re[NS3], im[NS3], magn[NS3];
+  re[0] = el[0].x;
+  im[0] = el[0].y;
+  re[1] = el[1].x;
+  im[1] = el[1].y;
+  re[2] = lane_bcast(el[0].y, 0);  // R128 sits in the imaginary slot of element 0 (lane 0, slot 0)
+  im[2] = 0.f;
+  if (lane == 0) im[0] = 0.f;
+  {
+    float m2[2] = {re[0] * re[0] + im[0] * im[0], re[1] * re[1] + im[1] * im[1]}, rt[2];
+    fsqrt_n<2>(m2, rt);
+    magn[0] = rt[0] + 1.f;
+    magn[1] = rt[1] + 1.f;
+  }
+  if (lane == 0) magn[0] = fabsf(re[0]) + 1.f;
+  magn[2] = fabsf(re[2]) + 1.f;
+
+  // per-lane partial of a per-bin quantity: the two owned bins, then the tail on lane 0
+#define PART3(dst, v)                     \
+  float dst = v[0] + v[1];                \
+  if (lane == 0) dst = dst + v[2];
+
+  int blockInd = SC_I(S_BLOCKIND);
+  const float overdrive = SC_F(S_OVERDRIVE);
+  const float denoiseBound = SC_F(S_DENOISEBOUND);
+  float priorSpeechProb = SC_F(S_PRIORSPEECHPROB);
+  const int gainmap = SC_I(S_GAINMAP);
+
+  float noise[NS3], prevStsa[NS3];
+  blockInd++;  // ns_core.c:1084
+  const int updateParsFlag = SC_I(S_MUP0);
+  int updates = SC_I(S_UPDATES);
+  int counter[3] = {SC_I(S_COUNTER0), SC_I(S_COUNTER1), SC_I(S_COUNTER2)};
+
+  float lmagn[NS3];
+  log_f32_via_tab_n<NS3>(magn, lmagn, logts);
+
+  NS_STAMP(3)
+  float signalEnergy, sumMagn;
+  {
+    float se[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) se[k] = re[k] * re[k] + im[k] * im[k];
+    PART3(t_se, se)
+    PART3(t_sm, magn)
+    signalEnergy = wave_sum(t_se);
+    sumMagn = wave_sum(t_sm);
+    signalEnergy = DIV129(signalEnergy);
+  }
+
+  NS_STAMP(4)
+  // ---- NoiseEstimation (ns_core.c:217-285)
+  if (updates < NS_END_STARTUP_LONG) updates++;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const float cnt = (float)counter[s];
+    const float cnt1 = (float)(counter[s] + 1);
+    const float rcnt1 = 1.f / cnt1;
+    {
+      F3 den(DEN[s]), lq(LQ[s]);
+      const F3 lm(lmagn);
+      const F3 dq = fdiv3v(F3(NS_FACTOR * 1.f), den);  // used where density > 1
+      const F3 delta = sel3(gt3(den, F3(1.0f)), dq, F3(NS_FACTOR));
+      const B3 up = gt3(lm, lq);
+      const F3 step = div_by_uniform3(sel3(up, NS_QUANTILE * delta, (1.f - NS_QUANTILE) * delta), cnt1, rcnt1);
+      lq = sel3(up, lq + step, lq - step);
+      const F3 nd = div_by_uniform3(cnt * den + 1.f / (2.f * NS_WIDTH), cnt1, rcnt1);
+      den = sel3(lt3(abs3(lm - lq), F3(NS_WIDTH)), nd, den);
+      den.store(DEN[s]);
+      lq.store(LQ[s]);
+    }
+    if (counter[s] >= NS_END_STARTUP_LONG) {
+      counter[s] = 0;
+      if (updates >= NS_END_STARTUP_LONG) exp_f32_via_f64_n<NS3>(LQ[s], quant, exp2s);
+    }
+    counter[s]++;
+  }
+  if (updates < NS_END_STARTUP_LONG) exp_f32_via_f64_n<NS3>(LQ[2], quant, exp2s);
+#pragma unroll
+  for (int k = 0; k < NS3; ++k) noise[k] = quant[k];
+  STORE3(V_LQ0, LQ[0]) STORE3(V_LQ1, LQ[1]) STORE3(V_LQ2, LQ[2])
+  STORE3(V_DEN0, DEN[0]) STORE3(V_DEN1, DEN[1]) STORE3(V_DEN2, DEN[2])
+  STORE3(V_QUANT, quant)
+
+  NS_STAMP(5)
+  // ---- startup noise model (ns_core.c:1091-1100, 1109-1162)
+  float whiteNoiseLevel = SC_F(S_WHITE);
+  float pinkNoiseNumerator = SC_F(S_PINKNUM);
+  float pinkNoiseExp = SC_F(S_PINKEXP);
+  float fd5 = SC_F(S_FD5);
+  const bool startup = blockInd < NS_END_STARTUP_SHORT;
+  if (startup) {
+    float lm3[NS3], lilm[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) {
+      const int bin = k < 2 ? binA + 32 * k : 128;
+      const float li = T->logi[bin];
+      lm3[k] = bin >= NS_START_BAND ? lmagn[k] : 0.f;
+      lilm[k] = bin >= NS_START_BAND ? li * lmagn[k] : 0.f;
+    }
+    PART3(t_lm, lm3)
+    PART3(t_lilm, lilm)
+    const float sum_log_magn = wave_sum(t_lm);
+    const float sum_log_i_log_magn = wave_sum(t_lilm);
+    const float sum_log_i = T->sum_log_i, sum_log_i_square = T->sum_log_i_square;
+    whiteNoiseLevel += DIV129(sumMagn) * overdrive;
+    float tmpFloat1 = sum_log_i_square * ((float)(kBins - NS_START_BAND));
+    tmpFloat1 -= (sum_log_i * sum_log_i);
+    float tmpFloat2 = (sum_log_i_square * sum_log_magn - sum_log_i * sum_log_i_log_magn);
+    float tmpFloat3 = tmpFloat2 / tmpFloat1;
+    if (tmpFloat3 < 0.f) tmpFloat3 = 0.f;
+    pinkNoiseNumerator += tmpFloat3;
+    tmpFloat2 = (sum_log_i * sum_log_magn);
+    tmpFloat2 -= ((float)(kBins - NS_START_BAND)) * sum_log_i_log_magn;
+    tmpFloat3 = tmpFloat2 / tmpFloat1;
+    if (tmpFloat3 < 0.f) tmpFloat3 = 0.f;
+    if (tmpFloat3 > 1.f) tmpFloat3 = 1.f;
+    pinkNoiseExp += tmpFloat3;
+    float parametric_num = 0.f, parametric_exp = 0.f;
+    if (pinkNoiseExp > 0.f) {
+      parametric_num = (float)exp((double)(pinkNoiseNumerator / (float)(blockInd + 1)));
+      parametric_num *= (float)(blockInd + 1);
+      parametric_exp = pinkNoiseExp / (float)(blockInd + 1);
+    }
+    float pn[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) {
+      const int bin = k < 2 ? binA + 32 * k : 128;
+      if (pinkNoiseExp == 0.f) {
+        pn[k] = whiteNoiseLevel;
+      } else {
+        const float use_band = (float)(bin < NS_START_BAND ? NS_START_BAND : bin);
+        pn[k] = (float)((double)parametric_num / pow((double)use_band, (double)parametric_exp));
+      }
+      noise[k] *= (blockInd);
+      const float t2 = pn[k] * (NS_END_STARTUP_SHORT - blockInd);
+      noise[k] += (t2 / (float)(blockInd + 1));
+      noise[k] /= NS_END_STARTUP_SHORT;
+    }
+    STORE3(V_PARAMNOISE, pn)
+  }
+  if (blockInd < NS_END_STARTUP_LONG) {  // ns_core.c:1165-1169
+    fd5 *= blockInd;
+    fd5 += signalEnergy;
+    fd5 /= (blockInd + 1);
+  }
+
+  NS_STAMP(6)
+  // ---- ComputeSnr (ns_core.c:566-588)
+  float snrLocPost[NS3], snrLocPrior[NS3];
+  {
+    float dn1[NS3], dn2[NS3], q1[NS3], q2[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) {
+      dn1[k] = noisePrev[k] + 0.0001f;
+      dn2[k] = noise[k] + 0.0001f;
+    }
+    fdiv3(magnPrevA, dn1, q1);
+    fdiv3(magn, dn2, q2);  // used where magn > noise
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) {
+      const float previousEstimateStsa = q1[k] * smooth[k];
+      prevStsa[k] = previousEstimateStsa;
+      snrLocPost[k] = 0.f;
+      if (magn[k] > noise[k]) snrLocPost[k] = q2[k] - 1.f;
+      snrLocPrior[k] = NS_DD_PR_SNR * previousEstimateStsa + (1.f - NS_DD_PR_SNR) * snrLocPost[k];
+    }
+  }
+
+  NS_STAMP(7)
+  // ---- ComputeSpectralFlatness (ns_core.c:523-556)
+  float fd0 = SC_F(S_FD0), fd4 = SC_F(S_FD4), fd6 = SC_F(S_FD6);
+  {
+    float fl3[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) fl3[k] = (k == 0 && lane == 0) ? 0.f : lmagn[k];
+    PART3(t_fl, fl3)
+    float num = wave_sum(t_fl);
+    float den = sumMagn - lane_bcast(magn[0], 0);
+    den = DIV129(den);
+    num = DIV129(num);
+    const float spectralTmp = fdiv(exp_f32_via_f64(num, exp2s), den);
+    fd0 += NS_SPECT_FL_TAVG * (spectralTmp - fd0);
+  }
+  // ---- ComputeSpectralDifference (ns_core.c:595-634)
+  {
+    PART3(t_ap, avgPause)
+    float avgPauseMean = wave_sum(t_ap);
+    float avgMagn = sumMagn;
+    avgPauseMean = DIV129(avgPauseMean);
+    avgMagn = DIV129(avgMagn);
+    float cv[NS3], vp[NS3], vm[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) {
+      const float dm = magn[k] - avgMagn, dp = avgPause[k] - avgPauseMean;
+      cv[k] = dm * dp;
+      vp[k] = dp * dp;
+      vm[k] = dm * dm;
+    }
+    PART3(t_cv, cv)
+    PART3(t_vp, vp)
+    PART3(t_vm, vm)
+    float covMagnPause = wave_sum(t_cv);
+    float varPause = wave_sum(t_vp);
+    float varMagn = wave_sum(t_vm);
+    covMagnPause = DIV129(covMagnPause);
+    varPause = DIV129(varPause);
+    varMagn = DIV129(varMagn);
+    fd6 += signalEnergy;
+    float avgDiffNormMagn = varMagn - fdiv(covMagnPause * covMagnPause, varPause + 0.0001f);
+    avgDiffNormMagn = fdiv(avgDiffNormMagn, fd5 + 0.0001f);
+    fd4 += NS_SPECT_DIFF_TAVG * (avgDiffNormMagn - fd4);
+  }
+
+  NS_STAMP(8)
+  // ---- histograms / prior model (FeatureUpdate, ns_core.c:766-790)
+  float fd3 = SC_F(S_FD3);  // previous frame's average LRT feeds the histogram
+  PriorModel pm;
+  pm.p0 = SC_F(S_PMP0);
+  pm.p1 = SC_F(S_PMP1);
+  pm.p3 = SC_F(S_PMP3);
+  pm.p4 = SC_F(S_PMP4);
+  pm.p5 = SC_F(S_PMP5);
+  pm.p6 = SC_F(S_PMP6);
+  const float pmp2 = SC_F(S_PMP2);
+  int mup0 = updateParsFlag, mup3 = SC_I(S_MUP3);
+  const int mup1 = SC_I(S_MUP1);
+  bool window_closed = false;
+  if (updateParsFlag >= 1) {
+    mup3--;
+    if (mup3 > 0) {
+      // FeatureParameterExtraction(self, 0), ns_core.c:309-334: lanes 0..2 take one histogram each
+      // (LRT, spectral flatness, spectral difference); one writer per bin and stream, so a
+      // no-return atomic add is the increment without the load -> add -> store round trip
+      const float fv = lane == 0 ? fd3 : (lane == 1 ? fd0 : fd4);
+      const float bw = lane == 1 ? 0.05f : 0.1f, rbw = lane == 1 ? 1.0f / 0.05f : 1.0f / 0.1f;
+      const float lim = lane == 1 ? kHist * 0.05f : kHist * 0.1f;
+      if (lane < 3 && (fv < lim) && (fv >= 0.0f))
+        atomicAdd(&hist[lane * kHistStride + (int)div_by_uniform(fv, bw, rbw)], 1);
+    }
+    if (mup3 == 0) {
+      pm = close_histogram_window(hist, lane, mup1, mup0 >= 1, pm);
+      window_closed = true;
+      mup3 = mup1;
+      if (updateParsFlag == 1) {
+        mup0 = 0;
+      } else {
+        fd6 = fd6 / ((float)mup1);
+        fd5 = 0.5f * (fd6 + fd5);
+        fd6 = 0.f;
+      }
+    }
+  }
+
+  NS_STAMP(9)
+  // ---- SpeechNoiseProb (ns_core.c:642-749)
+  {
+    float t1[NS3], lt1[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) t1[k] = 1.f + 2.f * snrLocPrior[k];
+    log_f32_via_tab_n<NS3>(t1, lt1, logts);
+    float tn[NS3], td3[NS3], t2v[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) {
+      tn[k] = 2.f * snrLocPrior[k];
+      td3[k] = t1[k] + 0.0001f;
+    }
+    fdiv3(tn, td3, t2v);
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) {
+      const float t2 = t2v[k];
+      const float besselTmp = (snrLocPost[k] + 1.f) * t2;
+      logLrt[k] += NS_LRT_TAVG * (besselTmp - lt1[k] - logLrt[k]);
+    }
+  }
+  PART3(t_ll, logLrt)
+  float logLrtTimeAvgKsum = wave_sum(t_ll);
+  logLrtTimeAvgKsum = DIV129(logLrtTimeAvgKsum);
+  fd3 = logLrtTimeAvgKsum;
+  {
+    const float widthPrior0 = NS_WIDTH_PR_MAP, widthPrior1 = 2.f * NS_WIDTH_PR_MAP,
+                widthPrior2 = 2.f * NS_WIDTH_PR_MAP;
+    const int sgnMap = (int)pmp2;
+    float widthPrior = widthPrior0;
+    if (logLrtTimeAvgKsum < pm.p0) widthPrior = widthPrior1;
+    const float arg0 = widthPrior * (logLrtTimeAvgKsum - pm.p0);
+    widthPrior = widthPrior0;
+    if (sgnMap == 1 && (fd0 > pm.p1)) widthPrior = widthPrior1;
+    if (sgnMap == -1 && (fd0 < pm.p1)) widthPrior = widthPrior1;
+    const float arg1 = (float)sgnMap * widthPrior * (pm.p1 - fd0);
+    widthPrior = widthPrior0;
+    if (fd4 < pm.p3) widthPrior = widthPrior2;
+    const float arg2 = widthPrior * (fd4 - pm.p3);
+    // the three tanh() of :696-725 evaluated on lanes 0..2 of one call
+    const float arg = lane == 0 ? arg0 : (lane == 1 ? arg1 : arg2);
+    const float th = tanh_f32_via_f64(arg, exp2s);
+    const float indicator0 = 0.5f * (lane_bcast(th, 0) + 1.f);
+    const float indicator1 = 0.5f * (lane_bcast(th, 1) + 1.f);
+    const float indicator2 = 0.5f * (lane_bcast(th, 2) + 1.f);
+    const float indPrior = pm.p4 * indicator0 + pm.p5 * indicator1 + pm.p6 * indicator2;
+    priorSpeechProb += NS_PRIOR_UPDATE * (indPrior - priorSpeechProb);
+    if (priorSpeechProb > 1.f) priorSpeechProb = 1.f;
+    if (priorSpeechProb < 0.01f) priorSpeechProb = 0.01f;
+  }
+  float probSpeech[NS3];
+  {
+    const float gainPrior = fdiv(1.f - priorSpeechProb, priorSpeechProb + 0.0001f);
+    float nl[NS3], ev[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) nl[k] = -logLrt[k];
+    exp_f32_via_f64_n<NS3>(nl, ev, exp2s);
+    {
+      float pd[NS3];
+      const float ones[NS3] = {1.f, 1.f, 1.f};
+#pragma unroll
+      for (int k = 0; k < NS3; ++k) {
+        float invLrt = ev[k];
+        invLrt = (float)gainPrior * invLrt;
+        pd[k] = 1.f + invLrt;
+      }
+      fdiv3(ones, pd, probSpeech);
+    }
+  }
+
+  NS_STAMP(10)
+  // ---- UpdateNoiseEstimate (ns_core.c:800-846): the time constant carried into bin i is the one
+  // bin i-1 selected.  For q > 0 bin i-1 is the same slot of lane L - 2; for q == 0 it is bin
+  // 15 + 16 (t - 1) + 64 g (t > 0) or bin 63 (bin 64), i.e. a slot of lane 30 / 31 (+ 32 g):
+  //   slot 0 (t = h):     h = 1: lane 30 + 32 g slot 0;   h = 0, g = 1: lane 31 slot 1;   bin 0: none
+  //   slot 1 (t = h + 2): h = 0: lane 31 + 32 g slot 0;   h = 1: lane 30 + 32 g slot 1
+  {
+    const int srcA = q > 0 ? lane - 2 : (h ? 30 + 32 * g : 31);
+    const int srcB = q > 0 ? lane - 2 : (h ? 30 + 32 * g : 31 + 32 * g);
+    const bool a_from1 = q == 0 && h == 0;  // slot 0 takes the source lane's slot 1
+    const bool b_from1 = q > 0 || h == 1;   // slot 1 takes the source lane's slot 1
+    const float a0 = __shfl(probSpeech[0], srcA, 64), a1 = __shfl(probSpeech[1], srcA, 64);
+    const float b0 = __shfl(probSpeech[0], srcB, 64), b1 = __shfl(probSpeech[1], srcB, 64);
+    float prevProb[NS3];
+    prevProb[0] = a_from1 ? a1 : a0;
+    prevProb[1] = b_from1 ? b1 : b0;
+    prevProb[2] = lane_bcast(probSpeech[1], 63);  // bin 128 <- bin 127 (q = 15, g = 1, t = 3)
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) {
+      float gammaOld = prevProb[k] > NS_PROB_RANGE ? NS_SPEECH_UPDATE : NS_NOISE_UPDATE;
+      if (k == 0 && lane == 0) gammaOld = NS_NOISE_UPDATE;  // bin 0 has no predecessor
+      const float ps = probSpeech[k], pns = 1.f - probSpeech[k];
+      const float noiseUpdateTmp =
+          gammaOld * noisePrev[k] + (1.f - gammaOld) * (pns * magn[k] + ps * noisePrev[k]);
+      float gammaNew = NS_NOISE_UPDATE;
+      if (ps > NS_PROB_RANGE) gammaNew = NS_SPEECH_UPDATE;
+      if (ps < NS_PROB_RANGE) avgPause[k] += NS_GAMMA_PAUSE * (magn[k] - avgPause[k]);
+      float nz;
+      if (gammaNew == gammaOld) {
+        nz = noiseUpdateTmp;
+      } else {
+        nz = gammaNew * noisePrev[k] + (1.f - gammaNew) * (pns * magn[k] + ps * noisePrev[k]);
+        if (noiseUpdateTmp < nz) nz = noiseUpdateTmp;
+      }
+      noise[k] = nz;
+    }
+  }
+  STORE3(V_LOGLRT, logLrt) STORE3(V_AVGPAUSE, avgPause)
+  STORE3(V_MAGNPREV_A, magn)  // ns_core.c:1180 (== magnPrevProcess while paired)
+
+  NS_STAMP(11)
+  // ---- Process: decision-directed Wiener gain (ns_core.c:985-1007, 1276-1307)
+  float initMagn[NS3], pnoise[NS3];
+  if (startup) {  // ns_core.c:1268-1272
+    LOAD3(initMagn, V_INITMAGN)
+    LOAD3(pnoise, V_PARAMNOISE)
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) initMagn[k] += magn[k];
+    STORE3(V_INITMAGN, initMagn)
+  }
+  float gainv[NS3];
+  float gq1[NS3], gq2[NS3], snrP[NS3];
+  {
+    float gd1[NS3], gd2[NS3];
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) gd1[k] = noise[k] + 0.0001f;
+    fdiv3(magn, gd1, gq1);  // used where magn > noise
+#pragma unroll
+    for (int k = 0; k < NS3; ++k) {
+      float currentEstimateStsa = 0.f;
+      if (magn[k] > noise[k]) currentEstimateStsa = gq1[k] - 1.f;
+      snrP[k] = NS_DD_PR_SNR * prevStsa[k] + (1.f - NS_DD_PR_SNR) * currentEstimateStsa;
+      gd2[k] = overdrive + snrP[k];
+    }
+    fdiv3(snrP, gd2, gq2);
+  }
+#pragma unroll
+  for (int k = 0; k < NS3; ++k) {
+    float gg = gq2[k];
+    if (gg < denoiseBound) gg = denoiseBound;
+    if (gg > 1.f) gg = 1.f;
+    if (startup) {
+      float tmp = (initMagn[k] - overdrive * pnoise[k]);
+      tmp /= (initMagn[k] + 0.0001f);
+      if (tmp < denoiseBound) tmp = denoiseBound;
+      if (tmp > 1.f) tmp = 1.f;
+      gg *= (blockInd);
+      tmp *= (NS_END_STARTUP_SHORT - blockInd);
+      gg += tmp;
+      gg /= (NS_END_STARTUP_SHORT);
+    }
+    gainv[k] = gg;
+    re[k] *= gg;
+    im[k] *= gg;
+  }
+  STORE3(V_SMOOTH, gainv)      // ns_core.c:1304
+  STORE3(V_NOISEPREV, noise)   // ns_core.c:1310
+
+  NS_STAMP(12)
+  // ---- IFFT (ns_core.c:923-944)
+  el[0] = make_float2(re[0], im[0]);
+  el[1] = make_float2(re[1], im[1]);
+  if (lane == 0) el[0].y = re[2];  // Ooura packing: a[1] = R128
+  real_split1(tile, spls, lane, el, true);
+  lds_sync1();
+  {
+    const int base = 64 * g + q + 16 * h;
+    tile[base] = el[0];
+    tile[base + 32] = el[1];
+  }
+  lds_sync1();
+  cft128_passes1(tile, tws, diagbits, lane, el[0], el[1]);
+  radix2_tail1(el[0], el[1], gmask, true);
+  // samples 2E, 2E+1 of elements E = binA (slot 0) and binA + 32 (slot 1)
+  const float td0 = el[0].x * (2.f / kAnal), td1 = el[0].y * (2.f / kAnal);
+  const float td2 = el[1].x * (2.f / kAnal), td3s = el[1].y * (2.f / kAnal);
+
+  NS_STAMP(13)
+  // ---- energy-based gain compensation (ns_core.c:1315-1342)
+  float factor = 1.f;
+  if (gainmap == 1 && blockInd > NS_END_STARTUP_LONG) {
+    float factor1 = 1.f, factor2 = 1.f;
+    float e2 = td0 * td0;
+    e2 += td1 * td1;
+    e2 += td2 * td2;
+    e2 += td3s * td3s;
+    const float energy2 = wave_sum(e2);
+    float gain = fsqrt(fdiv(energy2, energy1 + 1.f));
+    if (gain > NS_B_LIM) {
+      factor1 = 1.f + 1.3f * (gain - NS_B_LIM);
+      if (gain * factor1 > 1.f) factor1 = fdiv(1.f, gain);
+    }
+    if (gain < NS_B_LIM) {
+      if (gain <= denoiseBound) gain = denoiseBound;
+      factor2 = 1.f - 0.3f * (NS_B_LIM - gain);
+    }
+    factor = priorSpeechProb * factor1 + (1.f - priorSpeechProb) * factor2;
+  }
+
+  // ---- synthesis window, overlap-add, emit 160, carry 96 (ns_core.c:1344-1359)
+  {
+    float* sy = st + kOffSynt;
+    float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * kBlockL)
+                    : out + (size_t)stream * kBlockL;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int nA = 2 * binA, nB = nA + 64;  // sample index of td0 / td2
+    const float2 wA = *reinterpret_cast<const float2*>(wins + nA);
+    const float2 wB = *reinterpret_cast<const float2*>(wins + nB);
+    const float cA0 = g == 0 ? carryA.x : 0.f, cA1 = g == 0 ? carryA.y : 0.f;
+    const float cB0 = (g == 0 && h == 0) ? carryB.x : 0.f, cB1 = (g == 0 && h == 0) ? carryB.y : 0.f;
+    const float oA0 = cA0 + factor * (wA.x * td0), oA1 = cA1 + factor * (wA.y * td1);
+    const float oB0 = cB0 + factor * (wB.x * td2), oB1 = cB1 + factor * (wB.y * td3s);
+    if (nA >= 160) {
+      *reinterpret_cast<float2*>(sy + nA - 160) = make_float2(oA0, oA1);
+    } else {
+      store2p<IO16>(y, nA, sat16p(oA0), sat16p(oA1));
+    }
+    if (nB >= 160) {
+      *reinterpret_cast<float2*>(sy + nB - 160) = make_float2(oB0, oB1);
+    } else {
+      store2p<IO16>(y, nB, sat16p(oB0), sat16p(oB1));
+    }
+  }
+
+  NS_STAMP(14)
+  // ---- commit scalars
+  SC_SET_I(S_UPDATES, updates);
+  SC_SET_I(S_COUNTER0, counter[0]);
+  SC_SET_I(S_COUNTER1, counter[1]);
+  SC_SET_I(S_COUNTER2, counter[2]);
+  SC_SET_I(S_MUP0, mup0);
+  SC_SET_I(S_MUP3, mup3);
+  SC_SET_F(S_SIGNALENERGY, signalEnergy);
+  SC_SET_F(S_SUMMAGN, sumMagn);
+  if (startup) {
+    SC_SET_F(S_WHITE, whiteNoiseLevel);
+    SC_SET_F(S_PINKNUM, pinkNoiseNumerator);
+    SC_SET_F(S_PINKEXP, pinkNoiseExp);
+  }
+  if (window_closed) {
+    SC_SET_F(S_PMP0, pm.p0);
+    SC_SET_F(S_PMP1, pm.p1);
+    SC_SET_F(S_PMP3, pm.p3);
+    SC_SET_F(S_PMP4, pm.p4);
+    SC_SET_F(S_PMP5, pm.p5);
+    SC_SET_F(S_PMP6, pm.p6);
+  }
+  SC_SET_F(S_FD0, fd0);
+  SC_SET_F(S_FD3, fd3);
+  SC_SET_F(S_FD4, fd4);
+  SC_SET_F(S_FD5, fd5);
+  SC_SET_F(S_FD6, fd6);
+  SC_SET_I(S_BLOCKIND, blockInd);
+  SC_SET_F(S_PRIORSPEECHPROB, priorSpeechProb);
+  st[kOffScalars + lane] = sv;
+  NS_STAMP(15)
+#undef NS_STAMP
+#undef SC_I
+#undef SC_F
+#undef SC_SET_I
+#undef SC_SET_F
+#undef LOAD3
+#undef STORE3
+#undef PART3
+}
+
+}  // namespace
+
+namespace aspns {
+
+hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
+                            const float* in, float* out, int num_streams, hipStream_t s,
+                            unsigned long long* stamps) {
+  const dim3 grid((num_streams + 3) / 4), block(256);
+  if (io16)
+    hipLaunchKernelGGL(ns_frame1_kernel<true>, grid, block, 0, s, state, hist, T, in, out,
+                       num_streams, stamps);
+  else
+    hipLaunchKernelGGL(ns_frame1_kernel<false>, grid, block, 0, s, state, hist, T, in, out,
+                       num_streams, stamps);
+  return hipGetLastError();
+}
+
+}  // namespace aspns

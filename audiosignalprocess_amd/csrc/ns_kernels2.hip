@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, NS_MIN_WG_PER_CU) void ns_frame2_kernel(float*
 #define LOAD5(dst, f)                                                        \
   {                                                                          \
     const float4 v4_ = *reinterpret_cast<const float4*>(vec + (f)*kVecStride + 4 * lam);   \
-    dst[0] = v4_.x; dst[1] = v4_.y; dst[2] = v4_.z; dst[3] = v4_.w;           \
+    dst[0] = v4_.x; dst[2] = v4_.y; dst[1] = v4_.z; dst[3] = v4_.w; /* row order t = 0, 2, 1, 3 */ \
     dst[4] = SCF(S_TAIL0 + (f));                                             \
   }
 // bin 128 of a row lives in scalar slot S_TAIL0 + f (ns_layout.h): read by a broadcast from the
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, NS_MIN_WG_PER_CU) void ns_frame2_kernel(float*
 #define STORE5(f, srcv)                                                      \
   if (live) {                                                                \
     *reinterpret_cast<float4*>(vec + (f)*kVecStride + 4 * lam) =              \
-        make_float4(srcv[0], srcv[1], srcv[2], srcv[3]);                       \
+        make_float4(srcv[0], srcv[2], srcv[1], srcv[3]);                       \
     SET_F(S_TAIL0 + (f), srcv[4])                                            \
   }
 

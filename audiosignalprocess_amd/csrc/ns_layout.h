@@ -18,11 +18,15 @@ constexpr int kAnal = 256;     // ns/defines.h:15
 constexpr int kBins = 129;     // ns/defines.h:16
 constexpr int kHist = 1000;    // ns/defines.h:45
 constexpr int kVecStride = 128;  // one state row = bins 0..127 (bin 128 lives with the scalars): 512 B, cache-line aligned
-// Position of bin b inside a state row.  The four bins a lane of the two-streams-per-wave kernel
-// owns (q + 16 k + 64 g, k = 0..3, lane = q + 16 g) sit next to each other, so a row moves as one
-// 16-byte access per lane instead of four 4-byte ones (a quarter of the vector-memory
-// instructions; the per-CU address unit was the busiest part of the step).  b < 128.
-constexpr int row_pos(int b) { return 4 * ((b & 15) + 16 * (b >> 6)) + ((b >> 4) & 3); }
+// Position of bin b inside a state row.  Bins are grouped by (b & 15, b >> 6) = the "dual lane"
+// lam = (b & 15) + 16 (b >> 6) of the two-streams-per-wave kernel, which owns the four bins
+// q + 16 t + 64 g (t = 0..3) as one 16-byte access; inside a group the order is t = 0, 2, 1, 3, so
+// that lane 2 lam + h of the one-stream-per-wave kernel (ns_kernels1.hip), which owns t = h and
+// t = h + 2 (the two outputs of its half of a radix-4 butterfly), moves them as one 8-byte access.
+// b < 128.
+constexpr int row_pos(int b) {
+  return 4 * ((b & 15) + 16 * (b >> 6)) + 2 * ((b >> 4) & 1) + ((b >> 5) & 1);
+}
 constexpr int kCarry = kAnal - kBlockL;  // 96 live samples of each sliding buffer
 
 // 129-bin arrays, in block order.  "hot" = touched by the fused lock-step step.

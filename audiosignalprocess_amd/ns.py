@@ -61,6 +61,8 @@ def load_library():
         "AspNsBatch_SetKernel": [vp, ip],
         "AspNsBatch_Synchronize": [vp],
         "AspNsBatch_TimedSteps": [vp, vp, vp, ip, ip, fp],
+        "AspNsBatch_AnalyzeProcessReplay": [vp, vp, vp, ip, ip],
+        "AspNsBatch_SetGraph": [vp, ip],
         "AspNs_DeviceAlloc": [C.POINTER(vp), C.c_size_t, ip],
         "AspNs_DeviceFree": [vp],
         "AspNs_MemcpyH2D": [vp, vp, C.c_size_t],
@@ -215,6 +217,15 @@ class NsBatch:
         _check(self.lib.AspNsBatch_AnalyzeProcess(self.h, C.c_void_p(in_ptr), C.c_void_p(out_ptr),
                                                   num_frames, MEM_DEVICE),
                "AspNsBatch_AnalyzeProcess")
+
+    def analyze_process_replay(self, in_ptr, out_ptr, frames_in_ring, steps):
+        """`steps` fused frame steps over a device ring as one replay of a captured hipGraph (async)."""
+        _check(self.lib.AspNsBatch_AnalyzeProcessReplay(self.h, C.c_void_p(in_ptr), C.c_void_p(out_ptr),
+                                                        frames_in_ring, steps),
+               "AspNsBatch_AnalyzeProcessReplay")
+
+    def set_graph(self, on):
+        _check(self.lib.AspNsBatch_SetGraph(self.h, 1 if on else 0), "AspNsBatch_SetGraph")
 
     def timed_steps(self, in_ptr, out_ptr, frames_in_ring, steps):
         """K fused frame steps bracketed by hipEvents on the launch stream -> ms."""

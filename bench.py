@@ -123,16 +123,18 @@ def bench_bt(args):
     wall = time.perf_counter() - t0
     algo = 40 * (n // 2) * 2 * 1  # 10 B per sample: in + out + both tails read and written
     algo = 10 * g.macro
-    launch_s = ev_ms / 1e3 / steps
+    launch_s = ev_ms / 1e3 / steps             # one clock (hipEvents on the launch stream) for every number of the line
     achieved = algo * S / launch_s / 1e9
     line = {
-        "metric": "BlockThresholding macroblocks/sec (secondary)", "value": S * steps / wall,
+        "metric": "BlockThresholding macroblocks/sec (secondary)", "value": S / launch_s,
         "unit": "macroblocks/s", "n_gpus": 1, "steps": steps, "warmup": warm,
-        "ms_per_step": 1e3 * wall / steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * launch_s, "wall_ms_per_step": 1e3 * wall / steps,
+        "parity": "unpinned (the reference's kiss_fft does not compile: _kiss_fft_guts.h is absent; DESIGN.md section 2)",
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Denoise/BlockThresholding: %d-pt STFT, Stein block threshold, %d "
                                "stream-channels on 1 MI355X, one 8-hop macroblock per launch" % (n, S),
-                   "samples_per_s": S * steps * g.macro / wall},
+                   "samples_per_s": S * g.macro / launch_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "bt_macroblock_kernel<%d>" % n,
@@ -239,8 +241,9 @@ def bench_aec(args):
     step_s = ev_ms / 1e3 / steps
     achieved = algo * S / step_s / 1e9
     line = {
-        "metric": "AEC 10 ms frames/sec (secondary)", "value": S * steps / wall, "unit": "frames/s",
-        "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * wall / steps,
+        "metric": "AEC 10 ms frames/sec (secondary)", "value": S / step_s, "unit": "frames/s",
+        "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * step_s,
+        "wall_ms_per_step": 1e3 * wall / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "WebRTC AEC (test_aec_module): 10 ms/16 kHz far+near frames, %d concurrent "
@@ -254,15 +257,137 @@ def bench_aec(args):
     if not args.no_cpu_baseline:
         from tests import oracle_lib
         cores = host_cores()
-        Sc, Fc = 16 * cores, 300
-        farc, nearc = aec_frames(Sc, Fc)
-        t0 = time.perf_counter()
-        oracle_lib.aec_oracle_run_mt(farc, nearc, threads=cores)
-        dt = time.perf_counter() - t0
-        line["cpu_baseline"] = {"value": Sc * Fc / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-                                "sample": "%d streams x %d frames through oracle/aec_oracle.c (bit-exact "
-                                          "restatement of the reference), %d pthreads" % (Sc, Fc, cores)}
+        if oracle_lib.have_aec_ref():
+            # the reference's own aec_core.c / aec_rdft.c / echo_cancellation.c compiled in the build container
+            # (oracle/_ref/libaec_ref.so, plain-C path): one handle per thread, ctypes releases the GIL
+            from concurrent.futures import ThreadPoolExecutor
+            per, Fc = 8, 300
+            Sc = per * cores
+            farc, nearc = aec_frames(Sc, Fc)
+            engs = [[oracle_lib.RefAec(16000) for _ in range(per)] for _ in range(cores)]   # created one by one
+
+            def one(t):
+                for i, e in enumerate(engs[t]):
+                    s_ = t * per + i
+                    e.run(np.ascontiguousarray(farc[:, s_]), np.ascontiguousarray(nearc[:, s_]))
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                list(ex.map(one, range(cores)))
+            dt = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": Sc * Fc / dt, "unit": "frames/s", "cores": cores, "kind": "reference",
+                                    "sample": "%d streams x %d frames through the compiled reference (oracle/_ref/"
+                                              "libaec_ref.so, gcc -O2 -ffp-contract=off, plain-C path), %d threads"
+                                              % (Sc, Fc, cores)}
+        else:
+            Sc, Fc = 16 * cores, 300
+            farc, nearc = aec_frames(Sc, Fc)
+            t0 = time.perf_counter()
+            oracle_lib.aec_oracle_run_mt(farc, nearc, threads=cores)
+            dt = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": Sc * Fc / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+                                    "sample": "%d streams x %d frames through oracle/aec_oracle.c (bit-exact "
+                                              "restatement of the reference), %d pthreads" % (Sc, Fc, cores)}
     print(json.dumps(line), flush=True)
+
+
+def copy_ceiling_gbs():
+    """The box's measured streaming-copy rate (read + write bytes of a large float4 device copy,
+    hipEvent-timed): the practical HBM ceiling printed next to the 8 TB/s spec peak."""
+    import torch
+
+    n = 1 << 28                                    # 1 GiB source, 1 GiB destination (far beyond the 256 MiB Infinity Cache)
+    src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(4):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 4 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    torch.cuda.empty_cache()
+    return best
+
+
+def _secondary(args, workload):
+    """One secondary workload (AEC / BT-1024) in a child process of the same run, so its allocations
+    and library state never touch the headline measurement; returns its JSON line as a dict."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(args.secondary_steps),
+           "--warmup", str(args.secondary_warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    try:
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()
+        return json.loads(out[-1])
+    except Exception as e:  # noqa: BLE001  (a failed secondary must not take the headline down)
+        return {"workload": workload, "error": str(e)[:300]}
+
+
+def ns_measure(args, S, rank, world, local_rank, dist):
+    """Prime + warm up + time the fused NS frame step of S streams on this rank.  Returns the
+    per-region hipEvent and wall times (seconds, length R) of `args.steps` steps each."""
+    import torch
+
+    from audiosignalprocess_amd.ns import NsBatch
+    from audiosignalprocess_amd.shard import shard_streams
+    from audiosignalprocess_amd.synth import ns_frames
+
+    ring = args.ring
+    # every rank owns a disjoint contiguous shard of stream ids (no data-path collective)
+    stream0, S = shard_streams(rank, world, S)
+    x = ns_frames(S, ring, stream0=stream0, frame0=50)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    del x
+    ns = NsBatch(S, device=local_rank, policy=1, streams_per_wave=args.streams_per_wave)
+    ns.set_graph(not args.no_graph)
+    if args.split > 1:
+        ns.set_split(args.split)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # set-up: every stream is primed past the suppressor's start-up (END_STARTUP_LONG = 200 frames,
+    # ns/defines.h:20: different, heavier branches) whatever --warmup is, so the timed steps are
+    # the steady state of a long-running stream; the W warm-up steps then follow as asked
+    primed = max(0, NS_PRIME_FRAMES - args.warmup)
+    done = 0
+    while done < primed:
+        n = min(ring, primed - done)
+        ns.analyze_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
+        done += n
+    barrier()
+    if args.warmup > 0:
+        ns.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, args.warmup)
+    # the timed region: EXACTLY --steps fused frame steps between two barriers (+ device
+    # synchronisation), repeated R times so the median is stable at small --steps; each region is
+    # timed by hipEvents recorded on the launch stream around the K steps (the clock every number of
+    # the line uses) and by the host's wall clock around the same region (reported beside it)
+    R = args.regions if args.regions > 0 else max(5, min(200, -(-4000 // max(args.steps, 1))))
+    ev, wall = [], []
+    ns.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, args.steps)   # graph capture of the K-step region
+    for _ in range(R):
+        barrier()
+        t0 = time.perf_counter()
+        ev_ms = ns.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, args.steps)
+        barrier()
+        wall.append(time.perf_counter() - t0)
+        ev.append(ev_ms / 1e3)
+    if not torch.isfinite(d_out).all():
+        raise SystemExit("non-finite output")
+    ns.close()
+    del d_in, d_out
+    return np.array(ev), np.array(wall), S, primed
 
 
 def main():
@@ -270,15 +395,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=250)
-    ap.add_argument("--streams-per-gpu", type=int, default=4096)
+    ap.add_argument("--streams-per-gpu", type=int, default=0,
+                    help="default: 4096 at --gpus 1 (BASELINE config 2), 8192 at --gpus > 1 (config 5: 65 536 streams on 8 GPUs)")
     ap.add_argument("--ring", type=int, default=100, help="distinct input frames resident in HBM")
+    ap.add_argument("--regions", type=int, default=0, help="repeats of the K-step timed region (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the AEC / BT-1024 / config-5 lines of the N = 1 run")
+    ap.add_argument("--no-graph", action="store_true", help="plain kernel launches instead of a hipGraph replay")
+    ap.add_argument("--secondary-steps", type=int, default=1000)
+    ap.add_argument("--secondary-warmup", type=int, default=250)
     ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
-    ap.add_argument("--streams-per-wave", type=int, default=2, choices=[1, 2],
-                    help="fused-step kernel: 2 = two streams per wave64 (default), 1 = one")
+    ap.add_argument("--streams-per-wave", type=int, default=2, choices=[1, 2, 3],
+                    help="fused-step kernel: 2 = two streams per wave64 (default), 1 = one (bins q / q + 64), "
+                         "3 = one stream per wave, pair layout (ns_kernels1.hip)")
     ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256", "aec", "split48"],
                     help="ns = the headline metric (default); bt* / aec / split48 = secondary lines")
     args = ap.parse_args()
+    if args.streams_per_gpu <= 0:
+        args.streams_per_gpu = 4096 if (args.gpus == 1 or args.workload != "ns") else 8192
     if args.workload == "aec":
         return bench_aec(args)
     if args.workload == "split48":
@@ -305,67 +439,28 @@ def main():
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from audiosignalprocess_amd.ns import NsBatch
-    from audiosignalprocess_amd.shard import max_over_ranks, shard_streams
-    from audiosignalprocess_amd.synth import ns_frames
+    from audiosignalprocess_amd.shard import max_over_ranks
 
-    ring = args.ring
-    # every rank owns a disjoint contiguous shard of stream ids (no data-path collective)
-    stream0, S = shard_streams(rank, world, args.streams_per_gpu)
-    x = ns_frames(S, ring, stream0=stream0, frame0=50)
-    d_in = torch.from_numpy(x).cuda()
-    d_out = torch.empty_like(d_in)
-    del x
-    ns = NsBatch(S, device=local_rank, policy=1, streams_per_wave=args.streams_per_wave)
-    ns.set_stream(torch.cuda.current_stream().cuda_stream)
-    if args.split > 1:
-        ns.set_split(args.split)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # set-up: every stream is primed past the suppressor's start-up (END_STARTUP_LONG = 200 frames,
-    # ns/defines.h:20: different, heavier branches) whatever --warmup is, so the timed steps are
-    # the steady state of a long-running stream; the W warm-up steps then follow as asked
-    primed = max(0, NS_PRIME_FRAMES - args.warmup)
-    done = 0
-    while done < primed:
-        n = min(ring, primed - done)
-        ns.analyze_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
-        done += n
-    barrier()
-    done = 0
-    while done < args.warmup:
-        n = min(ring, args.warmup - done)
-        ns.analyze_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
-        done += n
-    barrier()
-    t0 = time.perf_counter()
-    ev_ms = ns.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, args.steps)
-    barrier()
-    wall = time.perf_counter() - t0
-    if not torch.isfinite(d_out).all():
-        raise SystemExit("non-finite output")
-
-    wall_max, ev_max = max_over_ranks(dist, [wall, ev_ms / 1e3], device="cuda")
+    ev, wall, S, primed = ns_measure(args, args.streams_per_gpu, rank, world, local_rank, dist)
+    # per region: the slowest rank's time (MAX over ranks), then the median over regions
+    ev = np.array(max_over_ranks(dist, list(ev), device="cuda"))
+    wall = np.array(max_over_ranks(dist, list(wall), device="cuda"))
 
     if rank == 0:
-        frames = S * world * args.steps
-        # average duration of one fused frame step (= of each of its `split` concurrent
-        # sub-launches, which run side by side on their own HIP streams)
-        launch_s = ev_max / max(args.steps, 1)
-        achieved = ALGO_BYTES_PER_FRAME * S / launch_s / 1e9
+        K = max(args.steps, 1)
+        step_s = float(np.median(ev)) / K            # THE clock of this line: hipEvents over the K-step region
+        frames_per_region = S * world * args.steps
+        achieved = ALGO_BYTES_PER_FRAME * S / step_s / 1e9
+        kernel = {2: "ns_frame2_kernel_ilp<false>" if S <= 6144 else "ns_frame2_kernel<false>",
+                  1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>"}[args.streams_per_wave]
         line = {
             "metric": "audio frames/sec (10 ms @16 kHz) Wiener NS",
-            "value": frames / wall_max,
+            "value": frames_per_region / (step_s * K),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * wall_max / max(args.steps, 1),
+            "ms_per_step": 1e3 * step_s,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -373,14 +468,29 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "WebRTC NS (test_ns_module): 10 ms/16 kHz frames, %d concurrent mono "
-                            "streams per MI355X, policy 1, Analyze+Process fused, "
-                            "frame-synchronous (1 launch per frame)" % S,
+                            "streams per MI355X (%d in total on %d GPU%s), policy 1, Analyze+Process fused, "
+                            "frame-synchronous (1 launch per frame and sub-launch)"
+                            % (S, S * world, world, "" if world == 1 else "s"),
                 "streams_per_gpu": S,
                 "total_streams": S * world,
-                "input_ring_frames": ring,
+                "input_ring_frames": args.ring,
                 "primed_frames_in_setup": primed,
                 "sub_launches_per_step": args.split,
+                "launch": "plain launches" if args.no_graph else "hipGraph replay of the K-step region (kernel nodes only)",
                 "parallelism": "stream-sharded x%d, no collectives" % world,
+            },
+            # one clock for value, ms_per_step and roofline: the median over `regions` repeats of the
+            # K-step region of the hipEvent time recorded on the launch stream (max over ranks per region);
+            # the host wall clock around the same regions is printed beside it
+            "timing": {
+                "clock": "hipEvent on the launch stream, median over regions (max over ranks per region)",
+                "regions": int(len(ev)),
+                "ms_per_step_min": 1e3 * float(ev.min()) / K,
+                "ms_per_step_p10": 1e3 * float(np.percentile(ev, 10)) / K,
+                "ms_per_step_p90": 1e3 * float(np.percentile(ev, 90)) / K,
+                "ms_per_step_max": 1e3 * float(ev.max()) / K,
+                "wall_ms_per_step_median": 1e3 * float(np.median(wall)) / K,
+                "wall_value_median": frames_per_region / float(np.median(wall)),
             },
             "roofline": {
                 "bound": "hbm",
@@ -389,22 +499,43 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (PMC_TRAFFIC_BYTES_PER_FRAME_DUAL if args.streams_per_wave == 2
-                            else PMC_TRAFFIC_BYTES_PER_FRAME) * S / max(args.split, 1),
-                "traffic_source": "profiles/README.md (PMC passes of round 1, per launch)",
-                # two builds of the two-streams-per-wave kernel: the ILP-scheduled one up to 6144 streams per
-                # GPU, the three-waves-per-SIMD one above (csrc/ns_kernels2.hip, ns_api.hip: kIlpMaxStreams)
-                "kernel": ("ns_frame2_kernel_ilp<false>" if S <= 6144 else "ns_frame2_kernel<false>")
-                          if args.streams_per_wave == 2 else "ns_frame_kernel<true,true>",
-                # one frame step = `concurrent_launches` launches of this kernel side by side
-                # (one per HIP stream, S / concurrent_launches streams each); each lasts about
-                # one step, so achieved = concurrent_launches * bytes_per_launch / avg_launch
+                            else PMC_TRAFFIC_BYTES_PER_FRAME) * S,
+                "traffic_source": "stored constant: PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE, "
+                                  "calibrated; not measured in this run), per frame step of all streams",
+                "kernel": kernel,
+                # one frame step = `concurrent_launches` launches of this kernel side by side (one per HIP
+                # stream, S / concurrent_launches streams each); achieved = algorithmic bytes of the step /
+                # ms_per_step of this line
                 "concurrent_launches": args.split,
+                "algorithmic_bytes_per_step": ALGO_BYTES_PER_FRAME * S,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * S // max(args.split, 1),
-                "avg_launch_us": launch_s * 1e6,
+                "avg_launch_us": step_s * 1e6,
             },
         }
+        if world == 1:
+            try:
+                cc = copy_ceiling_gbs()
+                line["roofline"]["copy_ceiling"] = cc
+                line["roofline"]["frac_of_copy_ceiling"] = achieved / cc
+            except Exception as e:  # noqa: BLE001
+                line["roofline"]["copy_ceiling"] = None
+                line["roofline"]["copy_ceiling_error"] = str(e)[:200]
+        if world == 1 and not args.no_secondary:
+            # BASELINE config 5 on one GPU (8192 streams): the like-for-like N = 1 point of the 8-GPU run
+            a2 = argparse.Namespace(**vars(args))
+            a2.steps, a2.warmup, a2.regions = min(args.steps, 200), min(args.warmup, 50), 0
+            ev5, wall5, S5, _ = ns_measure(a2, 8192, 0, 1, local_rank, None)
+            s5 = float(np.median(ev5)) / max(a2.steps, 1)
+            line["config5_single_gpu"] = {
+                "workload": "8192 streams on 1 MI355X (the per-GPU share of BASELINE config 5)",
+                "value": S5 / s5, "unit": "frames/s", "ms_per_step": 1e3 * s5, "steps": a2.steps, "regions": int(len(ev5)),
+                "roofline_frac": ALGO_BYTES_PER_FRAME * S5 / s5 / 1e9 / HBM_PEAK_GBS,
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_secondary:
+            torch.cuda.empty_cache()
+            line["secondary"] = [_secondary(args, "aec"), _secondary(args, "bt1024")]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

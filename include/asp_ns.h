@@ -186,6 +186,16 @@ int AspNs_DeviceFree(void* ptr);
 int AspNs_MemcpyH2D(void* dst, const void* src, size_t bytes);
 int AspNs_MemcpyD2H(void* dst, const void* src, size_t bytes);
 
+/* `steps` fused frame steps on device buffers in/out ([frames_in_ring][num_streams][160], step k
+ * uses ring slot k % frames_in_ring), enqueued asynchronously as ONE replay of a captured hipGraph
+ * (kernel nodes only, one launch per frame step and sub-launch, exactly the launches
+ * AspNsBatch_AnalyzeProcess would issue).  The capture is cached while the arguments stay the
+ * same, so a caller that feeds the same ring repeatedly pays one graph launch per call.
+ * AspNsBatch_SetGraph(b, 0) turns replay off (plain launches). */
+int AspNsBatch_AnalyzeProcessReplay(AspNsBatch* b, const float* in, float* out,
+                                    int frames_in_ring, int steps);
+int AspNsBatch_SetGraph(AspNsBatch* b, int on);
+
 /* Timed replay for bench.py: runs `steps` fused frame-steps on device buffers
  * in/out ([frames_in_ring][num_streams][160], step k uses ring slot k %
  * frames_in_ring) on the batch's stream, bracketed by hipEvents recorded on

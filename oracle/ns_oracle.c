@@ -324,6 +324,18 @@ static float butterfly32(float* t) {
  * lane 0 additionally bin 128.  TREE32: lane l < 16 holds bins l, l+16, l+32, l+48, lane
  * 16+l holds 64+l, 80+l, 96+l, 112+l (summed in that order), lane 0 additionally bin 128. */
 static float sum_bins(const float* x, int mode) {
+  if (mode == ASP_NS_REDUCE_TREE64P) {
+    /* ns_kernels1.hip: lane l = 2 lam + h holds bins q + 64 g + 16 h and that + 32
+     * (lam = q + 16 g), lane 0 additionally bin 128 */
+    float t[64];
+    for (int l = 0; l < 64; ++l) {
+      const int lam = l >> 1, h = l & 1;
+      const int b = (lam & 15) + 64 * (lam >> 4) + 16 * h;
+      t[l] = x[b] + x[b + 32];
+    }
+    t[0] = t[0] + x[128];
+    return butterfly64(t);
+  }
   if (mode == ASP_NS_REDUCE_TREE32) {
     float t[32];
     for (int l = 0; l < 32; ++l) {
@@ -349,6 +361,22 @@ static float sum_bins(const float* x, int mode) {
  * lane layout: 1 = lane l holds samples 4l..4l+3 (analysis side), 0 = lane l
  * holds samples 2l, 2l+1, 2l+128, 2l+129 (after the inverse FFT). */
 static float energy256(const float* x, int mode, int by4) {
+  if (mode == ASP_NS_REDUCE_TREE64P && !by4) {
+    /* synthesis side of ns_kernels1.hip: lane l = 2 lam + h holds complex elements
+     * E = q + 64 g + 16 h and E + 32, i.e. samples 2E, 2E+1, 2E+64, 2E+65 (the analysis side
+     * is the TREE layout: samples 4l .. 4l+3) */
+    float t[64];
+    for (int l = 0; l < 64; ++l) {
+      const int lam = l >> 1, h = l & 1;
+      const float* p = x + 2 * ((lam & 15) + 64 * (lam >> 4) + 16 * h);
+      float s = p[0] * p[0];
+      s += p[1] * p[1];
+      s += p[64] * p[64];
+      s += p[65] * p[65];
+      t[l] = s;
+    }
+    return butterfly64(t);
+  }
   if (mode == ASP_NS_REDUCE_TREE32) {
     /* analysis side: lane l holds samples 8l..8l+7; synthesis side: lane l holds complex
      * elements p = (l & 15) + 16 t + 64 (l >> 4), t = 0..3, i.e. samples 2p, 2p+1 */

@@ -17,7 +17,7 @@ import pytest
 
 from audiosignalprocess_amd.synth import ns_frames
 from tests.conftest import rel_l2_per_stream, state_diff, state_from_bytes
-from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, OracleNs
+from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P, OracleNs
 
 pytestmark = pytest.mark.gpu
 
@@ -585,6 +585,87 @@ def test_dual_then_unfused_continues(ns):
     o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE32)
     assert np.array_equal(g.analyze_process(x[:100]), o.run(x[:100]))
     o.mode = REDUCE_TREE  # separate Analyze / Process launches use the one-stream kernels
+    for f in range(100, F):
+        g.analyze(x[f])
+        o.analyze(x[f])
+        assert np.array_equal(g.process(x[f]), o.process(x[f])), f
+    g.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# The one-stream-per-wave, two-bins-per-lane fused kernel (ns_kernels1.hip, kernel id 3): bit-exact
+# against the oracle's ASP_NS_REDUCE_TREE64P association (outputs and every state array).
+
+def test_pair_kernel_free_running_bit_exact(ns):
+    S, F = 24, 1100  # crosses blockInd 50 / 200 and two 500-frame histogram windows
+    x = ns_frames(S, F, stream0=300)
+    g = ns.NsBatch(S, policy=1, streams_per_wave=3)
+    y = g.analyze_process(x)
+    o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE64P)
+    yo = o.run(x, threads=8)
+    assert np.isfinite(y).all()
+    bad = np.nonzero((y != yo).any(axis=2))
+    assert bad[0].size == 0, (bad[0][:5], bad[1][:5])
+    for s in range(0, S, 5):
+        assert state_diff(g.export_state(s), o.export_state(s)) == {}
+    g.close()
+
+
+def test_pair_kernel_edge_cases_policies_and_odd_count(ns):
+    S, F = 7, 260
+    x = ns_frames(S, F, stream0=40)
+    x[10:16, 1] = 0.0      # energy == 0 frames in the middle of a run
+    x[:, 2] = 0.0          # digital silence from the start
+    x[30:, 3] = 32767.0    # full-scale DC
+    x[100:104, 4] = 0.0
+    for policy in (0, 1, 2, 3):
+        g = ns.NsBatch(S, policy=policy, streams_per_wave=3)
+        y = g.analyze_process(x)
+        o = OracleNs(S, policy=policy, reduce_mode=REDUCE_TREE64P)
+        assert np.array_equal(y, o.run(x)), policy
+        for s in range(S):
+            assert state_diff(g.export_state(s), o.export_state(s)) == {}, (policy, s)
+        g.close()
+
+
+def test_pair_kernel_golden_int16_split_and_scale(ns, golden):
+    pcm = golden["in_i16"]
+    F, S, _ = pcm.shape
+    g = ns.NsBatch(S, policy=1, streams_per_wave=3)
+    y = g.analyze_process(pcm.astype(np.float32))
+    rel = rel_l2_per_stream(y, golden["out_f32"])
+    assert rel.max() <= REL_TOL, rel
+    g16 = ns.NsBatch(S, policy=1, streams_per_wave=3)
+    y16 = g16.analyze_process_s16(pcm)
+    ref = golden["wav_out_i16"][:F * 160].reshape(F, 160)
+    d = np.abs(y16[:, 0].astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.999
+    g.close()
+    g16.close()
+    # BASELINE config[1] size, 4 sub-launches, and config 5's per-GPU size, spot-checked against the oracle
+    for S2, parts in ((4096, 4), (8192, 2)):
+        F2 = 40
+        base = ns_frames(16, F2, stream0=11)
+        idx = np.arange(S2) % 16
+        x = np.ascontiguousarray(base[:, idx])
+        big = ns.NsBatch(S2, policy=1, streams_per_wave=3)
+        big.set_split(parts)
+        yb = big.analyze_process(x)
+        assert np.isfinite(yb).all()
+        yo = OracleNs(16, policy=1, reduce_mode=REDUCE_TREE64P).run(base)
+        for k in (0, 1, 2, 3, 1364, 1365, 2730, 2731, S2 - 2, S2 - 1):
+            assert np.array_equal(yb[:, k], yo[:, idx[k]]), (S2, k)
+        big.close()
+
+
+def test_pair_then_unfused_continues(ns):
+    """Fused one-per-wave (pair layout) steps, then the reference's two-call protocol on the same batch."""
+    S, F = 5, 130
+    x = ns_frames(S, F, stream0=77)
+    g = ns.NsBatch(S, policy=1, streams_per_wave=3)
+    o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE64P)
+    assert np.array_equal(g.analyze_process(x[:100]), o.run(x[:100]))
+    o.mode = REDUCE_TREE  # separate Analyze / Process launches use the q / q + 64 kernels
     for f in range(100, F):
         g.analyze(x[f])
         o.analyze(x[f])
