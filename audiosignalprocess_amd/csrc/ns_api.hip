@@ -26,13 +26,13 @@ hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables
                            const float* in, float* out, int num_streams, hipStream_t s);
 hipError_t launch_ns_frame2_ilp(bool io16, float* state, int32_t* hist, const NsTables* T,
                                 const float* in, float* out, int num_streams, hipStream_t s,
-                                unsigned long long* stamps = nullptr);
+                                unsigned long long* stamps = nullptr, int stagger = 0);
 hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps = nullptr);
+                            unsigned long long* stamps = nullptr, int stagger = 0);
 hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps = nullptr);
+                            unsigned long long* stamps = nullptr, int stagger = 0);
 hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_hb_live(const float* state, const NsTables* T, const float* in_low,
                              int32_t* live, int num_streams, int hist_off, hipStream_t s);
@@ -460,20 +460,28 @@ struct AspNsBatch {
   bool dual = true;  // fused paired step through the two-streams-per-wave kernel
   // fused step kernel: 1 = ns_frame_kernel (one stream per wave, bins q / q + 64), 2 = ns_frame2_kernel
   // (two streams per wave), 3 = ns_frame1_kernel (one stream per wave, pair layout: ns_kernels1.hip)
-  int kernel = 2;
+  int kernel = 0;  // 0 = by batch size: 3 up to kIlpMaxStreams streams per GPU, 2 above
+  int stagger = 0;  // ns_frame1_kernel: start delay per workgroup slot of a CU, shader cycles (ns_kernels1.hip)
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
   // A captured K-step replay (hipGraph): the launches of `g_steps` fused steps over the ring
   // (g_in, g_out, g_ring), still one launch per frame step and sub-launch; replayed while the
   // key is unchanged, so the host pays one graph launch instead of 2 K kernel launches.
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t gexec = nullptr;
+  hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
+  int g_parts = 0;
   const float* g_in = nullptr;
   float* g_out = nullptr;
   int g_ring = 0, g_steps = 0, g_split = 0;
   bool g_io16 = false, g_dual = false;
   int g_kernel = 0;
-  bool use_graph = true;
+  bool use_graph = false;  // plain launches measured 4-7 % faster per step than graph replay (round 2)
+  // TimedSteps gate: the K steps are enqueued behind a stream wait on this host-mapped word and
+  // released together, so the timed region holds no host enqueue latency (as a graph replay would)
+  volatile uint32_t* gate_host = nullptr;
+  uint32_t* gate_dev = nullptr;
+  uint32_t gate_seq = 0;
+  bool use_gate = false;  // measured: helps 2 % at K = 20, costs 10 % at K = 1000 (the launches queue up behind it)
   // > 16 kHz: 1 or 2 high bands next to the low band (ns_core.c:1362-1414)
   uint32_t fs = 16000;
   int num_high = 0;
@@ -542,6 +550,8 @@ int AspNsBatch_Create(AspNsBatch** out, int num_streams, int device) {
   AspNsBatch* b = new AspNsBatch();
   b->S = num_streams;
   b->device = device;
+  if (const char* e = getenv("ASP_NS_STAGGER")) b->stagger = atoi(e);
+  if (const char* e = getenv("ASP_NS_STAGGER_MODE")) b->stagger |= atoi(e) << 24;
   rc = device_tables(device, &b->tables);
   if (rc) {
     delete b;
@@ -574,8 +584,11 @@ int AspNsBatch_Free(AspNsBatch* b) {
   if (b->hb_stage) (void)hipFree(b->hb_stage);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
-  if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
-  if (b->graph) (void)hipGraphDestroy(b->graph);
+  for (int p = 0; p < 4; ++p) {
+    if (b->gexec[p]) (void)hipGraphExecDestroy(b->gexec[p]);
+    if (b->graph[p]) (void)hipGraphDestroy(b->graph[p]);
+  }
+  if (b->gate_host) (void)hipHostFree((void*)b->gate_host);
   if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
   for (int i = 0; i < 3; ++i) {
     if (b->join_ev[i]) (void)hipEventDestroy(b->join_ev[i]);
@@ -649,18 +662,28 @@ static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float
   int32_t* hist = b->hist + (size_t)s0 * kHistDwords;
   const float* in = din + (size_t)s0 * sper;
   float* out = dout + (size_t)s0 * sper;
-  if (b->kernel == 3) return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st);
-  if (!b->dual || n < 2) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
+  const int kernel = b->kernel ? b->kernel : (b->S <= kIlpMaxStreams ? 3 : 2);
+  if (kernel == 3) return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st, nullptr, b->stagger);
+  if (kernel == 1 || n < 2) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
   const int even = n & ~1;
   // two builds of the same kernel (ns_kernels2.hip): the ILP-scheduled one while the batch gives a
   // SIMD at most two waves to run, the 168-VGPR one (three resident waves) for larger batches
-  hipError_t e = b->S <= kIlpMaxStreams ? launch_ns_frame2_ilp(io16, state, hist, b->tables, in, out, even, st)
-                                        : launch_ns_frame2(io16, state, hist, b->tables, in, out, even, st);
+  hipError_t e = b->S <= kIlpMaxStreams ? launch_ns_frame2_ilp(io16, state, hist, b->tables, in, out, even, st, nullptr, b->stagger)
+                                        : launch_ns_frame2(io16, state, hist, b->tables, in, out, even, st, nullptr, b->stagger);
   if (e == hipSuccess && even != n)  // the odd last stream: one-stream-per-wave kernel
     e = launch_ns_frame(io16 ? 3 : 2, state + (size_t)even * kStreamDwords,
                         hist + (size_t)even * kHistDwords, b->tables, in + (size_t)even * sper,
                         out + (size_t)even * sper, 1, st);
   return e;
+}
+
+// stream boundaries of the sub-launch chains: multiples of 8 streams (one workgroup = 8 streams in
+// the two-per-wave kernel, 4 in the one-per-wave kernels)
+static int chain_parts(const AspNsBatch* b, int base[5]) {
+  const int parts = (b->split > 1 && b->S >= 8 * b->split) ? b->split : 1;
+  for (int p = 0; p <= parts; ++p) base[p] = (int)(((long long)b->S * p / parts) / 8 * 8);
+  base[parts] = b->S;
+  return parts;
 }
 
 // `steps` fused frame steps on device buffers; step k reads/writes ring slot k % ring.
@@ -669,7 +692,8 @@ static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, i
   // offsets below are in float units; int16 frames are half as wide
   const size_t per = (size_t)b->S * kBlockL / (io16 ? 2 : 1);
 
-  const int parts = (b->split > 1 && b->S >= 8 * b->split) ? b->split : 1;
+  int base[5];
+  const int parts = chain_parts(b, base);
   if (parts == 1) {
     for (int k = 0; k < steps; ++k) {
       const size_t off = per * (size_t)(k % ring);
@@ -677,10 +701,6 @@ static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, i
     }
     return ASP_OK;
   }
-  // parts are multiples of 8 streams (one workgroup = 8 streams in the two-per-wave kernel)
-  int base[5];
-  for (int p = 0; p <= parts; ++p) base[p] = (int)(((long long)b->S * p / parts) / 8 * 8);
-  base[parts] = b->S;
   HIP_TRY(hipEventRecord(b->fork_ev, b->stream));
   for (int p = 1; p < parts; ++p) HIP_TRY(hipStreamWaitEvent(b->side[p - 1], b->fork_ev, 0));
   for (int k = 0; k < steps; ++k) {
@@ -699,37 +719,52 @@ static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, i
 }
 
 static void drop_graph(AspNsBatch* b) {
-  if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
-  if (b->graph) (void)hipGraphDestroy(b->graph);
-  b->gexec = nullptr;
-  b->graph = nullptr;
+  for (int p = 0; p < 4; ++p) {
+    if (b->gexec[p]) (void)hipGraphExecDestroy(b->gexec[p]);
+    if (b->graph[p]) (void)hipGraphDestroy(b->graph[p]);
+    b->gexec[p] = nullptr;
+    b->graph[p] = nullptr;
+  }
   b->g_steps = 0;
 }
 
-// The same `steps` fused frame steps as fused_steps(), captured into a hipGraph (kernel nodes only:
-// one per frame step and sub-launch, the sub-launch chains as parallel branches).  The capture is
-// kept while (buffers, ring, steps, split, kernel) stay the same.
+// The same launches as fused_steps(), captured as ONE LINEAR hipGraph PER CHAIN (kernel nodes only,
+// one per frame step; a chain's graph is replayed on the chain's own HIP stream, so a replay is the
+// chain's in-order sequence of launches without a host enqueue per launch).  One graph with the chains
+// as parallel branches measured 15-20 % slower per step than plain launches (round 2), linear graphs
+// do not.  The captures are kept while (buffers, ring, steps, split, kernel) stay the same.
 static int ensure_graph(AspNsBatch* b, const float* din, float* dout, int ring, int steps, bool io16) {
-  const bool hit = b->gexec && b->g_in == din && b->g_out == dout && b->g_ring == ring &&
+  const bool hit = b->gexec[0] && b->g_in == din && b->g_out == dout && b->g_ring == ring &&
                    b->g_steps == steps && b->g_split == b->split && b->g_io16 == io16 &&
                    b->g_dual == b->dual && b->g_kernel == b->kernel;
   if (hit) return ASP_OK;
   drop_graph(b);
-  HIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
-  const int rc = fused_steps(b, din, dout, ring, steps, io16);
-  hipGraph_t g = nullptr;
-  hipError_t e = hipStreamEndCapture(b->stream, &g);
-  if (rc) {
-    if (g) (void)hipGraphDestroy(g);
-    return rc;
+  int base[5];
+  const int parts = chain_parts(b, base);
+  const size_t per = (size_t)b->S * kBlockL / (io16 ? 2 : 1);
+  for (int p = 0; p < parts; ++p) {
+    hipStream_t st = p == 0 ? b->stream : b->side[p - 1];
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    hipError_t le = hipSuccess;
+    for (int k = 0; k < steps && le == hipSuccess; ++k) {
+      const size_t off = per * (size_t)(k % ring);
+      le = fused_launch(b, io16, din + off, dout + off, base[p], base[p + 1] - base[p], st);
+    }
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (le != hipSuccess || e != hipSuccess) {
+      if (g) (void)hipGraphDestroy(g);
+      drop_graph(b);
+      return fail(ASP_ERR_HIP, "graph capture of the frame steps", le != hipSuccess ? le : e);
+    }
+    b->graph[p] = g;
+    e = hipGraphInstantiate(&b->gexec[p], g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+      drop_graph(b);
+      return fail(ASP_ERR_HIP, "hipGraphInstantiate", e);
+    }
   }
-  if (e != hipSuccess) return fail(ASP_ERR_HIP, "hipStreamEndCapture", e);
-  b->graph = g;
-  e = hipGraphInstantiate(&b->gexec, g, nullptr, nullptr, 0);
-  if (e != hipSuccess) {
-    drop_graph(b);
-    return fail(ASP_ERR_HIP, "hipGraphInstantiate", e);
-  }
+  b->g_parts = parts;
   b->g_in = din;
   b->g_out = dout;
   b->g_ring = ring;
@@ -738,6 +773,21 @@ static int ensure_graph(AspNsBatch* b, const float* din, float* dout, int ring, 
   b->g_io16 = io16;
   b->g_dual = b->dual;
   b->g_kernel = b->kernel;
+  return ASP_OK;
+}
+
+// replay: fork the side streams off the batch's stream, one graph launch per chain, join
+static int launch_graphs(AspNsBatch* b) {
+  const int parts = b->g_parts;
+  if (parts > 1) {
+    HIP_TRY(hipEventRecord(b->fork_ev, b->stream));
+    for (int p = 1; p < parts; ++p) HIP_TRY(hipStreamWaitEvent(b->side[p - 1], b->fork_ev, 0));
+  }
+  for (int p = 0; p < parts; ++p) HIP_TRY(hipGraphLaunch(b->gexec[p], p == 0 ? b->stream : b->side[p - 1]));
+  for (int p = 1; p < parts; ++p) {
+    HIP_TRY(hipEventRecord(b->join_ev[p - 1], b->side[p - 1]));
+    HIP_TRY(hipStreamWaitEvent(b->stream, b->join_ev[p - 1], 0));
+  }
   return ASP_OK;
 }
 
@@ -940,8 +990,7 @@ int AspNsBatch_AnalyzeProcessReplay(AspNsBatch* b, const float* in, float* out, 
   if (!b->use_graph || b->stream == nullptr) return fused_steps(b, in, out, frames_in_ring, steps);
   rc = ensure_graph(b, in, out, frames_in_ring, steps, false);
   if (rc) return rc;
-  HIP_TRY(hipGraphLaunch(b->gexec, b->stream));
-  return ASP_OK;
+  return launch_graphs(b);
 }
 
 int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames_in_ring,
@@ -957,10 +1006,41 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
     rc = ensure_graph(b, in, out, frames_in_ring, steps, false);
     if (rc) return rc;
   }
+  // gate: everything below is enqueued while the stream waits on a host-mapped word; the host
+  // opens it once the last launch is queued (falls back to no gate where the wait is unsupported)
+  bool gated = false;
+  if (b->use_gate && b->stream != nullptr && steps > 0) {
+    if (!b->gate_host) {
+      void* hp = nullptr;
+      if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+          b->gate_host = (volatile uint32_t*)hp;
+          b->gate_dev = (uint32_t*)dp;
+          *b->gate_host = 0;
+        } else {
+          (void)hipHostFree(hp);
+          b->use_gate = false;
+        }
+      } else {
+        b->use_gate = false;
+      }
+    }
+    if (b->gate_host) {
+      b->gate_seq += 1;
+      if (hipStreamWaitValue32(b->stream, b->gate_dev, b->gate_seq, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess)
+        gated = true;
+      else {
+        (void)hipGetLastError();
+        b->use_gate = false;
+      }
+    }
+  }
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   const auto h0 = std::chrono::steady_clock::now();
   if (graph) {
-    HIP_TRY(hipGraphLaunch(b->gexec, b->stream));
+    rc = launch_graphs(b);
+    if (rc) return rc;
   } else {
     rc = fused_steps(b, in, out, frames_in_ring, steps);
     if (rc) return rc;
@@ -969,6 +1049,11 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
     fprintf(stderr, "TimedSteps: host enqueue of %d steps took %.1f us per step\n", steps,
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count() / (steps > 0 ? steps : 1));
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  if (gated) {
+    __sync_synchronize();
+    *b->gate_host = b->gate_seq;  // open the gate
+    __sync_synchronize();
+  }
   HIP_TRY(hipEventSynchronize(b->ev1));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
   return ASP_OK;
@@ -1041,15 +1126,19 @@ int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
                            unsigned long long* stamps16) {
   int rc = check(b);
   if (rc) return rc;
-  if (!in_dev || !out_dev || !stamps16 || !b->paired || (b->S & 1))
+  if (!in_dev || !out_dev || !stamps16 || !b->paired || ((b->S & 1) && b->kernel == 2))
     return fail(ASP_ERR_PARAM, "DebugStamps: bad argument");
   unsigned long long* d = nullptr;
   HIP_TRY(hipMalloc((void**)&d, 16 * sizeof(unsigned long long)));
   hipError_t e = hipMemset(d, 0, 16 * sizeof(unsigned long long));
-  if (e == hipSuccess)
-    e = b->S <= kIlpMaxStreams  // the build the product path uses for this batch size
-            ? launch_ns_frame2_ilp(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d)
-            : launch_ns_frame2(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d);
+  if (e == hipSuccess) {
+    if ((b->kernel ? b->kernel : (b->S <= kIlpMaxStreams ? 3 : 2)) == 3)
+      e = launch_ns_frame1(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d, 0);
+    else
+      e = b->S <= kIlpMaxStreams  // the build the product path uses for this batch size
+              ? launch_ns_frame2_ilp(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d)
+              : launch_ns_frame2(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d);
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (e == hipSuccess) e = hipMemcpy(stamps16, d, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d);
@@ -1059,13 +1148,14 @@ int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
 
 int AspNsBatch_SetGraph(AspNsBatch* b, int on) {
   if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
-  b->use_graph = on != 0;
+  b->use_graph = (on & 1) != 0;
+  b->use_gate = (on & 2) != 0;  // bit 1: TimedSteps with the enqueue gate
   return ASP_OK;
 }
 
 int AspNsBatch_SetKernel(AspNsBatch* b, int streams_per_wave) {
-  if (!b || streams_per_wave < 1 || streams_per_wave > 3)
-    return fail(ASP_ERR_PARAM, "SetKernel: 1 (one stream per wave, q / q + 64), 2 (two streams per wave) or 3 (one stream per wave, pair layout)");
+  if (!b || streams_per_wave < 0 || streams_per_wave > 3)
+    return fail(ASP_ERR_PARAM, "SetKernel: 0 (by batch size), 1 (one stream per wave, q / q + 64), 2 (two streams per wave) or 3 (one stream per wave, pair layout)");
   b->dual = streams_per_wave == 2;
   b->kernel = streams_per_wave;
   return ASP_OK;
@@ -1087,6 +1177,61 @@ int AspNsBatch_Synchronize(AspNsBatch* b) {
   if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  return ASP_OK;
+}
+
+// ---- streaming-copy ceiling of the box (bench.py prints it next to the 8 TB/s spec peak) ----
+__global__ __launch_bounds__(256) void asp_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+  // 4 independent 16-byte loads per thread in flight, then 4 stores; consecutive threads touch
+  // consecutive float4s of each of the four slices a block owns
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  float4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t i = base + (size_t)k * 256;
+    v[k] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t i = base + (size_t)k * 256;
+    if (i < n4) dst[i] = v[k];
+  }
+}
+
+// Copies `bytes` (a multiple of 16) src -> dst `iters` times on `device`; *gbps = (read + written
+// bytes) / hipEvent time of the best of three timed passes.
+int AspNs_CopyCeiling(size_t bytes, int iters, int device, double* gbps) {
+  if (!gbps || bytes < 4096 || (bytes & 15) || iters < 1) return fail(ASP_ERR_PARAM, "CopyCeiling: bad argument");
+  int rc = select_device(device);
+  if (rc) return rc;
+  float4 *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc((void**)&src, bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&dst, bytes);
+  if (e == hipSuccess) e = hipMemset(src, 0x3c, bytes);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  const size_t n4 = bytes / 16;
+  const dim3 grid((unsigned)((n4 + 1023) / 1024)), block(256);
+  double best = 0.0;
+  for (int pass = 0; pass < 4 && e == hipSuccess; ++pass) {
+    e = hipEventRecord(e0, nullptr);
+    for (int k = 0; k < iters; ++k) hipLaunchKernelGGL(asp_copy_kernel, grid, block, 0, nullptr, src, dst, n4);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess && pass > 0 && ms > 0.f) {
+      const double g = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+      if (g > best) best = g;
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (src) (void)hipFree(src);
+  if (dst) (void)hipFree(dst);
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "CopyCeiling", e);
+  *gbps = best;
   return ASP_OK;
 }
 

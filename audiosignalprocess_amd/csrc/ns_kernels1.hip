@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
                                                            const float* __restrict__ in,
                                                            float* __restrict__ out,
                                                            int num_streams,
-                                                           unsigned long long* __restrict__ stamps) {
+                                                           unsigned long long* __restrict__ stamps,
+                                                           int stagger) {
 #define NS_STAMP(k)                                                                \
   if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {                  \
     __builtin_amdgcn_sched_barrier(0);                                             \
@@ -192,6 +193,22 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     __builtin_amdgcn_sched_barrier(0);                                             \
   }
   NS_STAMP(0)
+  // Phase stagger: every workgroup of a launch starts at once, so without it all resident waves
+  // load together, compute together and store together -- the memory pipe idles while the SIMDs
+  // work and the other way round.  The workgroup in slot k of its CU (HW_ID.TG_ID) starts
+  // k * stagger shader cycles late, so that the four waves a SIMD holds are in different phases.
+  if (stagger > 0) {
+    const int mode = stagger >> 24;  // experiment selector in the top byte
+    const unsigned hwtg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);  // HW_REG_HW_ID[19:16]
+    const unsigned tg = mode == 0 ? (hwtg & 3u) : mode == 1 ? (hwtg & 1u)
+                        : mode == 2 ? (blockIdx.x >= gridDim.x / 2 ? 1u : 0u) : (blockIdx.x & 1u);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long wait = (unsigned long long)tg * (unsigned)(stagger & 0xffffff);
+    for (int i = 0; i < 2048; ++i) {  // bounded: a wave always leaves the loop
+      if (__builtin_amdgcn_s_memtime() - t0 >= wait) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
   __shared__ float2 lds[4][128];
   // per-lane twiddles of the three passes (3 x 64 x 4), real-split factors (32 x 4 x 2) and the
   // window, staged in LDS once per workgroup behind the state loads
@@ -248,18 +265,34 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     s4.w = hsel ? ha.w : (float)a.w;
   }
 
-#define LOAD3(dst, f)                                                                          \
+#define LOADV(dst, f)                                                                          \
   {                                                                                            \
     const float2 v2_ = *reinterpret_cast<const float2*>(vec + (f)*kVecStride + 2 * lane);      \
     dst[0] = v2_.x; dst[1] = v2_.y;                                                            \
-    dst[2] = SC_F(S_TAIL0 + (f));                                                              \
   }
+#define LOADT(dst, f) dst[2] = SC_F(S_TAIL0 + (f));
+#define LOAD3(dst, f) LOADV(dst, f) LOADT(dst, f)
 #define STORE3(f, srcv)                                                                        \
   {                                                                                            \
     *reinterpret_cast<float2*>(vec + (f)*kVecStride + 2 * lane) = make_float2(srcv[0], srcv[1]); \
     SC_SET_F(S_TAIL0 + (f), srcv[2]);                                                          \
   }
 
+#ifndef NS1_FRONTLOAD
+#define NS1_FRONTLOAD 0
+#endif
+  // state rows: with NS1_FRONTLOAD every row of the step is requested here, before the first
+  // wait (a step of 4096 streams is bound by the memory pipe being busy from the first cycle of
+  // a launch to the last, not by one wave's registers); otherwise in two groups, just ahead of use
+  float LQ[3][NS3], DEN[3][NS3], quant[NS3];
+  float smooth[NS3], noisePrev[NS3], magnPrevA[NS3], logLrt[NS3], avgPause[NS3];
+  if (NS1_FRONTLOAD) {
+    LOADV(LQ[0], V_LQ0) LOADV(LQ[1], V_LQ1) LOADV(LQ[2], V_LQ2)
+    LOADV(DEN[0], V_DEN0) LOADV(DEN[1], V_DEN1) LOADV(DEN[2], V_DEN2)
+    LOADV(quant, V_QUANT)
+    LOADV(magnPrevA, V_MAGNPREV_A) LOADV(logLrt, V_LOGLRT) LOADV(avgPause, V_AVGPAUSE)
+    LOADV(smooth, V_SMOOTH) LOADV(noisePrev, V_NOISEPREV)
+  }
   // syntBuf[0..95]: the lane's output samples 2E, 2E+1 that still carry overlap are those of
   // slot 0 when g == 0 (2q + 32h) and of slot 1 when g == 0 and h == 0 (2q + 64); every lane
   // loads (no branch), the overlap-add uses the owners' values only
@@ -305,10 +338,14 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 
   // the tracker rows are requested once the frame's samples are in; they are used after the
   // transform, the magnitudes and the logarithms
-  float LQ[3][NS3], DEN[3][NS3], quant[NS3];
-  LOAD3(LQ[0], V_LQ0) LOAD3(LQ[1], V_LQ1) LOAD3(LQ[2], V_LQ2)
-  LOAD3(DEN[0], V_DEN0) LOAD3(DEN[1], V_DEN1) LOAD3(DEN[2], V_DEN2)
-  LOAD3(quant, V_QUANT)
+  if (!NS1_FRONTLOAD) {
+    LOADV(LQ[0], V_LQ0) LOADV(LQ[1], V_LQ1) LOADV(LQ[2], V_LQ2)
+    LOADV(DEN[0], V_DEN0) LOADV(DEN[1], V_DEN1) LOADV(DEN[2], V_DEN2)
+    LOADV(quant, V_QUANT)
+  }
+  LOADT(LQ[0], V_LQ0) LOADT(LQ[1], V_LQ1) LOADT(LQ[2], V_LQ2)
+  LOADT(DEN[0], V_DEN0) LOADT(DEN[1], V_DEN1) LOADT(DEN[2], V_DEN2)
+  LOADT(quant, V_QUANT)
   NS_STAMP(1)
   // ---- forward FFT (ns_core.c:886-911)
   *reinterpret_cast<float4*>(&tile[2 * lane]) = make_float4(wx0, wx1, wx2, wx3);
@@ -320,9 +357,12 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 
   NS_STAMP(2)
   // second group of state rows (latency hides under magnitude / log / trackers)
-  float smooth[NS3], noisePrev[NS3], magnPrevA[NS3], logLrt[NS3], avgPause[NS3];
-  LOAD3(magnPrevA, V_MAGNPREV_A) LOAD3(logLrt, V_LOGLRT) LOAD3(avgPause, V_AVGPAUSE)
-  LOAD3(smooth, V_SMOOTH) LOAD3(noisePrev, V_NOISEPREV)
+  if (!NS1_FRONTLOAD) {
+    LOADV(magnPrevA, V_MAGNPREV_A) LOADV(logLrt, V_LOGLRT) LOADV(avgPause, V_AVGPAUSE)
+    LOADV(smooth, V_SMOOTH) LOADV(noisePrev, V_NOISEPREV)
+  }
+  LOADT(magnPrevA, V_MAGNPREV_A) LOADT(logLrt, V_LOGLRT) LOADT(avgPause, V_AVGPAUSE)
+  LOADT(smooth, V_SMOOTH) LOADT(noisePrev, V_NOISEPREV)
 
   float re[NS3], im[NS3], magn[NS3];
   re[0] = el[0].x;
@@ -840,6 +880,8 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 #undef SC_SET_I
 #undef SC_SET_F
 #undef LOAD3
+#undef LOADV
+#undef LOADT
 #undef STORE3
 #undef PART3
 }
@@ -850,14 +892,14 @@ namespace aspns {
 
 hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps) {
+                            unsigned long long* stamps, int stagger) {
   const dim3 grid((num_streams + 3) / 4), block(256);
   if (io16)
     hipLaunchKernelGGL(ns_frame1_kernel<true>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps);
+                       num_streams, stamps, stagger);
   else
     hipLaunchKernelGGL(ns_frame1_kernel<false>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps);
+                       num_streams, stamps, stagger);
   return hipGetLastError();
 }
 

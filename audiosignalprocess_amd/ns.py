@@ -63,6 +63,7 @@ def load_library():
         "AspNsBatch_TimedSteps": [vp, vp, vp, ip, ip, fp],
         "AspNsBatch_AnalyzeProcessReplay": [vp, vp, vp, ip, ip],
         "AspNsBatch_SetGraph": [vp, ip],
+        "AspNs_CopyCeiling": [C.c_size_t, ip, ip, C.POINTER(C.c_double)],
         "AspNs_DeviceAlloc": [C.POINTER(vp), C.c_size_t, ip],
         "AspNs_DeviceFree": [vp],
         "AspNs_MemcpyH2D": [vp, vp, C.c_size_t],
@@ -84,6 +85,13 @@ def load_library():
 def _check(rc, what):
     if rc != 0:
         raise AspError("%s failed (%d): %s" % (what, rc, load_library().AspNs_last_error().decode()))
+
+
+def copy_ceiling_gbs(nbytes=1 << 30, iters=8, device=0):
+    """Measured streaming-copy rate of the box in GB/s (read + written bytes, float4 copy kernel)."""
+    g = C.c_double()
+    _check(load_library().AspNs_CopyCeiling(nbytes, iters, device, C.byref(g)), "AspNs_CopyCeiling")
+    return g.value
 
 
 def device_count():
@@ -224,8 +232,10 @@ class NsBatch:
                                                         frames_in_ring, steps),
                "AspNsBatch_AnalyzeProcessReplay")
 
-    def set_graph(self, on):
-        _check(self.lib.AspNsBatch_SetGraph(self.h, 1 if on else 0), "AspNsBatch_SetGraph")
+    def set_graph(self, on, gate=False):
+        """on: replay captured hipGraphs instead of plain launches; gate: TimedSteps enqueues the
+        K steps behind a host-opened stream gate (no host enqueue latency inside the timed region)."""
+        _check(self.lib.AspNsBatch_SetGraph(self.h, (1 if on else 0) | (2 if gate else 0)), "AspNsBatch_SetGraph")
 
     def timed_steps(self, in_ptr, out_ptr, frames_in_ring, steps):
         """K fused frame steps bracketed by hipEvents on the launch stream -> ms."""

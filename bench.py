@@ -290,29 +290,13 @@ def bench_aec(args):
     print(json.dumps(line), flush=True)
 
 
-def copy_ceiling_gbs():
-    """The box's measured streaming-copy rate (read + write bytes of a large float4 device copy,
-    hipEvent-timed): the practical HBM ceiling printed next to the 8 TB/s spec peak."""
-    import torch
+def copy_ceiling_gbs(device=0):
+    """The box's measured streaming-copy rate: a hand-written float4 copy of 1 GiB (read + written
+    bytes, hipEvent-timed, far beyond the 256 MiB Infinity Cache) and of 32 MiB (the size of one
+    NS frame step's traffic, which the Infinity Cache holds)."""
+    from audiosignalprocess_amd.ns import copy_ceiling_gbs as cc
 
-    n = 1 << 28                                    # 1 GiB source, 1 GiB destination (far beyond the 256 MiB Infinity Cache)
-    src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
-    dst = torch.empty_like(src)
-    for _ in range(3):
-        dst.copy_(src)
-    best = 0.0
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(4):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        best = max(best, 4 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-    del src, dst
-    torch.cuda.empty_cache()
-    return best
+    return cc(1 << 30, 8, device), cc(32 << 20, 64, device)
 
 
 def _secondary(args, workload):
@@ -346,8 +330,8 @@ def ns_measure(args, S, rank, world, local_rank, dist):
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.empty_like(d_in)
     del x
-    ns = NsBatch(S, device=local_rank, policy=1, streams_per_wave=args.streams_per_wave)
-    ns.set_graph(not args.no_graph)
+    ns = NsBatch(S, device=local_rank, policy=1, streams_per_wave=args.streams_per_wave or None)
+    ns.set_graph(args.graph, gate=args.gate)
     if args.split > 1:
         ns.set_split(args.split)
 
@@ -401,12 +385,15 @@ def main():
     ap.add_argument("--regions", type=int, default=0, help="repeats of the K-step timed region (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the AEC / BT-1024 / config-5 lines of the N = 1 run")
-    ap.add_argument("--no-graph", action="store_true", help="plain kernel launches instead of a hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs (one linear graph per chain) instead of plain launches")
+    ap.add_argument("--no-graph", action="store_true", help="(default) plain kernel launches")
+    ap.add_argument("--gate", action="store_true", help="enqueue the timed steps behind a host-opened stream gate (measured: no gain)")
     ap.add_argument("--secondary-steps", type=int, default=1000)
     ap.add_argument("--secondary-warmup", type=int, default=250)
     ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
-    ap.add_argument("--streams-per-wave", type=int, default=2, choices=[1, 2, 3],
-                    help="fused-step kernel: 2 = two streams per wave64 (default), 1 = one (bins q / q + 64), "
+    ap.add_argument("--streams-per-wave", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="fused-step kernel: 0 = the library's choice by batch size (default: 3 up to 6144 streams per "
+                         "GPU, 2 above), 2 = two streams per wave64, 1 = one (bins q / q + 64), "
                          "3 = one stream per wave, pair layout (ns_kernels1.hip)")
     ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256", "aec", "split48"],
                     help="ns = the headline metric (default); bt* / aec / split48 = secondary lines")
@@ -451,8 +438,9 @@ def main():
         step_s = float(np.median(ev)) / K            # THE clock of this line: hipEvents over the K-step region
         frames_per_region = S * world * args.steps
         achieved = ALGO_BYTES_PER_FRAME * S / step_s / 1e9
+        kid = args.streams_per_wave or (3 if S <= 6144 else 2)
         kernel = {2: "ns_frame2_kernel_ilp<false>" if S <= 6144 else "ns_frame2_kernel<false>",
-                  1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>"}[args.streams_per_wave]
+                  1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>"}[kid]
         line = {
             "metric": "audio frames/sec (10 ms @16 kHz) Wiener NS",
             "value": frames_per_region / (step_s * K),
@@ -476,7 +464,8 @@ def main():
                 "input_ring_frames": args.ring,
                 "primed_frames_in_setup": primed,
                 "sub_launches_per_step": args.split,
-                "launch": "plain launches" if args.no_graph else "hipGraph replay of the K-step region (kernel nodes only)",
+                "launch": ("hipGraph replay (one linear graph per chain, kernel nodes only)" if args.graph else "plain launches")
+                          + (", the K steps enqueued behind a host-opened stream gate" if args.gate else ""),
                 "parallelism": "stream-sharded x%d, no collectives" % world,
             },
             # one clock for value, ms_per_step and roofline: the median over `regions` repeats of the
@@ -498,8 +487,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (PMC_TRAFFIC_BYTES_PER_FRAME_DUAL if args.streams_per_wave == 2
-                            else PMC_TRAFFIC_BYTES_PER_FRAME) * S,
+                "traffic": PMC_TRAFFIC_BYTES_PER_FRAME_DUAL * S,
                 "traffic_source": "stored constant: PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE, "
                                   "calibrated; not measured in this run), per frame step of all streams",
                 "kernel": kernel,
@@ -514,8 +502,9 @@ def main():
         }
         if world == 1:
             try:
-                cc = copy_ceiling_gbs()
+                cc, cc_small = copy_ceiling_gbs(local_rank)
                 line["roofline"]["copy_ceiling"] = cc
+                line["roofline"]["copy_ceiling_32MiB_in_infinity_cache"] = cc_small
                 line["roofline"]["frac_of_copy_ceiling"] = achieved / cc
             except Exception as e:  # noqa: BLE001
                 line["roofline"]["copy_ceiling"] = None

@@ -180,6 +180,11 @@ int AspNsBatch_SetKernel(AspNsBatch* b, int streams_per_wave);
 void* AspNsBatch_GetStream(AspNsBatch* b);
 int AspNsBatch_Synchronize(AspNsBatch* b);
 
+/* The box's streaming-copy rate: a float4 copy of `bytes` bytes repeated `iters` times on
+ * `device`, *gbps = (bytes read + bytes written) / hipEvent time, best of three timed passes.
+ * bench.py prints it as roofline.copy_ceiling next to the 8 TB/s HBM spec peak. */
+int AspNs_CopyCeiling(size_t bytes, int iters, int device, double* gbps);
+
 /* Device scratch for callers without their own allocator (C drivers, bench). */
 int AspNs_DeviceAlloc(void** ptr, size_t bytes, int device);
 int AspNs_DeviceFree(void* ptr);

@@ -516,7 +516,7 @@ def test_dual_kernel_edge_cases_policies_and_odd_count(ns):
     x[100:104, 4] = 0.0
     x[100:104, 5] = 0.0    # both halves of a wave silent together
     for policy in (0, 3):
-        g = ns.NsBatch(S, policy=policy)  # default kernel = two per wave
+        g = ns.NsBatch(S, policy=policy, streams_per_wave=2)
         y = g.analyze_process(x)
         o32 = OracleNs(S - 1, policy=policy, reduce_mode=REDUCE_TREE32)
         o64 = OracleNs(1, policy=policy, reduce_mode=REDUCE_TREE)
