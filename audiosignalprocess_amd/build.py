@@ -94,7 +94,7 @@ def build_drivers(verbose=False):
     out_dir = os.path.join(ROOT, "drivers", "bin")
     os.makedirs(out_dir, exist_ok=True)
     built = []
-    for name in ["test_ns_module", "ns_batch_wav", "test_aec_module"]:
+    for name in ["test_ns_module", "ns_batch_wav", "test_aec_module", "bt_main"]:
         src = os.path.join(ROOT, "drivers", name + ".c")
         exe = os.path.join(out_dir, name)
         if _stale(exe, [src, LIB]):

@@ -294,11 +294,16 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
   }
   __syncthreads();
   BT_STAMP(1)
-  // carry the last HALF input samples (after every thread has read the old tail)
-  for (int i = tid; i < HALF; i += NC) {
-    const int p = total + i;  // position in B of the new tail
-    st[kOffInTail + i] = p < HALF ? st[kOffInTail + p] : x[p - HALF];
-  }
+  // carry the last HALF input samples (after every thread has read the old tail).  A flush
+  // (threshold == 0) leaves the input history alone: the reference transforms a hop when it is
+  // fed (.c:550-559) and its flush only inverse-transforms the cached spectra (.c:618-672), so the
+  // pending hops -- which stay pending, and are fed again when their macroblock completes -- must
+  // see the same history every time
+  if (threshold)
+    for (int i = tid; i < HALF; i += NC) {
+      const int p = total + i;  // position in B of the new tail
+      st[kOffInTail + i] = p < HALF ? st[kOffInTail + p] : x[p - HALF];
+    }
   kiss_stages<NC>(work, tw_f, frames, false, tid);
   BT_STAMP(2)
   real_split_forward<NC>(work, coef, sup_f, frames, tid);

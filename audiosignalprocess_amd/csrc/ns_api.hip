@@ -270,6 +270,17 @@ int device_tables(int device, NsTables** out) {
   return ASP_OK;
 }
 
+// The caller's current device is put back when an entry point returns (every entry point
+// selects the batch's device for its HIP calls).
+struct DeviceScope {
+  int prev = -1;
+  DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceScope() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
 int select_device(int device) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -545,6 +556,7 @@ int AspNs_device_count(void) {
 int AspNsBatch_Create(AspNsBatch** out, int num_streams, int device) {
   if (!out || num_streams <= 0) return fail(ASP_ERR_PARAM, "AspNsBatch_Create: bad argument");
   *out = nullptr;
+  DeviceScope dev_scope_;
   int rc = select_device(device);
   if (rc) return rc;
   AspNsBatch* b = new AspNsBatch();
@@ -573,6 +585,7 @@ int AspNsBatch_Create(AspNsBatch** out, int num_streams, int device) {
 
 int AspNsBatch_Free(AspNsBatch* b) {
   if (!b) return ASP_OK;
+  DeviceScope dev_scope_;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->state) (void)hipFree(b->state);
@@ -640,6 +653,7 @@ int AspNsBatch_Init(AspNsBatch* b, uint32_t fs) {
 }
 
 int AspNsBatch_set_policy(AspNsBatch* b, int mode) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (mode < 0 || mode > 3) return fail(ASP_ERR_PARAM, "set_policy: mode must be 0..3");
@@ -830,6 +844,7 @@ static int run_frames(AspNsBatch* b, int kmode, const float* in, float* out, int
 }
 
 int AspNsBatch_Analyze(AspNsBatch* b, const float* frames, int mem) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!frames) return fail(ASP_ERR_PARAM, "Analyze: null frames");
@@ -839,6 +854,7 @@ int AspNsBatch_Analyze(AspNsBatch* b, const float* frames, int mem) {
 }
 
 int AspNsBatch_Process(AspNsBatch* b, const float* in, float* out, int mem) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!in || !out) return fail(ASP_ERR_PARAM, "Process: null frames");
@@ -849,9 +865,12 @@ int AspNsBatch_Process(AspNsBatch* b, const float* in, float* out, int mem) {
 
 int AspNsBatch_AnalyzeProcess(AspNsBatch* b, const float* in, float* out, int num_frames,
                               int mem) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!in || !out || num_frames < 0) return fail(ASP_ERR_PARAM, "AnalyzeProcess: bad argument");
+  if (b->num_high > 0)  // the high-band delay line would fall out of step (ns_core.c:1227-1235)
+    return fail(ASP_ERR_STATE, "AnalyzeProcess: one-band entry point on a batch initialised at 32 / 48 kHz (use AnalyzeProcessBands)");
   return run_frames(b, 2, in, out, num_frames, mem);
 }
 
@@ -875,6 +894,7 @@ static int bands_frame_device(AspNsBatch* b, bool fused, const float* low_in, co
 
 static int bands_run(AspNsBatch* b, bool fused, const float* low_in, const float* high_in,
                      float* low_out, float* high_out, int num_frames, int mem) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (b->num_high < 1) return fail(ASP_ERR_STATE, "bands: the batch was initialised at 16 kHz (one band)");
@@ -908,6 +928,7 @@ static int bands_run(AspNsBatch* b, bool fused, const float* low_in, const float
 
 int AspNsBatch_AnalyzeProcessBands(AspNsBatch* b, const float* low_in, const float* high_in,
                                    float* low_out, float* high_out, int num_frames, int mem) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   return bands_run(b, true, low_in, high_in, low_out, high_out, num_frames, mem);
@@ -915,6 +936,7 @@ int AspNsBatch_AnalyzeProcessBands(AspNsBatch* b, const float* low_in, const flo
 
 int AspNsBatch_ProcessBands(AspNsBatch* b, const float* low_in, const float* high_in, float* low_out,
                             float* high_out, int mem) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   rc = ensure_unpaired(b);
@@ -925,6 +947,7 @@ int AspNsBatch_ProcessBands(AspNsBatch* b, const float* low_in, const float* hig
 int AspNsBatch_num_bands(const AspNsBatch* b) { return b ? 1 + b->num_high : ASP_ERR_PARAM; }
 
 int AspNsBatch_ExportHbState(AspNsBatch* b, int stream, AspNsHbState* out) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!out || stream < 0 || stream >= b->S || b->num_high < 1)
@@ -938,6 +961,7 @@ int AspNsBatch_ExportHbState(AspNsBatch* b, int stream, AspNsHbState* out) {
 }
 
 int AspNsBatch_ImportHbState(AspNsBatch* b, int stream, const AspNsHbState* in) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!in || stream < 0 || stream >= b->S || b->num_high < 1)
@@ -951,11 +975,14 @@ int AspNsBatch_ImportHbState(AspNsBatch* b, int stream, const AspNsHbState* in) 
 
 int AspNsBatch_AnalyzeProcessS16(AspNsBatch* b, const int16_t* in, int16_t* out, int num_frames,
                                  int mem) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!in || !out || num_frames < 0) return fail(ASP_ERR_PARAM, "AnalyzeProcessS16: bad argument");
   if (!b->paired)
     return fail(ASP_ERR_STATE, "AnalyzeProcessS16 needs streams driven only through the fused step");
+  if (b->num_high > 0)
+    return fail(ASP_ERR_STATE, "AnalyzeProcessS16: one-band entry point on a batch initialised at 32 / 48 kHz");
   if (num_frames == 0) return ASP_OK;
   const size_t bytes = (size_t)b->S * kBlockL * sizeof(int16_t) * (size_t)num_frames;
   const float* din = reinterpret_cast<const float*>(in);
@@ -980,6 +1007,7 @@ int AspNsBatch_AnalyzeProcessS16(AspNsBatch* b, const int16_t* in, int16_t* out,
 
 int AspNsBatch_AnalyzeProcessReplay(AspNsBatch* b, const float* in, float* out, int frames_in_ring,
                                     int steps) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!in || !out || frames_in_ring <= 0 || steps < 0)
@@ -995,11 +1023,13 @@ int AspNsBatch_AnalyzeProcessReplay(AspNsBatch* b, const float* in, float* out, 
 
 int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames_in_ring,
                           int steps, float* elapsed_ms) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!in || !out || frames_in_ring <= 0 || steps < 0 || !elapsed_ms)
     return fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
   if (!b->paired) return fail(ASP_ERR_STATE, "TimedSteps needs the fused (paired) representation");
+  if (b->num_high > 0) return fail(ASP_ERR_STATE, "TimedSteps: one-band entry point on a batch initialised at 32 / 48 kHz");
   // graph replay: capture + instantiate outside the timed region (the legacy null stream cannot capture)
   const bool graph = b->use_graph && b->stream != nullptr && steps > 0;
   if (graph) {
@@ -1060,6 +1090,7 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
 }
 
 int AspNsBatch_ExportState(AspNsBatch* b, int stream, AspNsState* out) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!out || stream < 0 || stream >= b->S) return fail(ASP_ERR_PARAM, "ExportState: bad argument");
@@ -1075,6 +1106,7 @@ int AspNsBatch_ExportState(AspNsBatch* b, int stream, AspNsState* out) {
 }
 
 int AspNsBatch_ImportState(AspNsBatch* b, int stream, const AspNsState* in) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!in || stream < 0 || stream >= b->S) return fail(ASP_ERR_PARAM, "ImportState: bad argument");
@@ -1099,6 +1131,7 @@ int AspNsBatch_ImportState(AspNsBatch* b, int stream, const AspNsState* in) {
 }
 
 int AspNsBatch_prior_speech_probability(AspNsBatch* b, float* out) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!out) return fail(ASP_ERR_PARAM, "null output");
@@ -1124,6 +1157,7 @@ int AspNsBatch_SetSplit(AspNsBatch* b, int parts) {
 // Diagnostic: one fused step of the two-per-wave kernel with phase stamps of wave 0 (16 values).
 int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
                            unsigned long long* stamps16) {
+  DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
   if (!in_dev || !out_dev || !stamps16 || !b->paired || ((b->S & 1) && b->kernel == 2))

@@ -71,7 +71,10 @@ int AspBtBatch_macro_size(const AspBtBatch* b); /* 8 * win_size / 2 samples per 
 int AspBtBatch_Denoise(AspBtBatch* b, const float* in, float* out, int mem);
 /* blockThreshold_flush_float for every stream with `hops` (0..7) pending hops:
  * in [num_streams][hops*half], out [num_streams][hops*half]; no thresholding
- * is applied to a partial macroblock (.c:648-672). */
+ * is applied to a partial macroblock (.c:648-672).  As in the reference the call
+ * consumes the overlap tail (a second flush, or the macroblock the pending hops
+ * later complete, starts from a cleared tail) and leaves the input history
+ * alone (the pending hops stay pending and are fed again with their macroblock). */
 int AspBtBatch_Flush(AspBtBatch* b, const float* in, int hops, float* out, int mem);
 int AspBtBatch_ExportState(AspBtBatch* b, int stream, AspBtState* out);
 int AspBtBatch_ImportState(AspBtBatch* b, int stream, const AspBtState* in);

@@ -29,6 +29,21 @@ def built_lib():
     return LIB
 
 
+def check_free_running(rel, what=""):
+    """SURVEY 8(c) item (3) for a free-running comparison with the reference: per-stream relative
+    L2 <= 1e-4 at the median and for all but at most one stream in eight, and never beyond 4e-4.
+    The suppressor is chaotic at the 1e-4 level against ITSELF: the reference rebuilt with
+    -O3 -ffp-contract=fast differs from its -O2 build by up to 3.6e-4 per stream (SURVEY 0.4,
+    branch flips in the quantile tracker and the histogram thresholds), so a reduction order other
+    than the reference's sequential one shows the same rare events (stream 6 of the eight-stream
+    fixture flips at frame 844 under the 32-lane and the 64-lane pair orders: 1.4e-4 over the run)."""
+    rel = np.asarray(rel, np.float64)
+    assert np.isfinite(rel).all(), (what, rel)
+    assert np.median(rel) <= 1e-5, (what, rel)
+    assert (rel > 1e-4).sum() <= max(1, rel.size // 8), (what, rel)
+    assert rel.max() <= 4e-4, (what, rel)
+
+
 def state_from_bytes(buf):
     from audiosignalprocess_amd._abi import AspNsState
 

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 from audiosignalprocess_amd.synth import aec_frames  # noqa: E402
 from tests.oracle_lib import RefAec, have_aec_ref  # noqa: E402
 
-S, F = 2, 700
+S, F = 8, 700  # eight streams
 
 
 def main():

@@ -14,8 +14,8 @@ import pytest
 
 from audiosignalprocess_amd.synth import ns_frames
 from tests import oracle_lib
-from tests.conftest import rel_l2_per_stream, state_diff, state_from_bytes
-from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, OracleNs
+from tests.conftest import check_free_running, rel_l2_per_stream, state_diff, state_from_bytes
+from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P, OracleNs
 
 needs_ref = pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built here")
 
@@ -70,13 +70,16 @@ def test_golden_teacher_forced_single_step(golden):
         assert np.array_equal(y, golden["out_f32"][frames:frames + 1]), frames
 
 
-def test_tree_association_within_tolerance(golden):
-    """The device's fixed reduction order stays within 1e-4 of the reference's sequential one."""
+@pytest.mark.parametrize("mode", [REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P])
+def test_tree_association_within_tolerance(golden, mode):
+    """The device's fixed reduction orders stay within 1e-4 of the reference's sequential one
+    (eight streams x 1100 frames of the reference's own outputs)."""
     x = golden["in_i16"].astype(np.float32)
     S = x.shape[1]
-    y = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE).run(x)
+    assert S >= 8
+    y = OracleNs(S, policy=1, reduce_mode=mode).run(x)
     rel = rel_l2_per_stream(y, golden["out_f32"])
-    assert rel.max() <= 1e-4, rel
+    check_free_running(rel, mode)
 
 
 def test_zero_input_and_recovery():
@@ -140,6 +143,31 @@ def test_free_running_vs_reference_bitwise(policy):
     assert np.array_equal(yo.view(np.uint32), yr.view(np.uint32))
     for s in range(S):
         assert state_diff(o.export_state(s), r.export_state(s), skip=set()) == {}
+
+
+@needs_ref
+@pytest.mark.parametrize("mode", [REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P])
+def test_device_associations_vs_live_reference_statistics(mode):
+    """the three device reduction orders against the compiled reference,
+    free running, 64 streams x 1500 frames: per-stream relative L2 median / 95th percentile / max
+    and the share of frames beyond 1e-4 (the reference's own -O3 -ffp-contract=fast self-distance
+    is max 3.6e-4 per stream with 2.1 % of frames beyond 1e-4).  Measured here:
+    median 2.2e-7, p95 6.2e-7 .. 4.2e-6, max 5.2e-5, 0.05 - 0.06 % of frames."""
+    S, F = 64, 1500
+    x = ns_frames(S, F, stream0=0)
+    yr = oracle_lib.RefNs(S, policy=1).run(x, threads=8)
+    yo = OracleNs(S, policy=1, reduce_mode=mode).run(x, threads=8)
+    rel = rel_l2_per_stream(yo, yr)
+    d = np.sqrt(((yo - yr).astype(np.float64) ** 2).sum(axis=2))
+    n = np.sqrt((yr.astype(np.float64) ** 2).sum(axis=2))
+    frame_rel = d / np.maximum(n, 1e-30)
+    share = float((frame_rel > 1e-4).mean())
+    print("mode %d: per-stream rel-L2 median %.3g p95 %.3g max %.3g; frames > 1e-4: %.4f %%"
+          % (mode, np.median(rel), np.percentile(rel, 95), rel.max(), 100 * share))
+    assert np.median(rel) <= 1e-6
+    assert np.percentile(rel, 95) <= 1e-5
+    assert rel.max() <= 1e-4
+    assert share <= 0.002
 
 
 # ---------------------------------------------------------------------------------------------
