@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libasp_amd.so")
-SOURCES = ["ns_kernels.hip", "ns_kernels1.hip", "ns_kernels2.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_api.hip",
+SOURCES = ["ns_kernels.hip", "ns_kernels1.hip", "ns_kernels4.hip", "ns_kernels2.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_api.hip",
            "aec_kernels.hip", "aec_api.hip", "qmf_kernels.hip", "qmf_api.hip", "sinc_kernels.hip", "sinc_api.hip"]
 C_SOURCES = ["wav_io.c"]  # host-only C (kept C, as in the reference)
 # -ffp-contract=off: parity with the reference depends on unfused mul/add.
@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 # with dependent scalar loads before the first vector load can issue (-0.5 us per NS step, measured);
 # the object carries a prologue for firmware without the feature
 _PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=8"]
-EXTRA = {"ns_kernels2.hip": list(_PRELOAD), "ns_kernels.hip": list(_PRELOAD), "ns_kernels1.hip": list(_PRELOAD)}
+EXTRA = {"ns_kernels2.hip": list(_PRELOAD), "ns_kernels.hip": list(_PRELOAD), "ns_kernels1.hip": list(_PRELOAD), "ns_kernels4.hip": list(_PRELOAD)}
 # second builds of a source under another object name: (source, object, extra flags).  The NS frame
 # kernel exists as the 168-VGPR / three-waves-per-SIMD build (large batches) and as an ILP-scheduled
 # build (ns_kernels2.hip explains; the library picks by batch size)
@@ -51,7 +51,7 @@ def build_library(force=False, verbose=False):
     """Compile csrc/*.hip into lib/libasp_amd.so; returns its path."""
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "ns_layout.h"), os.path.join(CSRC, "ns_device.h"), os.path.join(CSRC, "bt_layout.h"), os.path.join(CSRC, "aec_layout.h"), os.path.join(CSRC, "sinc_layout.h"),
+    deps = srcs + [os.path.join(CSRC, "ns_layout.h"), os.path.join(CSRC, "ns_device.h"), os.path.join(CSRC, "ns_pair_fft.h"), os.path.join(CSRC, "bt_layout.h"), os.path.join(CSRC, "aec_layout.h"), os.path.join(CSRC, "sinc_layout.h"),
                    os.path.join(ROOT, "include", "asp_ns.h"), os.path.join(ROOT, "include", "asp_bt.h"), os.path.join(ROOT, "include", "asp_aec.h"), os.path.join(ROOT, "include", "asp_split.h"), os.path.join(ROOT, "include", "asp_resample.h")]
     objs = []
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]

@@ -33,6 +33,8 @@ hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTabl
 hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
                             unsigned long long* stamps = nullptr, int stagger = 0);
+hipError_t launch_ns_frame4(bool io16, float* state, int32_t* hist, const NsTables* T,
+                            const float* in, float* out, int num_streams, hipStream_t s);
 hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_hb_live(const float* state, const NsTables* T, const float* in_low,
                              int32_t* live, int num_streams, int hist_off, hipStream_t s);
@@ -677,6 +679,7 @@ static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float
   const float* in = din + (size_t)s0 * sper;
   float* out = dout + (size_t)s0 * sper;
   const int kernel = b->kernel ? b->kernel : (b->S <= kIlpMaxStreams ? 3 : 2);
+  if (kernel == 4) return launch_ns_frame4(io16, state, hist, b->tables, in, out, n, st);
   if (kernel == 3) return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st, nullptr, b->stagger);
   if (kernel == 1 || n < 2) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
   const int even = n & ~1;
@@ -1188,8 +1191,8 @@ int AspNsBatch_SetGraph(AspNsBatch* b, int on) {
 }
 
 int AspNsBatch_SetKernel(AspNsBatch* b, int streams_per_wave) {
-  if (!b || streams_per_wave < 0 || streams_per_wave > 3)
-    return fail(ASP_ERR_PARAM, "SetKernel: 0 (by batch size), 1 (one stream per wave, q / q + 64), 2 (two streams per wave) or 3 (one stream per wave, pair layout)");
+  if (!b || streams_per_wave < 0 || streams_per_wave > 4)
+    return fail(ASP_ERR_PARAM, "SetKernel: 0 (by batch size), 1 (one stream per wave, q / q + 64), 2 (two streams per wave), 3 (one stream per wave, pair layout) or 4 (pair layout, scalar section shared by the workgroup)");
   b->dual = streams_per_wave == 2;
   b->kernel = streams_per_wave;
   return ASP_OK;

@@ -224,6 +224,52 @@ __device__ __forceinline__ void fdiv3(const float (&n)[3], const float (&d)[3], 
   q[0] = a.x; q[1] = a.y;
   q[2] = fdiv(n[2], d[2]);
 }
+// The two bins a lane of ns_kernels4.hip owns, as one packed pair (F3 without the tail).
+struct B2 {
+  bool v[2];
+};
+struct P2 {
+  f32x2 p;
+  __device__ __forceinline__ P2() {}
+  __device__ __forceinline__ P2(f32x2 p_) : p(p_) {}
+  __device__ __forceinline__ explicit P2(float c) : p(f32x2{c, c}) {}
+  __device__ __forceinline__ explicit P2(const float (&x)[2]) : p(f32x2{x[0], x[1]}) {}
+  __device__ __forceinline__ void store(float (&x)[2]) const {
+    x[0] = p.x; x[1] = p.y;
+  }
+};
+__device__ __forceinline__ P2 operator+(const P2& x, const P2& y) { return P2(x.p + y.p); }
+__device__ __forceinline__ P2 operator-(const P2& x, const P2& y) { return P2(x.p - y.p); }
+__device__ __forceinline__ P2 operator*(const P2& x, const P2& y) { return P2(x.p * y.p); }
+__device__ __forceinline__ P2 operator*(float c, const P2& y) { return P2(c) * y; }
+__device__ __forceinline__ P2 operator+(const P2& x, float c) { return x + P2(c); }
+__device__ __forceinline__ P2 fma2(const P2& x, const P2& y, const P2& z) {
+  return P2(__builtin_elementwise_fma(x.p, y.p, z.p));
+}
+__device__ __forceinline__ P2 abs2(const P2& x) { return P2(f32x2{fabsf(x.p.x), fabsf(x.p.y)}); }
+__device__ __forceinline__ B2 gt2(const P2& x, const P2& y) {
+  B2 r;
+  r.v[0] = x.p.x > y.p.x; r.v[1] = x.p.y > y.p.y;
+  return r;
+}
+__device__ __forceinline__ B2 lt2(const P2& x, const P2& y) {
+  B2 r;
+  r.v[0] = x.p.x < y.p.x; r.v[1] = x.p.y < y.p.y;
+  return r;
+}
+__device__ __forceinline__ P2 sel2(const B2& c, const P2& x, const P2& y) {  // c ? x : y
+  return P2(f32x2{c.v[0] ? x.p.x : y.p.x, c.v[1] ? x.p.y : y.p.y});
+}
+__device__ __forceinline__ P2 div_by_uniform2(const P2& a, float d, float rd) {
+  const P2 q0 = a * P2(rd);
+  const P2 r = fma2(P2(-d), q0, a);
+  return fma2(r, P2(rd), q0);
+}
+__device__ __forceinline__ P2 fdiv2v(const P2& n, const P2& d) { return P2(fdiv2(n.p, d.p)); }
+__device__ __forceinline__ void fdiv2a(const float (&n)[2], const float (&d)[2], float (&q)[2]) {
+  const f32x2 a = fdiv2(f32x2{n[0], n[1]}, f32x2{d[0], d[1]});
+  q[0] = a.x; q[1] = a.y;
+}
 #define DIV129(a) div_by_uniform((a), 129.0f, 1.0f / 129.0f)
 
 // (float)log((double)x), the reference's idiom (ns_core.c:228,540,681,1096), for

@@ -391,7 +391,7 @@ def main():
     ap.add_argument("--secondary-steps", type=int, default=1000)
     ap.add_argument("--secondary-warmup", type=int, default=250)
     ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
-    ap.add_argument("--streams-per-wave", type=int, default=0, choices=[0, 1, 2, 3],
+    ap.add_argument("--streams-per-wave", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="fused-step kernel: 0 = the library's choice by batch size (default: 3 up to 6144 streams per "
                          "GPU, 2 above), 2 = two streams per wave64, 1 = one (bins q / q + 64), "
                          "3 = one stream per wave, pair layout (ns_kernels1.hip)")
@@ -440,7 +440,7 @@ def main():
         achieved = ALGO_BYTES_PER_FRAME * S / step_s / 1e9
         kid = args.streams_per_wave or (3 if S <= 6144 else 2)
         kernel = {2: "ns_frame2_kernel_ilp<false>" if S <= 6144 else "ns_frame2_kernel<false>",
-                  1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>"}[kid]
+                  1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>", 4: "ns_frame4_kernel<false>"}[kid]
         line = {
             "metric": "audio frames/sec (10 ms @16 kHz) Wiener NS",
             "value": frames_per_region / (step_s * K),

@@ -17,7 +17,7 @@ import pytest
 
 from audiosignalprocess_amd.synth import ns_frames
 from tests.conftest import check_free_running, rel_l2_per_stream, state_diff, state_from_bytes
-from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P, OracleNs
+from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P, REDUCE_TREE64Q, OracleNs
 
 pytestmark = pytest.mark.gpu
 
@@ -593,15 +593,19 @@ def test_dual_then_unfused_continues(ns):
 
 
 # ---------------------------------------------------------------------------------------------
-# The one-stream-per-wave, two-bins-per-lane fused kernel (ns_kernels1.hip, kernel id 3): bit-exact
-# against the oracle's ASP_NS_REDUCE_TREE64P association (outputs and every state array).
+# The one-stream-per-wave, two-bins-per-lane fused kernels: ns_kernels1.hip (kernel id 3, bin 128 on every
+# lane: ASP_NS_REDUCE_TREE64P) and ns_kernels4.hip (kernel id 4, the scalar section and bin 128 of a
+# workgroup's four streams on one wave: ASP_NS_REDUCE_TREE64Q): bit-exact against the oracle in the matching
+# association, outputs and every state array.
+PAIR_KERNELS = [(3, REDUCE_TREE64P), (4, REDUCE_TREE64Q)]
 
-def test_pair_kernel_free_running_bit_exact(ns):
+@pytest.mark.parametrize("kid,mode", PAIR_KERNELS)
+def test_pair_kernel_free_running_bit_exact(ns, kid, mode):
     S, F = 24, 1100  # crosses blockInd 50 / 200 and two 500-frame histogram windows
     x = ns_frames(S, F, stream0=300)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=3)
+    g = ns.NsBatch(S, policy=1, streams_per_wave=kid)
     y = g.analyze_process(x)
-    o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE64P)
+    o = OracleNs(S, policy=1, reduce_mode=mode)
     yo = o.run(x, threads=8)
     assert np.isfinite(y).all()
     bad = np.nonzero((y != yo).any(axis=2))
@@ -611,7 +615,8 @@ def test_pair_kernel_free_running_bit_exact(ns):
     g.close()
 
 
-def test_pair_kernel_edge_cases_policies_and_odd_count(ns):
+@pytest.mark.parametrize("kid,mode", PAIR_KERNELS)
+def test_pair_kernel_edge_cases_policies_and_odd_count(ns, kid, mode):
     S, F = 7, 260
     x = ns_frames(S, F, stream0=40)
     x[10:16, 1] = 0.0      # energy == 0 frames in the middle of a run
@@ -619,23 +624,24 @@ def test_pair_kernel_edge_cases_policies_and_odd_count(ns):
     x[30:, 3] = 32767.0    # full-scale DC
     x[100:104, 4] = 0.0
     for policy in (0, 1, 2, 3):
-        g = ns.NsBatch(S, policy=policy, streams_per_wave=3)
+        g = ns.NsBatch(S, policy=policy, streams_per_wave=kid)
         y = g.analyze_process(x)
-        o = OracleNs(S, policy=policy, reduce_mode=REDUCE_TREE64P)
+        o = OracleNs(S, policy=policy, reduce_mode=mode)
         assert np.array_equal(y, o.run(x)), policy
         for s in range(S):
             assert state_diff(g.export_state(s), o.export_state(s)) == {}, (policy, s)
         g.close()
 
 
-def test_pair_kernel_golden_int16_split_and_scale(ns, golden):
+@pytest.mark.parametrize("kid,mode", PAIR_KERNELS)
+def test_pair_kernel_golden_int16_split_and_scale(ns, golden, kid, mode):
     pcm = golden["in_i16"]
     F, S, _ = pcm.shape
-    g = ns.NsBatch(S, policy=1, streams_per_wave=3)
+    g = ns.NsBatch(S, policy=1, streams_per_wave=kid)
     y = g.analyze_process(pcm.astype(np.float32))
     rel = rel_l2_per_stream(y, golden["out_f32"])
     check_free_running(rel)
-    g16 = ns.NsBatch(S, policy=1, streams_per_wave=3)
+    g16 = ns.NsBatch(S, policy=1, streams_per_wave=kid)
     y16 = g16.analyze_process_s16(pcm)
     ref = golden["wav_out_i16"][:F * 160].reshape(F, 160)
     d = np.abs(y16[:, 0].astype(np.int32) - ref.astype(np.int32))
@@ -648,22 +654,23 @@ def test_pair_kernel_golden_int16_split_and_scale(ns, golden):
         base = ns_frames(16, F2, stream0=11)
         idx = np.arange(S2) % 16
         x = np.ascontiguousarray(base[:, idx])
-        big = ns.NsBatch(S2, policy=1, streams_per_wave=3)
+        big = ns.NsBatch(S2, policy=1, streams_per_wave=kid)
         big.set_split(parts)
         yb = big.analyze_process(x)
         assert np.isfinite(yb).all()
-        yo = OracleNs(16, policy=1, reduce_mode=REDUCE_TREE64P).run(base)
+        yo = OracleNs(16, policy=1, reduce_mode=mode).run(base)
         for k in (0, 1, 2, 3, 1364, 1365, 2730, 2731, S2 - 2, S2 - 1):
             assert np.array_equal(yb[:, k], yo[:, idx[k]]), (S2, k)
         big.close()
 
 
-def test_pair_then_unfused_continues(ns):
+@pytest.mark.parametrize("kid,mode", PAIR_KERNELS)
+def test_pair_then_unfused_continues(ns, kid, mode):
     """Fused one-per-wave (pair layout) steps, then the reference's two-call protocol on the same batch."""
     S, F = 5, 130
     x = ns_frames(S, F, stream0=77)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=3)
-    o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE64P)
+    g = ns.NsBatch(S, policy=1, streams_per_wave=kid)
+    o = OracleNs(S, policy=1, reduce_mode=mode)
     assert np.array_equal(g.analyze_process(x[:100]), o.run(x[:100]))
     o.mode = REDUCE_TREE  # separate Analyze / Process launches use the q / q + 64 kernels
     for f in range(100, F):
