@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   for (int s = 0; s < 3; ++s) {
     const float cnt = (float)counter[s];
     const float cnt1 = (float)(counter[s] + 1);
-    const float rcnt1 = 1.f / cnt1;
+    const float rcnt1 = fdiv(1.f, cnt1);  // == 1.f / cnt1 (cnt1 = 1 .. 201)
     {
       F3 den(DEN[s]), lq(LQ[s]);
       const F3 lm(lmagn);

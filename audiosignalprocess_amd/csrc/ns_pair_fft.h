@@ -98,27 +98,34 @@ __device__ __forceinline__ void real_split1(float2* tile, const float* spls, int
   tile[base] = e[0];
   tile[base + 32] = e[1];
   lds_sync1();
+  // J - K and J + K of the reference (J = the j side, K = the k side) without selecting which is which:
+  // xr = J.x - K.x = +-(e.x - pe.x) with the sign of the side (a - b == -(b - a) exactly), xi = J.y + K.y
+  // = e.y + pe.y on either side; the updates e.x -+ yr likewise take yr's sign from the side.
+  const uint32_t himask = hi ? 0x80000000u : 0u;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int E = base + 32 * k;
     const float2 pe = tile[(128 - E) & 127];
     const float2 w = *reinterpret_cast<const float2*>(spls + (b * 4 + h + 2 * k) * 2);  // (wkr, wki)
-    const float2 J = hi ? pe : e[k], K = hi ? e[k] : pe;
-    const float xr = J.x - K.x, xi = J.y + K.y;
+    const float xr = xorf(e[k].x - pe.x, himask), xi = e[k].y + pe.y;
     float2 r;
     if (!backward) {
       const float yr = w.x * xr - w.y * xi, yi = w.x * xi + w.y * xr;
-      r = hi ? make_float2(e[k].x + yr, e[k].y - yi) : make_float2(e[k].x - yr, e[k].y - yi);
-      if (E == 0) r = make_float2(e[k].x + e[k].y, e[k].x - e[k].y);
-      if (E == 64) r = e[k];
+      r = make_float2(e[k].x - xorf(yr, himask), e[k].y - yi);
+      if (k == 0) {  // elements 0 and 64 are slot 0 of lanes 0 and 32
+        if (E == 0) r = make_float2(e[k].x + e[k].y, e[k].x - e[k].y);
+        if (E == 64) r = e[k];
+      }
     } else {
       const float yr = w.x * xr + w.y * xi, yi = w.x * xi - w.y * xr;
-      r = hi ? make_float2(e[k].x + yr, yi - e[k].y) : make_float2(e[k].x - yr, yi - e[k].y);
-      if (E == 0) {
-        const float hh = 0.5f * (e[k].x - e[k].y);
-        r = make_float2(e[k].x - hh, -hh);
+      r = make_float2(e[k].x - xorf(yr, himask), yi - e[k].y);
+      if (k == 0) {
+        if (E == 0) {
+          const float hh = 0.5f * (e[k].x - e[k].y);
+          r = make_float2(e[k].x - hh, -hh);
+        }
+        if (E == 64) r = make_float2(e[k].x, -e[k].y);
       }
-      if (E == 64) r = make_float2(e[k].x, -e[k].y);
     }
     e[k] = r;
   }
