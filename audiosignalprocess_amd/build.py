@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libasp_amd.so")
-SOURCES = ["ns_kernels.hip", "ns_kernels1.hip", "ns_kernels4.hip", "ns_kernels2.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_api.hip",
+SOURCES = ["ns_kernels.hip", "ns_kernels1.hip", "ns_kernels4.hip", "ns_kernels2.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_kernels8.hip", "bt_api.hip",
            "aec_kernels.hip", "aec_api.hip", "qmf_kernels.hip", "qmf_api.hip", "sinc_kernels.hip", "sinc_api.hip"]
 C_SOURCES = ["wav_io.c"]  # host-only C (kept C, as in the reference)
 # -ffp-contract=off: parity with the reference depends on unfused mul/add.
@@ -51,13 +51,13 @@ def build_library(force=False, verbose=False):
     """Compile csrc/*.hip into lib/libasp_amd.so; returns its path."""
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "ns_layout.h"), os.path.join(CSRC, "ns_device.h"), os.path.join(CSRC, "ns_pair_fft.h"), os.path.join(CSRC, "bt_layout.h"), os.path.join(CSRC, "aec_layout.h"), os.path.join(CSRC, "sinc_layout.h"),
+    hdrs = [os.path.join(CSRC, "ns_layout.h"), os.path.join(CSRC, "ns_device.h"), os.path.join(CSRC, "ns_pair_fft.h"), os.path.join(CSRC, "bt_layout.h"), os.path.join(CSRC, "aec_layout.h"), os.path.join(CSRC, "sinc_layout.h"),
                    os.path.join(ROOT, "include", "asp_ns.h"), os.path.join(ROOT, "include", "asp_bt.h"), os.path.join(ROOT, "include", "asp_aec.h"), os.path.join(ROOT, "include", "asp_split.h"), os.path.join(ROOT, "include", "asp_resample.h")]
     objs = []
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     for s in srcs:
         o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
-        if force or _stale(o, deps):
+        if force or _stale(o, [s] + hdrs):
             cmd = [hipcc()] + FLAGS + EXTRA.get(os.path.basename(s), []) + inc + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
@@ -66,7 +66,7 @@ def build_library(force=False, verbose=False):
     for src_name, obj_name, flags in VARIANTS:
         s = os.path.join(CSRC, src_name)
         o = os.path.join(LIBDIR, obj_name)
-        if force or _stale(o, deps):
+        if force or _stale(o, [s] + hdrs):
             cmd = [hipcc()] + FLAGS + EXTRA.get(src_name, []) + flags + inc + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))

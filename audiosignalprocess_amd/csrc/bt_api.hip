@@ -97,6 +97,11 @@ void build_bt_tables(BtTables* T) {
   memset(T, 0, sizeof *T);
   fill_size(&T->s256, 256, T->hann256, T->tw256_f, T->tw256_i, T->sup256_f, T->sup256_i);
   fill_size(&T->s1024, 1024, T->hann1024, T->tw1024_f, T->tw1024_i, T->sup1024_f, T->sup1024_i);
+  // bt_kernels8.hip derives the inverse twiddles from the forward tables: they must be exact conjugates
+  for (int i = 0; i < 512; ++i)
+    if (T->tw1024_i[2 * i] != T->tw1024_f[2 * i] || T->tw1024_i[2 * i + 1] != -T->tw1024_f[2 * i + 1]) abort();
+  for (int i = 0; i < 256; ++i)
+    if (T->sup1024_i[2 * i] != T->sup1024_f[2 * i] || T->sup1024_i[2 * i + 1] != -T->sup1024_f[2 * i + 1]) abort();
 }
 
 std::mutex g_bt_mu;

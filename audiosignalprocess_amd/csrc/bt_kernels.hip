@@ -18,6 +18,9 @@
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <stdint.h>
+#include <stdlib.h>
+
 #include "bt_layout.h"
 
 using namespace aspbt;
@@ -491,6 +494,12 @@ __global__ __launch_bounds__(N / 2) void bt_fftr_kernel(const float* __restrict_
 
 namespace aspbt {
 
+hipError_t launch_bt_macroblock8(float* state, const BtTables* T, const float* in, float* out,
+                                 int num_streams, int in_stride, int out_stride, hipStream_t s,
+                                 unsigned long long* stamps);
+hipError_t launch_bt_fftr8(const float* src, float* dst, int count, int inverse, const BtTables* T,
+                           hipStream_t s);
+
 size_t macroblock_lds_bytes(int n) {
   const int nb = n / 2 + 1, ncol = (n - 1) / 2 / 16;
   const size_t need = (size_t)ncol * 15 + 16 + (size_t)(n / 2 / 64) * 192;
@@ -502,6 +511,10 @@ hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const fl
                                 float* out, int num_streams, int frames, int threshold,
                                 int in_stride, int out_stride, hipStream_t s,
                                 unsigned long long* stamps) {
+  // whole macroblocks at N = 1024 take the one-wave-per-frame kernel (bt_kernels8.hip; 8-byte accesses)
+  if (n == 1024 && frames == 8 && threshold == 1 && ((uintptr_t)in & 7) == 0 && ((uintptr_t)out & 7) == 0 &&
+      (in_stride & 1) == 0 && (out_stride & 1) == 0 && !getenv("ASP_BT_OLD_KERNEL"))
+    return launch_bt_macroblock8(state, T, in, out, num_streams, in_stride, out_stride, s, stamps);
   const size_t lds = macroblock_lds_bytes(n);
   if (n == 1024) {
     static bool attr_set = false;
@@ -522,6 +535,7 @@ hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const fl
 
 hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int inverse,
                           const BtTables* T, hipStream_t s) {
+  if (n == 1024 && !getenv("ASP_BT_OLD_KERNEL")) return launch_bt_fftr8(src, dst, count, inverse, T, s);
   if (n == 1024)
     hipLaunchKernelGGL(bt_fftr_kernel<1024>, dim3(count), dim3(512), 0, s, src, dst, inverse, T);
   else

@@ -13,6 +13,6 @@ for S in (1, 512, 4096):
     for rep in range(2):
         assert g.lib.AspBtBatch_DebugStamps(g.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), st) == 0
     t = np.array(list(st), dtype=np.int64)
-    names = ["load", "tailcarry+fftF", "splitF", "sqtable", "SURE", "dc+thre", "wiener", "mergeI", "fftI", "ola"]
+    names = ["load+tables", "fftF", "splitF", "barrier1", "SURE", "barrier2", "stein+wiener", "barrier3", "merge+fftI", "ola"]
     d = np.diff(t)
     print("S=%d total %d ticks:" % (S, t[-1] - t[0]), {n: int(v) for n, v in zip(names, d)})
