@@ -41,7 +41,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int N = 1024, NC = 512, HALF = 512, NB = 513, NCOL = 31;
 constexpr int ROW = NB;   // complex slots per coefficient row
-constexpr int SQS = 33;   // floats per row of the squared-real table [r * 16 + cc][column]
+constexpr int SQS = 31;   // floats per row of the squared-real table [r * 16 + cc][column] (odd: the split's writes spread over the banks)
 
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -183,7 +183,8 @@ __device__ __forceinline__ void bfly4(cpx& a0, cpx& a1, cpx& a2, cpx& a3, cpx t1
 // Twiddles: the forward tables (the inverse ones are their conjugates bit for bit -- bt_api.hip checks
 // that when it builds them) are staged in LDS once per workgroup (kTwLds entries of kiss_fft's table,
 // all the stages below index, and the 256 super twiddles of kiss_fftr) and read just ahead of each stage.
-constexpr int kTwLds = 384, kSupLds = 256;
+constexpr int kTwLds = 382;  // 3 * 127 is the largest index any stage uses
+constexpr int SUS = 15;      // SURE values per macro-column
 template <bool INV>
 __device__ __forceinline__ cpx tw_at(const cpx* twl, int idx) {
   const cpx t = twl[idx];
@@ -238,15 +239,14 @@ __device__ __forceinline__ constexpr int la_input(int j) { return 64 * (j >> 1) 
 // lane takes k = 1 + lane + 64 i; lane 0 also k = 0.  SQ: also leave (re * norm)^2 of every bin of a
 // whole macro-column in the squared-real table.
 template <bool SQ>
-__device__ __forceinline__ void wave_split_forward(cpx* row, const cpx* sup, int lane,
+__device__ __forceinline__ void wave_split_forward(cpx* row, const cpx (&sp)[4], int lane,
                                                    float* sq_fr, float norm) {
-  cpx fp[4], fn[4], sp[4];
+  cpx fp[4], fn[4];  // sp[i] = super twiddle k - 1 = lane + 64 i
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = 1 + lane + 64 * i;
     fp[i] = row[k];
     fn[i] = row[NC - k];
-    sp[i] = sup[k - 1];
   }
   const cpx t0 = row[0];
   wave_lds_fence();
@@ -293,7 +293,13 @@ __device__ __forceinline__ void wave_split_forward(cpx* row, const cpx* sup, int
 
 // kiss_fftri pre-pass (kiss_fftr.c:137-157) from the row (natural order F[0..512]) straight into the
 // registers of layout LA: register j wants T[n], n = lane + la_input(j).
-__device__ __forceinline__ void wave_merge_inverse(cpx (&v)[8], const cpx* row, const cpx* sup,
+// register j's pair index k: n itself below 256, NC - n above (it is then the (NC - k) side of its pair)
+__device__ __forceinline__ int merge_sup_index(int lane, int j) {
+  const int n = lane + la_input(j);
+  const int k = (j & 1) ? NC - n : n;
+  return k > 0 ? k - 1 : 0;
+}
+__device__ __forceinline__ void wave_merge_inverse(cpx (&v)[8], const cpx* row, const cpx (&spf)[8],
                                                    int lane) {
   cpx u[8], w[8], sp[8];
 #pragma unroll
@@ -301,8 +307,7 @@ __device__ __forceinline__ void wave_merge_inverse(cpx (&v)[8], const cpx* row, 
     const int n = lane + la_input(j);
     u[j] = row[n];
     w[j] = row[NC - n];
-    const int k = (j & 1) ? NC - n : n;      // n >= 256: the (NC - k) side of pair k = NC - n
-    sp[j] = conj(sup[k > 0 ? k - 1 : 0]);    // inverse super twiddles = conjugates of the forward ones
+    sp[j] = conj(spf[j]);  // inverse super twiddles = conjugates of the forward ones
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -347,10 +352,56 @@ __device__ __forceinline__ float fdiv_checked(float n, float d) {
   return q;
 }
 
-// one term of the SURE sum (.c:391-398)
-__device__ __forceinline__ float sure_term(float e, const BtSeg& sg) {
-  const float q = fdiv_checked(sg.temp, e);
-  return sg.size_blk + q * (float)(e > sg.thr) + (e - sg.two_size) * (float)(e <= sg.thr);
+__device__ __forceinline__ f32x2 fdiv2_lean(f32x2 n, f32x2 d) {  // two quotients, packed-f32 issue slots
+  f32x2 r0;
+  r0.x = __builtin_amdgcn_rcpf(d.x);
+  r0.y = __builtin_amdgcn_rcpf(d.y);
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 e0 = __builtin_elementwise_fma(-d, r0, one);
+  const f32x2 r1 = __builtin_elementwise_fma(e0, r0, r0);
+  const f32x2 q0 = n * r1;
+  const f32x2 e1 = __builtin_elementwise_fma(-d, q0, n);
+  const f32x2 q1 = __builtin_elementwise_fma(e1, r1, q0);
+  const f32x2 e2 = __builtin_elementwise_fma(-d, q1, n);
+  return __builtin_elementwise_fma(e2, r1, q1);
+}
+
+// one term of the SURE sum (.c:391-398); q = temp / e
+__device__ __forceinline__ float sure_term_q(float e, float q, float size_blk, float thr, float two_size) {
+  return size_blk + q * (float)(e > thr) + (e - two_size) * (float)(e <= thr);
+}
+// The terms of NT block energies, in place (x: energies in, terms out): lean divisions, two terms per
+// packed instruction, when every energy is inside the range the lean division is exact for; IEEE
+// divisions otherwise (rare: one branch per segmentation).
+template <int NT>
+__device__ __forceinline__ void sure_terms(float (&x)[NT], float temp, float size_blk, float thr,
+                                           float two_size) {
+  float emin = x[0], emax = x[0];
+#pragma unroll
+  for (int q = 1; q < NT; ++q) {
+    emin = fminf(emin, x[q]);
+    emax = fmaxf(emax, x[q]);
+  }
+  if (__builtin_expect(emin >= 1e-18f && emax <= 1e18f, 1)) {
+    if constexpr (NT == 1) {
+      x[0] = sure_term_q(x[0], fdiv_lean(temp, x[0]), size_blk, thr, two_size);
+    } else {
+      const f32x2 temp2 = {temp, temp}, size2 = {size_blk, size_blk}, two2 = {two_size, two_size};
+#pragma unroll
+      for (int q = 0; q < NT; q += 2) {
+        const f32x2 e2 = {x[q], x[q + 1]};
+        const f32x2 q2 = fdiv2_lean(temp2, e2);
+        const f32x2 g2 = {(float)(e2.x > thr), (float)(e2.y > thr)};
+        const f32x2 l2 = {(float)(e2.x <= thr), (float)(e2.y <= thr)};
+        const f32x2 t2 = size2 + q2 * g2 + (e2 - two2) * l2;
+        x[q] = t2.x;
+        x[q + 1] = t2.y;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) x[q] = sure_term_q(x[q], temp / x[q], size_blk, thr, two_size);
+  }
 }
 
 // Sequential (rows outer, columns inner) sum of one TT x FF block of the squared-real table: compile-time
@@ -369,46 +420,81 @@ __device__ __forceinline__ float block_sum(const float* col, int r0, int c0) {
 // the blocks of the second half of the (ii major, jj minor) order when h = 1: rows 4..7 for T >= 1,
 // columns 8..15 for T = 0; its running sum starts from the first half's total.
 template <int T, int F>
-__device__ __forceinline__ void sure_seg(const float* sq, float* sure, const BtSeg sg, int lane) {
+__device__ __forceinline__ void sure_seg(const float* sq, float* sure, const BtSeg* __restrict__ sgp, int lane) {
+  const float temp = sgp->temp, size_blk = sgp->size_blk, thr = sgp->thr, two_size = sgp->two_size;
   constexpr int TT = 8 >> T, FF = 16 >> F, S = T + F, c = T * 5 + F;
   const int h = lane >> 5, m = lane & 31;
   if constexpr (S == 0) {
-    const float e = block_sum<8, 16>(sq + m, 0, 0);
+    float t[1];
+    t[0] = block_sum<8, 16>(sq + m, 0, 0);
+    sure_terms<1>(t, temp, size_blk, thr, two_size);
     float s = 0.0f;
-    s += sure_term(e, sg);
-    if (lane < NCOL) sure[m * 16 + c] = s;
+    s += t[0];
+    if (lane < NCOL) sure[m * SUS + c] = s;
   } else {
     constexpr int NTERM = 1 << (S - 1);
-    constexpr int NI = T >= 1 ? (1 << (T - 1)) : 1;  // ii values per half
     constexpr int NJ = T >= 1 ? (1 << F) : (1 << (F - 1));  // jj values per half
     const float* col = sq + m + (T >= 1 ? h * (4 * 16 * SQS) : h * (8 * SQS));
+    // terms in chunks of at most 8 blocks (a scheduling fence between chunks keeps the LDS reads of later
+    // chunks from being hoisted over the whole segmentation: 128 VGPRs, four waves per SIMD)
+    constexpr int CH = NTERM < 8 ? NTERM : 8;
     float t[NTERM];
 #pragma unroll
-    for (int il = 0; il < NI; ++il)
+    for (int c0 = 0; c0 < NTERM; c0 += CH) {
+      float x[CH];
 #pragma unroll
-      for (int jl = 0; jl < NJ; ++jl)
-        t[il * NJ + jl] = sure_term(block_sum<TT, FF>(col, TT * il, FF * jl), sg);
+      for (int q = 0; q < CH; ++q) x[q] = block_sum<TT, FF>(col, TT * ((c0 + q) / NJ), FF * ((c0 + q) % NJ));
+      sure_terms<CH>(x, temp, size_blk, thr, two_size);
+#pragma unroll
+      for (int q = 0; q < CH; ++q) t[c0 + q] = x[q];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     float s0 = 0.0f;
 #pragma unroll
     for (int q = 0; q < NTERM; ++q) s0 += t[q];
     float s1 = __shfl_xor(s0, 32);  // the first half's total, seen from the second half
 #pragma unroll
     for (int q = 0; q < NTERM; ++q) s1 += t[q];
-    if (h == 1 && m < NCOL) sure[m * 16 + c] = s1;
+    if (h == 1 && m < NCOL) sure[m * SUS + c] = s1;
+  }
+}
+
+// The segmented running sums of phase B2 for one DPP row (= one macro-column): see the kernel.  STEPS =
+// (widest segment of the wave's columns) - 1 scan steps per row, unrolled.
+template <int STEPS>
+__device__ __forceinline__ void scan_rows(const float (&pw)[8], bool segfirst, int lastlane, int TT,
+                                          float& tot1, float& tot3, float& tot5, float& tot7) {
+  float carry = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float acc = ((r & (TT - 1)) == 0 ? 0.0f : carry) + pw[r];
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+      const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0xF, 0xF, false));
+      const float t = left + pw[r];  // row_shr:1
+      acc = segfirst ? acc : t;
+    }
+    carry = __int_as_float(__builtin_amdgcn_ds_bpermute(lastlane, __float_as_int(acc)));
+    if (r == 1) tot1 = carry;
+    if (r == 3) tot3 = carry;
+    if (r == 5) tot5 = carry;
+    if (r == 7) tot7 = carry;
   }
 }
 
 #define BT8_STAMP(k) \
   if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
 
-__global__ __launch_bounds__(512, 4) void bt_macroblock8_kernel(
+#ifndef BT8_WAVES
+#define BT8_WAVES 4  // waves per SIMD the register allocation aims at (measured: 6 = three workgroups per CU is 4 % slower, it spills)
+#endif
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, BT8_WAVES))) void bt_macroblock8_kernel(
     float* __restrict__ state, const BtTables* __restrict__ Tb, const float* __restrict__ in,
     float* __restrict__ out, int in_stride, int out_stride, unsigned long long* __restrict__ stamps) {
   __shared__ __align__(16) cpx coef[8 * ROW];      // [frame][bin]; a wave's row is also its exchange buffer
-  __shared__ __align__(16) float sq[128 * SQS];    // squared normalised real parts; later block gains, OLA halves
-  __shared__ float sure[32 * 16];                  // [macro-column][segmentation]
+  __shared__ __align__(16) float sq[128 * SQS];    // squared normalised real parts; later the OLA halves
+  __shared__ float sure[NCOL * SUS + 15];          // [macro-column][segmentation], then a_const of the 15 segmentations
   __shared__ __align__(16) cpx twl[kTwLds];        // kiss_fft twiddles 0..383 (forward)
-  __shared__ __align__(16) cpx supl[kSupLds];      // kiss_fftr super twiddles (forward)
   BT8_STAMP(0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the phase switches are scalar branches
@@ -425,6 +511,9 @@ __global__ __launch_bounds__(512, 4) void bt_macroblock8_kernel(
   // ---------------------------------------------------------------- phase A: STFT of frame `wave`
   // (blockThreshold_STFT, .c:273-282): frame t sees B[HALF t .. HALF t + N) of B = [inbuf tail | new samples]
   cpx v[8];
+  cpx spf[4];  // the split's super twiddles, requested with the samples
+#pragma unroll
+  for (int i = 0; i < 4; ++i) spf[i] = sup[lane + 64 * i];
   {
     const f32x2* hann2 = reinterpret_cast<const f32x2*>(Tb->hann1024);
     f32x2 s[8], hw[8];
@@ -436,7 +525,8 @@ __global__ __launch_bounds__(512, 4) void bt_macroblock8_kernel(
       hw[j] = hann2[n];
     }
     if (tid < kTwLds) twl[tid] = tw[tid];
-    if (tid < kSupLds) supl[tid] = sup[tid];
+    float* segc = sure + NCOL * SUS;
+    if (tid < 15) segc[tid] = P.seg[tid / 5][tid % 5].a_const;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       v[j].r = s[j].x * hw[j].x;
@@ -450,7 +540,7 @@ __global__ __launch_bounds__(512, 4) void bt_macroblock8_kernel(
 #pragma unroll
   for (int j = 0; j < 8; ++j) row[lane + 64 * j] = v[j];
   wave_lds_fence();
-  wave_split_forward<true>(row, supl, lane, sq + wave * 16 * SQS, P.norm);
+  wave_split_forward<true>(row, spf, lane, sq + wave * 16 * SQS, P.norm);
   BT8_STAMP(3)
   __syncthreads();
   BT8_STAMP(4)
@@ -459,15 +549,15 @@ __global__ __launch_bounds__(512, 4) void bt_macroblock8_kernel(
 
   // ---------------------------------------------------------------- phase B1: SURE (.c:354-401)
   switch (wave) {  // segmentations dealt by cost (terms per half-wave: 32, 16, 16, 8, ...)
-    case 0: sure_seg<2, 4>(sq, sure, P.seg[2][4], lane); break;
-    case 1: sure_seg<2, 3>(sq, sure, P.seg[2][3], lane); sure_seg<0, 1>(sq, sure, P.seg[0][1], lane); break;
-    case 2: sure_seg<1, 4>(sq, sure, P.seg[1][4], lane); sure_seg<1, 0>(sq, sure, P.seg[1][0], lane); break;
-    case 3: sure_seg<2, 2>(sq, sure, P.seg[2][2], lane); sure_seg<0, 0>(sq, sure, P.seg[0][0], lane); break;
-    case 4: sure_seg<1, 3>(sq, sure, P.seg[1][3], lane); sure_seg<2, 1>(sq, sure, P.seg[2][1], lane); break;
-    case 5: sure_seg<0, 4>(sq, sure, P.seg[0][4], lane); sure_seg<1, 2>(sq, sure, P.seg[1][2], lane); break;
-    case 6: sure_seg<0, 3>(sq, sure, P.seg[0][3], lane); sure_seg<0, 2>(sq, sure, P.seg[0][2], lane);
-            sure_seg<1, 1>(sq, sure, P.seg[1][1], lane); break;
-    default: sure_seg<2, 0>(sq, sure, P.seg[2][0], lane); break;
+    case 0: sure_seg<2, 4>(sq, sure, &P.seg[2][4], lane); break;
+    case 1: sure_seg<2, 3>(sq, sure, &P.seg[2][3], lane); sure_seg<0, 1>(sq, sure, &P.seg[0][1], lane); break;
+    case 2: sure_seg<1, 4>(sq, sure, &P.seg[1][4], lane); sure_seg<1, 0>(sq, sure, &P.seg[1][0], lane); break;
+    case 3: sure_seg<2, 2>(sq, sure, &P.seg[2][2], lane); sure_seg<0, 0>(sq, sure, &P.seg[0][0], lane); break;
+    case 4: sure_seg<1, 3>(sq, sure, &P.seg[1][3], lane); sure_seg<2, 1>(sq, sure, &P.seg[2][1], lane); break;
+    case 5: sure_seg<0, 4>(sq, sure, &P.seg[0][4], lane); sure_seg<1, 2>(sq, sure, &P.seg[1][2], lane); break;
+    case 6: sure_seg<0, 3>(sq, sure, &P.seg[0][3], lane); sure_seg<0, 2>(sq, sure, &P.seg[0][2], lane);
+            sure_seg<1, 1>(sq, sure, &P.seg[1][1], lane); break;
+    default: sure_seg<2, 0>(sq, sure, &P.seg[2][0], lane); break;
   }
   BT8_STAMP(5)
   __syncthreads();
@@ -475,59 +565,103 @@ __global__ __launch_bounds__(512, 4) void bt_macroblock8_kernel(
 
   // ---------------------------------------------------------------- phase B2: attenuation + Wiener, in place
   {
-    float* av = sq;  // [macro-column][64 block gains]; the squared-real table is dead
     const int m = tid >> 4, u = tid & 15;
     if (m < NCOL) {
       // argmin, first minimum wins (.c:404-416)
-      float best = sure[m * 16];
+      float best = sure[m * SUS];
       int bc = 0;
 #pragma unroll
       for (int c = 1; c < 15; ++c) {
-        const float s = sure[m * 16 + c];
+        const float s = sure[m * SUS + c];
         if (s < best) {
           best = s;
           bc = c;
         }
       }
-      const int T = bc >= 10 ? 2 : bc >= 5 ? 1 : 0, F = bc - 5 * T, S = T + F;
-      const int TT = 8 >> T, FF = 16 >> F, len = 128 >> S, nblk = 1 << S;
-      const float a_const = P.seg[T][F].a_const;
-      cpx* col = coef + 1 + 16 * m;
-      // block powers of the chosen segmentation, each summed rows outer / columns inner (.c:421-454)
-      for (int b = u; b < nblk; b += 16) {
-        const int ii = b >> F, jj = b & ((1 << F) - 1);
-        const cpx* blk = col + ii * TT * ROW + jj * FF;
-        float power = 0.0f;
-        for (int i0 = 0; i0 < len; i0 += 8) {
-          cpx z[8];
+      BT8_STAMP(11)
+      const int T = bc >= 10 ? 2 : bc >= 5 ? 1 : 0, F = bc - 5 * T;
+      const int TT = 8 >> T, FF = 16 >> F;
+      const float a_const = sure[NCOL * SUS + bc];
+      cpx* col = coef + 1 + 16 * m + u;
+      // Block powers of the chosen segmentation (.c:421-454).  The column's 16 lanes are one DPP row: lane u
+      // owns bin u of every frame.  A block sum runs rows outer / columns inner, i.e. along the lanes of a
+      // segment of FF lanes and on into the next row: a segmented left-to-right scan per row (each step adds
+      // the left neighbour's running sum, so the adds are the reference's, in its order), the row's last
+      // lane handing the sum to the next row's first lane.
+      cpx z[8];
+      float pw[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int i = i0 + q < len ? i0 + q : 0;
-            z[q] = blk[(i >> (4 - F)) * ROW + (i & (FF - 1))];
-          }
+      for (int r = 0; r < 8; ++r) z[r] = col[r * ROW];
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (i0 + q < len) power += z[q].r * z[q].r + z[q].i * z[q].i;
-        }
-        float a = (float)(1.0 - (double)fdiv_checked(a_const, power));
-        a = a * (float)(a > 0);
-        av[m * 64 + b] = a;
+      for (int r = 0; r < 8; ++r) pw[r] = z[r].r * z[r].r + z[r].i * z[r].i;
+      BT8_STAMP(12)
+      const bool segfirst = (u & (FF - 1)) == 0;
+      const int lastlane = (lane | (FF - 1)) << 2;
+      int mf = FF;
+      mf = max(mf, __shfl_xor(mf, 16));
+      mf = max(mf, __shfl_xor(mf, 32));
+      const int steps = __builtin_amdgcn_readfirstlane(mf) - 1;
+      float tot1 = 1.0f, tot3 = 1.0f, tot5 = 1.0f, tot7 = 1.0f;  // running sums after rows 1, 3, 5, 7
+      switch (steps) {
+        case 15: scan_rows<15>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
+        case 7: scan_rows<7>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
+        case 3: scan_rows<3>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
+        case 1: scan_rows<1>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
+        default: scan_rows<0>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
       }
-      wave_lds_fence();  // a column's 16 lanes sit in one wave
+      BT8_STAMP(13)
+      // a block ends at row r when (r + 1) % TT == 0; its Stein gain (.c:440-444).  Rows 1 and 5 end blocks
+      // only for TT = 2, row 3 for TT <= 4, row 7 always; sums that end no block are replaced by 1
+      if (TT != 2) tot1 = 1.0f, tot5 = 1.0f;
+      if (TT == 8) tot3 = 1.0f;
+      const float pmin = fminf(fminf(tot1, tot3), fminf(tot5, tot7)), pmax = fmaxf(fmaxf(tot1, tot3), fmaxf(tot5, tot7));
+      float g1 = (float)(1.0 - (double)fdiv_lean(a_const, tot1));
+      float g3 = (float)(1.0 - (double)fdiv_lean(a_const, tot3));
+      float g5 = (float)(1.0 - (double)fdiv_lean(a_const, tot5));
+      float g7 = (float)(1.0 - (double)fdiv_lean(a_const, tot7));
+      if (__builtin_expect(!(pmin >= 1e-18f && pmax <= 1e18f), 0)) {
+        g1 = (float)(1.0 - (double)(a_const / tot1));
+        g3 = (float)(1.0 - (double)(a_const / tot3));
+        g5 = (float)(1.0 - (double)(a_const / tot5));
+        g7 = (float)(1.0 - (double)(a_const / tot7));
+      }
+      g1 = g1 * (float)(g1 > 0);
+      g3 = g3 * (float)(g3 > 0);
+      g5 = g5 * (float)(g5 > 0);
+      g7 = g7 * (float)(g7 > 0);
+      BT8_STAMP(14)
       // thresholded coefficient -> empirical Wiener gain on the original one (.c:446-452, 469-486)
+      float wn[8], den[8], wmin, wmax;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const cpx z = col[r * ROW + u];
-        const float a = av[m * 64 + ((r >> (3 - T)) << F) + (u >> (4 - F))];
-        const float tr = z.r * a, ti = z.i * a;
-        float wn = tr * tr + ti * ti;
-        const float den = wn + P.wiener_c;
-        float g = fdiv_lean(wn, den);
-        if (__builtin_expect(!(den <= 1e18f && (wn >= 1e-30f || wn == 0.0f)), 0)) g = wn / den;
+        // the block of row r ends at row r | (TT - 1): 7 (T = 0), 3 or 7 (T = 1), r | 1 (T = 2)
+        const float gpair = r < 2 ? g1 : r < 4 ? g3 : r < 6 ? g5 : g7;
+        const float a = T == 2 ? gpair : (T == 1 && r < 4) ? g3 : g7;
+        const float tr = z[r].r * a, ti = z[r].i * a;
+        wn[r] = tr * tr + ti * ti;
+        den[r] = wn[r] + P.wiener_c;
+        wmin = r == 0 ? wn[r] : fminf(wmin, wn[r]);
+        wmax = r == 0 ? wn[r] : fmaxf(wmax, wn[r]);
+      }
+      // lean divisions are exact for 0 and for [1e-30, 1e18]; anything else takes the IEEE form (rare)
+      const bool lean = wmax <= 1e18f && (wmin >= 1e-30f || wmin == 0.0f);
+      const bool all_lean = __builtin_expect(__all(lean), 1);
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) {
+        f32x2 gw;
+        if (all_lean) {
+          gw = fdiv2_lean(f32x2{wn[r], wn[r + 1]}, f32x2{den[r], den[r + 1]});
+        } else {
+          gw.x = wn[r] / den[r];
+          gw.y = wn[r + 1] / den[r + 1];
+        }
         cpx o;
-        o.r = z.r * g;
-        o.i = z.i * g;
-        col[r * ROW + u] = o;
+        o.r = z[r].r * gw.x;
+        o.i = z[r].i * gw.x;
+        col[r * ROW] = o;
+        o.r = z[r + 1].r * gw.y;
+        o.i = z[r + 1].i * gw.y;
+        col[(r + 1) * ROW] = o;
       }
     } else {
       // DC column and the bins past the last whole macro-column (.c:501-506, 518-532); the Nyquist bin
@@ -560,13 +694,16 @@ __global__ __launch_bounds__(512, 4) void bt_macroblock8_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) tail[j] = *reinterpret_cast<const f32x2*>(st + kOffOutTail + 2 * (lane + 64 * j));
   }
+  cpx spi[8];  // the merge's super twiddles, requested ahead of the barrier
+#pragma unroll
+  for (int j = 0; j < 8; ++j) spi[j] = sup[merge_sup_index(lane, j)];
   BT8_STAMP(7)
   __syncthreads();
   BT8_STAMP(8)
 
   // ---------------------------------------------------------------- phase C: inverse STFT + overlap-add
   // (blockThreshold_inverse_STFT, .c:284-300)
-  wave_merge_inverse(v, row, supl, lane);
+  wave_merge_inverse(v, row, spi, lane);
   wave_lds_fence();
   wave_fft512<true>(v, row, twl, tw, lane, xt);
   BT8_STAMP(9)
@@ -615,12 +752,10 @@ __global__ __launch_bounds__(64) void bt_fftr8_kernel(const float* __restrict__ 
                                                       int inverse, const BtTables* __restrict__ Tb) {
   __shared__ __align__(16) cpx row[ROW];
   __shared__ __align__(16) cpx twl[kTwLds];
-  __shared__ __align__(16) cpx supl[kSupLds];
   const int lane = threadIdx.x, r = blockIdx.x;
   const cpx* tw = reinterpret_cast<const cpx*>(Tb->tw1024_f);
   const cpx* sup = reinterpret_cast<const cpx*>(Tb->sup1024_f);
   for (int k = lane; k < kTwLds; k += 64) twl[k] = tw[k];
-  for (int k = lane; k < kSupLds; k += 64) supl[k] = sup[k];
   wave_lds_fence();
   const XTerms xt = exchange_terms(lane);
   cpx v[8];
@@ -632,7 +767,10 @@ __global__ __launch_bounds__(64) void bt_fftr8_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) row[lane + 64 * j] = v[j];
     wave_lds_fence();
-    wave_split_forward<false>(row, supl, lane, nullptr, 0.f);
+    cpx spf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) spf[i] = sup[lane + 64 * i];
+    wave_split_forward<false>(row, spf, lane, nullptr, 0.f);
     wave_lds_fence();
     cpx* o = reinterpret_cast<cpx*>(dst + (size_t)r * 2 * NB);
     for (int k = lane; k < NB; k += 64) o[k] = row[k];
@@ -640,7 +778,10 @@ __global__ __launch_bounds__(64) void bt_fftr8_kernel(const float* __restrict__ 
     const cpx* f = reinterpret_cast<const cpx*>(src + (size_t)r * 2 * NB);
     for (int k = lane; k < NB; k += 64) row[k] = f[k];
     wave_lds_fence();
-    wave_merge_inverse(v, row, supl, lane);
+    cpx spi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) spi[j] = sup[merge_sup_index(lane, j)];
+    wave_merge_inverse(v, row, spi, lane);
     wave_lds_fence();
     wave_fft512<true>(v, row, twl, tw, lane, xt);
     cpx* o = reinterpret_cast<cpx*>(dst + (size_t)r * N);
