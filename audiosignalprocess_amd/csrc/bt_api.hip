@@ -97,6 +97,15 @@ void build_bt_tables(BtTables* T) {
   memset(T, 0, sizeof *T);
   fill_size(&T->s256, 256, T->hann256, T->tw256_f, T->tw256_i, T->sup256_f, T->sup256_i);
   fill_size(&T->s1024, 1024, T->hann1024, T->tw1024_f, T->tw1024_i, T->sup1024_f, T->sup1024_i);
+  {  // lane terms of the three register exchanges of bt_kernels8.hip
+    const Lay* lay[4] = {&LA, &LB, &LC, &LD};
+    const Swz* sw[3] = {&S1, &S2, &S3};
+    for (int x = 0; x < 3; ++x)
+      for (int lane = 0; lane < 64; ++lane) {
+        T->xterm[2 * x][lane] = (uint16_t)(8 * swz(*sw[x], pos_lane(*lay[x], lane)));
+        T->xterm[2 * x + 1][lane] = (uint16_t)(8 * swz(*sw[x], pos_lane(*lay[x + 1], lane)));
+      }
+  }
   // bt_kernels8.hip derives the inverse twiddles from the forward tables: they must be exact conjugates
   for (int i = 0; i < 512; ++i)
     if (T->tw1024_i[2 * i] != T->tw1024_f[2 * i] || T->tw1024_i[2 * i + 1] != -T->tw1024_f[2 * i + 1]) abort();

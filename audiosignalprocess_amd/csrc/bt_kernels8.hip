@@ -34,13 +34,11 @@ using namespace aspbt;
 
 namespace {
 
-struct cpx {
-  float r, i;
-};
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 cpx;  // x = re, y = im: one 64-bit register pair, so complex arithmetic issues as packed f32
 
 constexpr int N = 1024, NC = 512, HALF = 512, NB = 513, NCOL = 31;
-constexpr int ROW = NB;   // complex slots per coefficient row
+constexpr int ROW = 544;  // complex slots per coefficient row (NB used; 4352 bytes: rows stay 256-byte aligned for the exchanges)
 constexpr int SQS = 31;   // floats per row of the squared-real table [r * 16 + cc][column] (odd: the split's writes spread over the banks)
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -49,80 +47,70 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ cpx cmul(cpx a, cpx b) {  // C_MUL
-  cpx m;
-  m.r = a.r * b.r - a.i * b.i;
-  m.i = a.r * b.i + a.i * b.r;
-  return m;
+// Packed adds with one half negated or the second operand's halves swapped (VOP3P neg_lo / neg_hi /
+// op_sel modifiers, which the compiler does not form from per-lane negations).  Each half is the IEEE
+// single-precision operation of its scalar spelling, so results are those of the reference's code.
+__device__ __forceinline__ f32x2 add_sub_lo(f32x2 a, f32x2 b) {  // {a.x - b.x, a.y + b.y}
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
-__device__ __forceinline__ cpx conj(cpx a) {
-  a.i = -a.i;
-  return a;
+__device__ __forceinline__ f32x2 add_sub_hi(f32x2 a, f32x2 b) {  // {a.x + b.x, a.y - b.y}
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
-
-// ---------------------------------------------------------------- register layouts of the FFT stages
-// A position p (9 bits) of the in-place kiss_fft work array lives in lane `lane`, register j of a
-// layout: reg[b] / lane[b] name the position bit held by register-index bit b / lane bit b.
-struct Lay {
-  int reg[3];
-  int lane[6];
-};
-constexpr Lay LA = {{0, 1, 2}, {7, 8, 5, 6, 3, 4}};  // after the loads: lane = k0 + 4 k1 + 16 k2 of n
-constexpr Lay LB = {{8, 3, 4}, {0, 1, 2, 5, 6, 7}};  // radix-4 stage m = 8 (position bits 3, 4 in registers)
-constexpr Lay LC = {{8, 5, 6}, {0, 1, 2, 3, 4, 7}};  // m = 32
-constexpr Lay LD = {{6, 7, 8}, {0, 1, 2, 3, 4, 5}};  // m = 128; natural order: p = lane + 64 j
-// XOR swizzles of the three exchanges (index bit b = parity(p & rows[b]) for b < 5, bits 5..8 kept):
-// found by search so that the ds_write_b64 of the source layout (16-lane groups, 16 8-byte banks) and
-// the ds_read_b64 of the destination layout (32-lane groups, 32 8-byte banks) are both conflict-free.
-struct Swz {
-  int rows[5];
-};
-constexpr Swz S1 = {{257, 322, 396, 40, 80}};
-constexpr Swz S2 = {{129, 34, 4, 56, 16}};
-constexpr Swz S3 = {{17, 66, 12, 264, 16}};
-
-__host__ __device__ constexpr int pos_reg(const Lay& L, int j) {
-  int p = 0;
-  for (int b = 0; b < 3; ++b) p |= ((j >> b) & 1) << L.reg[b];
-  return p;
+__device__ __forceinline__ f32x2 add_neg0_hi(f32x2 a, f32x2 b) {  // {a.x + b.x, -a.y + b.y}
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
-__device__ __forceinline__ int pos_lane(const Lay& L, int lane) {
-  int p = 0;
-#pragma unroll
-  for (int b = 0; b < 6; ++b) p |= ((lane >> b) & 1) << L.lane[b];
-  return p;
+__device__ __forceinline__ f32x2 sub_lo_rsub_hi(f32x2 a, f32x2 b) {  // {a.x - b.x, b.y - a.y}
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
-__host__ __device__ constexpr int parity9(int x) {
-  x ^= x >> 8;
-  x ^= x >> 4;
-  x ^= x >> 2;
-  x ^= x >> 1;
-  return x & 1;
+__device__ __forceinline__ f32x2 add_swap_sub_hi(f32x2 a, f32x2 b) {  // {a.x + b.y, a.y - b.x}
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
-__host__ __device__ constexpr int swz(const Swz& S, int p) {
-  int r = p & ~31;
-  for (int b = 0; b < 5; ++b) r |= parity9(p & S.rows[b]) << b;
+__device__ __forceinline__ f32x2 add_swap_sub_lo(f32x2 a, f32x2 b) {  // {a.x - b.y, a.y + b.x}
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 
-// One exchange through the wave's private 512-slot LDS row: registers of layout SRC -> layout DST.
-// swz is linear over GF(2) and a position is the XOR of its lane part and its register part, so the
-// slot is (lane term) ^ (compile-time register term).
-struct XTerms {  // the six lane terms, computed once per kernel
+// C_MUL(a, t): {a.r t.r - a.i t.i, a.r t.i + a.i t.r}.  CONJ: by the conjugate of t, as the reference
+// multiplies by its inverse-table entry {t.r, -t.i}: {a.r t.r - a.i (-t.i), a.r (-t.i) + a.i t.r}, i.e.
+// {p1.x + p2.x, -p1.y + p2.y} of the same two products (x - (-y) == x + y and (-x) + y bit for bit).
+template <bool CONJ>
+__device__ __forceinline__ cpx cmul(cpx a, cpx t) {
+  const f32x2 p1 = a.xx * t;     // {a.r t.r, a.r t.i}
+  const f32x2 p2 = a.yy * t.yx;  // {a.i t.i, a.i t.r}
+  return CONJ ? add_neg0_hi(p1, p2) : add_sub_lo(p1, p2);
+}
+
+// The six lane terms (byte offsets inside the wave's row, from the host-built table) with the row's
+// byte offset inside the coefficient tile added: rows are 256-byte aligned, so XOR-ing a register term
+// below 256 bytes into the sum equals XOR-ing it into the slot index.
+struct XTerms {
   int w[3], r[3];
 };
-__device__ __forceinline__ XTerms exchange_terms(int lane) {
+__device__ __forceinline__ XTerms exchange_terms(const BtTables* __restrict__ Tb, int lane, int row_bytes) {
   XTerms t;
-  t.w[0] = swz(S1, pos_lane(LA, lane));
-  t.r[0] = swz(S1, pos_lane(LB, lane));
-  t.w[1] = swz(S2, pos_lane(LB, lane));
-  t.r[1] = swz(S2, pos_lane(LC, lane));
-  t.w[2] = swz(S3, pos_lane(LC, lane));
-  t.r[2] = swz(S3, pos_lane(LD, lane));
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {
+    t.w[x] = Tb->xterm[2 * x][lane] + row_bytes;
+    t.r[x] = Tb->xterm[2 * x + 1][lane] + row_bytes;
+  }
   return t;
 }
+// One exchange through the wave's private LDS row: registers of layout SRC -> layout DST.  swz is linear
+// over GF(2) and a position is the XOR of its lane part and its register part; the register part's bits
+// above the swizzled five are disjoint from the lane part's, so they add (an immediate offset).
 template <int X>
-__device__ __forceinline__ void exchange(cpx (&v)[8], cpx* row, const XTerms& xt) {
+__device__ __forceinline__ void exchange(cpx (&v)[8], cpx* tile, const XTerms& xt) {
   constexpr Lay SRC = X == 1 ? LA : X == 2 ? LB : LC;
   constexpr Lay DST = X == 1 ? LB : X == 2 ? LC : LD;
   constexpr Swz S = X == 1 ? S1 : X == 2 ? S2 : S3;
@@ -130,53 +118,47 @@ __device__ __forceinline__ void exchange(cpx (&v)[8], cpx* row, const XTerms& xt
   // alive -- and spilled -- between the forward and the inverse transform
   int wl = xt.w[X - 1], rl = xt.r[X - 1];
   asm volatile("" : "+v"(wl), "+v"(rl));
+  char* base = reinterpret_cast<char*>(tile);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) row[wl ^ swz(S, pos_reg(SRC, j))] = v[j];
+  for (int j = 0; j < 8; ++j) {
+    const int c = swz(S, pos_reg(SRC, j));
+    *reinterpret_cast<cpx*>(base + ((wl ^ ((c & 31) * 8)) + (c & ~31) * 8)) = v[j];
+  }
   wave_lds_fence();
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = row[rl ^ swz(S, pos_reg(DST, j))];
+  for (int j = 0; j < 8; ++j) {
+    const int c = swz(S, pos_reg(DST, j));
+    v[j] = *reinterpret_cast<const cpx*>(base + ((rl ^ ((c & 31) * 8)) + (c & ~31) * 8));
+  }
   wave_lds_fence();
 }
 
 // kf_bfly2 (kiss_fft.c:21-42), m = 1
+template <bool INV>
 __device__ __forceinline__ void bfly2(cpx& f0, cpx& f1, cpx tw0) {
-  const cpx t = cmul(f1, tw0);
-  const cpx a = f0;
-  f1.r = a.r - t.r;
-  f1.i = a.i - t.i;
-  f0.r = a.r + t.r;
-  f0.i = a.i + t.i;
+  const cpx t = cmul<INV>(f1, tw0);
+  f1 = f0 - t;
+  f0 = f0 + t;
 }
-// kf_bfly4 (kiss_fft.c:44-90): a0..a3 = Fout[0], Fout[m], Fout[2m], Fout[3m]
+// kf_bfly4 (kiss_fft.c:44-90): a0..a3 = Fout[0], Fout[m], Fout[2m], Fout[3m]; the twiddles are the
+// forward table's (INV multiplies by their conjugates = the inverse table's entries)
 template <bool INV>
 __device__ __forceinline__ void bfly4(cpx& a0, cpx& a1, cpx& a2, cpx& a3, cpx t1, cpx t2, cpx t3) {
-  const cpx s0 = cmul(a1, t1);
-  const cpx s1 = cmul(a2, t2);
-  const cpx s2 = cmul(a3, t3);
-  cpx f0 = a0, s3, s4, s5;
-  s5.r = f0.r - s1.r;
-  s5.i = f0.i - s1.i;
-  f0.r += s1.r;
-  f0.i += s1.i;
-  s3.r = s0.r + s2.r;
-  s3.i = s0.i + s2.i;
-  s4.r = s0.r - s2.r;
-  s4.i = s0.i - s2.i;
-  a2.r = f0.r - s3.r;
-  a2.i = f0.i - s3.i;
-  f0.r += s3.r;
-  f0.i += s3.i;
-  a0 = f0;
+  const cpx s0 = cmul<INV>(a1, t1);
+  const cpx s1 = cmul<INV>(a2, t2);
+  const cpx s2 = cmul<INV>(a3, t3);
+  const cpx s5 = a0 - s1;
+  cpx f0 = a0 + s1;
+  const cpx s3 = s0 + s2;
+  const cpx s4 = s0 - s2;
+  a2 = f0 - s3;
+  a0 = f0 + s3;
   if (INV) {
-    a1.r = s5.r - s4.i;
-    a1.i = s5.i + s4.r;
-    a3.r = s5.r + s4.i;
-    a3.i = s5.i - s4.r;
+    a1 = add_swap_sub_lo(s5, s4);  // {s5.r - s4.i, s5.i + s4.r}
+    a3 = add_swap_sub_hi(s5, s4);  // {s5.r + s4.i, s5.i - s4.r}
   } else {
-    a1.r = s5.r + s4.i;
-    a1.i = s5.i - s4.r;
-    a3.r = s5.r - s4.i;
-    a3.i = s5.i + s4.r;
+    a1 = add_swap_sub_hi(s5, s4);
+    a3 = add_swap_sub_lo(s5, s4);
   }
 }
 
@@ -185,38 +167,32 @@ __device__ __forceinline__ void bfly4(cpx& a0, cpx& a1, cpx& a2, cpx& a3, cpx t1
 // all the stages below index, and the 256 super twiddles of kiss_fftr) and read just ahead of each stage.
 constexpr int kTwLds = 382;  // 3 * 127 is the largest index any stage uses
 constexpr int SUS = 15;      // SURE values per macro-column
-template <bool INV>
-__device__ __forceinline__ cpx tw_at(const cpx* twl, int idx) {
-  const cpx t = twl[idx];
-  return INV ? conj(t) : t;
-}
 
 // All stages of one 512-point complex FFT of kiss_fft (factors 4,4,4,4,2): in: layout LA, out: LD.
 // tw: the global table (wave-uniform entries of the first two stages), twl: its LDS copy
 template <bool INV>
-__device__ __forceinline__ void wave_fft512(cpx (&v)[8], cpx* row, const cpx* twl,
+__device__ __forceinline__ void wave_fft512(cpx (&v)[8], cpx* tile, const cpx* twl,
                                             const cpx* __restrict__ tw, int lane, const XTerms& xt) {
   {  // radix-2 leaves (m = 1, twiddle 0) and the radix-4 stage with m = 2: wave-uniform twiddles
-    cpx t0 = tw[0], t64 = tw[64], t128 = tw[128], t192 = tw[192];
-    if (INV) t0 = conj(t0), t64 = conj(t64), t128 = conj(t128), t192 = conj(t192);
-    bfly2(v[0], v[1], t0);
-    bfly2(v[2], v[3], t0);
-    bfly2(v[4], v[5], t0);
-    bfly2(v[6], v[7], t0);
+    const cpx t0 = tw[0], t64 = tw[64], t128 = tw[128], t192 = tw[192];
+    bfly2<INV>(v[0], v[1], t0);
+    bfly2<INV>(v[2], v[3], t0);
+    bfly2<INV>(v[4], v[5], t0);
+    bfly2<INV>(v[6], v[7], t0);
     bfly4<INV>(v[0], v[2], v[4], v[6], t0, t0, t0);
     bfly4<INV>(v[1], v[3], v[5], v[7], t64, t128, t192);
   }
   {
     const int kb = lane & 7;
-    const cpx t1 = tw_at<INV>(twl, kb * 16), t2 = tw_at<INV>(twl, kb * 32), t3 = tw_at<INV>(twl, kb * 48);
-    exchange<1>(v, row, xt);
+    const cpx t1 = twl[kb * 16], t2 = twl[kb * 32], t3 = twl[kb * 48];
+    exchange<1>(v, tile, xt);
 #pragma unroll
     for (int c = 0; c < 2; ++c) bfly4<INV>(v[c], v[c + 2], v[c + 4], v[c + 6], t1, t2, t3);
   }
   {
     const int kc = lane & 31;
-    const cpx t1 = tw_at<INV>(twl, kc * 4), t2 = tw_at<INV>(twl, kc * 8), t3 = tw_at<INV>(twl, kc * 12);
-    exchange<2>(v, row, xt);
+    const cpx t1 = twl[kc * 4], t2 = twl[kc * 8], t3 = twl[kc * 12];
+    exchange<2>(v, tile, xt);
 #pragma unroll
     for (int c = 0; c < 2; ++c) bfly4<INV>(v[c], v[c + 2], v[c + 4], v[c + 6], t1, t2, t3);
   }
@@ -225,8 +201,8 @@ __device__ __forceinline__ void wave_fft512(cpx (&v)[8], cpx* row, const cpx* tw
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) t[c][q] = tw_at<INV>(twl, (lane + 64 * c) * (q + 1));
-    exchange<3>(v, row, xt);
+      for (int q = 0; q < 3; ++q) t[c][q] = twl[(lane + 64 * c) * (q + 1)];
+    exchange<3>(v, tile, xt);
 #pragma unroll
     for (int c = 0; c < 2; ++c) bfly4<INV>(v[c], v[c + 2], v[c + 4], v[c + 6], t[c][0], t[c][1], t[c][2]);
   }
@@ -253,40 +229,30 @@ __device__ __forceinline__ void wave_split_forward(cpx* row, const cpx (&sp)[4],
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = 1 + lane + 64 * i;
-    cpx fpnk, f1k, f2k;
-    fpnk.r = fn[i].r;
-    fpnk.i = -fn[i].i;
-    f1k.r = fp[i].r + fpnk.r;
-    f1k.i = fp[i].i + fpnk.i;
-    f2k.r = fp[i].r - fpnk.r;
-    f2k.i = fp[i].i - fpnk.i;
-    const cpx twv = cmul(f2k, sp[i]);
-    cpx a, b;
-    a.r = (f1k.r + twv.r) * 0.5f;
-    a.i = (f1k.i + twv.i) * 0.5f;
-    b.r = (f1k.r - twv.r) * 0.5f;
-    b.i = (twv.i - f1k.i) * 0.5f;
+    // fpnk = conj(T[NC - k]); f1k = fpk + fpnk; f2k = fpk - fpnk
+    const cpx f1k = add_sub_hi(fp[i], fn[i]);
+    const cpx f2k = add_sub_lo(fp[i], fn[i]);
+    const cpx twv = cmul<false>(f2k, sp[i]);
+    const cpx a = (f1k + twv) * 0.5f;
+    const cpx b = sub_lo_rsub_hi(f1k, twv) * 0.5f;  // {(f1k.r - tw.r) / 2, (tw.i - f1k.i) / 2}
     if (k != NC - k) row[k] = a;
     row[NC - k] = b;  // for k = NC/2 the second assignment is the one that stays
     if (SQ) {
       // bins 1 .. 16 NCOL belong to macro-columns: bin = 1 + 16 m + cc
       const int ka = k - 1, kb = NC - k - 1;
-      if (k != NC - k) {
-        const float va = a.r * norm;
-        sq_fr[(ka & 15) * SQS + (ka >> 4)] = va * va;
-      }
-      if (kb < 16 * NCOL) {
-        const float vb = b.r * norm;
-        sq_fr[(kb & 15) * SQS + (kb >> 4)] = vb * vb;
-      }
+      f32x2 re = {a.x, b.x};
+      re = re * norm;
+      re = re * re;
+      if (k != NC - k) sq_fr[(ka & 15) * SQS + (ka >> 4)] = re.x;
+      if (kb < 16 * NCOL) sq_fr[(kb & 15) * SQS + (kb >> 4)] = re.y;
     }
   }
   if (lane == 0) {
     cpx z;
-    z.r = t0.r + t0.i;
-    z.i = 0.f;
+    z.x = t0.x + t0.y;
+    z.y = 0.f;
     row[0] = z;
-    z.r = t0.r - t0.i;
+    z.x = t0.x - t0.y;
     row[NC] = z;
   }
 }
@@ -301,34 +267,26 @@ __device__ __forceinline__ int merge_sup_index(int lane, int j) {
 }
 __device__ __forceinline__ void wave_merge_inverse(cpx (&v)[8], const cpx* row, const cpx (&spf)[8],
                                                    int lane) {
-  cpx u[8], w[8], sp[8];
+  cpx u[8], w[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int n = lane + la_input(j);
     u[j] = row[n];
     w[j] = row[NC - n];
-    sp[j] = conj(spf[j]);  // inverse super twiddles = conjugates of the forward ones
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const cpx fk = (j & 1) ? w[j] : u[j], fo = (j & 1) ? u[j] : w[j];  // F[k], F[NC - k]
-    cpx fek, tmp;
-    fek.r = fk.r + fo.r;
-    fek.i = fk.i - fo.i;
-    tmp.r = fk.r - fo.r;
-    tmp.i = fk.i + fo.i;
-    const cpx fok = cmul(tmp, sp[j]);
-    cpx t;
-    if (j & 1) {
-      t.r = fek.r - fok.r;
-      t.i = (fek.i - fok.i) * -1;
-    } else {
-      t.r = fek.r + fok.r;
-      t.i = fek.i + fok.i;
-    }
+    // fnkc = conj(F[NC - k]); fek = fk + fnkc; tmp = fk - fnkc; fok = tmp * (inverse super twiddle =
+    // conjugate of the forward one)
+    const cpx fek = add_sub_hi(fk, fo);
+    const cpx tmp = add_sub_lo(fk, fo);
+    const cpx fok = cmul<true>(tmp, spf[j]);
+    // n < 256: T[k] = fek + fok; above: T[NC - k] = {fek.r - fok.r, (fek.i - fok.i) * -1}
+    cpx t = (j & 1) ? sub_lo_rsub_hi(fek, fok) : fek + fok;
     if (j == 0 && lane == 0) {  // n = 0
-      t.r = u[0].r + w[0].r;
-      t.i = u[0].r - w[0].r;
+      t.x = u[0].x + w[0].x;
+      t.y = u[0].x - w[0].x;
     }
     v[j] = t;
   }
@@ -491,7 +449,7 @@ __device__ __forceinline__ void scan_rows(const float (&pw)[8], bool segfirst, i
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, BT8_WAVES))) void bt_macroblock8_kernel(
     float* __restrict__ state, const BtTables* __restrict__ Tb, const float* __restrict__ in,
     float* __restrict__ out, int in_stride, int out_stride, unsigned long long* __restrict__ stamps) {
-  __shared__ __align__(16) cpx coef[8 * ROW];      // [frame][bin]; a wave's row is also its exchange buffer
+  __shared__ __align__(256) cpx coef[8 * ROW];     // [frame][bin]; a wave's row is also its exchange buffer
   __shared__ __align__(16) float sq[128 * SQS];    // squared normalised real parts; later the OLA halves
   __shared__ float sure[NCOL * SUS + 15];          // [macro-column][segmentation], then a_const of the 15 segmentations
   __shared__ __align__(16) cpx twl[kTwLds];        // kiss_fft twiddles 0..383 (forward)
@@ -506,7 +464,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   const cpx* tw = reinterpret_cast<const cpx*>(Tb->tw1024_f);
   const cpx* sup = reinterpret_cast<const cpx*>(Tb->sup1024_f);
   cpx* row = coef + wave * ROW;
-  const XTerms xt = exchange_terms(lane);
+  cpx* tile = coef;
+  const XTerms xt = exchange_terms(Tb, lane, wave * ROW * 8);
 
   // ---------------------------------------------------------------- phase A: STFT of frame `wave`
   // (blockThreshold_STFT, .c:273-282): frame t sees B[HALF t .. HALF t + N) of B = [inbuf tail | new samples]
@@ -529,12 +488,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
     if (tid < 15) segc[tid] = P.seg[tid / 5][tid % 5].a_const;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      v[j].r = s[j].x * hw[j].x;
-      v[j].i = s[j].y * hw[j].y;
+      v[j] = s[j] * hw[j];
     }
     __syncthreads();  // the twiddle tables are staged (every wave is waiting for its samples here anyway)
     BT8_STAMP(1)
-    wave_fft512<false>(v, row, twl, tw, lane, xt);
+    wave_fft512<false>(v, tile, twl, tw, lane, xt);
   }
   BT8_STAMP(2)
 #pragma unroll
@@ -593,7 +551,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
 #pragma unroll
       for (int r = 0; r < 8; ++r) z[r] = col[r * ROW];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) pw[r] = z[r].r * z[r].r + z[r].i * z[r].i;
+      for (int r = 0; r < 8; ++r) {
+        const f32x2 zz = z[r] * z[r];
+        pw[r] = zz.x + zz.y;
+      }
       BT8_STAMP(12)
       const bool segfirst = (u & (FF - 1)) == 0;
       const int lastlane = (lane | (FF - 1)) << 2;
@@ -637,8 +598,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
         // the block of row r ends at row r | (TT - 1): 7 (T = 0), 3 or 7 (T = 1), r | 1 (T = 2)
         const float gpair = r < 2 ? g1 : r < 4 ? g3 : r < 6 ? g5 : g7;
         const float a = T == 2 ? gpair : (T == 1 && r < 4) ? g3 : g7;
-        const float tr = z[r].r * a, ti = z[r].i * a;
-        wn[r] = tr * tr + ti * ti;
+        f32x2 th = z[r] * a;
+        th = th * th;
+        wn[r] = th.x + th.y;
         den[r] = wn[r] + P.wiener_c;
         wmin = r == 0 ? wn[r] : fminf(wmin, wn[r]);
         wmax = r == 0 ? wn[r] : fmaxf(wmax, wn[r]);
@@ -655,13 +617,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
           gw.x = wn[r] / den[r];
           gw.y = wn[r + 1] / den[r + 1];
         }
-        cpx o;
-        o.r = z[r].r * gw.x;
-        o.i = z[r].i * gw.x;
-        col[r * ROW] = o;
-        o.r = z[r + 1].r * gw.y;
-        o.i = z[r + 1].i * gw.y;
-        col[(r + 1) * ROW] = o;
+        col[r * ROW] = z[r] * gw.x;
+        col[(r + 1) * ROW] = z[r + 1] * gw.y;
       }
     } else {
       // DC column and the bins past the last whole macro-column (.c:501-506, 518-532); the Nyquist bin
@@ -671,20 +628,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const cpx z = coef[t * ROW + colx];
-        sum += z.r * z.r + z.i * z.i;
+        sum += z.x * z.x + z.y * z.y;
       }
       float a = 1 - P.dc_const / sum;
       if (a < 0) a = 0;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const cpx z = coef[t * ROW + colx];
-        const float tr = z.r * a, ti = z.i * a;
+        const float tr = z.x * a, ti = z.y * a;
         float wn = tr * tr + ti * ti;
         wn = wn / (wn + P.wiener_c);
-        cpx o;
-        o.r = z.r * wn;
-        o.i = z.i * wn;
-        coef[t * ROW + colx] = o;
+        coef[t * ROW + colx] = z * wn;
       }
     }
   }
@@ -705,7 +659,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   // (blockThreshold_inverse_STFT, .c:284-300)
   wave_merge_inverse(v, row, spi, lane);
   wave_lds_fence();
-  wave_fft512<true>(v, row, twl, tw, lane, xt);
+  wave_fft512<true>(v, tile, twl, tw, lane, xt);
   BT8_STAMP(9)
   const float inv_n = 1.0f / (float)N;  // N is a power of two: x * (1/N) == x / N exactly
   cpx* ola = reinterpret_cast<cpx*>(sq);  // [frame][256]: second halves (samples 512..1023) of frames 0..6
@@ -713,9 +667,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   // (barrier 3 above: every wave is done with the block gains that share the table)
 #pragma unroll
   for (int j = 4; j < 8; ++j) {
-    cpx t;
-    t.r = v[j].r * inv_n;
-    t.i = v[j].i * inv_n;
+    const cpx t = v[j] * inv_n;
     if (wave < 7) ola[wave * 256 + lane + 64 * (j - 4)] = t;
     v[j] = t;
   }
@@ -728,20 +680,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
       acc = tail[j];
     } else {
       const cpx pr = ola[(wave - 1) * 256 + p];
-      acc.x = 0.0f + pr.r;
-      acc.y = 0.0f + pr.i;
+      acc = f32x2{0.0f, 0.0f} + pr;
     }
-    acc.x += v[j].r * inv_n;
-    acc.y += v[j].i * inv_n;
+    acc = acc + v[j] * inv_n;
     *reinterpret_cast<f32x2*>(y + HALF * wave + 2 * p) = acc;
   }
   if (wave == 7) {
 #pragma unroll
     for (int j = 4; j < 8; ++j) {
-      f32x2 t;
-      t.x = 0.0f + v[j].r;
-      t.y = 0.0f + v[j].i;
-      *reinterpret_cast<f32x2*>(st + kOffOutTail + 2 * (lane + 64 * (j - 4))) = t;
+      *reinterpret_cast<f32x2*>(st + kOffOutTail + 2 * (lane + 64 * (j - 4))) = f32x2{0.0f, 0.0f} + v[j];
     }
   }
   BT8_STAMP(10)
@@ -750,20 +697,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
 // kiss_fftr / kiss_fftri seam for N = 1024 through the same wave routines: one wave per row.
 __global__ __launch_bounds__(64) void bt_fftr8_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       int inverse, const BtTables* __restrict__ Tb) {
-  __shared__ __align__(16) cpx row[ROW];
+  __shared__ __align__(256) cpx row[ROW];
   __shared__ __align__(16) cpx twl[kTwLds];
   const int lane = threadIdx.x, r = blockIdx.x;
   const cpx* tw = reinterpret_cast<const cpx*>(Tb->tw1024_f);
   const cpx* sup = reinterpret_cast<const cpx*>(Tb->sup1024_f);
   for (int k = lane; k < kTwLds; k += 64) twl[k] = tw[k];
   wave_lds_fence();
-  const XTerms xt = exchange_terms(lane);
+  const XTerms xt = exchange_terms(Tb, lane, 0);
+  cpx* tile = row;
   cpx v[8];
   if (!inverse) {
     const cpx* xin = reinterpret_cast<const cpx*>(src + (size_t)r * N);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = xin[lane + la_input(j)];
-    wave_fft512<false>(v, row, twl, tw, lane, xt);
+    wave_fft512<false>(v, tile, twl, tw, lane, xt);
 #pragma unroll
     for (int j = 0; j < 8; ++j) row[lane + 64 * j] = v[j];
     wave_lds_fence();
@@ -783,7 +731,7 @@ __global__ __launch_bounds__(64) void bt_fftr8_kernel(const float* __restrict__ 
     for (int j = 0; j < 8; ++j) spi[j] = sup[merge_sup_index(lane, j)];
     wave_merge_inverse(v, row, spi, lane);
     wave_lds_fence();
-    wave_fft512<true>(v, row, twl, tw, lane, xt);
+    wave_fft512<true>(v, tile, twl, tw, lane, xt);
     cpx* o = reinterpret_cast<cpx*>(dst + (size_t)r * N);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[lane + 64 * j] = v[j];

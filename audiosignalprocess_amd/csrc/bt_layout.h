@@ -1,6 +1,12 @@
-// bt_layout.h -- device-side layout shared by bt_kernels.hip and bt_api.hip.
+// bt_layout.h -- device-side layout shared by bt_kernels.hip, bt_kernels8.hip and bt_api.hip.
 #pragma once
 #include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define BT_HD __host__ __device__
+#else
+#define BT_HD
+#endif
 
 namespace aspbt {
 
@@ -33,6 +39,53 @@ struct BtTables {
   float sup256_f[2 * 64], sup256_i[2 * 64];      // kiss_fftr super twiddles (kiss_fftr.c:57-63)
   float sup1024_f[2 * 256], sup1024_i[2 * 256];
   BtSize s256, s1024;
+  // bt_kernels8.hip: byte offset (8 * swizzled slot) of a lane's part of the exchange addresses,
+  // [2 x]: source layout of exchange x + 1, [2 x + 1]: its destination layout
+  uint16_t xterm[6][64];
 };
+
+// ---------------------------------------------------------------- register layouts of the FFT stages of bt_kernels8.hip
+// A position p (9 bits) of the in-place kiss_fft work array lives in lane `lane`, register j of a
+// layout: reg[b] / lane[b] name the position bit held by register-index bit b / lane bit b.
+struct Lay {
+  int reg[3];
+  int lane[6];
+};
+constexpr Lay LA = {{0, 1, 2}, {7, 8, 5, 6, 3, 4}};  // after the loads: lane = k0 + 4 k1 + 16 k2 of n
+constexpr Lay LB = {{8, 3, 4}, {0, 1, 2, 5, 6, 7}};  // radix-4 stage m = 8 (position bits 3, 4 in registers)
+constexpr Lay LC = {{8, 5, 6}, {0, 1, 2, 3, 4, 7}};  // m = 32
+constexpr Lay LD = {{6, 7, 8}, {0, 1, 2, 3, 4, 5}};  // m = 128; natural order: p = lane + 64 j
+// XOR swizzles of the three exchanges (index bit b = parity(p & rows[b]) for b < 5, bits 5..8 kept):
+// found by search so that the ds_write_b64 of the source layout (16-lane groups, 16 8-byte banks) and
+// the ds_read_b64 of the destination layout (32-lane groups, 32 8-byte banks) are both conflict-free.
+struct Swz {
+  int rows[5];
+};
+constexpr Swz S1 = {{257, 322, 396, 40, 80}};
+constexpr Swz S2 = {{129, 34, 4, 56, 16}};
+constexpr Swz S3 = {{17, 66, 12, 264, 16}};
+
+BT_HD constexpr int pos_reg(const Lay& L, int j) {
+  int p = 0;
+  for (int b = 0; b < 3; ++b) p |= ((j >> b) & 1) << L.reg[b];
+  return p;
+}
+BT_HD constexpr int pos_lane(const Lay& L, int lane) {
+  int p = 0;
+  for (int b = 0; b < 6; ++b) p |= ((lane >> b) & 1) << L.lane[b];
+  return p;
+}
+BT_HD constexpr int parity9(int x) {
+  x ^= x >> 8;
+  x ^= x >> 4;
+  x ^= x >> 2;
+  x ^= x >> 1;
+  return x & 1;
+}
+BT_HD constexpr int swz(const Swz& S, int p) {
+  int r = p & ~31;
+  for (int b = 0; b < 5; ++b) r |= parity9(p & S.rows[b]) << b;
+  return r;
+}
 
 }  // namespace aspbt
