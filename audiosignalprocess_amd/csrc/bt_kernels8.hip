@@ -335,10 +335,14 @@ template <int NT>
 __device__ __forceinline__ void sure_terms(float (&x)[NT], float temp, float size_blk, float thr,
                                            float two_size) {
   float emin = x[0], emax = x[0];
+  if constexpr (NT > 1) {
+    emin = fminf(x[0], x[1]);
+    emax = fmaxf(x[0], x[1]);
 #pragma unroll
-  for (int q = 1; q < NT; ++q) {
-    emin = fminf(emin, x[q]);
-    emax = fmaxf(emax, x[q]);
+    for (int q = 2; q < NT; q += 2) {
+      emin = __builtin_fminf(emin, __builtin_fminf(x[q], x[q + 1]));  // v_min3_f32
+      emax = __builtin_fmaxf(emax, __builtin_fmaxf(x[q], x[q + 1]));
+    }
   }
   if (__builtin_expect(emin >= 1e-18f && emax <= 1e18f, 1)) {
     if constexpr (NT == 1) {
@@ -350,7 +354,7 @@ __device__ __forceinline__ void sure_terms(float (&x)[NT], float temp, float siz
         const f32x2 e2 = {x[q], x[q + 1]};
         const f32x2 q2 = fdiv2_lean(temp2, e2);
         const f32x2 g2 = {(float)(e2.x > thr), (float)(e2.y > thr)};
-        const f32x2 l2 = {(float)(e2.x <= thr), (float)(e2.y <= thr)};
+        const f32x2 l2 = f32x2{1.0f, 1.0f} - g2;  // (float)(e <= thr) for every e that is not a NaN (a NaN term is a NaN either way)
         const f32x2 t2 = size2 + q2 * g2 + (e2 - two2) * l2;
         x[q] = t2.x;
         x[q + 1] = t2.y;
@@ -513,9 +517,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
     case 3: sure_seg<2, 2>(sq, sure, &P.seg[2][2], lane); sure_seg<0, 0>(sq, sure, &P.seg[0][0], lane); break;
     case 4: sure_seg<1, 3>(sq, sure, &P.seg[1][3], lane); sure_seg<2, 1>(sq, sure, &P.seg[2][1], lane); break;
     case 5: sure_seg<0, 4>(sq, sure, &P.seg[0][4], lane); sure_seg<1, 2>(sq, sure, &P.seg[1][2], lane); break;
-    case 6: sure_seg<0, 3>(sq, sure, &P.seg[0][3], lane); sure_seg<0, 2>(sq, sure, &P.seg[0][2], lane);
-            sure_seg<1, 1>(sq, sure, &P.seg[1][1], lane); break;
-    default: sure_seg<2, 0>(sq, sure, &P.seg[2][0], lane); break;
+    case 6: sure_seg<0, 3>(sq, sure, &P.seg[0][3], lane); sure_seg<0, 2>(sq, sure, &P.seg[0][2], lane); break;
+    default: sure_seg<2, 0>(sq, sure, &P.seg[2][0], lane); sure_seg<1, 1>(sq, sure, &P.seg[1][1], lane); break;
   }
   BT8_STAMP(5)
   __syncthreads();
