@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ sta
   __shared__ SharedTables T;
   __shared__ float lds[4 * kLdsWave];
   stage_tables(T, G);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: the stream's state block and LDS region get scalar bases
   const int stream = blockIdx.x * 4 + wave;
   if (stream >= num_streams) return;
   float* wl = lds + wave * kLdsWave;
@@ -511,6 +512,25 @@ __device__ __attribute__((noinline)) void metrics_block(float* __restrict__ met,
 // One ProcessBlock + NonLinearProcessing for this wave's stream.  kMetrics: metricsMode builds of
 // the kernel also gather the echo metrics (a separate instantiation keeps the plain one's
 // register allocation).
+// The stream's state block through a buffer resource: one descriptor in SGPRs, the row offset as the
+// scalar offset, the lane's dword as the only vector offset.  (With flat global addressing the compiler
+// kept a 64-bit VGPR address per state row alive across the whole block: 100 registers.)
+struct StateBuf {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ StateBuf state_buf(float* st) {
+  StateBuf b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc(st, 0, kStateDwords * 4, 0x00020000);
+  return b;
+}
+// dword `uni + vec` of the block: uni wave-uniform, vec per lane
+__device__ __forceinline__ float sld(const StateBuf& b, int uni, int vec) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, vec * 4, uni * 4, 0));
+}
+__device__ __forceinline__ void sst(const StateBuf& b, int uni, int vec, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, vec * 4, uni * 4, 0);
+}
+
 template <bool kMetrics>
 __device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
                                               const float* __restrict__ far_slot,
@@ -523,7 +543,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #define AEC_STAMP(k) \
   if (stamps != nullptr) stamps[k] = __builtin_amdgcn_s_memtime();
   AEC_STAMP(0)
-  float* rows = st + kOffRows;
+  const StateBuf sb = state_buf(st);
   float* sc = st + kOffScalars;
   int32_t* sci = reinterpret_cast<int32_t*>(sc);
   float* dbuf = wl + kLdsDbuf;
@@ -554,18 +574,18 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   // State rows: trip 0 (bin = lane) goes to HBM, trip 1 (bin 64) to a per-wave LDS copy of the
   // bin-64 column that is gathered once per block and scattered back at its end.
   float* c64 = wl + kLdsC64;
-#define ROW_LD(r) (t_ == 0 ? rows[(r) * kRowS + lane] : c64[r])
+#define ROW_LD(r) (t_ == 0 ? sld(sb, (r) * kRowS, lane) : c64[r])
 #define ROW_ST(r, v)                         \
   do {                                       \
     if (t_ == 0) {                           \
-      rows[(r) * kRowS + lane] = (v);        \
+      sst(sb, (r) * kRowS, lane, (v));       \
     } else {                                 \
       c64[r] = (v);                          \
     }                                        \
   } while (0)
   // loads return in order: the few the first FFT round waits for go first
-  const float c64_a = st[kOffC64 + lane];
-  const float c64_b = lane < R_COUNT - 64 ? st[kOffC64 + 64 + lane] : 0.f;
+  const float c64_a = sld(sb, kOffC64, lane);
+  const float c64_b = lane < R_COUNT - 64 ? sld(sb, kOffC64 + 64, lane) : 0.f;
   float fs_lane[4], fs_64[4];  // this block's far spectra (plain re/im, windowed re/im)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -573,31 +593,67 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     fs_64[k] = far_slot[k * kRow + 64];
   }
   // ---- near block (aec_core.c:1114-1124) and the far spectra of this block (:1137, 888-891)
-  const float ne = st[kOffNearFr + ring_idx(op.near_rpos, lane, kFrBufLen)];
-  dbuf[lane] = st[kOffDBuf + lane];
+  const float ne = sld(sb, kOffNearFr, ring_idx(op.near_rpos, lane, kFrBufLen));
+  dbuf[lane] = sld(sb, kOffDBuf, lane);
   dbuf[64 + lane] = ne;
-  ebuf[lane] = st[kOffEBuf + lane];
+  ebuf[lane] = sld(sb, kOffEBuf, lane);
   c64[lane] = c64_a;
   if (lane < R_COUNT - 64) c64[64 + lane] = c64_b;
-  // issued after the few loads the first FFT needs, consumed much later
-  // the lane's own bins of the far-spectrum history and of the filter stay in registers from
-  // here to the end of the filter update (logical partition order)
+  // The lane's bins of the far-spectrum history and of the filter, for FilterFar only (logical partition
+  // order; partition 0 is this block's spectrum).  FilterFar depends on nothing but these, so it runs
+  // ahead of the near FFT and the 46 registers are free again before the ten FFT rounds of the block;
+  // FilterAdaptation streams its partitions again, four at a time.
   float xr[kNumPart], xi[kNumPart], wr[kNumPart], wi[kNumPart];
 #pragma unroll
   for (int i = 0; i < kNumPart; ++i) {
     int px = i + op.xf_pos;
     if (px >= kNumPart) px -= kNumPart;
-    xr[i] = rows[(R_XF_RE + px) * kRowS + lane];  // i = 0 is replaced by this block's spectrum
-    xi[i] = rows[(R_XF_IM + px) * kRowS + lane];
-    wr[i] = rows[(R_WF_RE + i) * kRowS + lane];
-    wi[i] = rows[(R_WF_IM + i) * kRowS + lane];
+    if (i > 0) {
+      xr[i] = sld(sb, ((R_XF_RE + px)) * kRowS, lane);
+      xi[i] = sld(sb, ((R_XF_IM + px)) * kRowS, lane);
+    }
+    wr[i] = sld(sb, ((R_WF_RE + i)) * kRowS, lane);
+    wi[i] = sld(sb, ((R_WF_IM + i)) * kRowS, lane);
   }
 
   // rows of the power / noise-floor update and the overlap-add tail: in flight during the first FFT
-  const float p_xpow = rows[R_XPOW * kRowS + lane], p_dpow = rows[R_DPOW * kRowS + lane];
-  const float p_dmin = rows[R_DMINPOW * kRowS + lane], p_dinit = rows[R_DINITMINPOW * kRowS + lane];
-  const float p_outbuf = st[kOffOutBuf + lane];
+  const float p_xpow = sld(sb, (R_XPOW) * kRowS, lane), p_dpow = sld(sb, (R_DPOW) * kRowS, lane);
+  const float p_dmin = sld(sb, (R_DMINPOW) * kRowS, lane), p_dinit = sld(sb, (R_DINITMINPOW) * kRowS, lane);
+  const float p_outbuf = sld(sb, kOffOutBuf, lane);
   wave_fence();
+
+  // the far spectra of this block (aec_core.c:1137, 888-891)
+  xr[0] = fs_lane[0];
+  xi[0] = fs_lane[1];
+  BINS_2TRIPS {
+    XFR[bin] = t_ == 0 ? fs_lane[0] : fs_64[0];
+    XFI[bin] = t_ == 0 ? fs_lane[1] : fs_64[1];
+    const float xwr = t_ == 0 ? fs_lane[2] : fs_64[2], xwi = t_ == 0 ? fs_lane[3] : fs_64[3];
+    XWR[bin] = xwr;
+    XWI[bin] = xwi;
+    ROW_ST((R_XFW + 2 * op.xfw_head), xwr);
+    ROW_ST((R_XFW + 2 * op.xfw_head + 1), xwi);
+  }
+  wave_fence();
+  // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
+  BINS_2TRIPS {
+    float yr = 0.f, yi = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNumPart; ++i) {
+      int px = i + op.xf_pos;
+      if (px >= kNumPart) px -= kNumPart;
+      const float ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
+      const float ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
+      const float br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
+      const float bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
+      yr += ar * br - ai * bi;
+      yi += ar * bi + ai * br;
+    }
+    YFR[bin] = yr;
+    YFI[bin] = yi;
+  }
+  wave_fence();
+
 
   AEC_STAMP(1)
   // ---- near fft (aec_core.c:1140-1141)
@@ -613,18 +669,6 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   rdft_fwd_quad(wl, lane, T);
   unpack_tile(wl, 0, DFR, DFI, lane);
   unpack_tile(wl, 1, DWR, DWI, lane);
-  // the far spectra of this block (their loads were in flight during the transform)
-  xr[0] = fs_lane[0];
-  xi[0] = fs_lane[1];
-  BINS_2TRIPS {
-    XFR[bin] = t_ == 0 ? fs_lane[0] : fs_64[0];
-    XFI[bin] = t_ == 0 ? fs_lane[1] : fs_64[1];
-    const float wr = t_ == 0 ? fs_lane[2] : fs_64[2], wi = t_ == 0 ? fs_lane[3] : fs_64[3];
-    XWR[bin] = wr;
-    XWI[bin] = wi;
-    ROW_ST((R_XFW + 2 * op.xfw_head), wr);
-    ROW_ST((R_XFW + 2 * op.xfw_head + 1), wi);
-  }
   wave_fence();
 
   AEC_STAMP(2)
@@ -674,25 +718,6 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   if (noise_init) noiseEstCtr++;
 
   AEC_STAMP(3)
-  // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
-  BINS_2TRIPS {
-    float yr = 0.f, yi = 0.f;
-#pragma unroll
-    for (int i = 0; i < kNumPart; ++i) {
-      int px = i + op.xf_pos;
-      if (px >= kNumPart) px -= kNumPart;
-      const float ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
-      const float ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
-      const float br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
-      const float bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
-      yr += ar * br - ai * bi;
-      yi += ar * bi + ai * br;
-    }
-    YFR[bin] = yr;
-    YFI[bin] = yi;
-  }
-  wave_fence();
-
   AEC_STAMP(4)
   // ---- echo estimate and error (aec_core.c:1222-1238)
   {
@@ -751,18 +776,37 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 
   AEC_STAMP(7)
   // the PSD rows of the NLP: in flight during the six FFT rounds of the filter update
-  const float q_sd = rows[R_SD * kRowS + lane], q_se = rows[R_SE * kRowS + lane];
-  const float q_sx = rows[R_SX * kRowS + lane];
-  const float q_sde_r = rows[R_SDE_RE * kRowS + lane], q_sde_i = rows[R_SDE_IM * kRowS + lane];
-  const float q_sxd_r = rows[R_SXD_RE * kRowS + lane], q_sxd_i = rows[R_SXD_IM * kRowS + lane];
-  // ---- FilterAdaptation (aec_core.c:221-269): four partitions per round
+  const float q_sd = sld(sb, (R_SD) * kRowS, lane), q_se = sld(sb, (R_SE) * kRowS, lane);
+  const float q_sx = sld(sb, (R_SX) * kRowS, lane);
+  const float q_sde_r = sld(sb, (R_SDE_RE) * kRowS, lane), q_sde_i = sld(sb, (R_SDE_IM) * kRowS, lane);
+  const float q_sxd_r = sld(sb, (R_SXD_RE) * kRowS, lane), q_sxd_i = sld(sb, (R_SXD_IM) * kRowS, lane);
+  // ---- FilterAdaptation (aec_core.c:221-269): four partitions per round, streamed: a group's far
+  // spectra and filter rows are requested one group ahead (partition 0 = this block's spectrum, still in
+  // registers), the updated filter rows go straight back
+  float gx[2][8], gw[2][8];  // [buffer][re0 im0 re1 im1 ...] of a group's four partitions
+#define AEC_LOAD_GROUP(buf, g_)                                                     \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                   \
+    const int i_ = 4 * (g_) + k;                                                    \
+    int px_ = i_ + op.xf_pos;                                                       \
+    if (px_ >= kNumPart) px_ -= kNumPart;                                           \
+    gx[buf][2 * k] = i_ == 0 ? fs_lane[0] : sld(sb, ((R_XF_RE + px_)) * kRowS, lane);   \
+    gx[buf][2 * k + 1] = i_ == 0 ? fs_lane[1] : sld(sb, ((R_XF_IM + px_)) * kRowS, lane); \
+    gw[buf][2 * k] = sld(sb, ((R_WF_RE + i_)) * kRowS, lane);                           \
+    gw[buf][2 * k + 1] = sld(sb, ((R_WF_IM + i_)) * kRowS, lane);                       \
+  }
+  AEC_LOAD_GROUP(0, 0)
+#pragma unroll
   for (int g = 0; g < kNumPart / 4; ++g) {
+    const int cb = g & 1;
+    if (g + 1 < kNumPart / 4) {
+      AEC_LOAD_GROUP((cb ^ 1), (g + 1))
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = 4 * g + k;
       int px = i + op.xf_pos;
       if (px >= kNumPart) px -= kNumPart;
-      const float ar = xr[i], ai = -xi[i];
+      const float ar = gx[cb][2 * k], ai = -gx[cb][2 * k + 1];
       float2 v;
       v.x = ar * EFR[lane] - ai * EFI[lane];
       v.y = ar * EFI[lane] + ai * EFR[lane];
@@ -790,18 +834,16 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       const int i = 4 * g + k;
       const float2 v = tile(wl, k)[lane];
       // lane 0 carries (fft[0], fft[1]) = updates of the real parts of bins 0 and 64
-      wr[i] += v.x;
-      const float wi_new = wi[i] + v.y;
-      wi[i] = lane == 0 ? wi[i] : wi_new;
+      const float wr_new = gw[cb][2 * k] + v.x;
+      const float wi_sum = gw[cb][2 * k + 1] + v.y;
+      const float wi_new = lane == 0 ? gw[cb][2 * k + 1] : wi_sum;
       if (lane == 0) c64[R_WF_RE + i] += v.y;
+      sst(sb, ((R_WF_RE + i)) * kRowS, lane, wr_new);
+      sst(sb, ((R_WF_IM + i)) * kRowS, lane, wi_new);
     }
     wave_fence();
   }
-#pragma unroll
-  for (int i = 0; i < kNumPart; ++i) {
-    rows[(R_WF_RE + i) * kRowS + lane] = wr[i];
-    rows[(R_WF_IM + i) * kRowS + lane] = wi[i];
-  }
+#undef AEC_LOAD_GROUP
 
   AEC_STAMP(8)
   // =================================================== NonLinearProcessing (aec_core.c:852-1082)
@@ -1051,16 +1093,16 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     float a = tf[lane] * scale;
     a = a * T.hann[lane] + p_outbuf;
     const float b = tf[64 + lane] * scale;
-    st[kOffOutBuf + lane] = b * T.hann[64 - lane];
+    sst(sb, kOffOutBuf, lane, b * T.hann[64 - lane]);
     const float o = a > 32767.f ? 32767.f : (a < -32768.f ? -32768.f : a);
-    st[kOffOutFr + ring_idx(op.out_wpos, lane, kFrBufLen)] = o;
+    sst(sb, kOffOutFr, ring_idx(op.out_wpos, lane, kFrBufLen), o);
   }
   if (num_high > 0) high_band_block(st, wl, T, op.near_rpos, op.out_wpos, lane);
   if constexpr (kMetrics) metrics_block(met, wl, lane, echoState);
   AEC_STAMP(14)
   // ---- carry the block (aec_core.c:1069-1081; the xfwBuf shift is the host's circular head)
-  st[kOffDBuf + lane] = ne;
-  st[kOffEBuf + lane] = e;
+  sst(sb, kOffDBuf, lane, ne);
+  sst(sb, kOffEBuf, lane, e);
   if (lane == 0) {
     sc[S_HNLFBMIN] = hNlFbMin;
     sc[S_HNLFBLOCALMIN] = hNlFbLocalMin;
@@ -1078,7 +1120,8 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     reinterpret_cast<uint32_t*>(sc)[S_SEED] = new_seed;
   }
   wave_fence();
-  for (int r = lane; r < R_COUNT; r += 64) st[kOffC64 + r] = c64[r];
+  sst(sb, kOffC64, lane, c64[lane]);
+  if (lane < R_COUNT - 64) sst(sb, kOffC64 + 64, lane, c64[64 + lane]);
   AEC_STAMP(15)
 #undef AEC_STAMP
 #undef ROW_LD
@@ -1087,8 +1130,11 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 
 // WebRtcAec_ProcessFrames for every stream (running phase): per 80-sample sub-frame append the
 // near samples, run the scheduled blocks, emit 80 output samples.
+#ifndef AEC_WAVES
+#define AEC_WAVES 4  // waves per SIMD the register allocation aims at (4: every stream of a 4096-stream batch is resident at once)
+#endif
 template <bool kMetrics>
-__global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__ state,
+__global__ __launch_bounds__(256, AEC_WAVES) void aec_process_kernel(float* __restrict__ state,
                                                           float* far_ring,
                                                           const AecTables* __restrict__ G,
                                                           const float* __restrict__ nearend,
@@ -1102,7 +1148,8 @@ __global__ __launch_bounds__(256, 2) void aec_process_kernel(float* __restrict__
   constexpr int kWaveLds = kMetrics ? kLdsWaveMet : kLdsWave;
   __shared__ float lds[4 * kWaveLds];
   stage_tables(T, G);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: the stream's state block and LDS region get scalar bases
   const int stream = blockIdx.x * 4 + wave;
   if (stream >= num_streams) return;
   float* wl = lds + wave * kWaveLds;
@@ -1163,7 +1210,8 @@ __global__ __launch_bounds__(256) void aec_rdft128_kernel(const float* __restric
   __shared__ SharedTables T;
   __shared__ float lds[4 * kLdsWave];
   stage_tables(T, G);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: the stream's state block and LDS region get scalar bases
   float* wl = lds + wave * kLdsWave;
   const int row0 = (blockIdx.x * 4 + wave) * 4;
   for (int f = 0; f < 4; ++f) {
