@@ -24,8 +24,10 @@
 
 #include "aec_layout.h"
 #include "ns_device.h"  // lean fp64 pow / sincos shared with the NS kernels
+#include "pk_f32.h"     // complex arithmetic as packed f32
 
 using namespace aspaec;
+using namespace asppk;
 
 namespace {
 
@@ -58,14 +60,14 @@ static_assert(kNumPart * kLRow <= kLdsRows + 9 * kLRow, "partition-energy rows o
 
 struct SharedTables {
   double exp2_64[64];
+  float2 btw[16][4];  // twiddles of radix-4 block B: w1, w2, w3 (cft1st_128 / cftmdl_128), [3] unused
   float w[64], wk3a[16], wk3b[16], hann[68], weight[68], odrive[68];
   uint32_t lcg_a[64], lcg_c[64];
 };
 
 // ---------------------------------------------------------------- butterflies
-struct Tw {
-  float w1r, w1i, w2r, w2i, w3r, w3i;
-};
+__device__ __forceinline__ f32x2 pk(float2 v) { return f32x2{v.x, v.y}; }
+__device__ __forceinline__ float2 unpk(f32x2 v) { return make_float2(v.x, v.y); }
 
 // Radix-4 butterfly of cft1st_128 / cftmdl_128 for block B of a pass (aec_rdft.c:201-444):
 // B = 0 no twiddles, B = 1 the w[2] block, B = 2u / 2u + 1 general.
@@ -73,73 +75,50 @@ __device__ __forceinline__ void bfly(float2& e0, float2& e1, float2& e2, float2&
                                      const SharedTables& T) {
   // Branch-free: the lanes of a pass hold different blocks B, so the three forms of the reference
   // (no twiddles, the w[2] block, general) would otherwise run one after the other under divergent
-  // branches.  The general form is evaluated for every lane (B = 0 reads w[0..1] = (1, 0): harmless),
-  // the plain form is its own intermediate values, the w[2] form costs ten more operations; the lane
-  // then keeps the form of its block.  Every kept value comes from the reference's own operations.
-  const float x0r = e0.x + e1.x, x0i = e0.y + e1.y;
-  const float x1r = e0.x - e1.x, x1i = e0.y - e1.y;
-  const float x2r = e2.x + e3.x, x2i = e2.y + e3.y;
-  const float x3r = e2.x - e3.x, x3i = e2.y - e3.y;
-  e0.x = x0r + x2r;
-  e0.y = x0i + x2i;
-  const int odd = B & 1;
-  const int k1 = 2 * (B >> 1), k2 = 2 * k1;
-  const float wk2r = T.w[k1], wk2i = T.w[k1 + 1];
-  const float w1r = T.w[k2 + 2 * odd], w1i = T.w[k2 + 2 * odd + 1];
-  const float w3r = T.wk3a[k1 + 16 * odd], w3i = T.wk3a[k1 + 16 * odd + 1];  // wk3b follows wk3a
-  const float w2r = odd ? -wk2i : wk2r, w2i = odd ? wk2r : wk2i;
+  // branches.  The general form is evaluated for every lane (B = 0 multiplies by (1, 0): harmless),
+  // the plain form is its own intermediate values, the w[2] form costs seven more packed operations;
+  // the lane then keeps the form of its block.  Every kept value comes from the reference's own
+  // operations (complex values as register pairs, packed f32: pk_f32.h).
+  const f32x2 a0 = pk(e0), a1 = pk(e1), a2 = pk(e2), a3 = pk(e3);
+  const f32x2 x0 = a0 + a1, x1 = a0 - a1, x2 = a2 + a3, x3 = a2 - a3;
+  e0 = unpk(x0 + x2);
+  const f32x2 w1 = pk(T.btw[B][0]), w2 = pk(T.btw[B][1]), w3 = pk(T.btw[B][2]);
   // plain (B == 0) = the general form's operands
-  const float d0r = x0r - x2r, d0i = x0i - x2i;
-  const float y1r = x1r - x3i, y1i = x1i + x3r;
-  const float y3r = x1r + x3i, y3i = x1i - x3r;
-  // general
-  const float g2r = w2r * d0r - w2i * d0i, g2i = w2r * d0i + w2i * d0r;
-  const float g1r = w1r * y1r - w1i * y1i, g1i = w1r * y1i + w1i * y1r;
-  const float g3r = w3r * y3r - w3i * y3i, g3i = w3r * y3i + w3i * y3r;
+  const f32x2 d0 = x0 - x2;
+  const f32x2 y1 = add_swap_sub_lo(x1, x3);  // {x1r - x3i, x1i + x3r}
+  const f32x2 y3 = add_swap_sub_hi(x1, x3);  // {x1r + x3i, x1i - x3r}
+  // general: {wr vr - wi vi, wr vi + wi vr}
+  const f32x2 g2 = cmul<false>(w2, d0), g1 = cmul<false>(w1, y1), g3 = cmul<false>(w3, y3);
   // the w[2] block (B == 1)
   const float ws = T.w[2];
-  const float s2r = x2i - x0i, s2i = d0r;
-  const float s1r = ws * (y1r - y1i), s1i = ws * (y1r + y1i);
-  const float zr = x3i + x1r, zi = x3r - x1i;
-  const float s3r = ws * (zi - zr), s3i = ws * (zi + zr);
+  const f32x2 s2 = {x2.y - x0.y, d0.x};
+  const f32x2 s1 = diff_sum(y1) * ws;             // ws * {y1r - y1i, y1r + y1i}
+  const f32x2 z = swap0_add_sub_hi(x3, x1);       // {x3i + x1r, x3r - x1i}
+  const f32x2 s3 = rdiff_sum(z) * ws;             // ws * {zi - zr, zi + zr}
   const bool plain = B == 0, diag = B == 1;
-  e2.x = plain ? d0r : (diag ? s2r : g2r);
-  e2.y = plain ? d0i : (diag ? s2i : g2i);
-  e1.x = plain ? y1r : (diag ? s1r : g1r);
-  e1.y = plain ? y1i : (diag ? s1i : g1i);
-  e3.x = plain ? y3r : (diag ? s3r : g3r);
-  e3.y = plain ? y3i : (diag ? s3i : g3i);
+  e2 = unpk(plain ? d0 : (diag ? s2 : g2));
+  e1 = unpk(plain ? y1 : (diag ? s1 : g1));
+  e3 = unpk(plain ? y3 : (diag ? s3 : g3));
 }
 
 // Last pass of cftfsub_128 / cftbsub_128 (aec_rdft.c:446-507).
 __device__ __forceinline__ void bfly_last(float2& e0, float2& e1, float2& e2, float2& e3,
                                           bool backward) {
+  const f32x2 a0 = pk(e0), a1 = pk(e1), a2 = pk(e2), a3 = pk(e3);
+  const f32x2 x2 = a2 + a3, x3 = a2 - a3;
   if (!backward) {
-    const float x0r = e0.x + e1.x, x0i = e0.y + e1.y;
-    const float x1r = e0.x - e1.x, x1i = e0.y - e1.y;
-    const float x2r = e2.x + e3.x, x2i = e2.y + e3.y;
-    const float x3r = e2.x - e3.x, x3i = e2.y - e3.y;
-    e0.x = x0r + x2r;
-    e0.y = x0i + x2i;
-    e2.x = x0r - x2r;
-    e2.y = x0i - x2i;
-    e1.x = x1r - x3i;
-    e1.y = x1i + x3r;
-    e3.x = x1r + x3i;
-    e3.y = x1i - x3r;
+    const f32x2 x0 = a0 + a1, x1 = a0 - a1;
+    e0 = unpk(x0 + x2);
+    e2 = unpk(x0 - x2);
+    e1 = unpk(add_swap_sub_lo(x1, x3));  // {x1r - x3i, x1i + x3r}
+    e3 = unpk(add_swap_sub_hi(x1, x3));  // {x1r + x3i, x1i - x3r}
   } else {
-    const float x0r = e0.x + e1.x, x0i = -e0.y - e1.y;
-    const float x1r = e0.x - e1.x, x1i = -e0.y + e1.y;
-    const float x2r = e2.x + e3.x, x2i = e2.y + e3.y;
-    const float x3r = e2.x - e3.x, x3i = e2.y - e3.y;
-    e0.x = x0r + x2r;
-    e0.y = x0i - x2i;
-    e2.x = x0r - x2r;
-    e2.y = x0i + x2i;
-    e1.x = x1r - x3i;
-    e1.y = x1i - x3r;
-    e3.x = x1r + x3i;
-    e3.y = x1i + x3r;
+    const f32x2 x0 = add_neg_both_hi(a0, a1);  // {e0r + e1r, -e0i - e1i}
+    const f32x2 x1 = sub_lo_rsub_hi(a0, a1);   // {e0r - e1r, -e0i + e1i}
+    e0 = unpk(add_sub_hi(x0, x2));             // {x0r + x2r, x0i - x2i}
+    e2 = unpk(add_sub_lo(x0, x2));             // {x0r - x2r, x0i + x2i}
+    e1 = unpk(sub_swap(x1, x3));               // {x1r - x3i, x1i - x3r}
+    e3 = unpk(add_swap(x1, x3));               // {x1r + x3i, x1i + x3r}
   }
 }
 
@@ -195,12 +174,12 @@ __device__ __forceinline__ void rdft_fwd_quad(float* wl, int lane, const SharedT
     const float wkr = 0.5f - c[32 - jc], wki = c[jc];
     float2 aj = t[jc], ak = t[k];
     float2 a0 = t[0];
-    const float xr = aj.x - ak.x, xi = aj.y + ak.y;
-    const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
-    aj.x -= yr;
-    aj.y -= yi;
-    ak.x += yr;
-    ak.y -= yi;
+    {
+      const f32x2 x = add_sub_lo(pk(aj), pk(ak));              // {aj.r - ak.r, aj.i + ak.i}
+      const f32x2 y = cmul<false>(f32x2{wkr, wki}, x);          // {wkr xr - wki xi, wkr xi + wki xr}
+      aj = unpk(pk(aj) - y);
+      ak = unpk(add_sub_hi(pk(ak), y));                         // {ak.r + yr, ak.i - yi}
+    }
     const float x0 = a0.x - a0.y;
     a0.x += a0.y;
     a0.y = x0;
@@ -227,12 +206,12 @@ __device__ __forceinline__ void rdft_inv_quad(float* wl, int lane, const SharedT
     const float wkr = 0.5f - c[32 - jc], wki = c[jc];
     float2 aj = t[jc], ak = t[k];
     float2 a0 = t[0], am = t[32];
-    const float xr = aj.x - ak.x, xi = aj.y + ak.y;
-    const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
-    aj.x = aj.x - yr;
-    aj.y = yi - aj.y;
-    ak.x = yr + ak.x;
-    ak.y = yi - ak.y;
+    {
+      const f32x2 x = add_sub_lo(pk(aj), pk(ak));              // {aj.r - ak.r, aj.i + ak.i}
+      const f32x2 y = cmul_conj_w(f32x2{wkr, wki}, x);          // {wkr xr + wki xi, wkr xi - wki xr}
+      aj = unpk(sub_lo_rsub_hi(pk(aj), y));                     // {aj.r - yr, yi - aj.i}
+      ak = unpk(add_sub_hi(y, pk(ak)));                         // {yr + ak.r, yi - ak.i}
+    }
     a0.y = 0.5f * (a0.x - a0.y);
     a0.x -= a0.y;
     a0.y = -a0.y;
@@ -278,6 +257,15 @@ __device__ __forceinline__ void stage_tables(SharedTables& S, const AecTables* _
   for (int i = threadIdx.x; i < 16; i += blockDim.x) {
     S.wk3a[i] = G->wk3a[i];
     S.wk3b[i] = G->wk3b[i];
+    // twiddles of block B = i (aec_rdft.c:201-444): wk2 = w[k1..], wk1 = w[k2 + 2 odd ..], wk3 from the
+    // wk3ri tables; an odd block multiplies by (-wk2i, wk2r)
+    const int odd = i & 1, k1 = 2 * (i >> 1), k2 = 2 * k1;
+    const float wk2r = G->w[k1], wk2i = G->w[k1 + 1];
+    const float* wk3 = odd ? G->wk3b : G->wk3a;
+    S.btw[i][0] = make_float2(G->w[k2 + 2 * odd], G->w[k2 + 2 * odd + 1]);
+    S.btw[i][1] = odd ? make_float2(-wk2i, wk2r) : make_float2(wk2r, wk2i);
+    S.btw[i][2] = make_float2(wk3[k1], wk3[k1 + 1]);
+    S.btw[i][3] = make_float2(0.f, 0.f);
   }
   for (int i = threadIdx.x; i < 68; i += blockDim.x) {
     S.hann[i] = G->hann[i];

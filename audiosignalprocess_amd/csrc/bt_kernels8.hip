@@ -29,12 +29,13 @@
 #include <hip/hip_runtime.h>
 
 #include "bt_layout.h"
+#include "pk_f32.h"
 
 using namespace aspbt;
+using namespace asppk;
 
 namespace {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x2 cpx;  // x = re, y = im: one 64-bit register pair, so complex arithmetic issues as packed f32
 
 constexpr int N = 1024, NC = 512, HALF = 512, NB = 513, NCOL = 31;
@@ -45,50 +46,6 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Packed adds with one half negated or the second operand's halves swapped (VOP3P neg_lo / neg_hi /
-// op_sel modifiers, which the compiler does not form from per-lane negations).  Each half is the IEEE
-// single-precision operation of its scalar spelling, so results are those of the reference's code.
-__device__ __forceinline__ f32x2 add_sub_lo(f32x2 a, f32x2 b) {  // {a.x - b.x, a.y + b.y}
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x2 add_sub_hi(f32x2 a, f32x2 b) {  // {a.x + b.x, a.y - b.y}
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x2 add_neg0_hi(f32x2 a, f32x2 b) {  // {a.x + b.x, -a.y + b.y}
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x2 sub_lo_rsub_hi(f32x2 a, f32x2 b) {  // {a.x - b.x, b.y - a.y}
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x2 add_swap_sub_hi(f32x2 a, f32x2 b) {  // {a.x + b.y, a.y - b.x}
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x2 add_swap_sub_lo(f32x2 a, f32x2 b) {  // {a.x - b.y, a.y + b.x}
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// C_MUL(a, t): {a.r t.r - a.i t.i, a.r t.i + a.i t.r}.  CONJ: by the conjugate of t, as the reference
-// multiplies by its inverse-table entry {t.r, -t.i}: {a.r t.r - a.i (-t.i), a.r (-t.i) + a.i t.r}, i.e.
-// {p1.x + p2.x, -p1.y + p2.y} of the same two products (x - (-y) == x + y and (-x) + y bit for bit).
-template <bool CONJ>
-__device__ __forceinline__ cpx cmul(cpx a, cpx t) {
-  const f32x2 p1 = a.xx * t;     // {a.r t.r, a.r t.i}
-  const f32x2 p2 = a.yy * t.yx;  // {a.i t.i, a.i t.r}
-  return CONJ ? add_neg0_hi(p1, p2) : add_sub_lo(p1, p2);
 }
 
 // The six lane terms (byte offsets inside the wave's row, from the host-built table) with the row's
