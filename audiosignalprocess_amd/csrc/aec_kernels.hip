@@ -42,8 +42,10 @@ __device__ __forceinline__ void wave_fence() {
 }
 
 // ------------------------------------------------------------------ LDS map
-constexpr int kTileStride = 66;                 // float2 per transform tile (64 + 2 pad)
-constexpr int kLdsTile = 0;                     // 4 tiles: 4 * 66 float2 = 528 floats
+constexpr int kTileStride = 80;                 // float2 per transform tile: 64, or 79 in the padded
+                                                // order the passes use between them (ph below); 80 = 16 mod 32 keeps the two tiles of a
+                                                // 32-lane group on opposite halves of the 64 banks
+constexpr int kLdsTile = 0;                     // 4 tiles: 4 * 80 float2 = 640 floats
 constexpr int kLdsRows = 4 * kTileStride * 2;   // per-bin rows of 66 floats
 enum LRow { L_XFR = 0, L_XFI, L_DFR, L_DFI, L_YFR, L_YFI, L_EFR, L_EFI, L_XPOW, L_XWR, L_XWI,
             L_COHDE, L_COHXD, L_HNL, L_T0, L_T1, L_DWR, L_DWI, L_EWR, L_EWI, L_NROWS };
@@ -124,31 +126,40 @@ __device__ __forceinline__ void bfly_last(float2& e0, float2& e1, float2& e2, fl
 
 __device__ __forceinline__ int rev6(int x) { return (int)(__brev((unsigned)x) >> 26); }
 
+// Between the passes an element i sits in slot ph(i) = i + i / 4: the stride-4 writes of the first pass
+// and the stride-4 / stride-16 accesses of the second then spread over the LDS banks (in natural order
+// the first pass's 8-byte writes were 4-way bank conflicts, the second's accesses 2- to 4-way).
+__device__ __forceinline__ constexpr int ph(int i) { return i + (i >> 2); }
+
 // The three radix-4 passes of four transforms at once; t = this lane's tile, b = butterfly.
 __device__ __forceinline__ void cft64_quad(float2* t, int b, bool backward, const SharedTables& T) {
   {  // cft1st_128 on the bit-reversed input (bitrv2_128, aec_rdft.c:124-199)
     const int i0 = 4 * b;
     float2 a0 = t[rev6(i0)], a1 = t[rev6(i0 + 1)], a2 = t[rev6(i0 + 2)], a3 = t[rev6(i0 + 3)];
     bfly(a0, a1, a2, a3, b, T);
-    t[i0] = a0;
-    t[i0 + 1] = a1;
-    t[i0 + 2] = a2;
-    t[i0 + 3] = a3;
+    wave_fence();  // every lane has read its natural-order inputs before the padded order overwrites them
+    const int p0 = 5 * b;  // ph(4 b + k) = 5 b + k
+    t[p0] = a0;
+    t[p0 + 1] = a1;
+    t[p0 + 2] = a2;
+    t[p0 + 3] = a3;
   }
   wave_fence();
-  {  // cftmdl_128, l = 4 complex
-    const int i0 = 16 * (b >> 2) + (b & 3);
-    float2 a0 = t[i0], a1 = t[i0 + 4], a2 = t[i0 + 8], a3 = t[i0 + 12];
+  {  // cftmdl_128, l = 4 complex: elements 16 g + h + 4 k -> slots 20 g + h + 5 k
+    const int p0 = 20 * (b >> 2) + (b & 3);
+    float2 a0 = t[p0], a1 = t[p0 + 5], a2 = t[p0 + 10], a3 = t[p0 + 15];
     bfly(a0, a1, a2, a3, b >> 2, T);
-    t[i0] = a0;
-    t[i0 + 4] = a1;
-    t[i0 + 8] = a2;
-    t[i0 + 12] = a3;
+    t[p0] = a0;
+    t[p0 + 5] = a1;
+    t[p0 + 10] = a2;
+    t[p0 + 15] = a3;
   }
   wave_fence();
-  {
-    float2 a0 = t[b], a1 = t[b + 16], a2 = t[b + 32], a3 = t[b + 48];
+  {  // elements b + 16 k -> slots ph(b) + 20 k; the results go back in natural order
+    const int p0 = ph(b);
+    float2 a0 = t[p0], a1 = t[p0 + 20], a2 = t[p0 + 40], a3 = t[p0 + 60];
     bfly_last(a0, a1, a2, a3, backward);
+    wave_fence();
     t[b] = a0;
     t[b + 16] = a1;
     t[b + 32] = a2;
