@@ -991,10 +991,14 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     if (lane < prefBandSize) {
       const float v = HNL[minPrefBand + lane];
       int rank = 0;
+      // a laundered copy of the lane index: the 24 `j < lane` masks are block-invariant, and hoisted out of
+      // the block loop they took 48 SGPRs (which spilled into VGPR lanes, which spilled to scratch)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
 #pragma unroll
       for (int j = 0; j < 24; ++j) {
         const float u = HNL[minPrefBand + j];  // j < 24 + 4 stays inside the row
-        rank += (int)(j < prefBandSize) & ((int)(u < v) | ((int)(u == v) & (int)(j < lane)));  // no short-circuit branches
+        rank += (int)(j < prefBandSize) & ((int)(u < v) | ((int)(u == v) & (int)(j < ln)));  // no short-circuit branches
       }
       if (rank == iFb) misc[4] = v;
       if (rank == iLow) misc[5] = v;
@@ -1186,7 +1190,7 @@ __global__ __launch_bounds__(256, AEC_WAVES) void aec_process_kernel(float* __re
       const float* slot = far_ring + ((size_t)op.far_slot * num_streams + stream) * kFarSlotDwords;
       process_block<kMetrics>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
                     ops.num_high, met,
-                    (stamps != nullptr && stream == 0 && s == 0 && k == 0 && lane == 0) ? stamps : nullptr);
+                    (stamps != nullptr && stream == 0 && s == 0 && k == 0) ? stamps : nullptr);  // wave-uniform; every lane stores the same scalar time
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
