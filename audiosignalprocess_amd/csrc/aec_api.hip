@@ -21,12 +21,14 @@ using namespace aspaec;
 
 namespace aspaec {
 hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, const float* farend,
-                             int num_streams, const FarOps& ops, hipStream_t s);
+                             int num_streams, const FarOps& ops, hipStream_t s, int stream0 = 0,
+                             int stream_end = -1);
 hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
                               const float* near_high, float* out_high, float* metrics,
-                              hipStream_t s, unsigned long long* stamps = nullptr);
+                              hipStream_t s, unsigned long long* stamps = nullptr, int stream0 = 0,
+                              int stream_end = -1);
 hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
                               hipStream_t s);
 }  // namespace aspaec
@@ -204,6 +206,12 @@ struct AspAecBatch {
   AecTables* tables = nullptr;
   float *stage_far = nullptr, *stage_near = nullptr, *stage_out = nullptr;  // [S][160]
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // two launch chains over the two halves of the batch (the K-step path, AspAecBatch_TimedSteps): streams are
+  // independent, so half B's step k may still run while half A's step k + 1 starts -- the load burst of one
+  // overlaps the transforms of the other
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool dual = false;  // set only inside the K-step path
   // Aec (echo_cancellation_internal.h:17-65)
   int sampFreq = 0, scSampFreq = 0, splitSampFreq = 0, rate_factor = 0, initFlag = 0, lastError = 0;
   int farend_started = 0, skewMode = 0;
@@ -230,6 +238,32 @@ struct AspAecBatch {
   int metricsMode = 0;
   float* metrics = nullptr;
 };
+
+
+namespace {
+// every device launch of a batch goes through these two: one launch, or one per half on the two chains
+hipError_t batch_launch_farend(AspAecBatch* b, const float* far_dev, const FarOps& ops) {
+  if (!b->dual) return launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream);
+  const int half = ((b->S / 2 + 3) / 4) * 4;
+  hipError_t e = launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream, 0, half);
+  if (e == hipSuccess) e = launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->side, half, b->S);
+  return e;
+}
+hipError_t batch_launch_process(AspAecBatch* b, const float* near_dev, float* out_dev, int n, const ProcOps& ops,
+                                const float* far_src, const FarOps& fops, const float* near_high, float* out_high,
+                                float* metrics, unsigned long long* stamps) {
+  if (!b->dual)
+    return launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops, near_high,
+                              out_high, metrics, b->stream, stamps);
+  const int half = ((b->S / 2 + 3) / 4) * 4;
+  hipError_t e = launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
+                                    near_high, out_high, metrics, b->stream, stamps, 0, half);
+  if (e == hipSuccess)
+    e = launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops, near_high,
+                           out_high, metrics, b->side, nullptr, half, b->S);
+  return e;
+}
+}  // namespace
 
 namespace {
 
@@ -417,7 +451,7 @@ void init_canonical(AspAecState* s) {  // WebRtcAec_InitAec float state, aec_cor
 int flush_pending_farend(AspAecBatch* b) {
   if (b->far_pending) {
     b->far_pending = false;
-    if (!b->sim) AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, b->far_src, b->S, b->far_ops, b->stream));
+    if (!b->sim) AEC_TRY(batch_launch_farend(b, b->far_src, b->far_ops));
   }
   return 0;
 }
@@ -447,7 +481,7 @@ int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer
     ops.nparts++;
     rp_move_read(&b->pre_pos, -kPartLen);  // overlap, echo_cancellation.c:336
     if (ops.nparts == 3) {
-      if (!b->sim) AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
+      if (!b->sim) AEC_TRY(batch_launch_farend(b, far_dev, ops));
       memset(&ops, 0, sizeof ops);
       pending = false;
     }
@@ -458,7 +492,7 @@ int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer
       b->far_ops = ops;
       b->far_src = far_dev;
     } else {
-      if (!b->sim) AEC_TRY(launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream));
+      if (!b->sim) AEC_TRY(batch_launch_farend(b, far_dev, ops));
     }
   }
   return 0;
@@ -543,9 +577,8 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
     fops = b->far_ops;
   }
   if (!b->sim)
-    AEC_TRY(launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
-                               b->cur_near_high, b->cur_out_high, b->metricsMode ? b->metrics : nullptr, b->stream,
-                               b->debug_stamps));
+    AEC_TRY(batch_launch_process(b, near_dev, out_dev, n, ops, far_src, fops, b->cur_near_high, b->cur_out_high,
+                                 b->metricsMode ? b->metrics : nullptr, b->debug_stamps));
   return 0;
 }
 
@@ -710,6 +743,12 @@ int AspAecBatch_Free(AspAecBatch* b) {
   if (b->metrics) (void)hipFree(b->metrics);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->side) {
+    (void)hipStreamSynchronize(b->side);
+    (void)hipStreamDestroy(b->side);
+    (void)hipEventDestroy(b->ev_fork);
+    (void)hipEventDestroy(b->ev_join);
+  }
   if (b->stream && b->own_stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return 0;
@@ -991,14 +1030,34 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
   if (check_running(b, farend, nrOfSamples) != 0) return -1;
   AEC_TRY(hipSetDevice(b->device));
   const size_t per = (size_t)b->S * nrOfSamples;
+  // two chains when the batch is large enough to fill the chip twice over and past its start-up phase
+  // (whose pass-through copies stay on the main stream); ASP_AEC_CHAINS=1 keeps one
+  const char* ch = getenv("ASP_AEC_CHAINS");
+  const bool dual = b->S >= 2048 && !b->startup_phase && !(ch && atoi(ch) == 1);
+  if (dual && !b->side) {
+    AEC_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    AEC_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    AEC_TRY(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  }
   AEC_TRY(hipEventRecord(b->ev0, b->stream));
-  for (int k = 0; k < steps; ++k) {
+  if (dual) {
+    AEC_TRY(hipEventRecord(b->ev_fork, b->stream));
+    AEC_TRY(hipStreamWaitEvent(b->side, b->ev_fork, 0));
+    b->dual = true;
+  }
+  int err = 0;
+  for (int k = 0; k < steps && err == 0; ++k) {
     const size_t off = per * (size_t)(k % frames_in_ring);
     int rc = 0;
-    int err = buffer_farend_device(b, farend + off, nrOfSamples, true);
+    err = buffer_farend_device(b, farend + off, nrOfSamples, true);
     if (err == 0) err = process_device(b, nearend + off, out + off, nrOfSamples, 0, &rc);
-    if (err != 0) return err;
   }
+  if (dual) {
+    b->dual = false;
+    AEC_TRY(hipEventRecord(b->ev_join, b->side));
+    AEC_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+  }
+  if (err != 0) return err;
   AEC_TRY(hipEventRecord(b->ev1, b->stream));
   AEC_TRY(hipEventSynchronize(b->ev1));
   AEC_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));

@@ -327,7 +327,7 @@ __device__ __forceinline__ void farend_work(float* __restrict__ st, float* __res
 
 // WebRtcAec_BufferFarend for every stream: append to far_pre, then transform the partitions the
 // host scheduled (plain and sqrt-Hann windowed) into their far-ring slots.
-__global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ state,
+__global__ __launch_bounds__(256) void aec_farend_kernel(int stream0, int stream_end, float* __restrict__ state,
                                                          float* __restrict__ far_ring,
                                                          const AecTables* __restrict__ G,
                                                          const float* __restrict__ farend,
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(256) void aec_farend_kernel(float* __restrict__ sta
   stage_tables(T, G);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: the stream's state block and LDS region get scalar bases
-  const int stream = blockIdx.x * 4 + wave;
-  if (stream >= num_streams) return;
+  const int stream = stream0 + blockIdx.x * 4 + wave;  // this launch covers streams stream0 .. stream_end - 1
+  if (stream >= stream_end) return;
   float* wl = lds + wave * kLdsWave;
   float* st = state + (size_t)stream * kStateDwords;
   farend_work(st, far_ring, wl, T, farend, num_streams, stream, ops, lane);
@@ -1137,7 +1137,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #define AEC_WAVES 4  // waves per SIMD the register allocation aims at (4: every stream of a 4096-stream batch is resident at once)
 #endif
 template <bool kMetrics>
-__global__ __launch_bounds__(256, AEC_WAVES) void aec_process_kernel(float* __restrict__ state,
+__global__ __launch_bounds__(256, AEC_WAVES) void aec_process_kernel(int stream0, int stream_end, float* __restrict__ state,
                                                           float* far_ring,
                                                           const AecTables* __restrict__ G,
                                                           const float* __restrict__ nearend,
@@ -1153,8 +1153,8 @@ __global__ __launch_bounds__(256, AEC_WAVES) void aec_process_kernel(float* __re
   stage_tables(T, G);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: the stream's state block and LDS region get scalar bases
-  const int stream = blockIdx.x * 4 + wave;
-  if (stream >= num_streams) return;
+  const int stream = stream0 + blockIdx.x * 4 + wave;  // this launch covers streams stream0 .. stream_end - 1
+  if (stream >= stream_end) return;
   float* wl = lds + wave * kWaveLds;
   float* st = state + (size_t)stream * kStateDwords;
   const float* nin = nearend + (size_t)stream * nrOfSamples;
@@ -1247,9 +1247,10 @@ __global__ __launch_bounds__(256) void aec_rdft128_kernel(const float* __restric
 namespace aspaec {
 
 hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, const float* farend,
-                             int num_streams, const FarOps& ops, hipStream_t s) {
-  hipLaunchKernelGGL(aec_farend_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
-                     far_ring, T, farend, num_streams, ops);
+                             int num_streams, const FarOps& ops, hipStream_t s, int stream0, int stream_end) {
+  if (stream_end < 0) stream_end = num_streams;
+  hipLaunchKernelGGL(aec_farend_kernel, dim3((stream_end - stream0 + 3) / 4), dim3(256), 0, s, stream0,
+                     stream_end, state, far_ring, T, farend, num_streams, ops);
   return hipGetLastError();
 }
 
@@ -1257,13 +1258,15 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
                               const float* near_high, float* out_high, float* metrics,
-                              hipStream_t s, unsigned long long* stamps) {
+                              hipStream_t s, unsigned long long* stamps, int stream0, int stream_end) {
+  if (stream_end < 0) stream_end = num_streams;
+  const dim3 grid((stream_end - stream0 + 3) / 4);
   if (metrics != nullptr) {
-    hipLaunchKernelGGL(aec_process_kernel<true>, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
+    hipLaunchKernelGGL(aec_process_kernel<true>, grid, dim3(256), 0, s, stream0, stream_end, state,
                        far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,
                        out_high, metrics, stamps);
   } else {
-    hipLaunchKernelGGL(aec_process_kernel<false>, dim3((num_streams + 3) / 4), dim3(256), 0, s, state,
+    hipLaunchKernelGGL(aec_process_kernel<false>, grid, dim3(256), 0, s, stream0, stream_end, state,
                        far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,
                        out_high, metrics, stamps);
   }

@@ -230,6 +230,39 @@ def test_scale_4096_streams_identical_inputs(aec):
     assert not np.array_equal(out[F - 1, 0], near1[F - 1, 0])
 
 
+def test_timed_steps_two_chains_equal_one_chain(aec, monkeypatch):
+    """The K-step path (AspAecBatch_TimedSteps) runs large batches as two launch chains over the two halves
+    of the batch: outputs and the filter state must equal the single-chain run bit for bit, and an odd half
+    boundary (S / 2 not a multiple of four) must not lose streams."""
+    from audiosignalprocess_amd.ns import DeviceBuffer
+
+    S, F = 2050, 150
+    far4, near4 = aec_frames(4, F)
+    idx = np.arange(S) % 4
+    far = np.ascontiguousarray(far4[:, idx])
+    near = np.ascontiguousarray(near4[:, idx])
+    per = S * 160 * 4  # bytes per frame of all streams
+    df, dn = DeviceBuffer(far.nbytes), DeviceBuffer(near.nbytes)
+    df.upload(far)
+    dn.upload(near)
+    outs, states = [], []
+    for chains in ("1", "2"):
+        monkeypatch.setenv("ASP_AEC_CHAINS", chains)
+        g = aec.AecBatch(S)
+        do = DeviceBuffer(near.nbytes)
+        g.timed_steps(df.ptr, dn.ptr, do.ptr, 160, F, 100)   # through the start-up phase: one chain
+        g.timed_steps(df.ptr + 100 * per, dn.ptr + 100 * per, do.ptr + 100 * per, 160, F - 100, F - 100)
+        g.synchronize()
+        outs.append(do.download(near.shape))
+        states.append([np.ctypeslib.as_array(g.export_state(s).wfBuf).copy() for s in (0, 1023, 1027, 2049)])
+        g.close()
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    for a, b in zip(*states):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # and both equal the four distinct streams they replicate
+    assert np.array_equal(outs[1][:, 4:8].view(np.uint32), outs[1][:, 2044:2048].view(np.uint32))
+
+
 def test_wav_driver_end_to_end(aec, aec_golden, tmp_path):
     """drivers/test_aec_module (the reference's test_aec_module.cpp loop in C over WebRtcAec_*):
     mic.wav + speaker.wav -> result.wav equals the reference's float output rounded by
