@@ -152,6 +152,10 @@ struct AspBtBatch {
   BtTables* tables = nullptr;
   float *stage_in = nullptr, *stage_out = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // second launch chain of the K-step path (AspBtBatch_TimedSteps): stream-channels are independent, so
+  // the two halves of a large batch run as two chains whose launch boundaries overlap
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 extern "C" {
@@ -200,6 +204,12 @@ int AspBtBatch_Free(AspBtBatch* b) {
   if (b->stage_out) (void)hipFree(b->stage_out);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->side) {
+    (void)hipStreamSynchronize(b->side);
+    (void)hipStreamDestroy(b->side);
+    (void)hipEventDestroy(b->ev_fork);
+    (void)hipEventDestroy(b->ev_join);
+  }
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return ASP_OK;
@@ -262,11 +272,32 @@ int AspBtBatch_TimedSteps(AspBtBatch* b, const float* in, float* out, int blocks
     return bt_fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
   BT_TRY(hipSetDevice(b->device));
   const size_t per = (size_t)b->S * b->macro;
+  const char* ch = getenv("ASP_BT_CHAINS");
+  const bool dual = b->S >= 2048 && !(ch && atoi(ch) == 1);
+  if (dual && !b->side) {
+    BT_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    BT_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    BT_TRY(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  }
   BT_TRY(hipEventRecord(b->ev0, b->stream));
+  if (dual) {
+    BT_TRY(hipEventRecord(b->ev_fork, b->stream));
+    BT_TRY(hipStreamWaitEvent(b->side, b->ev_fork, 0));
+  }
+  const int half = dual ? b->S / 2 : b->S;
   for (int k = 0; k < steps; ++k) {
     const size_t off = per * (size_t)(k % blocks_in_ring);
-    BT_TRY(launch_bt_macroblock(b->win, b->state, b->tables, in + off, out + off, b->S, 8, 1,
-                                b->macro, b->macro, b->stream));
+    BT_TRY(launch_bt_macroblock(b->win, b->state, b->tables, in + off, out + off, half, 8, 1, b->macro, b->macro,
+                                b->stream));
+    if (dual) {
+      const size_t o2 = (size_t)half * b->macro;
+      BT_TRY(launch_bt_macroblock(b->win, b->state + (size_t)half * kStateFloats, b->tables, in + off + o2,
+                                  out + off + o2, b->S - half, 8, 1, b->macro, b->macro, b->side));
+    }
+  }
+  if (dual) {
+    BT_TRY(hipEventRecord(b->ev_join, b->side));
+    BT_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
   }
   BT_TRY(hipEventRecord(b->ev1, b->stream));
   BT_TRY(hipEventSynchronize(b->ev1));

@@ -113,6 +113,35 @@ def test_scale_2048_streams(bt):
     g2.close()
 
 
+def test_timed_steps_two_chains_equal_one_chain(bt, monkeypatch):
+    """AspBtBatch_TimedSteps runs large batches as two launch chains over the two halves of the batch:
+    outputs and carried state must equal the single-chain run bit for bit."""
+    from audiosignalprocess_amd.ns import DeviceBuffer
+
+    S, K = 2050, 3
+    x4 = bt_samples(4, K * 4096)
+    idx = np.arange(S) % 4
+    # ring layout of the K-step path: [block][stream][4096]
+    x = np.ascontiguousarray(x4[idx].reshape(S, K, 4096).transpose(1, 0, 2))
+    dx = DeviceBuffer(x.nbytes)
+    dx.upload(x)
+    outs, tails = [], []
+    for chains in ("1", "2"):
+        monkeypatch.setenv("ASP_BT_CHAINS", chains)
+        g = bt.BtBatch(S, 1024)
+        dy = DeviceBuffer(x.nbytes)
+        g.timed_steps(dx.ptr, dy.ptr, K, K)
+        g.synchronize()
+        outs.append(dy.download(x.shape))
+        tails.append([np.ctypeslib.as_array(g.export_state(s).out_tail).copy() for s in (0, 1024, 1025, 2049)])
+        g.close()
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    for a, b in zip(*tails):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    o = OracleBt(1024)
+    assert np.array_equal(outs[1][:, 2049].reshape(-1), o.run(x4[2049 % 4]))
+
+
 def test_layer1_reference_protocol(bt, built_lib):
     """blockThreshold_* (audioDenoiseBlockTreshold.h:46-74) over ctypes, float and int16 paths."""
     lib = C.CDLL(built_lib)
