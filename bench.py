@@ -31,6 +31,16 @@ ALGO_BYTES_PER_FRAME = 15716  # frame-synchronous NS mod
 # WRITE_SIZE (separate rocprofv3 --pmc passes, tools/traffic_ns.sh), calibrated on the kernel's own
 # known byte count at 32768 streams as MI355X_MICROARCH.md prescribes for access widths it does not
 # cover; see profiles/README.md ("HBM traffic of the NS kernel").  Measured once per round, not live.
+
+# Secondary lines: fabric-side bytes from the same counters (tools/traffic_sec.sh, profiles/r02_traffic_sec.txt),
+# stored per unit of work, not measured in the run.  BT: 2 x 10.0948 KB FETCH_SIZE + 20.000 KB WRITE_SIZE per
+# macroblock (8-byte lanes: the guide's factor 2 on reads; 1.005 x the algorithmic 40 960 B).  AEC: 33.40 KB
+# FETCH_SIZE and 32.98 KB WRITE_SIZE per stream and frame of 4-byte-per-lane accesses (a width the guide does not
+# calibrate; with its factor 2 on reads 1.40 x the algorithmic 71 400 B: FilterAdaptation reads the far history and
+# the filter a second time, from the Infinity Cache).
+BT_TRAFFIC_BYTES_PER_MACROBLOCK = (2 * 10.0948 + 20.0) * 1024
+AEC_TRAFFIC_BYTES_PER_FRAME = (2 * 33.4001 + 32.9825) * 1024
+
 PMC_TRAFFIC_BYTES_PER_FRAME = (4.832 * 1.638 + 9.158 / 1.09) * 1024      # ns_frame_kernel<true,true>
 # ns_frame2_kernel[_ilp] (default, end of round 1): FETCH_SIZE 3.8785 / WRITE_SIZE 7.7188 KB per stream at 4096
 # streams against 3.8269 / 7.7188 KB at 32768 streams, where the kernel's known 7 808 B each way (12 rows of
@@ -133,12 +143,14 @@ def bench_bt(args):
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Denoise/BlockThresholding: %d-pt STFT, Stein block threshold, %d "
-                               "stream-channels on 1 MI355X, one 8-hop macroblock per launch" % (n, S),
+                               "stream-channels on 1 MI355X, one 8-hop macroblock per stream-channel and step" % (n, S),
                    "samples_per_s": S * g.macro / launch_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "bt_macroblock_kernel<%d>" % n,
-                     "algorithmic_bytes_per_launch": algo * S, "avg_launch_us": launch_s * 1e6},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": BT_TRAFFIC_BYTES_PER_MACROBLOCK * S if n == 1024 else None,
+                     "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), per step of all stream-channels; not measured in this run",
+                     "kernel": "bt_macroblock8_kernel" if n == 1024 else "bt_macroblock_kernel<%d>" % n,
+                     "launch_chains": 2 if S >= 2048 else 1,
+                     "algorithmic_bytes_per_step": algo * S, "avg_step_us": launch_s * 1e6},
     }
     if not args.no_cpu_baseline:
         # the CPU restatement (oracle/bt_oracle.c; the reference itself is unbuildable here, DESIGN.md
@@ -247,12 +259,14 @@ def bench_aec(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "WebRTC AEC (test_aec_module): 10 ms/16 kHz far+near frames, %d concurrent "
-                               "streams on 1 MI355X, 12 partitions, one far-end launch + one process "
-                               "launch per frame" % S},
+                               "streams on 1 MI355X, 12 partitions, the far-end work fused into the process "
+                               "launch of each frame" % S},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "aec_process_kernel (+ aec_farend_kernel, both inside the timed step)",
-                     "algorithmic_bytes_per_launch": algo * S, "avg_launch_us": step_s * 1e6},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": AEC_TRAFFIC_BYTES_PER_FRAME * S,
+                     "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE; 4-byte-per-lane accesses, a width MI355X_MICROARCH.md does not calibrate), per frame step of all streams; not measured in this run",
+                     "kernel": "aec_process_kernel (the far-end work of the frame inside it)",
+                     "launch_chains": 2 if S >= 2048 else 1,
+                     "algorithmic_bytes_per_step": algo * S, "avg_step_us": step_s * 1e6},
     }
     if not args.no_cpu_baseline:
         from tests import oracle_lib
