@@ -29,6 +29,10 @@
 using namespace aspaec;
 using namespace asppk;
 
+#ifndef AEC_FILTERFAR_FIRST
+#define AEC_FILTERFAR_FIRST 1  // FilterFar ahead of the near FFT (0: behind it, its row loads in flight under the transform)
+#endif
+
 namespace {
 
 // Per-bin loops: trip 0 puts bin q on lane q, trip 1 is bin 64 computed by every lane (uniform
@@ -621,6 +625,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   const float p_outbuf = sld(sb, kOffOutBuf, lane);
   wave_fence();
 
+#if AEC_FILTERFAR_FIRST
   // the far spectra of this block (aec_core.c:1137, 888-891)
   xr[0] = fs_lane[0];
   xi[0] = fs_lane[1];
@@ -654,6 +659,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   wave_fence();
 
 
+#endif
   AEC_STAMP(1)
   // ---- near fft (aec_core.c:1140-1141)
   {
@@ -670,6 +676,41 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   unpack_tile(wl, 1, DWR, DWI, lane);
   wave_fence();
 
+#if !AEC_FILTERFAR_FIRST
+  // the far spectra of this block (aec_core.c:1137, 888-891)
+  xr[0] = fs_lane[0];
+  xi[0] = fs_lane[1];
+  BINS_2TRIPS {
+    XFR[bin] = t_ == 0 ? fs_lane[0] : fs_64[0];
+    XFI[bin] = t_ == 0 ? fs_lane[1] : fs_64[1];
+    const float xwr = t_ == 0 ? fs_lane[2] : fs_64[2], xwi = t_ == 0 ? fs_lane[3] : fs_64[3];
+    XWR[bin] = xwr;
+    XWI[bin] = xwi;
+    ROW_ST((R_XFW + 2 * op.xfw_head), xwr);
+    ROW_ST((R_XFW + 2 * op.xfw_head + 1), xwi);
+  }
+  wave_fence();
+  // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
+  BINS_2TRIPS {
+    float yr = 0.f, yi = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNumPart; ++i) {
+      int px = i + op.xf_pos;
+      if (px >= kNumPart) px -= kNumPart;
+      const float ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
+      const float ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
+      const float br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
+      const float bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
+      yr += ar * br - ai * bi;
+      yi += ar * bi + ai * br;
+    }
+    YFR[bin] = yr;
+    YFI[bin] = yi;
+  }
+  wave_fence();
+
+
+#endif
   AEC_STAMP(2)
   // ---- power smoothing and noise floor (aec_core.c:1144-1186)
   int noiseEstCtr = sci[S_NOISEESTCTR];
