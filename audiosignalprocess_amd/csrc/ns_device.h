@@ -65,6 +65,26 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// The same sum with the four row sums combined by two row-broadcast DPP adds instead of four v_readlane,
+// two moves and two adds: row_bcast:15 (rows 1, 3 written) leaves r0 + r1 and r2 + r3 in rows 1 and 3,
+// row_bcast:31 (row 3 written) adds row 1's into row 3's: (r0 + r1) + (r2 + r3), read from lane 63.
+// Same operands, same association as wave_sum: bit-identical; five VALU issue slots fewer (the frame step
+// of ns_kernels1.hip is bound by VALU issue).  The s_nops cover the VALU-write -> DPP-read hazard.
+__device__ __forceinline__ float wave_sum_bcast(float v) {
+  v = v + dpp_move<0xB1>(v);   // xor 1
+  v = v + dpp_move<0x4E>(v);   // xor 2
+  v = v + dpp_move<0x141>(v);  // xor 4
+  v = v + dpp_move<0x140>(v);  // xor 8: every lane of a row holds the row's sum
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // Correctly rounded a / d for a divisor shared by the whole wave: `rd` is the
 // correctly rounded reciprocal of d (one exact division per wave), then
 // Markstein's q0 = a*rd, r = a - d*q0, q = q0 + r*rd is the rounded quotient
