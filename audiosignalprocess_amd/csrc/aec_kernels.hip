@@ -136,6 +136,10 @@ __device__ __forceinline__ int rev6(int x) { return (int)(__brev((unsigned)x) >>
 __device__ __forceinline__ constexpr int ph(int i) { return i + (i >> 2); }
 
 // The three radix-4 passes of four transforms at once; t = this lane's tile, b = butterfly.
+// kAdapt (backward transforms of FilterAdaptation only): the time-domain result leaves the last pass already
+// scaled by 2 / 128 in its first half and zeroed in its second (aec_core.c:245-254), instead of a separate
+// trip through the tile.
+template <bool kAdapt = false>
 __device__ __forceinline__ void cft64_quad(float2* t, int b, bool backward, const SharedTables& T) {
   {  // cft1st_128 on the bit-reversed input (bitrv2_128, aec_rdft.c:124-199)
     const int i0 = 4 * b;
@@ -164,6 +168,15 @@ __device__ __forceinline__ void cft64_quad(float2* t, int b, bool backward, cons
     float2 a0 = t[p0], a1 = t[p0 + 20], a2 = t[p0 + 40], a3 = t[p0 + 60];
     bfly_last(a0, a1, a2, a3, backward);
     wave_fence();
+    if (kAdapt) {  // complex slots 0..31 = samples 0..63 (kept, scaled), 32..63 = samples 64..127 (zeroed)
+      const float scale = 2.0f / 128;
+      a0.x *= scale;
+      a0.y *= scale;
+      a1.x *= scale;
+      a1.y *= scale;
+      a2 = make_float2(0.f, 0.f);
+      a3 = make_float2(0.f, 0.f);
+    }
     t[b] = a0;
     t[b + 16] = a1;
     t[b + 32] = a2;
@@ -209,6 +222,7 @@ __device__ __forceinline__ void rdft_fwd_quad(float* wl, int lane, const SharedT
 }
 
 // aec_rdft_inverse_128 (aec_rdft.c:549-556) of the four tiles, in place (unscaled).
+template <bool kAdapt = false>
 __device__ __forceinline__ void rdft_inv_quad(float* wl, int lane, const SharedTables& T) {
   float2* t = reinterpret_cast<float2*>(wl + kLdsTile) + (lane >> 4) * kTileStride;
   const int b = lane & 15;
@@ -240,7 +254,7 @@ __device__ __forceinline__ void rdft_inv_quad(float* wl, int lane, const SharedT
     }
   }
   wave_fence();
-  cft64_quad(t, b, true, T);
+  cft64_quad<kAdapt>(t, b, true, T);
 }
 
 __device__ __forceinline__ float* lrow(float* wl, int r) { return wl + kLdsRows + r * kLRow; }
@@ -515,6 +529,15 @@ __device__ __attribute__((noinline)) void metrics_block(float* __restrict__ met,
 // One ProcessBlock + NonLinearProcessing for this wave's stream.  kMetrics: metricsMode builds of
 // the kernel also gather the echo metrics (a separate instantiation keeps the plain one's
 // register allocation).
+// n / d, correctly rounded: the lean Newton form of ns_device.h where it is exact (normal divisor and
+// quotient, far from the range limits), the IEEE expansion otherwise (rare; one branch per use).
+__device__ __forceinline__ float fdiv_aec(float n, float d) {
+  float q = aspns_dev::fdiv(n, d);
+  const float aq = fabsf(q);
+  if (__builtin_expect(!(d >= 1e-18f && d <= 1e18f && ((aq >= 1e-25f && aq <= 1e25f) || n == 0.0f)), 0)) q = n / d;
+  return q;
+}
+
 // The stream's state block through a buffer resource: one descriptor in SGPRs, the row offset as the
 // scalar offset, the lane's dword as the only vector offset.  (With flat global addressing the compiler
 // kept a 64-bit VGPR address per state row alive across the whole block: 100 registers.)
@@ -799,11 +822,11 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       MET[2 * kLRow + bin] = (bin == 0 || bin == 64) ? t / 2 : t;
     }
     const float den = XPW[bin] + 1e-10f;
-    er /= den;
-    ei /= den;
+    er = fdiv_aec(er, den);
+    ei = fdiv_aec(ei, den);
     float abs_ef = sqrtf(er * er + ei * ei);
     if (abs_ef > error_threshold) {
-      abs_ef = error_threshold / (abs_ef + 1e-10f);
+      abs_ef = fdiv_aec(error_threshold, abs_ef + 1e-10f);
       er *= abs_ef;
       ei *= abs_ef;
     }
@@ -859,15 +882,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       tile(wl, k)[lane] = v;
     }
     wave_fence();
-    rdft_inv_quad(wl, lane, T);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float2 v = tile(wl, k)[lane];
-      v.x = lane < 32 ? v.x * scale : 0.f;
-      v.y = lane < 32 ? v.y * scale : 0.f;
-      tile(wl, k)[lane] = v;
-    }
-    wave_fence();
+    rdft_inv_quad<true>(wl, lane, T);  // scaled first half, zeroed second half (aec_core.c:245-254)
     rdft_fwd_quad(wl, lane, T);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -946,8 +961,8 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     ROW_ST(R_SXD_IM, sxd_i);
     T0[bin] = sd;
     XPW[bin] = se;
-    COHDE[bin] = (sde_r * sde_r + sde_i * sde_i) / (sd * se + 1e-10f);
-    COHXD[bin] = (sxd_r * sxd_r + sxd_i * sxd_i) / (sx * sd + 1e-10f);
+    COHDE[bin] = fdiv_aec(sde_r * sde_r + sde_i * sde_i, sd * se + 1e-10f);
+    COHXD[bin] = fdiv_aec(sxd_r * sxd_r + sxd_i * sxd_i, sx * sd + 1e-10f);
   }
   wave_fence();
   const int prefBandSize = 24 / mult, minPrefBand = 4 / mult;
@@ -1081,6 +1096,16 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   AEC_STAMP(12)
   // ---- OverdriveAndSuppress + ComfortNoise (aec_core.c:271-292, 461-500)
   const uint32_t seed = reinterpret_cast<uint32_t*>(sc)[S_SEED];
+  // comfort-noise phase of every bin but bin 0 (which has none): lane q > 0 evaluates bin q, lane 0 evaluates
+  // bin 64, so that the second trip (bin 64 on every lane) needs no sincos of its own
+  float2 sc_lane;
+  {
+    const int nb = lane == 0 ? 64 : lane;
+    // rand[nb - 1]: the LCG after `nb` steps (randomization_functions.c:93-115)
+    const uint32_t s = (T.lcg_a[nb - 1] * seed + T.lcg_c[nb - 1]) & 0x7fffffffu;
+    const float rnd = ((float)(int16_t)(s >> 16)) / 32768;
+    sc_lane = nlp_sincos(6.28318530717959f * rnd);
+  }
   BINS_2TRIPS {
     float h = HNL[bin];
     if (h > hNlFb) h = T.weight[bin] * hNlFb + (1 - T.weight[bin]) * h;
@@ -1089,12 +1114,12 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     ei *= -1;
     float ur = 0.f, ui = 0.f;
     if (bin > 0) {
-      // rand[bin - 1]: the LCG after `bin` steps (randomization_functions.c:93-115)
-      const uint32_t s = (T.lcg_a[bin - 1] * seed + T.lcg_c[bin - 1]) & 0x7fffffffu;
-      const float rnd = ((float)(int16_t)(s >> 16)) / 32768;
-      const float tmp = 6.28318530717959f * rnd;
       const float noise = sqrtf(T1[bin]);
-      const float2 sc2 = nlp_sincos(tmp);
+      float2 sc2 = sc_lane;
+      if (t_ == 1) {  // bin 64: lane 0's evaluation
+        sc2.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc_lane.x), 0));
+        sc2.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc_lane.y), 0));
+      }
       ur = noise * sc2.y;
       ui = -noise * sc2.x;
       if (bin == 64) ui = 0.f;
