@@ -1203,7 +1203,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #define AEC_WAVES 4  // waves per SIMD the register allocation aims at (4: every stream of a 4096-stream batch is resident at once)
 #endif
 template <bool kMetrics>
-__global__ __launch_bounds__(256, AEC_WAVES) void aec_process_kernel(int stream0, int stream_end, float* __restrict__ state,
+__global__ __launch_bounds__(256, kMetrics ? 2 : AEC_WAVES) void aec_process_kernel(int stream0, int stream_end, float* __restrict__ state,
                                                           float* far_ring,
                                                           const AecTables* __restrict__ G,
                                                           const float* __restrict__ nearend,
