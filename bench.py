@@ -85,7 +85,7 @@ def cpu_baseline(seconds_budget=20.0):
     from tests import oracle_lib
 
     threads = host_cores()
-    warm, timed = 250, 500
+    warm, timed = 250, 2000   # 1024 streams x 2000 frames: about 15 core-seconds of the reference's code
     # ~90 k frames/s/core measured for the reference
     streams = int(max(threads, min(64 * threads, seconds_budget * 90e3 / (warm + timed))))
     x = ns_frames(streams, 50, frame0=50)
@@ -275,7 +275,7 @@ def bench_aec(args):
             # the reference's own aec_core.c / aec_rdft.c / echo_cancellation.c compiled in the build container
             # (oracle/_ref/libaec_ref.so, plain-C path): one handle per thread, ctypes releases the GIL
             from concurrent.futures import ThreadPoolExecutor
-            per, Fc = 8, 300
+            per, Fc = 8, 1500   # 128 streams x 1500 frames: about 10 core-seconds
             Sc = per * cores
             farc, nearc = aec_frames(Sc, Fc)
             engs = [[oracle_lib.RefAec(16000) for _ in range(per)] for _ in range(cores)]   # created one by one
