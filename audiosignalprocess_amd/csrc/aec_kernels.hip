@@ -569,6 +569,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #define AEC_STAMP(k) \
   if (stamps != nullptr) stamps[k] = __builtin_amdgcn_s_memtime();
   AEC_STAMP(0)
+  asm volatile("" : "+v"(lane));  // lane masks are recomputed per block instead of living in SGPR pairs across the block loop
   const StateBuf sb = state_buf(st);
   float* sc = st + kOffScalars;
   int32_t* sci = reinterpret_cast<int32_t*>(sc);
