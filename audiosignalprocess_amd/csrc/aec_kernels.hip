@@ -1050,12 +1050,12 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       int rank = 0;
       // a laundered copy of the lane index: the 24 `j < lane` masks are block-invariant, and hoisted out of
       // the block loop they took 48 SGPRs (which spilled into VGPR lanes, which spilled to scratch)
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
+      int ln = lane, pbs = prefBandSize;  // pbs: the band size as a vector value, for the same reason
+      asm volatile("" : "+v"(ln), "+v"(pbs));
 #pragma unroll
       for (int j = 0; j < 24; ++j) {
         const float u = HNL[minPrefBand + j];  // j < 24 + 4 stays inside the row
-        rank += (int)(j < prefBandSize) & ((int)(u < v) | ((int)(u == v) & (int)(j < ln)));  // no short-circuit branches
+        rank += (int)(j < pbs) & ((int)(u < v) | ((int)(u == v) & (int)(j < ln)));  // no short-circuit branches
       }
       if (rank == iFb) misc[4] = v;
       if (rank == iLow) misc[5] = v;
