@@ -538,6 +538,15 @@ __device__ __forceinline__ float fdiv_aec(float n, float d) {
   return q;
 }
 
+// v_writelane_b32: the (wave-uniform) value goes into lane K of the row
+template <int K>
+__device__ __forceinline__ float set_lane(float row, int bits) {
+  int r = __float_as_int(row);
+  const int u = __builtin_amdgcn_readfirstlane(bits);
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(r) : "s"(u), "n"(K));
+  return __int_as_float(r);
+}
+
 // The stream's state block through a buffer resource: one descriptor in SGPRs, the row offset as the
 // scalar offset, the lane's dword as the only vector offset.  (With flat global addressing the compiler
 // kept a 64-bit VGPR address per state row alive across the whole block: 100 registers.)
@@ -571,8 +580,13 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   AEC_STAMP(0)
   asm volatile("" : "+v"(lane));  // lane masks are recomputed per block instead of living in SGPR pairs across the block loop
   const StateBuf sb = state_buf(st);
-  float* sc = st + kOffScalars;
-  int32_t* sci = reinterpret_cast<int32_t*>(sc);
+  // the stream's 32 scalars: one row load, lane k holds scalar k (wave-uniform values read with v_readlane),
+  // one row store at the end -- a scalar address apiece had cost an SGPR pair each across the block loop
+  float scrow = sld(sb, kOffScalars, lane & 31);
+#define SCI(k) __builtin_amdgcn_readlane(__float_as_int(scrow), (k))
+#define SCF(k) __int_as_float(SCI(k))
+#define SC_SETI(k, val) scrow = set_lane<(k)>(scrow, (int)(val))
+#define SC_SETF(k, val) SC_SETI(k, __float_as_int(val))
   float* dbuf = wl + kLdsDbuf;
   float* ebuf = wl + kLdsEbuf;
   float* misc = wl + kLdsMisc;
@@ -737,7 +751,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #endif
   AEC_STAMP(2)
   // ---- power smoothing and noise floor (aec_core.c:1144-1186)
-  int noiseEstCtr = sci[S_NOISEESTCTR];
+  int noiseEstCtr = SCI(S_NOISEESTCTR);
   const bool noise_track = noiseEstCtr > 50;
   const bool noise_init = noiseEstCtr < 500 * mult;
   BINS_2TRIPS {
@@ -903,9 +917,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 
   AEC_STAMP(8)
   // =================================================== NonLinearProcessing (aec_core.c:852-1082)
-  int delayEstCtr = sci[S_DELAYESTCTR] + 1;
+  int delayEstCtr = SCI(S_DELAYESTCTR) + 1;
   if (delayEstCtr == 10 * mult) delayEstCtr = 0;
-  int delayIdx = sci[S_DELAYIDX];
+  int delayIdx = SCI(S_DELAYIDX);
   if (delayEstCtr == 0) {  // PartitionDelay (aec_core.c:294-318)
     float* pe = wl + kLdsTile;  // 12 rows of 66 overlaying the tiles and the dead rows
     for (int i = 0; i < kNumPart; ++i)
@@ -982,7 +996,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   const float sdSum = misc[0], seSum = misc[1];
   float hNlXdAvg = misc[2], hNlDeAvg = misc[3];
   wave_fence();
-  int divergeState = sci[S_DIVERGESTATE];
+  int divergeState = SCI(S_DIVERGESTATE);
   divergeState = (divergeState ? 1.05f : 1.0f) * seSum > sdSum;
   if (divergeState) {
     BINS_2TRIPS {
@@ -1000,10 +1014,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   hNlXdAvg /= prefBandSize;
   hNlXdAvg = 1 - hNlXdAvg;
   hNlDeAvg /= prefBandSize;
-  float hNlXdAvgMin = sc[S_HNLXDAVGMIN];
-  int stNearState = sci[S_STNEARSTATE];
+  float hNlXdAvgMin = SCF(S_HNLXDAVGMIN);
+  int stNearState = SCI(S_STNEARSTATE);
   int echoState;
-  float overDrive = sc[S_OVERDRIVE];
+  float overDrive = SCF(S_OVERDRIVE);
   if (hNlXdAvg < 0.75f && hNlXdAvg < hNlXdAvgMin) hNlXdAvgMin = hNlXdAvg;
   if (hNlDeAvg > 0.98f && hNlXdAvg > 0.9f) {
     stNearState = 1;
@@ -1067,9 +1081,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   }
 
   // ---- aec_core.c:962-992
-  float hNlFbLocalMin = sc[S_HNLFBLOCALMIN], hNlFbMin = sc[S_HNLFBMIN];
-  int hNlNewMin = sci[S_HNLNEWMIN], hNlMinCtr = sci[S_HNLMINCTR];
-  float overDriveSm = sc[S_OVERDRIVESM];
+  float hNlFbLocalMin = SCF(S_HNLFBLOCALMIN), hNlFbMin = SCF(S_HNLFBMIN);
+  int hNlNewMin = SCI(S_HNLNEWMIN), hNlMinCtr = SCI(S_HNLMINCTR);
+  float overDriveSm = SCF(S_OVERDRIVESM);
   if (hNlFbLow < 0.6f && hNlFbLow < hNlFbLocalMin) {
     hNlFbLocalMin = hNlFbLow;
     hNlFbMin = hNlFbLow;
@@ -1096,7 +1110,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 
   AEC_STAMP(12)
   // ---- OverdriveAndSuppress + ComfortNoise (aec_core.c:271-292, 461-500)
-  const uint32_t seed = reinterpret_cast<uint32_t*>(sc)[S_SEED];
+  const uint32_t seed = (uint32_t)SCI(S_SEED);
   // comfort-noise phase of every bin but bin 0 (which has none): lane q > 0 evaluates bin q, lane 0 evaluates
   // bin 64, so that the second trip (bin 64 on every lane) needs no sincos of its own
   float2 sc_lane;
@@ -1173,21 +1187,22 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   // ---- carry the block (aec_core.c:1069-1081; the xfwBuf shift is the host's circular head)
   sst(sb, kOffDBuf, lane, ne);
   sst(sb, kOffEBuf, lane, e);
-  if (lane == 0) {
-    sc[S_HNLFBMIN] = hNlFbMin;
-    sc[S_HNLFBLOCALMIN] = hNlFbLocalMin;
-    sc[S_HNLXDAVGMIN] = hNlXdAvgMin;
-    sc[S_OVERDRIVE] = overDrive;
-    sc[S_OVERDRIVESM] = overDriveSm;
-    sci[S_HNLNEWMIN] = hNlNewMin;
-    sci[S_HNLMINCTR] = hNlMinCtr;
-    sci[S_DELAYIDX] = delayIdx;
-    sci[S_STNEARSTATE] = stNearState;
-    sci[S_ECHOSTATE] = echoState;
-    sci[S_DIVERGESTATE] = divergeState;
-    sci[S_NOISEESTCTR] = noiseEstCtr;
-    sci[S_DELAYESTCTR] = delayEstCtr;
-    reinterpret_cast<uint32_t*>(sc)[S_SEED] = new_seed;
+  {
+    SC_SETF(S_HNLFBMIN, hNlFbMin);
+    SC_SETF(S_HNLFBLOCALMIN, hNlFbLocalMin);
+    SC_SETF(S_HNLXDAVGMIN, hNlXdAvgMin);
+    SC_SETF(S_OVERDRIVE, overDrive);
+    SC_SETF(S_OVERDRIVESM, overDriveSm);
+    SC_SETI(S_HNLNEWMIN, hNlNewMin);
+    SC_SETI(S_HNLMINCTR, hNlMinCtr);
+    SC_SETI(S_DELAYIDX, delayIdx);
+    SC_SETI(S_STNEARSTATE, stNearState);
+    SC_SETI(S_ECHOSTATE, echoState);
+    SC_SETI(S_DIVERGESTATE, divergeState);
+    SC_SETI(S_NOISEESTCTR, noiseEstCtr);
+    SC_SETI(S_DELAYESTCTR, delayEstCtr);
+    SC_SETI(S_SEED, (int)new_seed);
+    if (lane < 32) sst(sb, kOffScalars, lane, scrow);
   }
   wave_fence();
   sst(sb, kOffC64, lane, c64[lane]);
@@ -1196,6 +1211,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #undef AEC_STAMP
 #undef ROW_LD
 #undef ROW_ST
+#undef SCI
+#undef SCF
+#undef SC_SETI
+#undef SC_SETF
 }
 
 // WebRtcAec_ProcessFrames for every stream (running phase): per 80-sample sub-frame append the
