@@ -1,5 +1,5 @@
 #!/bin/bash
-export TMPDIR=/tmp
+export TMPDIR=/tmp ASP_AEC_CHAINS=1 ASP_BT_CHAINS=1   # one launch per step: a launch's counters are a step's
 OUT=gpurun_out/pmc_bt_$1; mkdir -p $OUT
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d $OUT/p1 -- python3 bench.py --workload bt1024 --steps 100 > $OUT/p1.json 2> $OUT/p1.err
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/p2 -- python3 bench.py --workload bt1024 --steps 100 > $OUT/p2.json 2> $OUT/p2.err
