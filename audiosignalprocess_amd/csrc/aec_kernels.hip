@@ -257,6 +257,73 @@ __device__ __forceinline__ void rdft_inv_quad(float* wl, int lane, const SharedT
   cft64_quad<kAdapt>(t, b, true, T);
 }
 
+// One round with both directions: the tiles named in inv_tiles take aec_rdft_inverse_128, the others
+// aec_rdft_forward_128 (the radix-4 passes are the same code; the real-FFT pre / post steps and the last
+// pass's variant go by the lane's tile).  Same operations per tile as the two functions above.
+__device__ __forceinline__ void rdft_mixed_quad(float* wl, int lane, const SharedTables& T, int inv_tiles) {
+  float2* t = reinterpret_cast<float2*>(wl + kLdsTile) + (lane >> 4) * kTileStride;
+  const int b = lane & 15;
+  const float* c = T.w + 32;
+  const bool inv = ((inv_tiles >> (lane >> 4)) & 1) != 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {  // rftbsub_128 on the inverse tiles (stores masked)
+    const int j1 = b + 1 + 16 * r;
+    const bool pair = j1 < 32;
+    const int jc = pair ? j1 : 31, k = 64 - jc;
+    const float wkr = 0.5f - c[32 - jc], wki = c[jc];
+    float2 aj = t[jc], ak = t[k];
+    float2 a0 = t[0], am = t[32];
+    {
+      const f32x2 x = add_sub_lo(pk(aj), pk(ak));
+      const f32x2 y = cmul_conj_w(f32x2{wkr, wki}, x);
+      aj = unpk(sub_lo_rsub_hi(pk(aj), y));
+      ak = unpk(add_sub_hi(y, pk(ak)));
+    }
+    a0.y = 0.5f * (a0.x - a0.y);
+    a0.x -= a0.y;
+    a0.y = -a0.y;
+    am.y = -am.y;
+    if (inv) {
+      if (pair) {
+        t[jc] = aj;
+        t[k] = ak;
+      } else {
+        t[0] = a0;
+        t[32] = am;
+      }
+    }
+  }
+  wave_fence();
+  cft64_quad(t, b, inv, T);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {  // rftfsub_128 on the forward tiles (stores masked)
+    const int j1 = b + 1 + 16 * r;
+    const bool pair = j1 < 32;
+    const int jc = pair ? j1 : 31, k = 64 - jc;
+    const float wkr = 0.5f - c[32 - jc], wki = c[jc];
+    float2 aj = t[jc], ak = t[k];
+    float2 a0 = t[0];
+    {
+      const f32x2 x = add_sub_lo(pk(aj), pk(ak));
+      const f32x2 y = cmul<false>(f32x2{wkr, wki}, x);
+      aj = unpk(pk(aj) - y);
+      ak = unpk(add_sub_hi(pk(ak), y));
+    }
+    const float x0 = a0.x - a0.y;
+    a0.x += a0.y;
+    a0.y = x0;
+    if (!inv) {
+      if (pair) {
+        t[jc] = aj;
+        t[k] = ak;
+      } else {
+        t[0] = a0;
+      }
+    }
+  }
+  wave_fence();
+}
+
 __device__ __forceinline__ float* lrow(float* wl, int r) { return wl + kLdsRows + r * kLRow; }
 __device__ __forceinline__ float2* tile(float* wl, int f) {
   return reinterpret_cast<float2*>(wl + kLdsTile) + f * kTileStride;
@@ -707,9 +774,22 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     float* t1 = reinterpret_cast<float*>(tile(wl, 1));
     t1[lane] = dbuf[lane] * T.hann[lane];
     t1[64 + lane] = dbuf[64 + lane] * T.hann[64 - lane];
+#if AEC_FILTERFAR_FIRST
+    // the echo estimate's spectrum (FilterFar ran above) rides in the same round, third tile, inverse
+    // (aec_core.c:1222-1238): one transform round fewer per block
+    float2 vy;
+    vy.x = YFR[lane];
+    vy.y = lane == 0 ? YFR[64] : YFI[lane];
+    tile(wl, 2)[lane] = vy;
+#endif
   }
   wave_fence();
+#if AEC_FILTERFAR_FIRST
+  rdft_mixed_quad(wl, lane, T, 1 << 2);
+  const float y_est = reinterpret_cast<float*>(tile(wl, 2))[64 + lane] * scale;
+#else
   rdft_fwd_quad(wl, lane, T);
+#endif
   unpack_tile(wl, 0, DFR, DFI, lane);
   unpack_tile(wl, 1, DWR, DWI, lane);
   wave_fence();
@@ -798,6 +878,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   AEC_STAMP(3)
   AEC_STAMP(4)
   // ---- echo estimate and error (aec_core.c:1222-1238)
+#if AEC_FILTERFAR_FIRST
+  const float y = y_est;
+#else
   {
     float2 v;
     v.x = YFR[lane];
@@ -807,6 +890,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   wave_fence();
   rdft_inv_quad(wl, lane, T);
   const float y = reinterpret_cast<float*>(tile(wl, 0))[64 + lane] * scale;
+#endif
   const float e = ne - y;
   wave_fence();
 
