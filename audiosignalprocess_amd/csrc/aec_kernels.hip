@@ -390,22 +390,28 @@ __device__ __forceinline__ void farend_work(float* __restrict__ st, float* __res
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  for (int p = 0; p < ops.nparts; ++p) {
-    // 128 samples of far_pre -> tile 0 (plain) and tile 1 (windowed, aec_core.c:779-784)
-    float* t0 = reinterpret_cast<float*>(tile(wl, 0));
-    float* t1 = reinterpret_cast<float*>(tile(wl, 1));
+  for (int p = 0; p < ops.nparts; p += 2) {
+    // two partitions per transform round: 128 samples of far_pre -> tiles 0 / 2 (plain) and 1 / 3 (windowed,
+    // aec_core.c:779-784)
+    const int np = ops.nparts - p < 2 ? ops.nparts - p : 2;  // wave-uniform
+    for (int q = 0; q < np; ++q) {
+      float* t0 = reinterpret_cast<float*>(tile(wl, 2 * q));
+      float* t1 = reinterpret_cast<float*>(tile(wl, 2 * q + 1));
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = lane + 64 * h;
-      const float x = pre[ring_idx(ops.rpos[p], i, kPreLen)];
-      t0[i] = x;
-      t1[i] = x * (h == 0 ? T.hann[i] : T.hann[128 - i]);
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        const float x = pre[ring_idx(ops.rpos[p + q], i, kPreLen)];
+        t0[i] = x;
+        t1[i] = x * (h == 0 ? T.hann[i] : T.hann[128 - i]);
+      }
     }
     wave_fence();
     rdft_fwd_quad(wl, lane, T);
-    float* slot = far_ring + ((size_t)ops.slot[p] * num_streams + stream) * kFarSlotDwords;
-    unpack_tile(wl, 0, slot, slot + kRow, lane);
-    unpack_tile(wl, 1, slot + 2 * kRow, slot + 3 * kRow, lane);
+    for (int q = 0; q < np; ++q) {
+      float* slot = far_ring + ((size_t)ops.slot[p + q] * num_streams + stream) * kFarSlotDwords;
+      unpack_tile(wl, 2 * q, slot, slot + kRow, lane);
+      unpack_tile(wl, 2 * q + 1, slot + 2 * kRow, slot + 3 * kRow, lane);
+    }
     wave_fence();
   }
 }
