@@ -307,17 +307,17 @@ int AspBtBatch_TimedSteps(AspBtBatch* b, const float* in, float* out, int blocks
 
 // Diagnostic: one macroblock launch with phase time stamps of workgroup 0 (s_memtime ticks).
 int AspBtBatch_DebugStamps(AspBtBatch* b, const float* in_dev, float* out_dev,
-                           unsigned long long* stamps11) {  // 16 slots (0..10 phases, 11..15 sub-phases)
+                           unsigned long long* stamps11) {  // 48 slots (0..10 phases, 11..15 sub-phases, 16..47 per-wave stamps of the N = 1024 kernel)
   if (!b || !in_dev || !out_dev || !stamps11) return bt_fail(ASP_ERR_PARAM, "DebugStamps: bad argument");
   BT_TRY(hipSetDevice(b->device));
   unsigned long long* d = nullptr;
-  BT_TRY(hipMalloc((void**)&d, 16 * sizeof(unsigned long long)));
-  hipError_t e = hipMemset(d, 0, 16 * sizeof(unsigned long long));
+  BT_TRY(hipMalloc((void**)&d, 48 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d, 0, 48 * sizeof(unsigned long long));
   if (e == hipSuccess)
     e = launch_bt_macroblock(b->win, b->state, b->tables, in_dev, out_dev, b->S, 8, 1, b->macro,
                              b->macro, b->stream, d);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-  if (e == hipSuccess) e = hipMemcpy(stamps11, d, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(stamps11, d, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return bt_fail(ASP_ERR_HIP, "DebugStamps", e);
   return ASP_OK;

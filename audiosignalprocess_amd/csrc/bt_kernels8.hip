@@ -401,6 +401,9 @@ __device__ __forceinline__ void scan_rows(const float (&pw)[8], bool segfirst, i
   }
 }
 
+// per-wave stamps (diagnostic): slots 16 + 4 wave + {0: end of phase A, 1: end of SURE, 2: end of phase B2, 3: end}
+#define BT8_WSTAMP(k) \
+  if (stamps != nullptr && blockIdx.x == 0 && lane == 0) stamps[16 + 4 * wave + (k)] = __builtin_amdgcn_s_memtime();
 #define BT8_STAMP(k) \
   if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
 
@@ -461,6 +464,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   wave_lds_fence();
   wave_split_forward<true>(row, spf, lane, sq + wave * 16 * SQS, P.norm);
   BT8_STAMP(3)
+  BT8_WSTAMP(0)
   __syncthreads();
   BT8_STAMP(4)
   // carry the last HALF input samples (wave 0 has read the old tail before the barrier)
@@ -478,13 +482,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
     default: sure_seg<2, 0>(sq, sure, &P.seg[2][0], lane); sure_seg<1, 1>(sq, sure, &P.seg[1][1], lane); break;
   }
   BT8_STAMP(5)
+  BT8_WSTAMP(1)
   __syncthreads();
   BT8_STAMP(6)
 
   // ---------------------------------------------------------------- phase B2: attenuation + Wiener, in place
   {
     const int m = tid >> 4, u = tid & 15;
-    if (m < NCOL) {
+    {
+      // Lanes 496..511 (m == NCOL) own the DC column and the bins past the last whole macro-column
+      // (.c:501-506, 518-532): one column per lane, a block of the 8 frames, and a gain formed in float.
+      // They run the columns' code as a (T, F) = (0, 4) block (one lane wide, 8 rows: the same sums in
+      // the same order) and swap the gain in at the end.  The Nyquist bin (512) is thresholded by the
+      // reference but never reaches the Wiener step: it stays as it is.
+      const bool edge = m >= NCOL;
       // argmin, first minimum wins (.c:404-416)
       float best = sure[m * SUS];
       int bc = 0;
@@ -497,10 +508,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
         }
       }
       BT8_STAMP(11)
+      if (edge) bc = 4;
       const int T = bc >= 10 ? 2 : bc >= 5 ? 1 : 0, F = bc - 5 * T;
       const int TT = 8 >> T, FF = 16 >> F;
       const float a_const = sure[NCOL * SUS + bc];
-      cpx* col = coef + 1 + 16 * m + u;
+      cpx* col = coef + (edge ? (u == 0 ? 0 : 16 * NCOL + u) : 1 + 16 * m + u);
       // Block powers of the chosen segmentation (.c:421-454).  The column's 16 lanes are one DPP row: lane u
       // owns bin u of every frame.  A block sum runs rows outer / columns inner, i.e. along the lanes of a
       // segment of FF lanes and on into the next row: a segmented left-to-right scan per row (each step adds
@@ -550,6 +562,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
       g3 = g3 * (float)(g3 > 0);
       g5 = g5 * (float)(g5 > 0);
       g7 = g7 * (float)(g7 > 0);
+      if (edge) {  // (.c:503-505, 523-525)
+        g7 = 1 - fdiv_checked(P.dc_const, tot7);
+        if (g7 < 0) g7 = 0;
+      }
       BT8_STAMP(14)
       // thresholded coefficient -> empirical Wiener gain on the original one (.c:446-452, 469-486)
       float wn[8], den[8], wmin, wmax;
@@ -580,26 +596,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
         col[r * ROW] = z[r] * gw.x;
         col[(r + 1) * ROW] = z[r + 1] * gw.y;
       }
-    } else {
-      // DC column and the bins past the last whole macro-column (.c:501-506, 518-532); the Nyquist bin
-      // (512) is thresholded by the reference but never reaches the Wiener step: it stays as it is
-      const int colx = u == 0 ? 0 : 16 * NCOL + u;
-      float sum = 0.0f;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const cpx z = coef[t * ROW + colx];
-        sum += z.x * z.x + z.y * z.y;
-      }
-      float a = 1 - P.dc_const / sum;
-      if (a < 0) a = 0;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const cpx z = coef[t * ROW + colx];
-        const float tr = z.x * a, ti = z.y * a;
-        float wn = tr * tr + ti * ti;
-        wn = wn / (wn + P.wiener_c);
-        coef[t * ROW + colx] = z * wn;
-      }
     }
   }
   // the old output tail, for wave 0's overlap-add (requested ahead of the barrier)
@@ -612,6 +608,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) spi[j] = sup[merge_sup_index(lane, j)];
   BT8_STAMP(7)
+  BT8_WSTAMP(2)
   __syncthreads();
   BT8_STAMP(8)
 
@@ -652,6 +649,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
     }
   }
   BT8_STAMP(10)
+  BT8_WSTAMP(3)
 }
 
 // kiss_fftr / kiss_fftri seam for N = 1024 through the same wave routines: one wave per row.
