@@ -379,25 +379,75 @@ __device__ __forceinline__ void sure_seg(const float* sq, float* sure, const BtS
 }
 
 // The segmented running sums of phase B2 for one DPP row (= one macro-column): see the kernel.  STEPS =
-// (widest segment of the wave's columns) - 1 scan steps per row, unrolled.
+// (widest segment of the wave's columns) - 1, unrolled.  One `v_add_f32_dpp acc, acc, pw row_shr:1` per
+// step, with no select: a lane whose DPP source is invalid -- outside the row, or switched off in EXEC --
+// keeps its value (bound_ctrl 0).  With the LAST lane of every segment switched off, the first lane of the
+// next segment keeps its start value (carry + own power) while the sums run along the segment; one more
+// step with every lane on gives the last lanes their sums (it spoils the first lanes, which are done: the
+// next row starts them afresh; one-lane segments take their start value).  Lanes that already hold their
+// final sum recompute the same value.  The DPP reads follow VALU writes of the same register: two wait
+// states each, given here because the hazard recogniser does not look into inline assembly.
+#define BT8_DPP1 "s_nop 1\n\tv_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define BT8_DPP2 BT8_DPP1 BT8_DPP1
+#define BT8_DPP6 BT8_DPP2 BT8_DPP2 BT8_DPP2
+#define BT8_DPP14 BT8_DPP6 BT8_DPP6 BT8_DPP2
+#define BT8_DPP_STEPS(reps, acc, p) asm volatile(reps : "+v"(acc) : "v"(p))
 template <int STEPS>
-__device__ __forceinline__ void scan_rows(const float (&pw)[8], bool segfirst, int lastlane, int TT,
+__device__ __forceinline__ void scan_rows(const float (&pw)[8], bool seglast, bool single, int lastlane, int TT,
                                           float& tot1, float& tot3, float& tot5, float& tot7) {
   float carry = 0.0f;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    float acc = ((r & (TT - 1)) == 0 ? 0.0f : carry) + pw[r];
-#pragma unroll
-    for (int k = 0; k < STEPS; ++k) {
-      const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0xF, 0xF, false));
-      const float t = left + pw[r];  // row_shr:1
-      acc = segfirst ? acc : t;
+    const float base = ((r & (TT - 1)) == 0 ? 0.0f : carry) + pw[r];
+    float acc = base;
+    if constexpr (STEPS >= 2) {
+      if (!seglast) {  // one block per row: nothing of the compiler's between the steps
+        static_assert(STEPS == 15 || STEPS == 7 || STEPS == 3 || STEPS < 2, "segment widths are powers of two");
+        if constexpr (STEPS == 15) BT8_DPP_STEPS(BT8_DPP14, acc, pw[r]);
+        if constexpr (STEPS == 7) BT8_DPP_STEPS(BT8_DPP6, acc, pw[r]);
+        if constexpr (STEPS == 3) BT8_DPP_STEPS(BT8_DPP2, acc, pw[r]);
+      }
+    }
+    if constexpr (STEPS >= 1) {
+      BT8_DPP_STEPS(BT8_DPP1, acc, pw[r]);
+      acc = single ? base : acc;
     }
     carry = __int_as_float(__builtin_amdgcn_ds_bpermute(lastlane, __float_as_int(acc)));
     if (r == 1) tot1 = carry;
     if (r == 3) tot3 = carry;
     if (r == 5) tot5 = carry;
     if (r == 7) tot7 = carry;
+  }
+}
+
+// The same running sums when every macro-column of the wave has chosen segments 16 bins wide (F = 0; the
+// usual choice in stationary noise): a block sum then runs along the whole DPP row and on into the next
+// row, so a row is one rotate-add (lane 0 takes lane 15's sum of the row before) and 15 shift-adds whose
+// lane 0 keeps its value (row_shr with no source lane leaves the destination alone): 128 dependent adds
+// per column, the reference's own count, with no select and no LDS hop on the chain.  The DPP reads follow
+// VALU writes of the same register: two wait states each, given here because the hazard recogniser does
+// not look into inline assembly.  Lanes of the DC / tail row (`edge`: one-lane blocks of 8 rows) add
+// their own eight powers in order.
+__device__ __forceinline__ void scan_rows_full(const float (&pw)[8], int lastlane, int TT, bool edge,
+                                               float& tot1, float& tot3, float& tot5, float& tot7) {
+  float acc = pw[0], own = pw[0];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    if (r > 0) {
+      own += pw[r];
+      float nxt;
+      asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:0xf" : "=&v"(nxt) : "v"(acc), "v"(pw[r]));
+      const bool starts = (r & 1) == 0 && (r & (TT - 1)) == 0;  // a block starts at rows 2 / 4 / 6 for TT = 2 / <= 4 / 2
+      acc = starts ? pw[r] : nxt;
+    }
+    BT8_DPP_STEPS(BT8_DPP14 BT8_DPP1, acc, pw[r]);
+    if (r & 1) {
+      const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(lastlane, __float_as_int(acc)));
+      if (r == 1) tot1 = t;
+      if (r == 3) tot3 = t;
+      if (r == 5) tot5 = t;
+      if (r == 7) tot7 = edge ? own : t;
+    }
   }
 }
 
@@ -528,19 +578,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
         pw[r] = zz.x + zz.y;
       }
       BT8_STAMP(12)
-      const bool segfirst = (u & (FF - 1)) == 0;
+      const bool seglast = (u & (FF - 1)) == FF - 1, single = FF == 1;
       const int lastlane = (lane | (FF - 1)) << 2;
       int mf = FF;
       mf = max(mf, __shfl_xor(mf, 16));
       mf = max(mf, __shfl_xor(mf, 32));
       const int steps = __builtin_amdgcn_readfirstlane(mf) - 1;
       float tot1 = 1.0f, tot3 = 1.0f, tot5 = 1.0f, tot7 = 1.0f;  // running sums after rows 1, 3, 5, 7
-      switch (steps) {
-        case 15: scan_rows<15>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
-        case 7: scan_rows<7>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
-        case 3: scan_rows<3>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
-        case 1: scan_rows<1>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
-        default: scan_rows<0>(pw, segfirst, lastlane, TT, tot1, tot3, tot5, tot7); break;
+      const bool full = steps == 15 && __builtin_expect(__all(edge || FF == 16), 1);
+      if (full) {
+        scan_rows_full(pw, lastlane, TT, edge, tot1, tot3, tot5, tot7);
+      } else switch (steps) {
+        case 15: scan_rows<15>(pw, seglast, single, lastlane, TT, tot1, tot3, tot5, tot7); break;
+        case 7: scan_rows<7>(pw, seglast, single, lastlane, TT, tot1, tot3, tot5, tot7); break;
+        case 3: scan_rows<3>(pw, seglast, single, lastlane, TT, tot1, tot3, tot5, tot7); break;
+        case 1: scan_rows<1>(pw, seglast, single, lastlane, TT, tot1, tot3, tot5, tot7); break;
+        default: scan_rows<0>(pw, seglast, single, lastlane, TT, tot1, tot3, tot5, tot7); break;
       }
       BT8_STAMP(13)
       // a block ends at row r when (r + 1) % TT == 0; its Stein gain (.c:440-444).  Rows 1 and 5 end blocks
