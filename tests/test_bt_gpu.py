@@ -53,6 +53,24 @@ def test_macroblocks_bit_exact_vs_oracle(bt, n):
     g.close()
 
 
+def test_wide_segment_signals_bit_exact(bt):
+    """Signals far above the noise floor make every macro-column choose the 8 x 16 block (oracle seg (0, 0)):
+    the full-row scan of bt_kernels8.hip; a chirp and a tone mix that with narrow segments in the low columns."""
+    n, K = 1024, 3
+    g = bt.BtBatch(4, n)
+    rng = np.random.default_rng(5)
+    t = np.arange(K * g.macro, dtype=np.float64)
+    x = np.stack([0.5 * rng.standard_normal(t.size), 0.4 * np.sin(1e-5 * t * t), 0.5 * np.sin(0.3 * t),
+                  0.5 * rng.standard_normal(t.size) * np.where(t < 1.5 * g.macro, 1.0, 0.02)]).astype(np.float32)
+    o = OracleBt(n)
+    _, seg = o.macroblock(x[0, :g.macro], want_seg=True)
+    assert not np.asarray(seg).any()  # the case this test is for
+    y = g.run(x)
+    for s in range(4):
+        assert np.array_equal(y[s], OracleBt(n).run(x[s])), s
+    g.close()
+
+
 def test_stereo_48k_config3_shape(bt):
     """BASELINE config 3: stereo = two independent stream-channels, 1024-point STFT."""
     g = bt.BtBatch(2, 1024)
