@@ -16,6 +16,12 @@ hipError_t launch_analysis(int32_t* state, const int16_t* in, int16_t* low, int1
                            int num_channels, int band_length, hipStream_t s);
 hipError_t launch_synthesis(int32_t* state, const int16_t* low, const int16_t* high, int16_t* out,
                             int num_channels, int band_length, hipStream_t s);
+hipError_t launch_analysis_pair(int32_t* state0, const int16_t* in0, int16_t* low0, int16_t* high0,
+                                int32_t* state1, const int16_t* in1, int16_t* low1, int16_t* high1,
+                                int16_t* drop_scratch, int num_channels, int band_length, hipStream_t s);
+hipError_t launch_synthesis_pair(int32_t* state0, const int16_t* low0, const int16_t* high0, int16_t* out0,
+                                 int32_t* state1, const int16_t* low1, const int16_t* high1, int16_t* out1,
+                                 int num_channels, int band_length, hipStream_t s);
 }  // namespace aspqmf
 
 namespace {
@@ -299,9 +305,10 @@ int AspSplitBatch_Analysis(AspSplitBatch* b, const int16_t* in, int16_t* bands, 
     const int rc = AspSincBatch_Resample(b->up, din, b->buf640, ASP_MEM_DEVICE);
     if (rc != ASP_OK) return rc;
     QMF_TRY(aspqmf::launch_analysis(stA, b->buf640, b->low320, b->high320, b->C, 320, b->stream));
-    QMF_TRY(aspqmf::launch_analysis(stB, b->low320, dbands, dbands + c * 160, b->C, 160, b->stream));
-    // the lower output of the upper half is the empty 24-32 kHz band: written to scratch, dropped
-    QMF_TRY(aspqmf::launch_analysis(stC, b->high320, b->low320, dbands + 2 * c * 160, b->C, 160, b->stream));
+    // the two second-stage banks as one launch; the lower output of the upper half is the empty
+    // 24-32 kHz band: dropped
+    QMF_TRY(aspqmf::launch_analysis_pair(stB, b->low320, dbands, dbands + c * 160, stC, b->high320, nullptr,
+                                         dbands + 2 * c * 160, b->low320, b->C, 160, b->stream));
   }
   if (mem == ASP_MEM_HOST) {
     QMF_TRY(hipMemcpyAsync(bands, dbands, total, hipMemcpyDeviceToHost, b->stream));
@@ -327,8 +334,8 @@ int AspSplitBatch_Synthesis(AspSplitBatch* b, const int16_t* bands, int16_t* out
   if (b->nb == 2) {  // TwoBandsSynthesis, splitting_filter.cc:77-88
     QMF_TRY(aspqmf::launch_synthesis(stA, dbands, dbands + c * 160, dout, b->C, 160, b->stream));
   } else {  // ThreeBandsSynthesis, splitting_filter.cc:137-169 (the uppermost band is empty)
-    QMF_TRY(aspqmf::launch_synthesis(stB, dbands, dbands + c * 160, b->low320, b->C, 160, b->stream));
-    QMF_TRY(aspqmf::launch_synthesis(stC, b->zeros160, dbands + 2 * c * 160, b->high320, b->C, 160, b->stream));
+    QMF_TRY(aspqmf::launch_synthesis_pair(stB, dbands, dbands + c * 160, b->low320, stC, b->zeros160,
+                                          dbands + 2 * c * 160, b->high320, b->C, 160, b->stream));
     QMF_TRY(aspqmf::launch_synthesis(stA, b->low320, b->high320, b->buf640, b->C, 320, b->stream));
     const int rc = AspSincBatch_Resample(b->down, b->buf640, dout, ASP_MEM_DEVICE);
     if (rc != ASP_OK) return rc;

@@ -43,9 +43,18 @@ struct AspSincBatch {
   hipStream_t stream = nullptr, own_stream = nullptr;
   float* state = nullptr;   // [C][buf_len]
   float* ktable = nullptr;  // [33 * 32]
-  OutDesc* desc = nullptr;  // [max outputs per call]
+  // descriptor tables: a ring of kDescRing slots on the device, each with a pinned host twin and the
+  // event of the last kernel that read it (a call whose table differs from the previous one takes
+  // the next slot: no stream synchronisation on the way)
+  static constexpr int kDescRing = 4;
+  OutDesc* desc = nullptr;         // [kDescRing][max_out]
+  OutDesc* desc_pinned = nullptr;  // [kDescRing][max_out], hipHostMalloc
+  hipEvent_t desc_ev[kDescRing] = {};
+  size_t max_out = 0;
+  int desc_slot = 0;
   int16_t *s_in = nullptr, *s_out = nullptr;
   std::vector<float> kernel_host;
+  std::vector<OutDesc> desc_dev;  // the descriptor table as last uploaded
   std::vector<OutDesc> desc_host;
   // SincResampler / PushSincResampler position state (identical for every channel)
   double ratio = 0, vsi = 0;
@@ -164,11 +173,15 @@ int AspSincBatch_Create(AspSincBatch** out, int num_channels, int source_frames,
   update_regions(b, false);
   init_kernel(b);
   const size_t max_out = (size_t)destination_frames * 2 + 64;
+  b->max_out = max_out;
   hipError_t e = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
   b->stream = b->own_stream;
   if (e == hipSuccess) e = hipMalloc((void**)&b->state, (size_t)num_channels * b->buf_len * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->ktable, b->kernel_host.size() * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&b->desc, max_out * sizeof(OutDesc));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->desc, AspSincBatch::kDescRing * max_out * sizeof(OutDesc));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&b->desc_pinned, AspSincBatch::kDescRing * max_out * sizeof(OutDesc));
+  for (int i = 0; i < AspSincBatch::kDescRing && e == hipSuccess; ++i)
+    e = hipEventCreateWithFlags(&b->desc_ev[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&b->s_in, (size_t)num_channels * source_frames * sizeof(int16_t));
   if (e == hipSuccess) e = hipMalloc((void**)&b->s_out, (size_t)num_channels * destination_frames * sizeof(int16_t));
   if (e == hipSuccess) e = hipMemsetAsync(b->state, 0, (size_t)num_channels * b->buf_len * sizeof(float), b->stream);
@@ -191,6 +204,9 @@ int AspSincBatch_Free(AspSincBatch* b) {
   if (b->state) (void)hipFree(b->state);
   if (b->ktable) (void)hipFree(b->ktable);
   if (b->desc) (void)hipFree(b->desc);
+  if (b->desc_pinned) (void)hipHostFree(b->desc_pinned);
+  for (int i = 0; i < AspSincBatch::kDescRing; ++i)
+    if (b->desc_ev[i]) (void)hipEventDestroy(b->desc_ev[i]);
   if (b->s_in) (void)hipFree(b->s_in);
   if (b->s_out) (void)hipFree(b->s_out);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -228,11 +244,23 @@ int AspSincBatch_Resample(AspSincBatch* b, const int16_t* in, int16_t* out, int 
   } else if (mem != ASP_MEM_DEVICE) {
     return sinc_fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
   }
-  // the descriptor table of the previous call may still be in use by its kernel: order on the stream
-  SINC_TRY(hipStreamSynchronize(b->stream));
-  SINC_TRY(hipMemcpyAsync(b->desc, b->desc_host.data(), b->desc_host.size() * sizeof(OutDesc),
-                          hipMemcpyHostToDevice, b->stream));
-  SINC_TRY(launch_sinc(b->state, b->ktable, b->desc, din, dout, b->C, b->buf_len, b->src, b->dst, plan, b->stream));
+  // The descriptor table repeats from call to call while the fractional position does: upload it only
+  // when it differs from the one last uploaded, into the next slot of the ring (the kernel that read
+  // that slot kDescRing uploads ago has long finished; its event says so without draining the stream).
+  if (b->desc_host.size() > b->max_out) return sinc_fail(ASP_ERR_STATE, "descriptor table overflow");
+  if (b->desc_dev.size() != b->desc_host.size() ||
+      memcmp(b->desc_dev.data(), b->desc_host.data(), b->desc_host.size() * sizeof(OutDesc)) != 0) {
+    b->desc_slot = (b->desc_slot + 1) % AspSincBatch::kDescRing;
+    SINC_TRY(hipEventSynchronize(b->desc_ev[b->desc_slot]));
+    OutDesc* pin = b->desc_pinned + (size_t)b->desc_slot * b->max_out;
+    memcpy(pin, b->desc_host.data(), b->desc_host.size() * sizeof(OutDesc));
+    SINC_TRY(hipMemcpyAsync(b->desc + (size_t)b->desc_slot * b->max_out, pin, b->desc_host.size() * sizeof(OutDesc),
+                            hipMemcpyHostToDevice, b->stream));
+    b->desc_dev = b->desc_host;
+  }
+  SINC_TRY(launch_sinc(b->state, b->ktable, b->desc + (size_t)b->desc_slot * b->max_out, din, dout, b->C, b->buf_len,
+                       b->src, b->dst, plan, b->stream));
+  SINC_TRY(hipEventRecord(b->desc_ev[b->desc_slot], b->stream));
   if (mem == ASP_MEM_HOST) {
     SINC_TRY(hipMemcpyAsync(out, dout, (size_t)b->C * b->dst * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
     SINC_TRY(hipStreamSynchronize(b->stream));

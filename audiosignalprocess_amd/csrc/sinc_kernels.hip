@@ -18,6 +18,15 @@ __device__ __forceinline__ int16_t float_s16_to_s16(float v) {  // audio_util.h:
   return v <= kMinRound ? (int16_t)-32768 : (int16_t)(v - 0.5f);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The kernel table [33 offsets][32 taps] staged in LDS per workgroup (4.1 KB): a lane reads the two
+// rows of its output as eight 16-byte chunks each.  Lanes of a wave sit on different rows (offset
+// 0 / 8 / 16 / 24 for 48 -> 64 kHz), which all start at bank 0: chunk c of row r is kept at chunk
+// c ^ (r / 8 mod 8), so those rows' equal chunks fall into different banks.
+constexpr int kTabFloats = (kKernelOffsetCount + 1) * kKernelSize;
+__device__ __forceinline__ int tab_swz(int row) { return (row >> 3) & 7; }
+
 __global__ __launch_bounds__(256) void sinc_resample_kernel(float* __restrict__ state,
                                                             const float* __restrict__ kernel_table,
                                                             const OutDesc* __restrict__ desc,
@@ -25,9 +34,15 @@ __global__ __launch_bounds__(256) void sinc_resample_kernel(float* __restrict__ 
                                                             int16_t* __restrict__ out,
                                                             int buf_len, int src_frames,
                                                             int dst_frames, SincPlan plan) {
-  extern __shared__ float buf[];  // [buf_len]
+  extern __shared__ __align__(16) float smem[];  // [kTabFloats] table, [buf_len] the channel's buffer
+  float4* ktab = reinterpret_cast<float4*>(smem);
+  float* buf = smem + kTabFloats;
   const int ch = blockIdx.x, tid = threadIdx.x;
   float* st = state + (size_t)ch * buf_len;
+  for (int i = tid; i < kTabFloats / 4; i += 256) {
+    const int row = i >> 3, c = i & 7;
+    ktab[row * 8 + (c ^ tab_swz(row))] = reinterpret_cast<const float4*>(kernel_table)[i];
+  }
   for (int i = tid; i < buf_len; i += 256) buf[i] = st[i];
   __syncthreads();
   for (int s = 0; s < plan.nseg; ++s) {
@@ -45,20 +60,23 @@ __global__ __launch_bounds__(256) void sinc_resample_kernel(float* __restrict__ 
     for (int m = sg.out_begin + tid; m < sg.out_end; m += 256) {
       const OutDesc d = desc[m];
       const float* x = buf + d.source_idx;
-      const float* k1 = kernel_table + d.offset_idx * kKernelSize;
-      const float* k2 = k1 + kKernelSize;
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      const float4* k1 = ktab + d.offset_idx * 8;
+      const float4* k2 = k1 + 8;
+      const int z1 = tab_swz(d.offset_idx), z2 = tab_swz(d.offset_idx + 1);
+      // Convolve_SSE's four partial sums per kernel, as two packed pairs each: the multiply and the add
+      // of a tap stay separate IEEE operations (no contraction)
+      f32x2 s1a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2a = {0.f, 0.f}, s2b = {0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < kKernelSize; i += 4)
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-          s1[l] = s1[l] + x[i + l] * k1[i + l];
-          s2[l] = s2[l] + x[i + l] * k2[i + l];
-        }
-      float t[4];
-#pragma unroll
-      for (int l = 0; l < 4; ++l) t[l] = s1[l] * d.f1 + s2[l] * d.f2;
-      const float r = (t[2] + t[0]) + (t[3] + t[1]);
+      for (int c = 0; c < kKernelSize / 4; ++c) {
+        const float4 a = k1[c ^ z1], b = k2[c ^ z2];
+        const f32x2 xa = {x[4 * c], x[4 * c + 1]}, xb = {x[4 * c + 2], x[4 * c + 3]};
+        s1a = s1a + xa * f32x2{a.x, a.y};
+        s1b = s1b + xb * f32x2{a.z, a.w};
+        s2a = s2a + xa * f32x2{b.x, b.y};
+        s2b = s2b + xb * f32x2{b.z, b.w};
+      }
+      const f32x2 ta = s1a * d.f1 + s2a * d.f2, tb = s1b * d.f1 + s2b * d.f2;  // t[0], t[1]; t[2], t[3]
+      const float r = (tb.x + ta.x) + (tb.y + ta.y);
       if (d.dest >= 0) out[(size_t)ch * dst_frames + d.dest] = float_s16_to_s16(r);
     }
     __syncthreads();
@@ -73,7 +91,7 @@ namespace aspsinc {
 hipError_t launch_sinc(float* state, const float* kernel_table, const OutDesc* desc,
                        const int16_t* in, int16_t* out, int num_channels, int buf_len,
                        int src_frames, int dst_frames, const SincPlan& plan, hipStream_t s) {
-  hipLaunchKernelGGL(sinc_resample_kernel, dim3(num_channels), dim3(256), (size_t)buf_len * sizeof(float), s,
+  hipLaunchKernelGGL(sinc_resample_kernel, dim3(num_channels), dim3(256), (size_t)(kTabFloats + buf_len) * sizeof(float), s,
                      state, kernel_table, desc, in, out, buf_len, src_frames, dst_frames, plan);
   return hipGetLastError();
 }
