@@ -217,7 +217,7 @@ def bench_split(args):
                                "Synthesis per 10 ms frame, 1 MI355X" % Cn},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "sinc_resample_kernel + qmf_analysis_kernel / qmf_synthesis_kernel (several launches per step; "
+                     "kernel": "sinc_resample_kernel + qmf_analysis4_kernel / qmf_synthesis4_kernel (six launches per step; "
                                "wall-clock figure, launch-bound)",
                      "algorithmic_bytes_per_launch": algo * Cn, "avg_launch_us": None},
     }
