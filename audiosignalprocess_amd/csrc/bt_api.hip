@@ -25,6 +25,9 @@ hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const fl
                                 unsigned long long* stamps = nullptr);
 hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int inverse,
                           const BtTables* T, hipStream_t s);
+hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const float* in, float* out, int num_streams,
+                                    int frames, int threshold, int in_stride, int out_stride, hipStream_t s);
+hipError_t launch_bt_fftr_any(const BtAnyTables& A, const float* src, float* dst, int count, int inverse, hipStream_t s);
 }  // namespace aspbt
 
 namespace {
@@ -113,6 +116,78 @@ void build_bt_tables(BtTables* T) {
     if (T->sup1024_i[2 * i] != T->sup1024_f[2 * i] || T->sup1024_i[2 * i + 1] != -T->sup1024_f[2 * i + 1]) abort();
 }
 
+// Tables of a window other than 256 / 1024 samples (bt_macroblock_any_kernel): one device block per batch.
+// kf_factor (kiss_fft.c:308-330) and the decimation order of kf_work (kiss_fft.c:237-302) run here.
+bool bt_any_window_ok(int win) {
+  if (win < 4 || win > kAnyMaxWin || (win & 1)) return false;
+  int n = win / 2, p = 4;
+  const double floor_sqrt = floor(sqrt((double)n));
+  do {  // the generic butterfly's scratch holds kAnyMaxRadix points
+    while (n % p) {
+      p = p == 4 ? 2 : p == 2 ? 3 : p + 2;
+      if (p > floor_sqrt) p = n;
+    }
+    if (p > kAnyMaxRadix) return false;
+    n /= p;
+  } while (n > 1);
+  return true;
+}
+
+int bt_build_any(int win, BtAnyTables* A, void** dev_block) {
+  const int nc = win / 2;
+  memset(A, 0, sizeof *A);
+  A->n = win;
+  A->nc = nc;
+  A->ncol = (win - 1) / 2 / ASP_BT_NBLK_FREQ;  // .c:493
+  {
+    int n = nc, p = 4, k = 0;
+    const double floor_sqrt = floor(sqrt((double)nc));
+    do {
+      while (n % p) {
+        p = p == 4 ? 2 : p == 2 ? 3 : p + 2;
+        if (p > floor_sqrt) p = n;
+      }
+      n /= p;
+      if (k >= 32) return bt_fail(ASP_ERR_PARAM, "window has too many factors");
+      A->fac[k++] = p;
+      A->fac[k++] = n;
+    } while (n > 1);
+    A->nfac = k / 2;
+  }
+  // one host block: hann[win] | tw_f[2 nc] | tw_i[2 nc] | sup_f[2 (nc/2)] | sup_i[2 (nc/2)] | perm (uint16)[nc]
+  const size_t nf = (size_t)win + 4 * (size_t)nc + 4 * (size_t)(nc / 2);
+  const size_t bytes = nf * sizeof(float) + (size_t)nc * sizeof(uint16_t);
+  std::vector<unsigned char> host(bytes);
+  float* hf = reinterpret_cast<float*>(host.data());
+  float *hann = hf, *tw_f = hann + win, *tw_i = tw_f + 2 * nc, *sup_f = tw_i + 2 * nc, *sup_i = sup_f + 2 * (nc / 2);
+  uint16_t* perm = reinterpret_cast<uint16_t*>(sup_i + 2 * (nc / 2));
+  fill_size(&A->P, win, hann, tw_f, tw_i, sup_f, sup_i);
+  for (int n = 0; n < nc; ++n) {  // input n = sum k_s fstride_s lands at sum k_s m_s
+    int t = n, pos = 0;
+    for (int q = 0; q < A->nfac; ++q) {
+      pos += (t % A->fac[2 * q]) * A->fac[2 * q + 1];
+      t /= A->fac[2 * q];
+    }
+    perm[n] = (uint16_t)pos;
+  }
+  unsigned char* dev = nullptr;
+  BT_TRY(hipMalloc((void**)&dev, bytes));
+  hipError_t e = hipMemcpy(dev, host.data(), bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(dev);
+    return bt_fail(ASP_ERR_HIP, "uploading the window's tables", e);
+  }
+  float* df = reinterpret_cast<float*>(dev);
+  A->hann = df;
+  A->tw_f = df + win;
+  A->tw_i = A->tw_f + 2 * nc;
+  A->sup_f = A->tw_i + 2 * nc;
+  A->sup_i = A->sup_f + 2 * (nc / 2);
+  A->perm = reinterpret_cast<const uint16_t*>(A->sup_i + 2 * (nc / 2));
+  *dev_block = dev;
+  return ASP_OK;
+}
+
 std::mutex g_bt_mu;
 BtTables* g_bt_dev[64] = {nullptr};
 
@@ -150,6 +225,9 @@ struct AspBtBatch {
   hipStream_t stream = nullptr;
   float* state = nullptr;
   BtTables* tables = nullptr;
+  bool any = false;            // a window other than 256 / 1024 samples: bt_macroblock_any_kernel
+  BtAnyTables any_tables = {};
+  void* any_block = nullptr;   // the device block any_tables points into
   float *stage_in = nullptr, *stage_out = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // second launch chain of the K-step path (AspBtBatch_TimedSteps): stream-channels are independent, so
@@ -163,8 +241,9 @@ extern "C" {
 int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int device) {
   if (!out || num_streams <= 0) return bt_fail(ASP_ERR_PARAM, "AspBtBatch_Create: bad argument");
   *out = nullptr;
-  if (win_size != 256 && win_size != 1024)
-    return bt_fail(ASP_ERR_PARAM, "AspBtBatch_Create: win_size must be 256 or 1024");
+  const bool any = win_size != 256 && win_size != 1024;
+  if (any && !bt_any_window_ok(win_size))
+    return bt_fail(ASP_ERR_PARAM, "AspBtBatch_Create: win_size must be even, 4 .. 1024, with no prime factor of win_size / 2 above 32");
   int rc = bt_select_device(device);
   if (rc) return rc;
   AspBtBatch* b = new AspBtBatch();
@@ -173,7 +252,8 @@ int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int devic
   b->half = win_size / 2;
   b->macro = 8 * b->half;
   b->device = device;
-  rc = bt_tables(device, &b->tables);
+  b->any = any;
+  rc = any ? bt_build_any(win_size, &b->any_tables, &b->any_block) : bt_tables(device, &b->tables);
   if (rc) {
     delete b;
     return rc;
@@ -200,6 +280,7 @@ int AspBtBatch_Free(AspBtBatch* b) {
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->state) (void)hipFree(b->state);
+  if (b->any_block) (void)hipFree(b->any_block);
   if (b->stage_in) (void)hipFree(b->stage_in);
   if (b->stage_out) (void)hipFree(b->stage_out);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -225,6 +306,16 @@ int AspBtBatch_Reset(AspBtBatch* b) {
 int AspBtBatch_num_streams(const AspBtBatch* b) { return b ? b->S : ASP_ERR_PARAM; }
 int AspBtBatch_macro_size(const AspBtBatch* b) { return b ? b->macro : ASP_ERR_PARAM; }
 
+static hipError_t bt_launch(AspBtBatch* b, float* state, const float* in, float* out, int num_streams, int frames,
+                            int threshold, int in_stride, int out_stride, hipStream_t s,
+                            unsigned long long* stamps = nullptr) {
+  if (b->any)
+    return launch_bt_macroblock_any(b->any_tables, state, in, out, num_streams, frames, threshold, in_stride,
+                                    out_stride, s);
+  return launch_bt_macroblock(b->win, state, b->tables, in, out, num_streams, frames, threshold, in_stride, out_stride,
+                              s, stamps);
+}
+
 static int bt_run(AspBtBatch* b, const float* in, float* out, int frames, int threshold, int mem) {
   if (!b || !out || (!in && frames > 0)) return bt_fail(ASP_ERR_PARAM, "null argument");
   if (frames < 0 || frames > 8) return bt_fail(ASP_ERR_PARAM, "frames must be 0..8");
@@ -240,8 +331,7 @@ static int bt_run(AspBtBatch* b, const float* in, float* out, int frames, int th
   } else if (mem != ASP_MEM_DEVICE) {
     return bt_fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
   }
-  BT_TRY(launch_bt_macroblock(b->win, b->state, b->tables, din, dout, b->S, frames, threshold, n,
-                              n, b->stream));
+  BT_TRY(bt_launch(b, b->state, din, dout, b->S, frames, threshold, n, n, b->stream));
   if (mem == ASP_MEM_HOST) {
     BT_TRY(hipMemcpyAsync(out, b->stage_out, (size_t)b->S * n * 4, hipMemcpyDeviceToHost,
                           b->stream));
@@ -287,12 +377,11 @@ int AspBtBatch_TimedSteps(AspBtBatch* b, const float* in, float* out, int blocks
   const int half = dual ? b->S / 2 : b->S;
   for (int k = 0; k < steps; ++k) {
     const size_t off = per * (size_t)(k % blocks_in_ring);
-    BT_TRY(launch_bt_macroblock(b->win, b->state, b->tables, in + off, out + off, half, 8, 1, b->macro, b->macro,
-                                b->stream));
+    BT_TRY(bt_launch(b, b->state, in + off, out + off, half, 8, 1, b->macro, b->macro, b->stream));
     if (dual) {
       const size_t o2 = (size_t)half * b->macro;
-      BT_TRY(launch_bt_macroblock(b->win, b->state + (size_t)half * kStateFloats, b->tables, in + off + o2,
-                                  out + off + o2, b->S - half, 8, 1, b->macro, b->macro, b->side));
+      BT_TRY(bt_launch(b, b->state + (size_t)half * kStateFloats, in + off + o2, out + off + o2, b->S - half, 8, 1,
+                       b->macro, b->macro, b->side));
     }
   }
   if (dual) {
@@ -314,8 +403,7 @@ int AspBtBatch_DebugStamps(AspBtBatch* b, const float* in_dev, float* out_dev,
   BT_TRY(hipMalloc((void**)&d, 48 * sizeof(unsigned long long)));
   hipError_t e = hipMemset(d, 0, 48 * sizeof(unsigned long long));
   if (e == hipSuccess)
-    e = launch_bt_macroblock(b->win, b->state, b->tables, in_dev, out_dev, b->S, 8, 1, b->macro,
-                             b->macro, b->stream, d);
+    e = bt_launch(b, b->state, in_dev, out_dev, b->S, 8, 1, b->macro, b->macro, b->stream, d);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (e == hipSuccess) e = hipMemcpy(stamps11, d, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d);
@@ -350,22 +438,27 @@ int AspBtBatch_ImportState(AspBtBatch* b, int stream, const AspBtState* in) {
 }
 
 static int bt_fft_seam(const float* src, float* dst, int n, int count, int inverse, int device) {
-  if (!src || !dst || count <= 0 || (n != 256 && n != 1024))
+  const bool any = n != 256 && n != 1024;
+  if (!src || !dst || count <= 0 || (any && !bt_any_window_ok(n)))
     return bt_fail(ASP_ERR_PARAM, "kiss_fftr seam: bad argument");
   int rc = bt_select_device(device);
   if (rc) return rc;
   BtTables* T = nullptr;
-  rc = bt_tables(device, &T);
+  BtAnyTables A;
+  void* any_block = nullptr;
+  rc = any ? bt_build_any(n, &A, &any_block) : bt_tables(device, &T);
   if (rc) return rc;
   const size_t tb = (size_t)count * n * 4, fb = (size_t)count * (n + 2) * 4;
   float *ds = nullptr, *dd = nullptr;
   BT_TRY(hipMalloc((void**)&ds, inverse ? fb : tb));
   BT_TRY(hipMalloc((void**)&dd, inverse ? tb : fb));
   hipError_t e = hipMemcpy(ds, src, inverse ? fb : tb, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = launch_bt_fftr(n, ds, dd, count, inverse, T, nullptr);
+  if (e == hipSuccess)
+    e = any ? launch_bt_fftr_any(A, ds, dd, count, inverse, nullptr) : launch_bt_fftr(n, ds, dd, count, inverse, T, nullptr);
   if (e == hipSuccess) e = hipMemcpy(dst, dd, inverse ? tb : fb, hipMemcpyDeviceToHost);
   (void)hipFree(ds);
   (void)hipFree(dd);
+  if (any_block) (void)hipFree(any_block);
   if (e != hipSuccess) return bt_fail(ASP_ERR_HIP, "kiss_fftr seam", e);
   return ASP_OK;
 }
@@ -407,8 +500,10 @@ MarsBlockThreshold_t* blockThreshold_init(int32_t time_win, int32_t fs, int32_t*
   }
   int32_t win = fs / 1000 * time_win;  // .c:91-94
   if (win & 0x01) win += 1;
-  if (win != 256 && win != 1024) {
-    fprintf(stderr, "blockThreshold_init: window of %d samples is not built (256 / 1024 only)\n", win);
+  if (win != 256 && win != 1024 && !bt_any_window_ok(win)) {
+    fprintf(stderr,
+            "blockThreshold_init: window of %d samples is not built (even, 4 .. 1024 samples, no prime factor of "
+            "half the window above 32)\n", win);
     *err = MARS_ERROR_PARAMS;
     return NULL;
   }

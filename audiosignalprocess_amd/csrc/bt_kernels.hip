@@ -446,6 +446,437 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
 #undef BT_STAMP
 }
 
+// --------------------------------------------------------------------------
+// Any even window of 4 .. 1024 samples (20 ms at 16 kHz = 320, 50 ms = 800, 10 ms at 48 kHz = 480, ...):
+// the same phases with run-time sizes and kiss_fft's mixed-radix plan -- radix 4, 2, 3, 5 and the generic
+// butterfly for larger primes (kiss_fft.c:21-235).  One butterfly per thread and stage, the reference's
+// float operations in the reference's order (butterflies of a stage are independent, so their order
+// across threads does not matter).  A plain path: 256 threads per macroblock, a barrier per stage.
+constexpr int kAnyThreads = 256;
+constexpr int kAnySqw = 32;  // columns of the squared-real table (at most 31 macro-columns)
+
+__device__ __forceinline__ void any_bfly2(cpx* F, int m, const cpx* tw, int fstride, int u) {
+  const cpx t = cmul(F[m], tw[u * fstride]);
+  const cpx a = F[0];
+  F[m].r = a.r - t.r;
+  F[m].i = a.i - t.i;
+  F[0].r = a.r + t.r;
+  F[0].i = a.i + t.i;
+}
+
+__device__ __forceinline__ void any_bfly3(cpx* F, int m, const cpx* tw, int fstride, int u) {  // kiss_fft.c:92-136
+  const int m2 = 2 * m;
+  const cpx epi3 = tw[fstride * m];
+  const cpx s1 = cmul(F[m], tw[u * fstride]), s2 = cmul(F[m2], tw[2 * u * fstride]);
+  cpx s3, s0, f0 = F[0], f1;
+  s3.r = s1.r + s2.r;
+  s3.i = s1.i + s2.i;
+  s0.r = s1.r - s2.r;
+  s0.i = s1.i - s2.i;
+  f1.r = f0.r - s3.r * .5f;
+  f1.i = f0.i - s3.i * .5f;
+  s0.r *= epi3.i;
+  s0.i *= epi3.i;
+  f0.r += s3.r;
+  f0.i += s3.i;
+  F[0] = f0;
+  F[m2].r = f1.r + s0.i;
+  F[m2].i = f1.i - s0.r;
+  F[m].r = f1.r - s0.i;
+  F[m].i = f1.i + s0.r;
+}
+
+__device__ __forceinline__ void any_bfly4(cpx* F, int M, const cpx* tw, int fstride, int k, bool inverse) {
+  const cpx s0 = cmul(F[M], tw[k * fstride]);
+  const cpx s1 = cmul(F[2 * M], tw[k * fstride * 2]);
+  const cpx s2 = cmul(F[3 * M], tw[k * fstride * 3]);
+  cpx f0 = F[0], s3, s4, s5;
+  s5.r = f0.r - s1.r;
+  s5.i = f0.i - s1.i;
+  f0.r += s1.r;
+  f0.i += s1.i;
+  s3.r = s0.r + s2.r;
+  s3.i = s0.i + s2.i;
+  s4.r = s0.r - s2.r;
+  s4.i = s0.i - s2.i;
+  F[2 * M].r = f0.r - s3.r;
+  F[2 * M].i = f0.i - s3.i;
+  f0.r += s3.r;
+  f0.i += s3.i;
+  F[0] = f0;
+  if (inverse) {
+    F[M].r = s5.r - s4.i;
+    F[M].i = s5.i + s4.r;
+    F[3 * M].r = s5.r + s4.i;
+    F[3 * M].i = s5.i - s4.r;
+  } else {
+    F[M].r = s5.r + s4.i;
+    F[M].i = s5.i - s4.r;
+    F[3 * M].r = s5.r - s4.i;
+    F[3 * M].i = s5.i + s4.r;
+  }
+}
+
+__device__ __forceinline__ void any_bfly5(cpx* F, int m, const cpx* tw, int fstride, int u) {  // kiss_fft.c:138-197
+  const cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
+  const cpx s0 = F[0];
+  const cpx s1 = cmul(F[m], tw[u * fstride]), s2 = cmul(F[2 * m], tw[2 * u * fstride]);
+  const cpx s3 = cmul(F[3 * m], tw[3 * u * fstride]), s4 = cmul(F[4 * m], tw[4 * u * fstride]);
+  cpx s7, s10, s8, s9, s5, s6, s11, s12;
+  s7.r = s1.r + s4.r;
+  s7.i = s1.i + s4.i;
+  s10.r = s1.r - s4.r;
+  s10.i = s1.i - s4.i;
+  s8.r = s2.r + s3.r;
+  s8.i = s2.i + s3.i;
+  s9.r = s2.r - s3.r;
+  s9.i = s2.i - s3.i;
+  F[0].r = s0.r + (s7.r + s8.r);
+  F[0].i = s0.i + (s7.i + s8.i);
+  s5.r = s0.r + s7.r * ya.r + s8.r * yb.r;
+  s5.i = s0.i + s7.i * ya.r + s8.i * yb.r;
+  s6.r = s10.i * ya.i + s9.i * yb.i;
+  s6.i = -(s10.r * ya.i) - s9.r * yb.i;
+  F[m].r = s5.r - s6.r;
+  F[m].i = s5.i - s6.i;
+  F[4 * m].r = s5.r + s6.r;
+  F[4 * m].i = s5.i + s6.i;
+  s11.r = s0.r + s7.r * yb.r + s8.r * ya.r;
+  s11.i = s0.i + s7.i * yb.r + s8.i * ya.r;
+  s12.r = -(s10.i * yb.i) + s9.i * ya.i;
+  s12.i = s10.r * yb.i - s9.r * ya.i;
+  F[2 * m].r = s11.r + s12.r;
+  F[2 * m].i = s11.i + s12.i;
+  F[3 * m].r = s11.r - s12.r;
+  F[3 * m].i = s11.i - s12.i;
+}
+
+// kf_bfly_generic (kiss_fft.c:199-235), the unit u of the sub-transform starting at `base` (index into
+// the frame's array; the twiddle index runs on the position inside the sub-transform)
+__device__ __forceinline__ void any_bfly_generic(cpx* F, int m, int p, const cpx* tw, int fstride, int u, int norig) {
+  cpx scratch[kAnyMaxRadix];
+  int k = u;
+  for (int q1 = 0; q1 < p; ++q1, k += m) scratch[q1] = F[k];
+  k = u;
+  for (int q1 = 0; q1 < p; ++q1, k += m) {
+    int twidx = 0;
+    cpx acc = scratch[0];
+    for (int q = 1; q < p; ++q) {
+      twidx += fstride * k;
+      if (twidx >= norig) twidx -= norig;
+      const cpx t = cmul(scratch[q], tw[twidx]);
+      acc.r += t.r;
+      acc.i += t.i;
+    }
+    F[k] = acc;
+  }
+}
+
+// every stage of `frames` nc-point transforms in work[frame][nc] (inputs already in kiss order)
+__device__ __forceinline__ void any_stages(cpx* work, const cpx* __restrict__ tw, const BtAnyTables& A, int frames,
+                                           bool inverse, int tid) {
+  const int nc = A.nc;
+  for (int s = A.nfac - 1; s >= 0; --s) {
+    const int p = A.fac[2 * s], m = A.fac[2 * s + 1];
+    const int span = p * m, fstride = nc / span, units = nc / p;  // butterflies per frame
+    for (int w = tid; w < frames * units; w += kAnyThreads) {
+      const int fr = w / units, b = w % units;
+      const int g = b / m, u = b % m;
+      cpx* F = work + fr * nc + g * span;
+      switch (p) {
+        case 2: any_bfly2(F + u, m, tw, fstride, u); break;
+        case 3: any_bfly3(F + u, m, tw, fstride, u); break;
+        case 4: any_bfly4(F + u, m, tw, fstride, u, inverse); break;
+        case 5: any_bfly5(F + u, m, tw, fstride, u); break;
+        default: any_bfly_generic(F, m, p, tw, fstride, u, nc); break;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
+    float* __restrict__ state, BtAnyTables A, const float* __restrict__ in, float* __restrict__ out, int frames,
+    int threshold, int in_stride, int out_stride) {
+  const int N = A.n, NC = A.nc, HALF = A.nc, NB = A.nc + 1, NCOL = A.ncol;
+  extern __shared__ __align__(16) unsigned char smem[];
+  cpx* coef = reinterpret_cast<cpx*>(smem);                 // [8][NB]
+  cpx* thre = coef + 8 * NB;                                // [8][NB]; the FFT work tile aliases it
+  cpx* work = thre;                                         // [8][NC]
+  float* sq = reinterpret_cast<float*>(thre + 8 * NB);      // [128][kAnySqw]
+  float* sure = sq + 128 * kAnySqw;                         // [NCOL][15], then 16 spare, then 4 x (128 + 64)
+  float* stage = sure + 31 * 15 + 16 + 4 * (128 + 64);      // [HALF] new output tail
+  const int tid = threadIdx.x;
+  const int stream = blockIdx.x;
+  float* st = state + (size_t)stream * kStateFloats;
+  const float* x = in + (size_t)stream * in_stride;
+  float* y = out + (size_t)stream * out_stride;
+  const BtSize& P = A.P;
+  const cpx* tw_f = reinterpret_cast<const cpx*>(A.tw_f);
+  const cpx* tw_i = reinterpret_cast<const cpx*>(A.tw_i);
+  const cpx* sup_f = reinterpret_cast<const cpx*>(A.sup_f);
+  const cpx* sup_i = reinterpret_cast<const cpx*>(A.sup_i);
+
+  // ---- STFT (blockThreshold_STFT, .c:273-282)
+  const int total = frames * HALF;
+  for (int w = tid; w < frames * NC; w += kAnyThreads) {
+    const int fr = w / NC, n = w % NC;
+    const int p0 = HALF * fr + 2 * n;
+    const float b0 = p0 < HALF ? st[kOffInTail + p0] : x[p0 - HALF];
+    const float b1 = p0 + 1 < HALF ? st[kOffInTail + p0 + 1] : x[p0 + 1 - HALF];
+    cpx z;
+    z.r = b0 * A.hann[2 * n];
+    z.i = b1 * A.hann[2 * n + 1];
+    work[fr * NC + A.perm[n]] = z;
+  }
+  __syncthreads();
+  if (threshold)  // a flush leaves the input history alone (see bt_macroblock_kernel)
+    for (int i = tid; i < HALF; i += kAnyThreads) {
+      const int p = total + i;
+      st[kOffInTail + i] = p < HALF ? st[kOffInTail + p] : x[p - HALF];
+    }
+  any_stages(work, tw_f, A, frames, false, tid);
+  // kiss_fftr post-pass (kiss_fftr.c:92-120)
+  for (int w = tid; w < frames * (NC / 2 + 1); w += kAnyThreads) {
+    const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
+    const cpx* T = work + fr * NC;
+    cpx* Fq = coef + fr * NB;
+    if (k == 0) {
+      const float tdr = T[0].r, tdi = T[0].i;
+      Fq[0].r = tdr + tdi;
+      Fq[0].i = 0.f;
+      Fq[NC].r = tdr - tdi;
+      Fq[NC].i = 0.f;
+    } else {
+      const cpx fpk = T[k];
+      cpx fpnk, f1k, f2k;
+      fpnk.r = T[NC - k].r;
+      fpnk.i = -T[NC - k].i;
+      f1k.r = fpk.r + fpnk.r;
+      f1k.i = fpk.i + fpnk.i;
+      f2k.r = fpk.r - fpnk.r;
+      f2k.i = fpk.i - fpnk.i;
+      const cpx twv = cmul(f2k, sup_f[k - 1]);
+      const float a_r = (f1k.r + twv.r) * 0.5f, a_i = (f1k.i + twv.i) * 0.5f;
+      const float b_r = (f1k.r - twv.r) * 0.5f, b_i = (twv.i - f1k.i) * 0.5f;
+      if (k != NC - k) {
+        Fq[k].r = a_r;
+        Fq[k].i = a_i;
+      }
+      Fq[NC - k].r = b_r;
+      Fq[NC - k].i = b_i;
+    }
+  }
+  __syncthreads();
+
+  if (threshold) {
+    for (int w = tid; w < 128 * kAnySqw; w += kAnyThreads) {  // squared normalised real parts (.c:365-375)
+      const int m = w % kAnySqw, e = w / kAnySqw;
+      float v2 = 0.0f;
+      if (m < NCOL) {
+        const float v = coef[(e >> 4) * NB + 1 + m * 16 + (e & 15)].r * P.norm;
+        v2 = v * v;
+      }
+      sq[w] = v2;
+    }
+    __syncthreads();
+    {  // SURE of the 15 segmentations of every macro-column (.c:354-401): lane = column
+      const int wave = tid >> 6, lane = tid & 63, nwaves = kAnyThreads / 64;
+      for (int c = wave; c < 15; c += nwaves) {
+        const float v = sure_dispatch<kAnySqw>(c, sq + (lane % kAnySqw), P.seg[c / 5][c % 5]);
+        if (lane < NCOL) sure[lane * 15 + c] = v;
+      }
+    }
+    __syncthreads();
+    // DC column and the bins past the last whole macro-column (.c:501-506, 518-532)
+    for (int w = tid; w < 1 + (NB - (1 + NCOL * 16)); w += kAnyThreads) {
+      const int col = w == 0 ? 0 : (1 + NCOL * 16) + (w - 1);
+      float sum = 0.0f;
+      for (int t = 0; t < 8; ++t) {
+        const float r = coef[t * NB + col].r, i = coef[t * NB + col].i;
+        sum += r * r + i * i;
+      }
+      float a = 1 - P.dc_const / sum;
+      if (a < 0) a = 0;
+      for (int t = 0; t < 8; ++t) {
+        thre[t * NB + col].r = coef[t * NB + col].r * a;
+        thre[t * NB + col].i = coef[t * NB + col].i * a;
+      }
+    }
+    {  // argmin (first wins, .c:404-416) + Stein attenuation of the chosen blocks (.c:421-454)
+      const int wave = tid >> 6, lane = tid & 63, nwaves = kAnyThreads / 64;
+      float* pw = sure + 31 * 15 + 16 + wave * (128 + 64);
+      float* av = pw + 128;
+      for (int m = wave; m < NCOL; m += nwaves) {
+        const int base = 1 + m * 16;
+        float best = sure[m * 15];
+        int bc = 0;
+        for (int c = 1; c < 15; ++c)
+          if (sure[m * 15 + c] < best) {
+            best = sure[m * 15 + c];
+            bc = c;
+          }
+        const int T = bc / 5, F = bc % 5;
+        cpx ce[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = lane + 64 * h;
+          ce[h] = coef[(e >> 4) * NB + base + (e & 15)];
+          pw[e] = ce[h].r * ce[h].r + ce[h].i * ce[h].i;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < (1 << (T + F))) {
+          const float power = block_sum_dispatch<1>(bc, pw, lane >> F, lane & ((1 << F) - 1));
+          float a = (float)(1.0 - (double)(P.seg[T][F].a_const / power));
+          av[lane] = a * (float)(a > 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = lane + 64 * h, r = e >> 4, cc = e & 15;
+          const float a = av[((r >> (3 - T)) << F) + (cc >> (4 - F))];
+          thre[r * NB + base + cc].r = ce[h].r * a;
+          thre[r * NB + base + cc].i = ce[h].i * a;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    __syncthreads();
+    for (int w = tid; w < 8 * NC; w += kAnyThreads) {  // empirical Wiener, Nyquist untouched (.c:469-486)
+      const int t = w / NC, f = w % NC;
+      const float r = thre[t * NB + f].r, i = thre[t * NB + f].i;
+      float wiener = r * r + i * i;
+      wiener = wiener / (wiener + P.wiener_c);
+      coef[t * NB + f].r *= wiener;
+      coef[t * NB + f].i *= wiener;
+    }
+    __syncthreads();
+  }
+
+  // ---- inverse STFT + overlap-add (blockThreshold_inverse_STFT, .c:284-300); kiss_fftri pre-pass
+  // (kiss_fftr.c:137-157) straight into kiss order
+  for (int w = tid; w < frames * (NC / 2 + 1); w += kAnyThreads) {
+    const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
+    const cpx* Fq = coef + fr * NB;
+    cpx* T = work + fr * NC;
+    if (k == 0) {
+      cpx v;
+      v.r = Fq[0].r + Fq[NC].r;
+      v.i = Fq[0].r - Fq[NC].r;
+      T[A.perm[0]] = v;
+    } else {
+      const cpx fk = Fq[k];
+      cpx fnkc, fek, tmp;
+      fnkc.r = Fq[NC - k].r;
+      fnkc.i = -Fq[NC - k].i;
+      fek.r = fk.r + fnkc.r;
+      fek.i = fk.i + fnkc.i;
+      tmp.r = fk.r - fnkc.r;
+      tmp.i = fk.i - fnkc.i;
+      const cpx fok = cmul(tmp, sup_i[k - 1]);
+      cpx a, b;
+      a.r = fek.r + fok.r;
+      a.i = fek.i + fok.i;
+      b.r = fek.r - fok.r;
+      b.i = (fek.i - fok.i) * -1;
+      if (k != NC - k) T[A.perm[k]] = a;
+      T[A.perm[NC - k]] = b;
+    }
+  }
+  __syncthreads();
+  any_stages(work, tw_i, A, frames, true, tid);
+  const float* td = reinterpret_cast<const float*>(work);  // frame fr sample j at fr * N + j
+  const float fn = (float)N;
+  for (int q = tid; q < total + HALF; q += kAnyThreads) {
+    const int t2 = q / HALF, t1 = t2 - 1;
+    float v = q < HALF ? st[kOffOutTail + q] : 0.0f;
+    if (t1 >= 0 && t1 < frames) v += td[t1 * N + (q - HALF * t1)] / fn;
+    if (t2 < frames) v += td[t2 * N + (q - HALF * t2)] / fn;
+    if (q < total)
+      y[q] = v;
+    else
+      stage[q - total] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < HALF; i += kAnyThreads) st[kOffOutTail + i] = threshold ? stage[i] : 0.0f;
+}
+
+// kiss_fftr / kiss_fftri seam for any even length: one workgroup per row
+__global__ __launch_bounds__(kAnyThreads) void bt_fftr_any_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                   int inverse, BtAnyTables A) {
+  const int NC = A.nc, N = A.n, tid = threadIdx.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  cpx* work = reinterpret_cast<cpx*>(smem);  // [NC]
+  cpx* freq = work + NC;                     // [NC + 1]
+  const cpx* tw = reinterpret_cast<const cpx*>(inverse ? A.tw_i : A.tw_f);
+  const cpx* sup = reinterpret_cast<const cpx*>(inverse ? A.sup_i : A.sup_f);
+  if (!inverse) {
+    const float* x = src + (size_t)blockIdx.x * N;
+    for (int n = tid; n < NC; n += kAnyThreads) work[A.perm[n]] = cpx{x[2 * n], x[2 * n + 1]};
+    __syncthreads();
+    any_stages(work, tw, A, 1, false, tid);
+    for (int k = tid; k < NC / 2 + 1; k += kAnyThreads) {
+      if (k == 0) {
+        const float tdr = work[0].r, tdi = work[0].i;
+        freq[0] = cpx{tdr + tdi, 0.f};
+        freq[NC] = cpx{tdr - tdi, 0.f};
+      } else {
+        const cpx fpk = work[k];
+        cpx fpnk, f1k, f2k;
+        fpnk.r = work[NC - k].r;
+        fpnk.i = -work[NC - k].i;
+        f1k.r = fpk.r + fpnk.r;
+        f1k.i = fpk.i + fpnk.i;
+        f2k.r = fpk.r - fpnk.r;
+        f2k.i = fpk.i - fpnk.i;
+        const cpx twv = cmul(f2k, sup[k - 1]);
+        if (k != NC - k) freq[k] = cpx{(f1k.r + twv.r) * 0.5f, (f1k.i + twv.i) * 0.5f};
+        freq[NC - k] = cpx{(f1k.r - twv.r) * 0.5f, (twv.i - f1k.i) * 0.5f};
+      }
+    }
+    __syncthreads();
+    float* y = dst + (size_t)blockIdx.x * 2 * (NC + 1);
+    for (int i = tid; i < NC + 1; i += kAnyThreads) {
+      y[2 * i] = freq[i].r;
+      y[2 * i + 1] = freq[i].i;
+    }
+  } else {
+    const float* f = src + (size_t)blockIdx.x * 2 * (NC + 1);
+    for (int i = tid; i < NC + 1; i += kAnyThreads) freq[i] = cpx{f[2 * i], f[2 * i + 1]};
+    __syncthreads();
+    for (int k = tid; k < NC / 2 + 1; k += kAnyThreads) {
+      if (k == 0) {
+        work[A.perm[0]] = cpx{freq[0].r + freq[NC].r, freq[0].r - freq[NC].r};
+      } else {
+        const cpx fk = freq[k];
+        cpx fnkc, fek, tmp;
+        fnkc.r = freq[NC - k].r;
+        fnkc.i = -freq[NC - k].i;
+        fek.r = fk.r + fnkc.r;
+        fek.i = fk.i + fnkc.i;
+        tmp.r = fk.r - fnkc.r;
+        tmp.i = fk.i - fnkc.i;
+        const cpx fok = cmul(tmp, sup[k - 1]);
+        if (k != NC - k) work[A.perm[k]] = cpx{fek.r + fok.r, fek.i + fok.i};
+        work[A.perm[NC - k]] = cpx{fek.r - fok.r, (fek.i - fok.i) * -1};
+      }
+    }
+    __syncthreads();
+    any_stages(work, tw, A, 1, true, tid);
+    float* y = dst + (size_t)blockIdx.x * N;
+    for (int n = tid; n < NC; n += kAnyThreads) {
+      y[2 * n] = work[n].r;
+      y[2 * n + 1] = work[n].i;
+    }
+  }
+}
+
 // kiss_fftr / kiss_fftri seam: one workgroup per row.
 template <int N>
 __global__ __launch_bounds__(N / 2) void bt_fftr_kernel(const float* __restrict__ src,
@@ -540,6 +971,30 @@ hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int in
     hipLaunchKernelGGL(bt_fftr_kernel<1024>, dim3(count), dim3(512), 0, s, src, dst, inverse, T);
   else
     hipLaunchKernelGGL(bt_fftr_kernel<256>, dim3(count), dim3(128), 0, s, src, dst, inverse, T);
+  return hipGetLastError();
+}
+
+// any even window of 4 .. kAnyMaxWin samples (bt_macroblock_any_kernel)
+hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const float* in, float* out, int num_streams,
+                                    int frames, int threshold, int in_stride, int out_stride, hipStream_t s) {
+  auto lds_of = [](int nc) {
+    return (size_t)16 * (nc + 1) * sizeof(cpx) + (size_t)(128 * kAnySqw + 31 * 15 + 16 + 4 * (128 + 64) + nc) * sizeof(float);
+  };
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bt_macroblock_any_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(kAnyMaxWin / 2));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(bt_macroblock_any_kernel, dim3(num_streams), dim3(kAnyThreads), lds_of(A.nc), s, state, A, in, out,
+                     frames, threshold, in_stride, out_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_bt_fftr_any(const BtAnyTables& A, const float* src, float* dst, int count, int inverse, hipStream_t s) {
+  hipLaunchKernelGGL(bt_fftr_any_kernel, dim3(count), dim3(kAnyThreads), (size_t)(2 * A.nc + 1) * sizeof(cpx), s, src, dst,
+                     inverse, A);
   return hipGetLastError();
 }
 

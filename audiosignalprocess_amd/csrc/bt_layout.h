@@ -44,6 +44,24 @@ struct BtTables {
   uint16_t xterm[6][64];
 };
 
+// Any other even window (4 .. 1024 samples): the tables of one batch, handed to
+// bt_macroblock_any_kernel by value.  kiss_fft's plan (kf_factor, kiss_fft.c:308-330) as
+// (radix, remaining length) pairs, outermost first; `perm[n]` is where input n of the
+// N/2-point transform lands after kf_work's recursive decimation (kiss_fft.c:237-302).
+constexpr int kAnyMaxWin = 1024;    // the carried state keeps half a window (<= 512) per tail
+constexpr int kAnyMaxRadix = 32;    // largest prime factor the generic butterfly's scratch holds
+struct BtAnyTables {
+  int n, nc, ncol, nfac;
+  int fac[2 * 16];
+  BtSize P;
+  const float* hann;     // [n]
+  const float* tw_f;     // [nc] complex, forward
+  const float* tw_i;     // [nc] complex, inverse
+  const float* sup_f;    // [nc / 2] complex
+  const float* sup_i;
+  const uint16_t* perm;  // [nc]
+};
+
 // ---------------------------------------------------------------- register layouts of the FFT stages of bt_kernels8.hip
 // A position p (9 bits) of the in-place kiss_fft work array lives in lane `lane`, register j of a
 // layout: reg[b] / lane[b] name the position bit held by register-index bit b / lane bit b.

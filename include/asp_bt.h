@@ -10,9 +10,12 @@
  * 8-hop macroblock per stream-channel per call.
  *
  * Window sizes: the reference derives win_size = fs/1000*time_win (.c:91) and
- * kiss_fft factors any length; this build implements power-of-two windows
- * 256 and 1024 (BASELINE configs 1 and 3), e.g. (16 ms, 16 kHz) and
- * (64 ms, 16 kHz) / (32 ms, 32 kHz); other sizes return MARS_ERROR_PARAMS.
+ * kiss_fft factors any length.  This build: every even window of 4 .. 1024
+ * samples whose half has no prime factor above 32 (20 ms at 16 kHz = 320,
+ * 50 ms = 800, 10 / 20 ms at 48 kHz = 480 / 960, ...) through kiss_fft's
+ * mixed-radix plan (radix 4, 2, 3, 5 and the generic butterfly), with tuned
+ * kernels for 256 and 1024 (BASELINE configs 1 and 3); anything else
+ * (longer than 1024 samples, a larger prime) returns MARS_ERROR_PARAMS.
  */
 #ifndef ASP_BT_H_
 #define ASP_BT_H_

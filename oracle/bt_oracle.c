@@ -1,8 +1,8 @@
 /*
  * bt_oracle.c -- CPU restatement of the reference's block-thresholding denoiser
  * (Denoise/BlockThresholding/src/audioDenoiseBlockTreshold.c) and of the part of
- * kiss_fft it uses (common/kiss_fft/kiss_fft.c, kiss_fftr.c; power-of-two
- * lengths only: radix-4 and radix-2 butterflies).
+ * kiss_fft it uses (common/kiss_fft/kiss_fft.c, kiss_fftr.c: every radix --
+ * 4, 2, 3, 5 and the generic butterfly -- so any even window length).
  * TEST INFRASTRUCTURE ONLY -- see bt_oracle.h.
  *
  * PARITY UNPINNED for the FFT internals: common/kiss_fft/_kiss_fft_guts.h is
@@ -50,10 +50,20 @@ static void kiss_cfg_init(KissCfg* st, int nfft, int inverse) { /* kiss_fft.c:33
     st->tw[i].r = (float)cos(phase);
     st->tw[i].i = (float)sin(phase);
   }
-  /* kf_factor, kiss_fft.c:308-330, for n = 2^k: fours first, then a two */
+  /* kf_factor, kiss_fft.c:308-330: fours first, then twos, then the odd primes in turn; once the
+   * trial factor passes floor(sqrt(n)) what is left is prime and taken whole */
   int n = nfft, p = 4, k = 0;
+  const double floor_sqrt = floor(sqrt((double)nfft));
   do {
-    while (n % p) p = 2;
+    while (n % p) {
+      if (p == 4)
+        p = 2;
+      else if (p == 2)
+        p = 3;
+      else
+        p += 2;
+      if (p > floor_sqrt) p = n;
+    }
     n /= p;
     st->factors[k++] = p;
     st->factors[k++] = n;
@@ -115,6 +125,101 @@ static void bfly4(cpx* F, int fstride, const KissCfg* st, int m) { /* kiss_fft.c
   }
 }
 
+static cpx cmul(cpx a, cpx b) { /* C_MUL: the plain four-multiply product */
+  cpx m;
+  m.r = a.r * b.r - a.i * b.i;
+  m.i = a.r * b.i + a.i * b.r;
+  return m;
+}
+
+static void bfly3(cpx* F, int fstride, const KissCfg* st, int m) { /* kiss_fft.c:92-136 */
+  const int m2 = 2 * m;
+  const cpx *tw1 = st->tw, *tw2 = st->tw;
+  const cpx epi3 = st->tw[fstride * m];
+  for (int k = 0; k < m; ++k, ++F) {
+    const cpx s1 = cmul(F[m], *tw1), s2 = cmul(F[m2], *tw2);
+    cpx s3, s0;
+    s3.r = s1.r + s2.r;
+    s3.i = s1.i + s2.i;
+    s0.r = s1.r - s2.r;
+    s0.i = s1.i - s2.i;
+    tw1 += fstride;
+    tw2 += fstride * 2;
+    F[m].r = F->r - s3.r * .5f; /* HALF_OF */
+    F[m].i = F->i - s3.i * .5f;
+    s0.r *= epi3.i; /* C_MULBYSCALAR */
+    s0.i *= epi3.i;
+    F->r += s3.r;
+    F->i += s3.i;
+    F[m2].r = F[m].r + s0.i;
+    F[m2].i = F[m].i - s0.r;
+    F[m].r -= s0.i;
+    F[m].i += s0.r;
+  }
+}
+
+static void bfly5(cpx* F, int fstride, const KissCfg* st, int m) { /* kiss_fft.c:138-197 */
+  const cpx* tw = st->tw;
+  const cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
+  cpx *F0 = F, *F1 = F + m, *F2 = F + 2 * m, *F3 = F + 3 * m, *F4 = F + 4 * m;
+  for (int u = 0; u < m; ++u) {
+    cpx s[13];
+    s[0] = *F0;
+    s[1] = cmul(*F1, tw[u * fstride]);
+    s[2] = cmul(*F2, tw[2 * u * fstride]);
+    s[3] = cmul(*F3, tw[3 * u * fstride]);
+    s[4] = cmul(*F4, tw[4 * u * fstride]);
+    s[7].r = s[1].r + s[4].r;
+    s[7].i = s[1].i + s[4].i;
+    s[10].r = s[1].r - s[4].r;
+    s[10].i = s[1].i - s[4].i;
+    s[8].r = s[2].r + s[3].r;
+    s[8].i = s[2].i + s[3].i;
+    s[9].r = s[2].r - s[3].r;
+    s[9].i = s[2].i - s[3].i;
+    F0->r += s[7].r + s[8].r;
+    F0->i += s[7].i + s[8].i;
+    s[5].r = s[0].r + s[7].r * ya.r + s[8].r * yb.r;
+    s[5].i = s[0].i + s[7].i * ya.r + s[8].i * yb.r;
+    s[6].r = s[10].i * ya.i + s[9].i * yb.i;
+    s[6].i = -(s[10].r * ya.i) - s[9].r * yb.i;
+    F1->r = s[5].r - s[6].r;
+    F1->i = s[5].i - s[6].i;
+    F4->r = s[5].r + s[6].r;
+    F4->i = s[5].i + s[6].i;
+    s[11].r = s[0].r + s[7].r * yb.r + s[8].r * ya.r;
+    s[11].i = s[0].i + s[7].i * yb.r + s[8].i * ya.r;
+    s[12].r = -(s[10].i * yb.i) + s[9].i * ya.i;
+    s[12].i = s[10].r * yb.i - s[9].r * ya.i;
+    F2->r = s[11].r + s[12].r;
+    F2->i = s[11].i + s[12].i;
+    F3->r = s[11].r - s[12].r;
+    F3->i = s[11].i - s[12].i;
+    ++F0, ++F1, ++F2, ++F3, ++F4;
+  }
+}
+
+static void bfly_generic(cpx* F, int fstride, const KissCfg* st, int m, int p) { /* kiss_fft.c:199-235 */
+  cpx* scratch = (cpx*)malloc(sizeof(cpx) * (size_t)p);
+  for (int u = 0; u < m; ++u) {
+    int k = u;
+    for (int q1 = 0; q1 < p; ++q1, k += m) scratch[q1] = F[k];
+    k = u;
+    for (int q1 = 0; q1 < p; ++q1, k += m) {
+      int twidx = 0;
+      F[k] = scratch[0];
+      for (int q = 1; q < p; ++q) {
+        twidx += fstride * k;
+        if (twidx >= st->nfft) twidx -= st->nfft;
+        const cpx t = cmul(scratch[q], st->tw[twidx]);
+        F[k].r += t.r;
+        F[k].i += t.i;
+      }
+    }
+  }
+  free(scratch);
+}
+
 static void kf_work(cpx* Fout, const cpx* f, int fstride, const int* factors,
                     const KissCfg* st) { /* kiss_fft.c:237-302 */
   const int p = factors[0], m = factors[1];
@@ -123,10 +228,13 @@ static void kf_work(cpx* Fout, const cpx* f, int fstride, const int* factors,
   } else {
     for (int k = 0; k < p; ++k) kf_work(Fout + (size_t)k * m, f + (size_t)k * fstride, fstride * p, factors + 2, st);
   }
-  if (p == 2)
-    bfly2(Fout, fstride, st, m);
-  else
-    bfly4(Fout, fstride, st, m);
+  switch (p) {
+    case 2: bfly2(Fout, fstride, st, m); break;
+    case 3: bfly3(Fout, fstride, st, m); break;
+    case 4: bfly4(Fout, fstride, st, m); break;
+    case 5: bfly5(Fout, fstride, st, m); break;
+    default: bfly_generic(Fout, fstride, st, m, p); break;
+  }
 }
 
 typedef struct {
@@ -223,7 +331,7 @@ struct BtOracle {
 static cpx* row(cpx* base, const BtOracle* h, int t) { return base + (size_t)t * (h->win / 2 + 1); }
 
 BtOracle* bt_oracle_create(int win_size) {
-  if (win_size != 256 && win_size != 1024) return NULL;
+  if (win_size < 4 || win_size > 1024 || (win_size & 1)) return NULL; /* the state structs carry half <= 512 */
   BtOracle* h = (BtOracle*)calloc(1, sizeof *h);
   h->win = win_size;
   h->half = win_size / 2;

@@ -71,6 +71,48 @@ def test_wide_segment_signals_bit_exact(bt):
     g.close()
 
 
+ANY_WINDOWS = [320, 480, 800, 960, 224, 136, 62, 1000]  # 20 / 30 / 50 / 60 ms at 16 kHz, 10 / 20 ms at 48 kHz,
+# and lengths whose half has the prime factors 7, 17, 31 (generic butterfly) or is odd / 4 5^3
+
+
+@pytest.mark.parametrize("n", ANY_WINDOWS)
+def test_kiss_fftr_any_length_bit_exact(bt, n):
+    """kiss_fft's mixed-radix plan (radix 4, 2, 3, 5, generic) on the device against the oracle, and numpy."""
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal((64, n)) * rng.choice([1e-3, 1.0, 100.0], size=(64, 1))).astype(np.float32)
+    o = OracleBt(n)
+    f = bt.kiss_fftr(x, n)
+    fo = np.stack([o.kiss_fftr(r) for r in x])
+    assert np.array_equal(f, fo)
+    t = bt.kiss_fftri(f, n)
+    assert np.array_equal(t, np.stack([o.kiss_fftri(r) for r in fo]))
+    X = np.fft.rfft(x.astype(np.float64), axis=1)
+    assert np.abs((f[:, 0::2] + 1j * f[:, 1::2]) - X).max() <= 2e-6 * np.abs(X).max()
+
+
+@pytest.mark.parametrize("n", ANY_WINDOWS)
+def test_any_window_macroblocks_bit_exact_vs_oracle(bt, n):
+    S, K = 5, 4
+    g = bt.BtBatch(S, n)
+    assert g.macro == 4 * n
+    x = bt_samples(S, K * g.macro)
+    y = g.run(x)
+    assert np.isfinite(y).all()
+    for s in range(S):
+        o = OracleBt(n)
+        assert np.array_equal(y[s], o.run(x[s])), s
+        so, sg = o.export_state(), g.export_state(s)
+        assert np.array_equal(np.ctypeslib.as_array(so.inbuf_tail), np.ctypeslib.as_array(sg.inbuf_tail))
+        assert np.array_equal(np.ctypeslib.as_array(so.out_tail), np.ctypeslib.as_array(sg.out_tail))
+    g.close()
+
+
+def test_any_window_refusals(bt):
+    for n in (1026, 2048, 255, 2, 2 * 37, 2 * 4 * 41):  # too long, odd, too short, prime factor above 32
+        with pytest.raises(Exception):
+            bt.BtBatch(1, n)
+
+
 def test_stereo_48k_config3_shape(bt):
     """BASELINE config 3: stereo = two independent stream-channels, 1024-point STFT."""
     g = bt.BtBatch(2, 1024)
@@ -101,7 +143,7 @@ def test_state_roundtrip_and_reset(bt):
 
 
 def test_flush_partial_macroblock(bt):
-    for n in (256, 1024):
+    for n in (256, 1024, 320, 480):
         g = bt.BtBatch(2, n)
         x = bt_samples(2, g.macro + 5 * g.half, stream0=31)
         g.denoise(x[:, :g.macro])
@@ -172,7 +214,21 @@ def test_layer1_reference_protocol(bt, built_lib):
     lib.blockThreshold_samples_per_time.argtypes = [C.c_void_p]
     err = C.c_int32(-1)
     assert lib.blockThreshold_init(0, 16000, C.byref(err)) is None and err.value == 0x02
-    assert lib.blockThreshold_init(20, 16000, C.byref(err)) is None and err.value == 0x02  # 320: not built
+    assert lib.blockThreshold_init(65, 16000, C.byref(err)) is None and err.value == 0x02  # 1040 samples: not built
+    # 20 ms at 16 kHz (320 samples; the reference takes any time_win, .c:91-95): the mixed-radix path
+    h = lib.blockThreshold_init(20, 16000, C.byref(err))
+    assert h and err.value == 0
+    assert lib.blockThreshold_max_output(h) == 1280 and lib.blockThreshold_samples_per_time(h) == 160
+    o = OracleBt(320)
+    x20 = bt_samples(1, 1280, stream0=9)[0]
+    for k, hop in enumerate(np.ascontiguousarray(x20).reshape(8, 160)):
+        hop = np.ascontiguousarray(hop)
+        rc = lib.blockThreshold_denoise_float(h, hop.ctypes.data, 160)
+        assert rc == o.denoise_float(hop) == (0x20 if k == 7 else 0x10)
+    out20 = np.zeros(1280, np.float32)
+    assert lib.blockThreshold_output_float(h, out20.ctypes.data, 1280) == 1280
+    assert np.array_equal(out20, o.output_float()[1])
+    lib.blockThreshold_free(h)
     h = lib.blockThreshold_init(16, 16000, C.byref(err))  # win 256
     assert h and err.value == 0
     assert lib.blockThreshold_max_output(h) == 1024 and lib.blockThreshold_samples_per_time(h) == 128

@@ -12,7 +12,7 @@ from tests.oracle_lib import OracleBt
 NEED_MORE, CAN_OUTPUT, ERR_PARAMS = 0x10, 0x20, 0x02
 
 
-@pytest.mark.parametrize("n", [256, 1024])
+@pytest.mark.parametrize("n", [256, 1024, 320, 480, 800, 960, 224, 136, 62, 1000])  # radix 4 / 2, then 3, 5, generic
 def test_kiss_fftr_matches_numpy_and_roundtrips(n):
     o = OracleBt(n)
     rng = np.random.default_rng(n)
@@ -36,7 +36,7 @@ def test_hann_window_is_the_symmetric_form():
         assert np.array_equal(h, ref) and h[0] == 0 and h[-1] == 0
 
 
-@pytest.mark.parametrize("n", [256, 1024])
+@pytest.mark.parametrize("n", [256, 1024, 320, 480])
 def test_hop_protocol_and_macroblock_equivalence(n):
     """denoise x7 -> NEED_MORE, 8th -> CAN_OUTPUT (.c:541-575); output lags input by n/2."""
     o1, o2 = OracleBt(n), OracleBt(n)
@@ -149,7 +149,7 @@ def _bt_float64(x, n):
     return np.concatenate(out), np.stack(segs), np.stack(sures)
 
 
-@pytest.mark.parametrize("n", [256, 1024])
+@pytest.mark.parametrize("n", [256, 1024, 320, 800])
 def test_oracle_against_an_independent_float64_restatement(n):
     """The reference cannot be built here (its kiss_fft internals header is not in the tree), so the C
     oracle is at least held against a second, independent reading of the reference source in numpy
