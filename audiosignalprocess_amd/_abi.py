@@ -91,7 +91,7 @@ class AspNsHbState(C.Structure):
 class AspBtState(C.Structure):
     """include/asp_bt.h: AspBtState (carried state between macroblocks)."""
 
-    _fields_ = [("win_size", C.c_int32), ("inbuf_tail", C.c_float * 512), ("out_tail", C.c_float * 512)]
+    _fields_ = [("win_size", C.c_int32), ("inbuf_tail", C.c_float * 1024), ("out_tail", C.c_float * 1024)]
 
 
 class AecConfig(C.Structure):

@@ -224,6 +224,7 @@ struct AspBtBatch {
   int S = 0, win = 0, half = 0, macro = 0, device = 0;
   hipStream_t stream = nullptr;
   float* state = nullptr;
+  int state_floats = kStateFloats, off_out = kOffOutTail;  // per-stream state block (kAny* for other windows)
   BtTables* tables = nullptr;
   bool any = false;            // a window other than 256 / 1024 samples: bt_macroblock_any_kernel
   BtAnyTables any_tables = {};
@@ -243,7 +244,7 @@ int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int devic
   *out = nullptr;
   const bool any = win_size != 256 && win_size != 1024;
   if (any && !bt_any_window_ok(win_size))
-    return bt_fail(ASP_ERR_PARAM, "AspBtBatch_Create: win_size must be even, 4 .. 1024, with no prime factor of win_size / 2 above 32");
+    return bt_fail(ASP_ERR_PARAM, "AspBtBatch_Create: win_size must be even, 4 .. 2048, with no prime factor of win_size / 2 above 32");
   int rc = bt_select_device(device);
   if (rc) return rc;
   AspBtBatch* b = new AspBtBatch();
@@ -253,6 +254,7 @@ int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int devic
   b->macro = 8 * b->half;
   b->device = device;
   b->any = any;
+  if (any) b->state_floats = kAnyStateFloats, b->off_out = kAnyOffOutTail;
   rc = any ? bt_build_any(win_size, &b->any_tables, &b->any_block) : bt_tables(device, &b->tables);
   if (rc) {
     delete b;
@@ -260,8 +262,8 @@ int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int devic
   }
   const size_t frame_bytes = (size_t)num_streams * b->macro * sizeof(float);
   hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipMalloc((void**)&b->state, (size_t)num_streams * kStateFloats * 4);
-  if (e == hipSuccess) e = hipMemsetAsync(b->state, 0, (size_t)num_streams * kStateFloats * 4, b->stream);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->state, (size_t)num_streams * b->state_floats * 4);
+  if (e == hipSuccess) e = hipMemsetAsync(b->state, 0, (size_t)num_streams * b->state_floats * 4, b->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_in, frame_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out, frame_bytes);
@@ -299,7 +301,7 @@ int AspBtBatch_Free(AspBtBatch* b) {
 int AspBtBatch_Reset(AspBtBatch* b) {
   if (!b) return bt_fail(ASP_ERR_PARAM, "null batch handle");
   BT_TRY(hipSetDevice(b->device));
-  BT_TRY(hipMemsetAsync(b->state, 0, (size_t)b->S * kStateFloats * 4, b->stream));
+  BT_TRY(hipMemsetAsync(b->state, 0, (size_t)b->S * b->state_floats * 4, b->stream));
   return ASP_OK;
 }
 
@@ -380,7 +382,7 @@ int AspBtBatch_TimedSteps(AspBtBatch* b, const float* in, float* out, int blocks
     BT_TRY(bt_launch(b, b->state, in + off, out + off, half, 8, 1, b->macro, b->macro, b->stream));
     if (dual) {
       const size_t o2 = (size_t)half * b->macro;
-      BT_TRY(bt_launch(b, b->state + (size_t)half * kStateFloats, in + off + o2, out + off + o2, b->S - half, 8, 1,
+      BT_TRY(bt_launch(b, b->state + (size_t)half * b->state_floats, in + off + o2, out + off + o2, b->S - half, 8, 1,
                        b->macro, b->macro, b->side));
     }
   }
@@ -415,12 +417,12 @@ int AspBtBatch_ExportState(AspBtBatch* b, int stream, AspBtState* out) {
   if (!b || !out || stream < 0 || stream >= b->S) return bt_fail(ASP_ERR_PARAM, "ExportState: bad argument");
   BT_TRY(hipSetDevice(b->device));
   BT_TRY(hipStreamSynchronize(b->stream));
-  float blk[kStateFloats];
-  BT_TRY(hipMemcpy(blk, b->state + (size_t)stream * kStateFloats, sizeof blk, hipMemcpyDeviceToHost));
+  float blk[kAnyStateFloats];
+  BT_TRY(hipMemcpy(blk, b->state + (size_t)stream * b->state_floats, sizeof(float) * b->state_floats, hipMemcpyDeviceToHost));
   memset(out, 0, sizeof *out);
   out->win_size = b->win;
   memcpy(out->inbuf_tail, blk + kOffInTail, sizeof(float) * b->half);
-  memcpy(out->out_tail, blk + kOffOutTail, sizeof(float) * b->half);
+  memcpy(out->out_tail, blk + b->off_out, sizeof(float) * b->half);
   return ASP_OK;
 }
 
@@ -429,11 +431,11 @@ int AspBtBatch_ImportState(AspBtBatch* b, int stream, const AspBtState* in) {
   if (in->win_size != b->win) return bt_fail(ASP_ERR_PARAM, "ImportState: win_size mismatch");
   BT_TRY(hipSetDevice(b->device));
   BT_TRY(hipStreamSynchronize(b->stream));
-  float blk[kStateFloats];
+  float blk[kAnyStateFloats];
   memset(blk, 0, sizeof blk);
   memcpy(blk + kOffInTail, in->inbuf_tail, sizeof(float) * b->half);
-  memcpy(blk + kOffOutTail, in->out_tail, sizeof(float) * b->half);
-  BT_TRY(hipMemcpy(b->state + (size_t)stream * kStateFloats, blk, sizeof blk, hipMemcpyHostToDevice));
+  memcpy(blk + b->off_out, in->out_tail, sizeof(float) * b->half);
+  BT_TRY(hipMemcpy(b->state + (size_t)stream * b->state_floats, blk, sizeof(float) * b->state_floats, hipMemcpyHostToDevice));
   return ASP_OK;
 }
 
@@ -502,7 +504,7 @@ MarsBlockThreshold_t* blockThreshold_init(int32_t time_win, int32_t fs, int32_t*
   if (win & 0x01) win += 1;
   if (win != 256 && win != 1024 && !bt_any_window_ok(win)) {
     fprintf(stderr,
-            "blockThreshold_init: window of %d samples is not built (even, 4 .. 1024 samples, no prime factor of "
+            "blockThreshold_init: window of %d samples is not built (even, 4 .. 2048 samples, no prime factor of "
             "half the window above 32)\n", win);
     *err = MARS_ERROR_PARAMS;
     return NULL;

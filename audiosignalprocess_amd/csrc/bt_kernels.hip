@@ -447,13 +447,14 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
 }
 
 // --------------------------------------------------------------------------
-// Any even window of 4 .. 1024 samples (20 ms at 16 kHz = 320, 50 ms = 800, 10 ms at 48 kHz = 480, ...):
+// Any even window of 4 .. 2048 samples (20 ms at 16 kHz = 320, 50 ms = 800, 10 / 40 ms at 48 kHz = 480 / 1920, ...):
 // the same phases with run-time sizes and kiss_fft's mixed-radix plan -- radix 4, 2, 3, 5 and the generic
 // butterfly for larger primes (kiss_fft.c:21-235).  One butterfly per thread and stage, the reference's
 // float operations in the reference's order (butterflies of a stage are independent, so their order
 // across threads does not matter).  A plain path: 256 threads per macroblock, a barrier per stage.
 constexpr int kAnyThreads = 256;
-constexpr int kAnySqw = 32;  // columns of the squared-real table (at most 31 macro-columns)
+constexpr int kAnySqw = 64;  // columns of the squared-real table (at most 63 macro-columns)
+constexpr int kAnyMaxCol = 63;
 
 __device__ __forceinline__ void any_bfly2(cpx* F, int m, const cpx* tw, int fstride, int u) {
   const cpx t = cmul(F[m], tw[u * fstride]);
@@ -603,12 +604,16 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
   cpx* coef = reinterpret_cast<cpx*>(smem);                 // [8][NB]
   cpx* thre = coef + 8 * NB;                                // [8][NB]; the FFT work tile aliases it
   cpx* work = thre;                                         // [8][NC]
-  float* sq = reinterpret_cast<float*>(thre + 8 * NB);      // [128][kAnySqw]
-  float* sure = sq + 128 * kAnySqw;                         // [NCOL][15], then 16 spare, then 4 x (128 + 64)
-  float* stage = sure + 31 * 15 + 16 + 4 * (128 + 64);      // [HALF] new output tail
+  // [128][kAnySqw] squared real parts: inside the thre tile when that is large enough (it is dead until the
+  // SURE values are out), else behind it (launch_bt_macroblock_any sizes the allocation the same way)
+  const bool sq_in_thre = (size_t)8 * NB * sizeof(cpx) >= (size_t)128 * kAnySqw * sizeof(float);
+  float* after = reinterpret_cast<float*>(thre + 8 * NB);
+  float* sq = sq_in_thre ? reinterpret_cast<float*>(thre) : after;
+  float* sure = sq_in_thre ? after : after + 128 * kAnySqw;  // [NCOL][15], then 16 spare, then 4 x (128 + 64)
+  float* stage = sure + kAnyMaxCol * 15 + 16 + 4 * (128 + 64);  // [HALF] new output tail
   const int tid = threadIdx.x;
   const int stream = blockIdx.x;
-  float* st = state + (size_t)stream * kStateFloats;
+  float* st = state + (size_t)stream * kAnyStateFloats;
   const float* x = in + (size_t)stream * in_stride;
   float* y = out + (size_t)stream * out_stride;
   const BtSize& P = A.P;
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
     {  // SURE of the 15 segmentations of every macro-column (.c:354-401): lane = column
       const int wave = tid >> 6, lane = tid & 63, nwaves = kAnyThreads / 64;
       for (int c = wave; c < 15; c += nwaves) {
-        const float v = sure_dispatch<kAnySqw>(c, sq + (lane % kAnySqw), P.seg[c / 5][c % 5]);
+        const float v = sure_dispatch<kAnySqw>(c, sq + lane, P.seg[c / 5][c % 5]);
         if (lane < NCOL) sure[lane * 15 + c] = v;
       }
     }
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
     }
     {  // argmin (first wins, .c:404-416) + Stein attenuation of the chosen blocks (.c:421-454)
       const int wave = tid >> 6, lane = tid & 63, nwaves = kAnyThreads / 64;
-      float* pw = sure + 31 * 15 + 16 + wave * (128 + 64);
+      float* pw = sure + kAnyMaxCol * 15 + 16 + wave * (128 + 64);
       float* av = pw + 128;
       for (int m = wave; m < NCOL; m += nwaves) {
         const int base = 1 + m * 16;
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
   const float fn = (float)N;
   for (int q = tid; q < total + HALF; q += kAnyThreads) {
     const int t2 = q / HALF, t1 = t2 - 1;
-    float v = q < HALF ? st[kOffOutTail + q] : 0.0f;
+    float v = q < HALF ? st[kAnyOffOutTail + q] : 0.0f;
     if (t1 >= 0 && t1 < frames) v += td[t1 * N + (q - HALF * t1)] / fn;
     if (t2 < frames) v += td[t2 * N + (q - HALF * t2)] / fn;
     if (q < total)
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
       stage[q - total] = v;
   }
   __syncthreads();
-  for (int i = tid; i < HALF; i += kAnyThreads) st[kOffOutTail + i] = threshold ? stage[i] : 0.0f;
+  for (int i = tid; i < HALF; i += kAnyThreads) st[kAnyOffOutTail + i] = threshold ? stage[i] : 0.0f;
 }
 
 // kiss_fftr / kiss_fftri seam for any even length: one workgroup per row
@@ -974,11 +979,12 @@ hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int in
   return hipGetLastError();
 }
 
-// any even window of 4 .. kAnyMaxWin samples (bt_macroblock_any_kernel)
+// any even window of 4 .. kAnyMaxWin samples (bt_macroblock_any_kernel); `state` has kAnyStateFloats per stream
 hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const float* in, float* out, int num_streams,
                                     int frames, int threshold, int in_stride, int out_stride, hipStream_t s) {
   auto lds_of = [](int nc) {
-    return (size_t)16 * (nc + 1) * sizeof(cpx) + (size_t)(128 * kAnySqw + 31 * 15 + 16 + 4 * (128 + 64) + nc) * sizeof(float);
+    const size_t tile = (size_t)8 * (nc + 1) * sizeof(cpx), sq = (size_t)128 * kAnySqw * sizeof(float);
+    return 2 * tile + (tile >= sq ? 0 : sq) + (size_t)(kAnyMaxCol * 15 + 16 + 4 * (128 + 64) + nc) * sizeof(float);
   };
   static bool attr_set = false;
   if (!attr_set) {

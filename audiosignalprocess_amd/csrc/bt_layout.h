@@ -44,12 +44,14 @@ struct BtTables {
   uint16_t xterm[6][64];
 };
 
-// Any other even window (4 .. 1024 samples): the tables of one batch, handed to
+// Any other even window (4 .. 2048 samples): the tables of one batch, handed to
 // bt_macroblock_any_kernel by value.  kiss_fft's plan (kf_factor, kiss_fft.c:308-330) as
 // (radix, remaining length) pairs, outermost first; `perm[n]` is where input n of the
 // N/2-point transform lands after kf_work's recursive decimation (kiss_fft.c:237-302).
-constexpr int kAnyMaxWin = 1024;    // the carried state keeps half a window (<= 512) per tail
-constexpr int kAnyMaxRadix = 32;    // largest prime factor the generic butterfly's scratch holds
+constexpr int kAnyMaxWin = 2048;        // 8 x (win / 2 + 1) coefficients twice over must fit the 160 KB of LDS
+constexpr int kAnyMaxRadix = 32;        // largest prime factor the generic butterfly's scratch holds
+constexpr int kAnyStateFloats = 2048;   // per-stream carried state of these batches: [inbuf tail (<= 1024)] [outbuf tail]
+constexpr int kAnyOffOutTail = 1024;
 struct BtAnyTables {
   int n, nc, ncol, nfac;
   int fac[2 * 16];

@@ -59,8 +59,8 @@ int main(int argc, char* argv[]) {
   const int32_t num_samples = (int32_t)(header.data.size / channels / bits_per_sample / 8); /* main.cpp:61 */
   MarsBlockThreshold_t* handle = blockThreshold_init(time_win, freq, &ret);
   if (ret != MARS_OK || !handle) {
-    fprintf(stderr, "error: blockThreshold_init (%d ms at %d Hz): this build has windows of up to 1024 "
-                    "samples (64 ms at 16 kHz, 21 ms at 48 kHz)\n", (int)time_win, (int)freq);
+    fprintf(stderr, "error: blockThreshold_init (%d ms at %d Hz): this build has windows of up to 2048 "
+                    "samples (128 ms at 16 kHz, 42 ms at 48 kHz)\n", (int)time_win, (int)freq);
     return -1;
   }
   const int32_t frame_size = blockThreshold_samples_per_time(handle);

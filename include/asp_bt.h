@@ -10,12 +10,12 @@
  * 8-hop macroblock per stream-channel per call.
  *
  * Window sizes: the reference derives win_size = fs/1000*time_win (.c:91) and
- * kiss_fft factors any length.  This build: every even window of 4 .. 1024
+ * kiss_fft factors any length.  This build: every even window of 4 .. 2048
  * samples whose half has no prime factor above 32 (20 ms at 16 kHz = 320,
- * 50 ms = 800, 10 / 20 ms at 48 kHz = 480 / 960, ...) through kiss_fft's
+ * 50 ms = 800, 10 / 20 / 40 ms at 48 kHz = 480 / 960 / 1920, ...) through kiss_fft's
  * mixed-radix plan (radix 4, 2, 3, 5 and the generic butterfly), with tuned
  * kernels for 256 and 1024 (BASELINE configs 1 and 3); anything else
- * (longer than 1024 samples, a larger prime) returns MARS_ERROR_PARAMS.
+ * (longer than 2048 samples, a larger prime) returns MARS_ERROR_PARAMS.
  */
 #ifndef ASP_BT_H_
 #define ASP_BT_H_
@@ -59,8 +59,8 @@ typedef struct AspBtBatch AspBtBatch;
  * the second half of the analysis buffer and the overlap-add tail. */
 typedef struct AspBtState {
   int32_t win_size;
-  float inbuf_tail[512]; /* inbuf[half..win), first half_win entries used */
-  float out_tail[512];   /* outbuf[macro..macro+half)                     */
+  float inbuf_tail[1024]; /* inbuf[half..win), first half_win entries used */
+  float out_tail[1024];   /* outbuf[macro..macro+half)                     */
 } AspBtState;
 
 int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int device);

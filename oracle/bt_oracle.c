@@ -331,7 +331,7 @@ struct BtOracle {
 static cpx* row(cpx* base, const BtOracle* h, int t) { return base + (size_t)t * (h->win / 2 + 1); }
 
 BtOracle* bt_oracle_create(int win_size) {
-  if (win_size < 4 || win_size > 1024 || (win_size & 1)) return NULL; /* the state structs carry half <= 512 */
+  if (win_size < 4 || win_size > 2048 || (win_size & 1)) return NULL; /* the state structs carry half <= 1024 */
   BtOracle* h = (BtOracle*)calloc(1, sizeof *h);
   h->win = win_size;
   h->half = win_size / 2;

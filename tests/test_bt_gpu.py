@@ -71,8 +71,9 @@ def test_wide_segment_signals_bit_exact(bt):
     g.close()
 
 
-ANY_WINDOWS = [320, 480, 800, 960, 224, 136, 62, 1000]  # 20 / 30 / 50 / 60 ms at 16 kHz, 10 / 20 ms at 48 kHz,
-# and lengths whose half has the prime factors 7, 17, 31 (generic butterfly) or is odd / 4 5^3
+ANY_WINDOWS = [320, 480, 800, 960, 224, 136, 62, 1000, 1440, 1920, 2048]  # 20 / 30 / 50 / 60 ms at 16 kHz,
+# 10 / 20 / 30 / 40 ms at 48 kHz, lengths whose half has the prime factors 7, 17, 31 (generic butterfly) or is
+# odd / 4 5^3, and the longest window the LDS tiles hold
 
 
 @pytest.mark.parametrize("n", ANY_WINDOWS)
@@ -108,7 +109,7 @@ def test_any_window_macroblocks_bit_exact_vs_oracle(bt, n):
 
 
 def test_any_window_refusals(bt):
-    for n in (1026, 2048, 255, 2, 2 * 37, 2 * 4 * 41):  # too long, odd, too short, prime factor above 32
+    for n in (2050, 4096, 255, 2, 2 * 37, 2 * 4 * 41):  # too long, odd, too short, prime factor above 32
         with pytest.raises(Exception):
             bt.BtBatch(1, n)
 
@@ -214,7 +215,7 @@ def test_layer1_reference_protocol(bt, built_lib):
     lib.blockThreshold_samples_per_time.argtypes = [C.c_void_p]
     err = C.c_int32(-1)
     assert lib.blockThreshold_init(0, 16000, C.byref(err)) is None and err.value == 0x02
-    assert lib.blockThreshold_init(65, 16000, C.byref(err)) is None and err.value == 0x02  # 1040 samples: not built
+    assert lib.blockThreshold_init(129, 16000, C.byref(err)) is None and err.value == 0x02  # 2064 samples: not built
     # 20 ms at 16 kHz (320 samples; the reference takes any time_win, .c:91-95): the mixed-radix path
     h = lib.blockThreshold_init(20, 16000, C.byref(err))
     assert h and err.value == 0
