@@ -303,30 +303,32 @@ def test_bt_main_wav_driver(bt, tmp_path):
                 struct.pack("<ihhiihh", 16, 1, ch, fs, fs * ch * 2, ch * 2, 16) + b"data" +
                 struct.pack("<i", len(data)) + data)
 
-    half, macro = 128, 1024
-    n = 20 * macro + 3 * half + 77
-    pcm = np.clip(np.rint(bt_samples(1, n, stream0=3)[0] * 32767), -32768, 32767).astype(np.int16)
-    (tmp_path / "in.wav").write_bytes(wav_bytes(pcm))
-    subprocess.run([exe, str(tmp_path / "in.wav"), str(tmp_path / "out.wav"), "16", "-q"], check=True)
-    raw = (tmp_path / "out.wav").read_bytes()
-    assert raw[:44] == wav_bytes(pcm)[:44]                       # header verbatim (sizes not fixed up)
-    got = np.frombuffer(raw[44:], "<i2")
-    o = OracleBt(256)
-    to_f = lambda v: np.array([o.lib.bt_oracle_s16_to_float(int(t)) for t in v], np.float32)
-    to_i = lambda v: np.array([o.lib.bt_oracle_float_to_s16(float(t)) for t in v], np.int16)
-    want = []
-    full = n // half
-    for k in range(full):
-        rc = o.denoise_float(to_f(pcm[k * half:(k + 1) * half]))
-        if rc == 0x20:
-            want.append(to_i(o.output_float()[1]))
-    cnt, fl = o.flush_float(3 * half)
-    assert cnt == 3 * half
-    want.append(to_i(fl))
-    want.append(pcm[full * half:])                               # the partial frame, unprocessed
-    want = np.concatenate(want)
-    assert got.size == want.size
-    assert np.array_equal(got, want)
+    for ms, win in ((16, 256), (20, 320)):                           # 20 ms: the mixed-radix window path
+        half, macro = win // 2, 4 * win
+        n = 20 * macro + 3 * half + 77
+        pcm = np.clip(np.rint(bt_samples(1, n, stream0=3)[0] * 32767), -32768, 32767).astype(np.int16)
+        (tmp_path / "in.wav").write_bytes(wav_bytes(pcm))
+        subprocess.run([exe, str(tmp_path / "in.wav"), str(tmp_path / "out.wav"), str(ms), "-q"], check=True)
+        raw = (tmp_path / "out.wav").read_bytes()
+        assert raw[:44] == wav_bytes(pcm)[:44]                       # header verbatim (sizes not fixed up)
+        got = np.frombuffer(raw[44:], "<i2")
+        o = OracleBt(win)
+        to_f = lambda v: np.array([o.lib.bt_oracle_s16_to_float(int(t)) for t in v], np.float32)
+        to_i = lambda v: np.array([o.lib.bt_oracle_float_to_s16(float(t)) for t in v], np.int16)
+        want = []
+        full = n // half
+        for k in range(full):
+            rc = o.denoise_float(to_f(pcm[k * half:(k + 1) * half]))
+            if rc == 0x20:
+                want.append(to_i(o.output_float()[1]))
+        cnt, fl = o.flush_float(3 * half)
+        assert cnt == 3 * half
+        want.append(to_i(fl))
+        want.append(pcm[full * half:])                               # the partial frame, unprocessed
+        want = np.concatenate(want)
+        assert got.size == want.size
+        assert np.array_equal(got, want)
+    half = 128
     # main.cpp:61: data.size / channels / bits / 8 <= frame_size -> nothing but the header
     short = pcm[:half * 16]                                      # 4096 bytes -> num_samples = 32 <= 128
     (tmp_path / "s.wav").write_bytes(wav_bytes(short))
