@@ -452,9 +452,8 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
 // butterfly for larger primes (kiss_fft.c:21-235).  One butterfly per thread and stage, the reference's
 // float operations in the reference's order (butterflies of a stage are independent, so their order
 // across threads does not matter).  A plain path: 256 threads per macroblock, a barrier per stage.
-constexpr int kAnyThreads = 256;
-constexpr int kAnySqw = 64;  // columns of the squared-real table (at most 63 macro-columns)
-constexpr int kAnyMaxCol = 63;
+constexpr int kAnyThreads = 256;   // the seam kernel's workgroup; the macroblock kernel runs 256 or 512 threads
+constexpr int kAnyMaxCol = 63;     // macro-columns of a 2048-sample window
 
 __device__ __forceinline__ void any_bfly2(cpx* F, int m, const cpx* tw, int fstride, int u) {
   const cpx t = cmul(F[m], tw[u * fstride]);
@@ -574,13 +573,14 @@ __device__ __forceinline__ void any_bfly_generic(cpx* F, int m, int p, const cpx
 }
 
 // every stage of `frames` nc-point transforms in work[frame][nc] (inputs already in kiss order)
+template <int THREADS>
 __device__ __forceinline__ void any_stages(cpx* work, const cpx* __restrict__ tw, const BtAnyTables& A, int frames,
                                            bool inverse, int tid) {
   const int nc = A.nc;
   for (int s = A.nfac - 1; s >= 0; --s) {
     const int p = A.fac[2 * s], m = A.fac[2 * s + 1];
     const int span = p * m, fstride = nc / span, units = nc / p;  // butterflies per frame
-    for (int w = tid; w < frames * units; w += kAnyThreads) {
+    for (int w = tid; w < frames * units; w += THREADS) {
       const int fr = w / units, b = w % units;
       const int g = b / m, u = b % m;
       cpx* F = work + fr * nc + g * span;
@@ -596,7 +596,9 @@ __device__ __forceinline__ void any_stages(cpx* work, const cpx* __restrict__ tw
   }
 }
 
-__global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
+// SQW: columns of the squared-real table (32 for windows of up to 1024 samples: at most 31 macro-columns; else 64)
+template <int THREADS, int SQW>
+__global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
     float* __restrict__ state, BtAnyTables A, const float* __restrict__ in, float* __restrict__ out, int frames,
     int threshold, int in_stride, int out_stride) {
   const int N = A.n, NC = A.nc, HALF = A.nc, NB = A.nc + 1, NCOL = A.ncol;
@@ -604,13 +606,13 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
   cpx* coef = reinterpret_cast<cpx*>(smem);                 // [8][NB]
   cpx* thre = coef + 8 * NB;                                // [8][NB]; the FFT work tile aliases it
   cpx* work = thre;                                         // [8][NC]
-  // [128][kAnySqw] squared real parts: inside the thre tile when that is large enough (it is dead until the
+  // [128][SQW] squared real parts: inside the thre tile when that is large enough (it is dead until the
   // SURE values are out), else behind it (launch_bt_macroblock_any sizes the allocation the same way)
-  const bool sq_in_thre = (size_t)8 * NB * sizeof(cpx) >= (size_t)128 * kAnySqw * sizeof(float);
+  const bool sq_in_thre = (size_t)8 * NB * sizeof(cpx) >= (size_t)128 * SQW * sizeof(float);
   float* after = reinterpret_cast<float*>(thre + 8 * NB);
   float* sq = sq_in_thre ? reinterpret_cast<float*>(thre) : after;
-  float* sure = sq_in_thre ? after : after + 128 * kAnySqw;  // [NCOL][15], then 16 spare, then 4 x (128 + 64)
-  float* stage = sure + kAnyMaxCol * 15 + 16 + 4 * (128 + 64);  // [HALF] new output tail
+  float* sure = sq_in_thre ? after : after + 128 * SQW;  // [NCOL][15], then 16 spare, then 4 x (128 + 64)
+  float* stage = sure + kAnyMaxCol * 15 + 16 + 8 * (128 + 64);  // [HALF] new output tail
   const int tid = threadIdx.x;
   const int stream = blockIdx.x;
   float* st = state + (size_t)stream * kAnyStateFloats;
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
 
   // ---- STFT (blockThreshold_STFT, .c:273-282)
   const int total = frames * HALF;
-  for (int w = tid; w < frames * NC; w += kAnyThreads) {
+  for (int w = tid; w < frames * NC; w += THREADS) {
     const int fr = w / NC, n = w % NC;
     const int p0 = HALF * fr + 2 * n;
     const float b0 = p0 < HALF ? st[kOffInTail + p0] : x[p0 - HALF];
@@ -636,13 +638,13 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
   }
   __syncthreads();
   if (threshold)  // a flush leaves the input history alone (see bt_macroblock_kernel)
-    for (int i = tid; i < HALF; i += kAnyThreads) {
+    for (int i = tid; i < HALF; i += THREADS) {
       const int p = total + i;
       st[kOffInTail + i] = p < HALF ? st[kOffInTail + p] : x[p - HALF];
     }
-  any_stages(work, tw_f, A, frames, false, tid);
+  any_stages<THREADS>(work, tw_f, A, frames, false, tid);
   // kiss_fftr post-pass (kiss_fftr.c:92-120)
-  for (int w = tid; w < frames * (NC / 2 + 1); w += kAnyThreads) {
+  for (int w = tid; w < frames * (NC / 2 + 1); w += THREADS) {
     const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
     const cpx* T = work + fr * NC;
     cpx* Fq = coef + fr * NB;
@@ -675,8 +677,8 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
   __syncthreads();
 
   if (threshold) {
-    for (int w = tid; w < 128 * kAnySqw; w += kAnyThreads) {  // squared normalised real parts (.c:365-375)
-      const int m = w % kAnySqw, e = w / kAnySqw;
+    for (int w = tid; w < 128 * SQW; w += THREADS) {  // squared normalised real parts (.c:365-375)
+      const int m = w % SQW, e = w / SQW;
       float v2 = 0.0f;
       if (m < NCOL) {
         const float v = coef[(e >> 4) * NB + 1 + m * 16 + (e & 15)].r * P.norm;
@@ -686,15 +688,15 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
     }
     __syncthreads();
     {  // SURE of the 15 segmentations of every macro-column (.c:354-401): lane = column
-      const int wave = tid >> 6, lane = tid & 63, nwaves = kAnyThreads / 64;
+      const int wave = tid >> 6, lane = tid & 63, nwaves = THREADS / 64;
       for (int c = wave; c < 15; c += nwaves) {
-        const float v = sure_dispatch<kAnySqw>(c, sq + lane, P.seg[c / 5][c % 5]);
+        const float v = sure_dispatch<SQW>(c, sq + (lane % SQW), P.seg[c / 5][c % 5]);
         if (lane < NCOL) sure[lane * 15 + c] = v;
       }
     }
     __syncthreads();
     // DC column and the bins past the last whole macro-column (.c:501-506, 518-532)
-    for (int w = tid; w < 1 + (NB - (1 + NCOL * 16)); w += kAnyThreads) {
+    for (int w = tid; w < 1 + (NB - (1 + NCOL * 16)); w += THREADS) {
       const int col = w == 0 ? 0 : (1 + NCOL * 16) + (w - 1);
       float sum = 0.0f;
       for (int t = 0; t < 8; ++t) {
@@ -709,8 +711,8 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
       }
     }
     {  // argmin (first wins, .c:404-416) + Stein attenuation of the chosen blocks (.c:421-454)
-      const int wave = tid >> 6, lane = tid & 63, nwaves = kAnyThreads / 64;
-      float* pw = sure + kAnyMaxCol * 15 + 16 + wave * (128 + 64);
+      const int wave = tid >> 6, lane = tid & 63, nwaves = THREADS / 64;
+      float* pw = sure + kAnyMaxCol * 15 + 16 + wave * (128 + 64);  // up to 8 waves
       float* av = pw + 128;
       for (int m = wave; m < NCOL; m += nwaves) {
         const int base = 1 + m * 16;
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
       }
     }
     __syncthreads();
-    for (int w = tid; w < 8 * NC; w += kAnyThreads) {  // empirical Wiener, Nyquist untouched (.c:469-486)
+    for (int w = tid; w < 8 * NC; w += THREADS) {  // empirical Wiener, Nyquist untouched (.c:469-486)
       const int t = w / NC, f = w % NC;
       const float r = thre[t * NB + f].r, i = thre[t * NB + f].i;
       float wiener = r * r + i * i;
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
 
   // ---- inverse STFT + overlap-add (blockThreshold_inverse_STFT, .c:284-300); kiss_fftri pre-pass
   // (kiss_fftr.c:137-157) straight into kiss order
-  for (int w = tid; w < frames * (NC / 2 + 1); w += kAnyThreads) {
+  for (int w = tid; w < frames * (NC / 2 + 1); w += THREADS) {
     const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
     const cpx* Fq = coef + fr * NB;
     cpx* T = work + fr * NC;
@@ -795,10 +797,10 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
     }
   }
   __syncthreads();
-  any_stages(work, tw_i, A, frames, true, tid);
+  any_stages<THREADS>(work, tw_i, A, frames, true, tid);
   const float* td = reinterpret_cast<const float*>(work);  // frame fr sample j at fr * N + j
   const float fn = (float)N;
-  for (int q = tid; q < total + HALF; q += kAnyThreads) {
+  for (int q = tid; q < total + HALF; q += THREADS) {
     const int t2 = q / HALF, t1 = t2 - 1;
     float v = q < HALF ? st[kAnyOffOutTail + q] : 0.0f;
     if (t1 >= 0 && t1 < frames) v += td[t1 * N + (q - HALF * t1)] / fn;
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_macroblock_any_kernel(
       stage[q - total] = v;
   }
   __syncthreads();
-  for (int i = tid; i < HALF; i += kAnyThreads) st[kAnyOffOutTail + i] = threshold ? stage[i] : 0.0f;
+  for (int i = tid; i < HALF; i += THREADS) st[kAnyOffOutTail + i] = threshold ? stage[i] : 0.0f;
 }
 
 // kiss_fftr / kiss_fftri seam for any even length: one workgroup per row
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_fftr_any_kernel(const float* _
     const float* x = src + (size_t)blockIdx.x * N;
     for (int n = tid; n < NC; n += kAnyThreads) work[A.perm[n]] = cpx{x[2 * n], x[2 * n + 1]};
     __syncthreads();
-    any_stages(work, tw, A, 1, false, tid);
+    any_stages<kAnyThreads>(work, tw, A, 1, false, tid);
     for (int k = tid; k < NC / 2 + 1; k += kAnyThreads) {
       if (k == 0) {
         const float tdr = work[0].r, tdi = work[0].i;
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_fftr_any_kernel(const float* _
       }
     }
     __syncthreads();
-    any_stages(work, tw, A, 1, true, tid);
+    any_stages<kAnyThreads>(work, tw, A, 1, true, tid);
     float* y = dst + (size_t)blockIdx.x * N;
     for (int n = tid; n < NC; n += kAnyThreads) {
       y[2 * n] = work[n].r;
@@ -982,19 +984,30 @@ hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int in
 // any even window of 4 .. kAnyMaxWin samples (bt_macroblock_any_kernel); `state` has kAnyStateFloats per stream
 hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const float* in, float* out, int num_streams,
                                     int frames, int threshold, int in_stride, int out_stride, hipStream_t s) {
-  auto lds_of = [](int nc) {
-    const size_t tile = (size_t)8 * (nc + 1) * sizeof(cpx), sq = (size_t)128 * kAnySqw * sizeof(float);
-    return 2 * tile + (tile >= sq ? 0 : sq) + (size_t)(kAnyMaxCol * 15 + 16 + 4 * (128 + 64) + nc) * sizeof(float);
-  };
+  const int sqw = A.ncol <= 31 ? 32 : 64;
+  const int threads = A.nc >= 192 ? 512 : 256;  // measured: 320-sample windows prefer 256 threads, 480 and up 512
+  const size_t tile = (size_t)8 * (A.nc + 1) * sizeof(cpx), sq = (size_t)128 * sqw * sizeof(float);
+  const size_t lds = 2 * tile + (tile >= sq ? 0 : sq) + (size_t)(kAnyMaxCol * 15 + 16 + 8 * (128 + 64) + A.nc) * sizeof(float);
   static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bt_macroblock_any_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(kAnyMaxWin / 2));
+  if (!attr_set) {  // the longest window needs 143 KB
+    const int max_lds = 150 * 1024;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bt_macroblock_any_kernel<512, 64>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(bt_macroblock_any_kernel<512, 32>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(bt_macroblock_any_kernel, dim3(num_streams), dim3(kAnyThreads), lds_of(A.nc), s, state, A, in, out,
-                     frames, threshold, in_stride, out_stride);
+  if (threads == 512 && sqw == 64)
+    hipLaunchKernelGGL((bt_macroblock_any_kernel<512, 64>), dim3(num_streams), dim3(512), lds, s, state, A, in, out, frames,
+                       threshold, in_stride, out_stride);
+  else if (threads == 512)
+    hipLaunchKernelGGL((bt_macroblock_any_kernel<512, 32>), dim3(num_streams), dim3(512), lds, s, state, A, in, out, frames,
+                       threshold, in_stride, out_stride);
+  else
+    hipLaunchKernelGGL((bt_macroblock_any_kernel<256, 32>), dim3(num_streams), dim3(256), lds, s, state, A, in, out, frames,
+                       threshold, in_stride, out_stride);
   return hipGetLastError();
 }
 
