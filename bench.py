@@ -388,6 +388,30 @@ def ns_measure(args, S, rank, world, local_rank, dist):
     return np.array(ev), np.array(wall), S, primed
 
 
+def pcie_inclusive(S, device):
+    """The same fused step fed from and returning to pageable host buffers (ASP_MEM_HOST: copy in, K frame steps,
+    copy out per call): what a caller that keeps its audio on the host sees.  Never `value`."""
+    from audiosignalprocess_amd.ns import NsBatch
+    from audiosignalprocess_amd.synth import ns_frames
+    F, reps = 50, 4
+    try:
+        x = ns_frames(S, F, frame0=50)
+        g = NsBatch(S, device=device, policy=1)
+        g.set_split(2)
+        for _ in range(2):
+            g.analyze_process(x)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.analyze_process(x)
+        dt = time.perf_counter() - t0
+        g.close()
+        return {"value": S * F * reps / dt, "unit": "frames/s", "streams": S,
+                "GB_per_s_each_way": S * F * reps * 640 / dt / 1e9,
+                "sample": "%d calls of %d frames x %d streams, pageable host buffers in and out, wall clock" % (reps, F, S)}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "error": str(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -534,6 +558,8 @@ def main():
                 "value": S5 / s5, "unit": "frames/s", "ms_per_step": 1e3 * s5, "steps": a2.steps, "regions": int(len(ev5)),
                 "roofline_frac": ALGO_BYTES_PER_FRAME * S5 / s5 / 1e9 / HBM_PEAK_GBS,
             }
+        if world == 1 and not args.no_secondary:
+            line["pcie_inclusive"] = pcie_inclusive(args.streams_per_gpu, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_secondary:
