@@ -612,7 +612,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   float* after = reinterpret_cast<float*>(thre + 8 * NB);
   float* sq = sq_in_thre ? reinterpret_cast<float*>(thre) : after;
   float* sure = sq_in_thre ? after : after + 128 * SQW;  // [NCOL][15], then 16 spare, then 4 x (128 + 64)
-  float* stage = sure + kAnyMaxCol * 15 + 16 + 8 * (128 + 64);  // [HALF] new output tail
+  float* stage = sure + NCOL * 15 + 16 + (THREADS / 64) * (128 + 64);  // [HALF] new output tail
   const int tid = threadIdx.x;
   const int stream = blockIdx.x;
   float* st = state + (size_t)stream * kAnyStateFloats;
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
     }
     {  // argmin (first wins, .c:404-416) + Stein attenuation of the chosen blocks (.c:421-454)
       const int wave = tid >> 6, lane = tid & 63, nwaves = THREADS / 64;
-      float* pw = sure + kAnyMaxCol * 15 + 16 + wave * (128 + 64);  // up to 8 waves
+      float* pw = sure + NCOL * 15 + 16 + wave * (128 + 64);
       float* av = pw + 128;
       for (int m = wave; m < NCOL; m += nwaves) {
         const int base = 1 + m * 16;
@@ -984,10 +984,10 @@ hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int in
 // any even window of 4 .. kAnyMaxWin samples (bt_macroblock_any_kernel); `state` has kAnyStateFloats per stream
 hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const float* in, float* out, int num_streams,
                                     int frames, int threshold, int in_stride, int out_stride, hipStream_t s) {
-  const int sqw = A.ncol <= 31 ? 32 : 64;
+  const int sqw = A.ncol <= 15 ? 16 : A.ncol <= 31 ? 32 : 64;  // narrow table: it fits inside the attenuated tile sooner
   const int threads = A.nc >= 192 ? 512 : 256;  // measured: 320-sample windows prefer 256 threads, 480 and up 512
   const size_t tile = (size_t)8 * (A.nc + 1) * sizeof(cpx), sq = (size_t)128 * sqw * sizeof(float);
-  const size_t lds = 2 * tile + (tile >= sq ? 0 : sq) + (size_t)(kAnyMaxCol * 15 + 16 + 8 * (128 + 64) + A.nc) * sizeof(float);
+  const size_t lds = 2 * tile + (tile >= sq ? 0 : sq) + (size_t)(A.ncol * 15 + 16 + (threads / 64) * (128 + 64) + A.nc) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {  // the longest window needs 143 KB
     const int max_lds = 150 * 1024;
@@ -999,15 +999,20 @@ hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const fl
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+#define BT_ANY_LAUNCH(TH, SQ)                                                                                          \
+  hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ>), dim3(num_streams), dim3(TH), lds, s, state, A, in, out, frames, \
+                     threshold, in_stride, out_stride)
   if (threads == 512 && sqw == 64)
-    hipLaunchKernelGGL((bt_macroblock_any_kernel<512, 64>), dim3(num_streams), dim3(512), lds, s, state, A, in, out, frames,
-                       threshold, in_stride, out_stride);
+    BT_ANY_LAUNCH(512, 64);
+  else if (threads == 512 && sqw == 32)
+    BT_ANY_LAUNCH(512, 32);
   else if (threads == 512)
-    hipLaunchKernelGGL((bt_macroblock_any_kernel<512, 32>), dim3(num_streams), dim3(512), lds, s, state, A, in, out, frames,
-                       threshold, in_stride, out_stride);
+    BT_ANY_LAUNCH(512, 16);
+  else if (sqw == 32)
+    BT_ANY_LAUNCH(256, 32);
   else
-    hipLaunchKernelGGL((bt_macroblock_any_kernel<256, 32>), dim3(num_streams), dim3(256), lds, s, state, A, in, out, frames,
-                       threshold, in_stride, out_stride);
+    BT_ANY_LAUNCH(256, 16);
+#undef BT_ANY_LAUNCH
   return hipGetLastError();
 }
 
