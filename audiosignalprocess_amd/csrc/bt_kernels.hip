@@ -573,7 +573,9 @@ __device__ __forceinline__ void any_bfly_generic(cpx* F, int m, int p, const cpx
 }
 
 // every stage of `frames` nc-point transforms in work[frame][nc] (inputs already in kiss order)
-template <int THREADS>
+// GENERIC: the plan has a radix other than 2, 3, 4, 5 (the generic butterfly's scratch lives in private memory:
+// kernels for the usual windows are built without it)
+template <int THREADS, bool GENERIC>
 __device__ __forceinline__ void any_stages(cpx* work, const cpx* __restrict__ tw, const BtAnyTables& A, int frames,
                                            bool inverse, int tid) {
   const int nc = A.nc;
@@ -589,7 +591,9 @@ __device__ __forceinline__ void any_stages(cpx* work, const cpx* __restrict__ tw
         case 3: any_bfly3(F + u, m, tw, fstride, u); break;
         case 4: any_bfly4(F + u, m, tw, fstride, u, inverse); break;
         case 5: any_bfly5(F + u, m, tw, fstride, u); break;
-        default: any_bfly_generic(F, m, p, tw, fstride, u, nc); break;
+        default:
+          if constexpr (GENERIC) any_bfly_generic(F, m, p, tw, fstride, u, nc);
+          break;
       }
     }
     __syncthreads();
@@ -597,7 +601,7 @@ __device__ __forceinline__ void any_stages(cpx* work, const cpx* __restrict__ tw
 }
 
 // SQW: columns of the squared-real table (32 for windows of up to 1024 samples: at most 31 macro-columns; else 64)
-template <int THREADS, int SQW>
+template <int THREADS, int SQW, bool GENERIC>
 __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
     float* __restrict__ state, BtAnyTables A, const float* __restrict__ in, float* __restrict__ out, int frames,
     int threshold, int in_stride, int out_stride) {
@@ -609,7 +613,8 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   // [128][SQW] squared real parts: inside the thre tile when that is large enough (it is dead until the
   // SURE values are out), else behind it (launch_bt_macroblock_any sizes the allocation the same way)
   const bool sq_in_thre = (size_t)8 * NB * sizeof(cpx) >= (size_t)128 * SQW * sizeof(float);
-  float* after = reinterpret_cast<float*>(thre + 8 * NB);
+  cpx* twl = thre + 8 * NB;  // [NC] twiddles of the running direction (every butterfly reads three or four of them)
+  float* after = reinterpret_cast<float*>(twl + NC);
   float* sq = sq_in_thre ? reinterpret_cast<float*>(thre) : after;
   float* sure = sq_in_thre ? after : after + 128 * SQW;  // [NCOL][15], then 16 spare, then 4 x (128 + 64)
   float* stage = sure + NCOL * 15 + 16 + (THREADS / 64) * (128 + 64);  // [HALF] new output tail
@@ -624,6 +629,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   const cpx* sup_f = reinterpret_cast<const cpx*>(A.sup_f);
   const cpx* sup_i = reinterpret_cast<const cpx*>(A.sup_i);
 
+  for (int i = tid; i < NC; i += THREADS) twl[i] = tw_f[i];
   // ---- STFT (blockThreshold_STFT, .c:273-282)
   const int total = frames * HALF;
   for (int w = tid; w < frames * NC; w += THREADS) {
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
       const int p = total + i;
       st[kOffInTail + i] = p < HALF ? st[kOffInTail + p] : x[p - HALF];
     }
-  any_stages<THREADS>(work, tw_f, A, frames, false, tid);
+  any_stages<THREADS, GENERIC>(work, twl, A, frames, false, tid);
   // kiss_fftr post-pass (kiss_fftr.c:92-120)
   for (int w = tid; w < frames * (NC / 2 + 1); w += THREADS) {
     const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
@@ -768,6 +774,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
 
   // ---- inverse STFT + overlap-add (blockThreshold_inverse_STFT, .c:284-300); kiss_fftri pre-pass
   // (kiss_fftr.c:137-157) straight into kiss order
+  for (int i = tid; i < NC; i += THREADS) twl[i] = tw_i[i];  // the forward stages ended at a barrier long ago
   for (int w = tid; w < frames * (NC / 2 + 1); w += THREADS) {
     const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
     const cpx* Fq = coef + fr * NB;
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
     }
   }
   __syncthreads();
-  any_stages<THREADS>(work, tw_i, A, frames, true, tid);
+  any_stages<THREADS, GENERIC>(work, twl, A, frames, true, tid);
   const float* td = reinterpret_cast<const float*>(work);  // frame fr sample j at fr * N + j
   const float fn = (float)N;
   for (int q = tid; q < total + HALF; q += THREADS) {
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_fftr_any_kernel(const float* _
     const float* x = src + (size_t)blockIdx.x * N;
     for (int n = tid; n < NC; n += kAnyThreads) work[A.perm[n]] = cpx{x[2 * n], x[2 * n + 1]};
     __syncthreads();
-    any_stages<kAnyThreads>(work, tw, A, 1, false, tid);
+    any_stages<kAnyThreads, true>(work, tw, A, 1, false, tid);
     for (int k = tid; k < NC / 2 + 1; k += kAnyThreads) {
       if (k == 0) {
         const float tdr = work[0].r, tdi = work[0].i;
@@ -875,7 +882,7 @@ __global__ __launch_bounds__(kAnyThreads) void bt_fftr_any_kernel(const float* _
       }
     }
     __syncthreads();
-    any_stages<kAnyThreads>(work, tw, A, 1, true, tid);
+    any_stages<kAnyThreads, true>(work, tw, A, 1, true, tid);
     float* y = dst + (size_t)blockIdx.x * N;
     for (int n = tid; n < NC; n += kAnyThreads) {
       y[2 * n] = work[n].r;
@@ -987,21 +994,32 @@ hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const fl
   const int sqw = A.ncol <= 15 ? 16 : A.ncol <= 31 ? 32 : 64;  // narrow table: it fits inside the attenuated tile sooner
   const int threads = A.nc >= 192 ? 512 : 256;  // measured: 320-sample windows prefer 256 threads, 480 and up 512
   const size_t tile = (size_t)8 * (A.nc + 1) * sizeof(cpx), sq = (size_t)128 * sqw * sizeof(float);
-  const size_t lds = 2 * tile + (tile >= sq ? 0 : sq) + (size_t)(A.ncol * 15 + 16 + (threads / 64) * (128 + 64) + A.nc) * sizeof(float);
+  const size_t lds = 2 * tile + (size_t)A.nc * sizeof(cpx) + (tile >= sq ? 0 : sq) +
+                     (size_t)(A.ncol * 15 + 16 + (threads / 64) * (128 + 64) + A.nc) * sizeof(float);
   static bool attr_set = false;
-  if (!attr_set) {  // the longest window needs 143 KB
-    const int max_lds = 150 * 1024;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bt_macroblock_any_kernel<512, 64>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(bt_macroblock_any_kernel<512, 32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  if (!attr_set) {  // the longest window needs 151 KB
+    const int max_lds = 156 * 1024;
+    hipError_t e = hipSuccess;
+    const void* big[] = {reinterpret_cast<const void*>(bt_macroblock_any_kernel<512, 64, false>),
+                         reinterpret_cast<const void*>(bt_macroblock_any_kernel<512, 64, true>),
+                         reinterpret_cast<const void*>(bt_macroblock_any_kernel<512, 32, false>),
+                         reinterpret_cast<const void*>(bt_macroblock_any_kernel<512, 32, true>)};
+    for (const void* f : big)
+      if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-#define BT_ANY_LAUNCH(TH, SQ)                                                                                          \
-  hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ>), dim3(num_streams), dim3(TH), lds, s, state, A, in, out, frames, \
-                     threshold, in_stride, out_stride)
+  bool generic = false;
+  for (int q = 0; q < A.nfac; ++q) generic |= A.fac[2 * q] > 5;
+#define BT_ANY_LAUNCH(TH, SQ)                                                                                  \
+  do {                                                                                                         \
+    if (generic)                                                                                               \
+      hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ, true>), dim3(num_streams), dim3(TH), lds, s, state, A, in, \
+                         out, frames, threshold, in_stride, out_stride);                                       \
+    else                                                                                                       \
+      hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ, false>), dim3(num_streams), dim3(TH), lds, s, state, A, in, \
+                         out, frames, threshold, in_stride, out_stride);                                       \
+  } while (0)
   if (threads == 512 && sqw == 64)
     BT_ANY_LAUNCH(512, 64);
   else if (threads == 512 && sqw == 32)
