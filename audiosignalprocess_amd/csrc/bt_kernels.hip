@@ -942,6 +942,8 @@ namespace aspbt {
 hipError_t launch_bt_macroblock8(float* state, const BtTables* T, const float* in, float* out,
                                  int num_streams, int in_stride, int out_stride, hipStream_t s,
                                  unsigned long long* stamps);
+hipError_t launch_bt_macroblock8_q4(float* state, const BtTables* T, const float* in, float* out, int groups,
+                                    int in_stride, int out_stride, hipStream_t s);
 hipError_t launch_bt_fftr8(const float* src, float* dst, int count, int inverse, const BtTables* T,
                            hipStream_t s);
 
@@ -960,6 +962,19 @@ hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const fl
   if (n == 1024 && frames == 8 && threshold == 1 && ((uintptr_t)in & 7) == 0 && ((uintptr_t)out & 7) == 0 &&
       (in_stride & 1) == 0 && (out_stride & 1) == 0 && !getenv("ASP_BT_OLD_KERNEL"))
     return launch_bt_macroblock8(state, T, in, out, num_streams, in_stride, out_stride, s, stamps);
+  // whole macroblocks at N = 256: four stream-channels per workgroup in the same kernel; the last
+  // num_streams % 4 stream-channels take the plain kernel below
+  if (n == 256 && frames == 8 && threshold == 1 && num_streams >= 4 && ((uintptr_t)in & 7) == 0 &&
+      ((uintptr_t)out & 7) == 0 && (in_stride & 1) == 0 && (out_stride & 1) == 0 && !getenv("ASP_BT_OLD_KERNEL")) {
+    const int groups = num_streams / 4, rest = num_streams - 4 * groups;
+    hipError_t e = launch_bt_macroblock8_q4(state, T, in, out, groups, in_stride, out_stride, s);
+    if (e != hipSuccess || rest == 0) return e;
+    const size_t done = (size_t)4 * groups;
+    hipLaunchKernelGGL(bt_macroblock_kernel<256>, dim3(rest), dim3(128), macroblock_lds_bytes(256), s,
+                       state + done * kStateFloats, T, in + done * in_stride, out + done * out_stride, frames, threshold,
+                       in_stride, out_stride, (unsigned long long*)nullptr);
+    return hipGetLastError();
+  }
   const size_t lds = macroblock_lds_bytes(n);
   if (n == 1024) {
     static bool attr_set = false;

@@ -127,7 +127,11 @@ constexpr int SUS = 15;      // SURE values per macro-column
 
 // All stages of one 512-point complex FFT of kiss_fft (factors 4,4,4,4,2): in: layout LA, out: LD.
 // tw: the global table (wave-uniform entries of the first two stages), twl: its LDS copy
-template <bool INV>
+// Q4: four independent 128-point transforms (kiss factors 4,4,4,2) of four streams whose inputs are interleaved
+// (input 4 n' + s = sample n' of stream s): they are this network without its last stage, and their twiddles are
+// entries of the same table (tw128[j] == tw512[4 j] bit for bit: the phases differ by exact powers of two).  The
+// last exchange still runs: stream s ends in natural order at positions 128 s .. 128 s + 127 (layout LD).
+template <bool INV, bool Q4 = false>
 __device__ __forceinline__ void wave_fft512(cpx (&v)[8], cpx* tile, const cpx* twl,
                                             const cpx* __restrict__ tw, int lane, const XTerms& xt) {
   {  // radix-2 leaves (m = 1, twiddle 0) and the radix-4 stage with m = 2: wave-uniform twiddles
@@ -153,7 +157,9 @@ __device__ __forceinline__ void wave_fft512(cpx (&v)[8], cpx* tile, const cpx* t
 #pragma unroll
     for (int c = 0; c < 2; ++c) bfly4<INV>(v[c], v[c + 2], v[c + 4], v[c + 6], t1, t2, t3);
   }
-  {
+  if constexpr (Q4) {
+    exchange<3>(v, tile, xt);
+  } else {
     cpx t[2][3];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -242,6 +248,81 @@ __device__ __forceinline__ void wave_merge_inverse(cpx (&v)[8], const cpx* row, 
     // n < 256: T[k] = fek + fok; above: T[NC - k] = {fek.r - fok.r, (fek.i - fok.i) * -1}
     cpx t = (j & 1) ? sub_lo_rsub_hi(fek, fok) : fek + fok;
     if (j == 0 && lane == 0) {  // n = 0
+      t.x = u[0].x + w[0].x;
+      t.y = u[0].x - w[0].x;
+    }
+    v[j] = t;
+  }
+}
+
+// ---- four streams of 256-sample windows per workgroup (Q4): the row holds T_s[k] at 128 s + k after the
+// transform; the spectra F_s[0 .. 128] go to 129 s + b.  Pairs (k, 128 - k): lane takes k = 1 + lane of every
+// stream; lanes 0..3 also bin 0 / 128 of stream `lane`.
+constexpr int NCQ = 128, NBQ = 129, NCOLQ = 7;  // per stream: complex points, bins, whole macro-columns
+template <bool SQ>
+__device__ __forceinline__ void wave_split_forward_q4(cpx* row, cpx spq, int lane, float* sq_fr, float norm) {
+  cpx fp[4], fn[4];
+  const int k = 1 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    fp[q] = row[NCQ * q + k];
+    fn[q] = row[NCQ * q + NCQ - k];
+  }
+  const cpx t0 = row[NCQ * (lane & 3)];
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const cpx f1k = add_sub_hi(fp[q], fn[q]);
+    const cpx f2k = add_sub_lo(fp[q], fn[q]);
+    const cpx twv = cmul<false>(f2k, spq);
+    const cpx a = (f1k + twv) * 0.5f;
+    const cpx b = sub_lo_rsub_hi(f1k, twv) * 0.5f;
+    if (k != NCQ - k) row[NBQ * q + k] = a;
+    row[NBQ * q + NCQ - k] = b;  // for k = 64 the second assignment is the one that stays
+    if (SQ) {
+      const int ka = k - 1, kb = NCQ - k - 1;  // bin = 1 + 16 m' + cc of column 7 q + m'
+      f32x2 re = {a.x, b.x};
+      re = re * norm;
+      re = re * re;
+      if (k != NCQ - k) sq_fr[(ka & 15) * SQS + NCOLQ * q + (ka >> 4)] = re.x;
+      if (kb < 16 * NCOLQ) sq_fr[(kb & 15) * SQS + NCOLQ * q + (kb >> 4)] = re.y;
+    }
+  }
+  if (lane < 4) {
+    cpx z;
+    z.x = t0.x + t0.y;
+    z.y = 0.f;
+    row[NBQ * lane] = z;
+    z.x = t0.x - t0.y;
+    row[NBQ * lane + NCQ] = z;
+  }
+}
+
+// register j of layout LA holds input 4 n' + s of the interleaved array: s = lane & 3,
+// n' = (lane >> 2) + 16 (j >> 1) + 64 (j & 1)
+__device__ __forceinline__ constexpr int q4_input(int lane, int j) { return (lane >> 2) + 16 * (j >> 1) + 64 * (j & 1); }
+__device__ __forceinline__ int merge_sup_index_q4(int lane, int j) {
+  const int n = q4_input(lane, j);
+  const int k = (j & 1) ? NCQ - n : n;
+  return k > 0 ? k - 1 : 0;
+}
+__device__ __forceinline__ void wave_merge_inverse_q4(cpx (&v)[8], const cpx* row, const cpx (&spf)[8], int lane) {
+  const cpx* F = row + NBQ * (lane & 3);
+  cpx u[8], w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = q4_input(lane, j);
+    u[j] = F[n];
+    w[j] = F[NCQ - n];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const cpx fk = (j & 1) ? w[j] : u[j], fo = (j & 1) ? u[j] : w[j];  // F[k], F[128 - k]
+    const cpx fek = add_sub_hi(fk, fo);
+    const cpx tmp = add_sub_lo(fk, fo);
+    const cpx fok = cmul<true>(tmp, spf[j]);
+    cpx t = (j & 1) ? sub_lo_rsub_hi(fek, fok) : fek + fok;
+    if (j == 0 && lane < 4) {  // n' = 0
       t.x = u[0].x + w[0].x;
       t.y = u[0].x - w[0].x;
     }
@@ -460,6 +541,10 @@ __device__ __forceinline__ void scan_rows_full(const float (&pw)[8], int lastlan
 #ifndef BT8_WAVES
 #define BT8_WAVES 4  // waves per SIMD the register allocation aims at (measured: 6 = three workgroups per CU is 4 % slower, it spills)
 #endif
+// Q4: four stream-channels of 256-sample windows per workgroup (workgroup g takes streams 4 g .. 4 g + 3): wave w =
+// frame w of all four, their samples interleaved on the way in so that the 512-point network computes four 128-point
+// transforms; 4 x 7 macro-columns + 4 x 16 edge lanes are the 512 threads of phase B2.
+template <bool Q4>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, BT8_WAVES))) void bt_macroblock8_kernel(
     float* __restrict__ state, const BtTables* __restrict__ Tb, const float* __restrict__ in,
     float* __restrict__ out, int in_stride, int out_stride, unsigned long long* __restrict__ stamps) {
@@ -470,13 +555,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   BT8_STAMP(0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the phase switches are scalar branches
-  const int stream = blockIdx.x;
+  constexpr int HALFV = Q4 ? 128 : HALF, NCOLV = Q4 ? 4 * NCOLQ : NCOL;
+  // the stream whose samples this lane loads (Q4: input 4 n' + s of the interleaved array sits on lanes with lane & 3 = s)
+  const int stream = Q4 ? 4 * blockIdx.x + (lane & 3) : blockIdx.x;
   float* st = state + (size_t)stream * kStateFloats;
   const float* x = in + (size_t)stream * in_stride;
   float* y = out + (size_t)stream * out_stride;
-  const BtSize& P = Tb->s1024;
+  const BtSize& P = Q4 ? Tb->s256 : Tb->s1024;
   const cpx* tw = reinterpret_cast<const cpx*>(Tb->tw1024_f);
-  const cpx* sup = reinterpret_cast<const cpx*>(Tb->sup1024_f);
+  const cpx* sup = reinterpret_cast<const cpx*>(Q4 ? Tb->sup256_f : Tb->sup1024_f);
   cpx* row = coef + wave * ROW;
   cpx* tile = coef;
   const XTerms xt = exchange_terms(Tb, lane, wave * ROW * 8);
@@ -486,14 +573,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   cpx v[8];
   cpx spf[4];  // the split's super twiddles, requested with the samples
 #pragma unroll
-  for (int i = 0; i < 4; ++i) spf[i] = sup[lane + 64 * i];
+  for (int i = 0; i < 4; ++i) spf[i] = sup[Q4 ? lane : lane + 64 * i];
   {
-    const f32x2* hann2 = reinterpret_cast<const f32x2*>(Tb->hann1024);
+    const f32x2* hann2 = reinterpret_cast<const f32x2*>(Q4 ? Tb->hann256 : Tb->hann1024);
     f32x2 s[8], hw[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int n = lane + la_input(j);  // complex input index: samples 2n, 2n + 1 of the frame
-      const float* src = (wave == 0 && (j & 1) == 0) ? st + kOffInTail + 2 * n : x + HALF * (wave - 1) + 2 * n;
+      const int n = Q4 ? q4_input(lane, j) : lane + la_input(j);  // complex input index: samples 2n, 2n + 1 of the frame
+      const float* src = (wave == 0 && (j & 1) == 0) ? st + kOffInTail + 2 * n : x + HALFV * (wave - 1) + 2 * n;
       s[j] = *reinterpret_cast<const f32x2*>(src);
       hw[j] = hann2[n];
     }
@@ -506,19 +593,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
     }
     __syncthreads();  // the twiddle tables are staged (every wave is waiting for its samples here anyway)
     BT8_STAMP(1)
-    wave_fft512<false>(v, tile, twl, tw, lane, xt);
+    wave_fft512<false, Q4>(v, tile, twl, tw, lane, xt);
   }
   BT8_STAMP(2)
 #pragma unroll
   for (int j = 0; j < 8; ++j) row[lane + 64 * j] = v[j];
   wave_lds_fence();
-  wave_split_forward<true>(row, spf, lane, sq + wave * 16 * SQS, P.norm);
+  if constexpr (Q4)
+    wave_split_forward_q4<true>(row, spf[0], lane, sq + wave * 16 * SQS, P.norm);
+  else
+    wave_split_forward<true>(row, spf, lane, sq + wave * 16 * SQS, P.norm);
   BT8_STAMP(3)
   BT8_WSTAMP(0)
   __syncthreads();
   BT8_STAMP(4)
   // carry the last HALF input samples (wave 0 has read the old tail before the barrier)
-  st[kOffInTail + tid] = x[7 * HALF + tid];
+  if constexpr (Q4) {
+    const size_t sq4 = (size_t)4 * blockIdx.x + (tid >> 7);
+    state[sq4 * kStateFloats + kOffInTail + (tid & 127)] = in[sq4 * in_stride + 7 * HALFV + (tid & 127)];
+  } else {
+    st[kOffInTail + tid] = x[7 * HALF + tid];
+  }
 
   // ---------------------------------------------------------------- phase B1: SURE (.c:354-401)
   switch (wave) {  // segmentations dealt by cost (terms per half-wave: 32, 16, 16, 8, ...)
@@ -545,7 +640,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
       // They run the columns' code as a (T, F) = (0, 4) block (one lane wide, 8 rows: the same sums in
       // the same order) and swap the gain in at the end.  The Nyquist bin (512) is thresholded by the
       // reference but never reaches the Wiener step: it stays as it is.
-      const bool edge = m >= NCOL;
+      const bool edge = m >= NCOLV;
       // argmin, first minimum wins (.c:404-416)
       float best = sure[m * SUS];
       int bc = 0;
@@ -562,7 +657,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
       const int T = bc >= 10 ? 2 : bc >= 5 ? 1 : 0, F = bc - 5 * T;
       const int TT = 8 >> T, FF = 16 >> F;
       const float a_const = sure[NCOL * SUS + bc];
-      cpx* col = coef + (edge ? (u == 0 ? 0 : 16 * NCOL + u) : 1 + 16 * m + u);
+      cpx* col;
+      if constexpr (Q4) {  // column m = 7 q + m' of stream q; edge group 28 + q: bin 0 and bins 113..127 of stream q
+        const int q = edge ? m - NCOLV : m / NCOLQ;
+        col = coef + NBQ * q + (edge ? (u == 0 ? 0 : 16 * NCOLQ + u) : 1 + 16 * (m - NCOLQ * q) + u);
+      } else {
+        col = coef + (edge ? (u == 0 ? 0 : 16 * NCOL + u) : 1 + 16 * m + u);
+      }
       // Block powers of the chosen segmentation (.c:421-454).  The column's 16 lanes are one DPP row: lane u
       // owns bin u of every frame.  A block sum runs rows outer / columns inner, i.e. along the lanes of a
       // segment of FF lanes and on into the next row: a segmented left-to-right scan per row (each step adds
@@ -652,14 +753,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
     }
   }
   // the old output tail, for wave 0's overlap-add (requested ahead of the barrier)
+  // (Q4: after the inverse transform register pair (2 q, 2 q + 1) is stream q: samples 2 lane, 2 lane + 1 of the
+  // frame's first / second half)
+  const size_t g4 = (size_t)4 * blockIdx.x;
   f32x2 tail[4];
   if (wave == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tail[j] = *reinterpret_cast<const f32x2*>(st + kOffOutTail + 2 * (lane + 64 * j));
+    for (int j = 0; j < 4; ++j)
+      tail[j] = Q4 ? *reinterpret_cast<const f32x2*>(state + (g4 + j) * kStateFloats + kOffOutTail + 2 * lane)
+                   : *reinterpret_cast<const f32x2*>(st + kOffOutTail + 2 * (lane + 64 * j));
   }
   cpx spi[8];  // the merge's super twiddles, requested ahead of the barrier
 #pragma unroll
-  for (int j = 0; j < 8; ++j) spi[j] = sup[merge_sup_index(lane, j)];
+  for (int j = 0; j < 8; ++j) spi[j] = sup[Q4 ? merge_sup_index_q4(lane, j) : merge_sup_index(lane, j)];
   BT8_STAMP(7)
   BT8_WSTAMP(2)
   __syncthreads();
@@ -667,14 +773,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
 
   // ---------------------------------------------------------------- phase C: inverse STFT + overlap-add
   // (blockThreshold_inverse_STFT, .c:284-300)
-  wave_merge_inverse(v, row, spi, lane);
+  if constexpr (Q4)
+    wave_merge_inverse_q4(v, row, spi, lane);
+  else
+    wave_merge_inverse(v, row, spi, lane);
   wave_lds_fence();
-  wave_fft512<true>(v, tile, twl, tw, lane, xt);
+  wave_fft512<true, Q4>(v, tile, twl, tw, lane, xt);
   BT8_STAMP(9)
-  const float inv_n = 1.0f / (float)N;  // N is a power of two: x * (1/N) == x / N exactly
-  cpx* ola = reinterpret_cast<cpx*>(sq);  // [frame][256]: second halves (samples 512..1023) of frames 0..6
-  // v[j] = samples 2p, 2p + 1 of the frame, p = lane + 64 j
+  const float inv_n = 1.0f / (float)(Q4 ? 256 : N);  // a power of two: x * (1/N) == x / N exactly
+  cpx* ola = reinterpret_cast<cpx*>(sq);  // [frame][256]: second halves of frames 0..6
   // (barrier 3 above: every wave is done with the block gains that share the table)
+  if constexpr (Q4) {
+    // v[2 q] / v[2 q + 1] = samples 2 lane, 2 lane + 1 of the first / second half of stream q's frame
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const cpx t = v[2 * q + 1] * inv_n;
+      if (wave < 7) ola[wave * 256 + 64 * q + lane] = t;
+      v[2 * q + 1] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x2 acc;
+      if (wave == 0) {
+        acc = tail[q];
+      } else {
+        const cpx pr = ola[(wave - 1) * 256 + 64 * q + lane];
+        acc = f32x2{0.0f, 0.0f} + pr;
+      }
+      acc = acc + v[2 * q] * inv_n;
+      *reinterpret_cast<f32x2*>(out + (g4 + q) * out_stride + HALFV * wave + 2 * lane) = acc;
+    }
+    if (wave == 7) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x2*>(state + (g4 + q) * kStateFloats + kOffOutTail + 2 * lane) = f32x2{0.0f, 0.0f} + v[2 * q + 1];
+    }
+  } else {
+  // v[j] = samples 2p, 2p + 1 of the frame, p = lane + 64 j
 #pragma unroll
   for (int j = 4; j < 8; ++j) {
     const cpx t = v[j] * inv_n;
@@ -700,6 +836,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
     for (int j = 4; j < 8; ++j) {
       *reinterpret_cast<f32x2*>(st + kOffOutTail + 2 * (lane + 64 * (j - 4))) = f32x2{0.0f, 0.0f} + v[j];
     }
+  }
   }
   BT8_STAMP(10)
   BT8_WSTAMP(3)
@@ -756,8 +893,17 @@ namespace aspbt {
 hipError_t launch_bt_macroblock8(float* state, const BtTables* T, const float* in, float* out,
                                  int num_streams, int in_stride, int out_stride, hipStream_t s,
                                  unsigned long long* stamps) {
-  hipLaunchKernelGGL(bt_macroblock8_kernel, dim3(num_streams), dim3(512), 0, s, state, T, in, out,
+  hipLaunchKernelGGL(bt_macroblock8_kernel<false>, dim3(num_streams), dim3(512), 0, s, state, T, in, out,
                      in_stride, out_stride, stamps);
+  return hipGetLastError();
+}
+
+// N = 256: `groups` workgroups of four consecutive stream-channels each (the caller runs what is left over
+// through bt_macroblock_kernel<256>)
+hipError_t launch_bt_macroblock8_q4(float* state, const BtTables* T, const float* in, float* out, int groups,
+                                    int in_stride, int out_stride, hipStream_t s) {
+  hipLaunchKernelGGL(bt_macroblock8_kernel<true>, dim3(groups), dim3(512), 0, s, state, T, in, out, in_stride,
+                     out_stride, (unsigned long long*)nullptr);
   return hipGetLastError();
 }
 

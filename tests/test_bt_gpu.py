@@ -53,6 +53,30 @@ def test_macroblocks_bit_exact_vs_oracle(bt, n):
     g.close()
 
 
+def test_256_four_streams_per_workgroup(bt, monkeypatch):
+    """N = 256 macroblocks run four stream-channels per workgroup (bt_kernels8.hip, Q4) and the last
+    num_streams % 4 through the plain kernel: 13 streams = 3 groups + 1, every stream against the oracle, and
+    against the plain kernel for all of them (ASP_BT_OLD_KERNEL)."""
+    S, K, n = 13, 3, 256
+    x = bt_samples(S, K * 4 * n, stream0=40)
+    rng = np.random.default_rng(3)
+    x[5] = (0.5 * rng.standard_normal(x.shape[1])).astype(np.float32)      # wide segments everywhere
+    x[6, 2048:] *= 0.01
+    g = bt.BtBatch(S, n)
+    y = g.run(x)
+    for s in range(S):
+        o = OracleBt(n)
+        assert np.array_equal(y[s], o.run(x[s])), s
+        so, sg = o.export_state(), g.export_state(s)
+        assert np.array_equal(np.ctypeslib.as_array(so.inbuf_tail), np.ctypeslib.as_array(sg.inbuf_tail)), s
+        assert np.array_equal(np.ctypeslib.as_array(so.out_tail), np.ctypeslib.as_array(sg.out_tail)), s
+    g.close()
+    monkeypatch.setenv("ASP_BT_OLD_KERNEL", "1")
+    g = bt.BtBatch(S, n)
+    assert np.array_equal(g.run(x), y)
+    g.close()
+
+
 def test_wide_segment_signals_bit_exact(bt):
     """Signals far above the noise floor make every macro-column choose the 8 x 16 block (oracle seg (0, 0)):
     the full-row scan of bt_kernels8.hip; a chirp and a tone mix that with narrow segments in the low columns."""
