@@ -148,7 +148,7 @@ def bench_bt(args):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": BT_TRAFFIC_BYTES_PER_MACROBLOCK * S if n == 1024 else None,
                      "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), per step of all stream-channels; not measured in this run",
-                     "kernel": "bt_macroblock8_kernel" if n == 1024 else "bt_macroblock_kernel<%d>" % n,
+                     "kernel": "bt_macroblock8_kernel<false>" if n == 1024 else "bt_macroblock8_kernel<true> (four stream-channels per workgroup)",
                      "launch_chains": 2 if S >= 2048 else 1,
                      "algorithmic_bytes_per_step": algo * S, "avg_step_us": launch_s * 1e6},
     }
