@@ -313,13 +313,13 @@ def copy_ceiling_gbs(device=0):
     return cc(1 << 30, 8, device), cc(32 << 20, 64, device)
 
 
-def _secondary(args, workload):
+def _secondary(args, workload, cpu_baseline=True):
     """One secondary workload (AEC / BT-1024) in a child process of the same run, so its allocations
     and library state never touch the headline measurement; returns its JSON line as a dict."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(args.secondary_steps),
            "--warmup", str(args.secondary_warmup)]
-    if args.no_cpu_baseline:
+    if args.no_cpu_baseline or not cpu_baseline:
         cmd.append("--no-cpu-baseline")
     try:
         out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()
@@ -564,7 +564,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_secondary:
             torch.cuda.empty_cache()
-            line["secondary"] = [_secondary(args, "aec"), _secondary(args, "bt1024")]
+            line["secondary"] = [_secondary(args, "aec"), _secondary(args, "bt1024"),
+                                 _secondary(args, "bt256", cpu_baseline=False)]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
