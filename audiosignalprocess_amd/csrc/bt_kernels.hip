@@ -572,6 +572,11 @@ __device__ __forceinline__ void any_bfly_generic(cpx* F, int m, int p, const cpx
   }
 }
 
+// w / d for 0 <= w < 2^16 and 1 <= d <= 2^11 through one float multiply (rd = 1.0f / d): (w + 0.5) / d is at
+// least 0.5 / d away from every integer, far more than the rounding of the product, so the truncation is exact.
+// (The loops below run a handful of butterflies per thread: four integer divisions each were most of their cost.)
+__device__ __forceinline__ int fast_div(int w, float rd) { return (int)(((float)w + 0.5f) * rd); }
+
 // every stage of `frames` nc-point transforms in work[frame][nc] (inputs already in kiss order)
 // GENERIC: the plan has a radix other than 2, 3, 4, 5 (the generic butterfly's scratch lives in private memory:
 // kernels for the usual windows are built without it)
@@ -582,9 +587,10 @@ __device__ __forceinline__ void any_stages(cpx* work, const cpx* __restrict__ tw
   for (int s = A.nfac - 1; s >= 0; --s) {
     const int p = A.fac[2 * s], m = A.fac[2 * s + 1];
     const int span = p * m, fstride = nc / span, units = nc / p;  // butterflies per frame
+    const float r_units = 1.0f / (float)units, r_m = 1.0f / (float)m;
     for (int w = tid; w < frames * units; w += THREADS) {
-      const int fr = w / units, b = w % units;
-      const int g = b / m, u = b % m;
+      const int fr = fast_div(w, r_units), b = w - fr * units;
+      const int g = fast_div(b, r_m), u = b - g * m;
       cpx* F = work + fr * nc + g * span;
       switch (p) {
         case 2: any_bfly2(F + u, m, tw, fstride, u); break;
@@ -632,8 +638,9 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   for (int i = tid; i < NC; i += THREADS) twl[i] = tw_f[i];
   // ---- STFT (blockThreshold_STFT, .c:273-282)
   const int total = frames * HALF;
+  const float r_nc = 1.0f / (float)NC, r_nh = 1.0f / (float)(NC / 2 + 1);
   for (int w = tid; w < frames * NC; w += THREADS) {
-    const int fr = w / NC, n = w % NC;
+    const int fr = fast_div(w, r_nc), n = w - fr * NC;
     const int p0 = HALF * fr + 2 * n;
     const float b0 = p0 < HALF ? st[kOffInTail + p0] : x[p0 - HALF];
     const float b1 = p0 + 1 < HALF ? st[kOffInTail + p0 + 1] : x[p0 + 1 - HALF];
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   any_stages<THREADS, GENERIC>(work, twl, A, frames, false, tid);
   // kiss_fftr post-pass (kiss_fftr.c:92-120)
   for (int w = tid; w < frames * (NC / 2 + 1); w += THREADS) {
-    const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
+    const int fr = fast_div(w, r_nh), k = w - fr * (NC / 2 + 1);
     const cpx* T = work + fr * NC;
     cpx* Fq = coef + fr * NB;
     if (k == 0) {
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
     }
     __syncthreads();
     for (int w = tid; w < 8 * NC; w += THREADS) {  // empirical Wiener, Nyquist untouched (.c:469-486)
-      const int t = w / NC, f = w % NC;
+      const int t = fast_div(w, r_nc), f = w - t * NC;
       const float r = thre[t * NB + f].r, i = thre[t * NB + f].i;
       float wiener = r * r + i * i;
       wiener = wiener / (wiener + P.wiener_c);
@@ -776,7 +783,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   // (kiss_fftr.c:137-157) straight into kiss order
   for (int i = tid; i < NC; i += THREADS) twl[i] = tw_i[i];  // the forward stages ended at a barrier long ago
   for (int w = tid; w < frames * (NC / 2 + 1); w += THREADS) {
-    const int fr = w / (NC / 2 + 1), k = w % (NC / 2 + 1);
+    const int fr = fast_div(w, r_nh), k = w - fr * (NC / 2 + 1);
     const cpx* Fq = coef + fr * NB;
     cpx* T = work + fr * NC;
     if (k == 0) {
@@ -808,7 +815,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   const float* td = reinterpret_cast<const float*>(work);  // frame fr sample j at fr * N + j
   const float fn = (float)N;
   for (int q = tid; q < total + HALF; q += THREADS) {
-    const int t2 = q / HALF, t1 = t2 - 1;
+    const int t2 = fast_div(q, r_nc), t1 = t2 - 1;
     float v = q < HALF ? st[kAnyOffOutTail + q] : 0.0f;
     if (t1 >= 0 && t1 < frames) v += td[t1 * N + (q - HALF * t1)] / fn;
     if (t2 < frames) v += td[t2 * N + (q - HALF * t2)] / fn;
