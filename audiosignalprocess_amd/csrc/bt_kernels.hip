@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "bt_layout.h"
+#include "bt_sure.h"
 
 using namespace aspbt;
 
@@ -453,7 +454,6 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
 // float operations in the reference's order (butterflies of a stage are independent, so their order
 // across threads does not matter).  A plain path: 256 threads per macroblock, a barrier per stage.
 constexpr int kAnyThreads = 256;   // the seam kernel's workgroup; the macroblock kernel runs 256 or 512 threads
-constexpr int kAnyMaxCol = 63;     // macro-columns of a 2048-sample window
 
 __device__ __forceinline__ void any_bfly2(cpx* F, int m, const cpx* tw, int fstride, int u) {
   const cpx t = cmul(F[m], tw[u * fstride]);
@@ -700,12 +700,12 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
       sq[w] = v2;
     }
     __syncthreads();
-    {  // SURE of the 15 segmentations of every macro-column (.c:354-401): lane = column
-      const int wave = tid >> 6, lane = tid & 63, nwaves = THREADS / 64;
-      for (int c = wave; c < 15; c += nwaves) {
-        const float v = sure_dispatch<SQW>(c, sq + (lane % SQW), P.seg[c / 5][c % 5]);
-        if (lane < NCOL) sure[lane * 15 + c] = v;
-      }
+    {  // SURE of the 15 segmentations of every macro-column (.c:354-401): bt_sure.h (lane = column, the two
+       // half-waves share a segmentation's blocks), 32 columns per pass, the segmentations dealt to eight slots
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = THREADS / 64;
+      for (int slot = wave; slot < 8; slot += nwaves)
+        for (int c0 = 0; c0 < NCOL; c0 += 32)
+          aspbt_sure::sure_slot<SQW>(slot, sq + c0, sure + c0 * 15, P, lane, min(NCOL - c0, 32));
     }
     __syncthreads();
     // DC column and the bins past the last whole macro-column (.c:501-506, 518-532)
