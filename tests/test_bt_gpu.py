@@ -198,22 +198,24 @@ def test_scale_2048_streams(bt):
     g2.close()
 
 
-def test_timed_steps_two_chains_equal_one_chain(bt, monkeypatch):
+@pytest.mark.parametrize("n", [1024, 256])
+def test_timed_steps_two_chains_equal_one_chain(bt, monkeypatch, n):
     """AspBtBatch_TimedSteps runs large batches as two launch chains over the two halves of the batch:
-    outputs and carried state must equal the single-chain run bit for bit."""
+    outputs and carried state must equal the single-chain run bit for bit.  (At n = 256 each half of 1025
+    stream-channels is 256 workgroups of four and one left over for the plain kernel.)"""
     from audiosignalprocess_amd.ns import DeviceBuffer
 
-    S, K = 2050, 3
-    x4 = bt_samples(4, K * 4096)
+    S, K, macro = 2050, 3, 4 * n
+    x4 = bt_samples(4, K * macro)
     idx = np.arange(S) % 4
-    # ring layout of the K-step path: [block][stream][4096]
-    x = np.ascontiguousarray(x4[idx].reshape(S, K, 4096).transpose(1, 0, 2))
+    # ring layout of the K-step path: [block][stream][macro]
+    x = np.ascontiguousarray(x4[idx].reshape(S, K, macro).transpose(1, 0, 2))
     dx = DeviceBuffer(x.nbytes)
     dx.upload(x)
     outs, tails = [], []
     for chains in ("1", "2"):
         monkeypatch.setenv("ASP_BT_CHAINS", chains)
-        g = bt.BtBatch(S, 1024)
+        g = bt.BtBatch(S, n)
         dy = DeviceBuffer(x.nbytes)
         g.timed_steps(dx.ptr, dy.ptr, K, K)
         g.synchronize()
@@ -223,8 +225,8 @@ def test_timed_steps_two_chains_equal_one_chain(bt, monkeypatch):
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
     for a, b in zip(*tails):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    o = OracleBt(1024)
-    assert np.array_equal(outs[1][:, 2049].reshape(-1), o.run(x4[2049 % 4]))
+    for s in (2049, 1024, 3):
+        assert np.array_equal(outs[1][:, s].reshape(-1), OracleBt(n).run(x4[s % 4])), s
 
 
 def test_layer1_reference_protocol(bt, built_lib):
