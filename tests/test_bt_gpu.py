@@ -77,6 +77,31 @@ def test_256_four_streams_per_workgroup(bt, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("n", [1024, 256, 320])
+def test_silence_and_tiny_signals_equal_oracle_including_nans(bt, n):
+    """Digital silence makes the reference divide 0 by 0 (block energies, .c:397-398, 440-444): whatever comes out --
+    NaNs included -- must be what the oracle produces, sample for sample; also denormal-range and huge inputs (the
+    lean divisions' range checks fall back to IEEE division)."""
+    macro, K = 4 * n, 3
+    rng = np.random.default_rng(n)
+    base = bt_samples(8, K * macro, stream0=60)
+    x = base.copy()
+    x[0] = 0.0                                            # silence throughout
+    x[1, macro // 2: macro + macro // 3] = 0.0            # a silent stretch inside and across macroblocks
+    x[2] *= 1e-20                                         # squares underflow to denormals / zero
+    x[3] *= 1e15                                          # squares near the top of the float range
+    x[4, ::2] = 0.0
+    x[5] = (1e-3 * rng.standard_normal(K * macro)).astype(np.float32)
+    x[6, :macro] = 0.0
+    g = bt.BtBatch(8, n)
+    with np.errstate(all="ignore"):
+        y = g.run(x)
+        for s in range(8):
+            want = OracleBt(n).run(x[s])
+            assert np.array_equal(y[s], want, equal_nan=True), (s, int(np.isnan(want).sum()))
+    g.close()
+
+
 def test_wide_segment_signals_bit_exact(bt):
     """Signals far above the noise floor make every macro-column choose the 8 x 16 block (oracle seg (0, 0)):
     the full-row scan of bt_kernels8.hip; a chirp and a tone mix that with narrow segments in the low columns."""
