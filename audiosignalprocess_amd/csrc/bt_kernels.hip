@@ -23,6 +23,7 @@
 
 #include "bt_layout.h"
 #include "bt_sure.h"
+#include "pk_f32.h"
 
 using namespace aspbt;
 
@@ -455,118 +456,94 @@ __global__ __launch_bounds__(N / 2) void bt_macroblock_kernel(
 // across threads does not matter).  A plain path: 256 threads per macroblock, a barrier per stage.
 constexpr int kAnyThreads = 256;   // the seam kernel's workgroup; the macroblock kernel runs 256 or 512 threads
 
-__device__ __forceinline__ void any_bfly2(cpx* F, int m, const cpx* tw, int fstride, int u) {
-  const cpx t = cmul(F[m], tw[u * fstride]);
-  const cpx a = F[0];
-  F[m].r = a.r - t.r;
-  F[m].i = a.i - t.i;
-  F[0].r = a.r + t.r;
-  F[0].i = a.i + t.i;
+// Complex arithmetic as packed f32 (pk_f32.h: a complex value is one register pair; every half is the IEEE
+// operation of the reference's scalar spelling).  F / tw are the LDS arrays seen as pairs.
+typedef asppk::f32x2 pcx;
+__device__ __forceinline__ pcx* as_pcx(cpx* p) { return reinterpret_cast<pcx*>(p); }
+__device__ __forceinline__ const pcx* as_pcx(const cpx* p) { return reinterpret_cast<const pcx*>(p); }
+
+__device__ __forceinline__ void any_bfly2(cpx* F_, int m, const cpx* tw_, int fstride, int u) {
+  pcx* F = as_pcx(F_);
+  const pcx* tw = as_pcx(tw_);
+  const pcx t = asppk::cmul<false>(F[m], tw[u * fstride]);
+  const pcx a = F[0];
+  F[m] = a - t;
+  F[0] = a + t;
 }
 
-__device__ __forceinline__ void any_bfly3(cpx* F, int m, const cpx* tw, int fstride, int u) {  // kiss_fft.c:92-136
+__device__ __forceinline__ void any_bfly3(cpx* F_, int m, const cpx* tw_, int fstride, int u) {  // kiss_fft.c:92-136
+  pcx* F = as_pcx(F_);
+  const pcx* tw = as_pcx(tw_);
   const int m2 = 2 * m;
-  const cpx epi3 = tw[fstride * m];
-  const cpx s1 = cmul(F[m], tw[u * fstride]), s2 = cmul(F[m2], tw[2 * u * fstride]);
-  cpx s3, s0, f0 = F[0], f1;
-  s3.r = s1.r + s2.r;
-  s3.i = s1.i + s2.i;
-  s0.r = s1.r - s2.r;
-  s0.i = s1.i - s2.i;
-  f1.r = f0.r - s3.r * .5f;
-  f1.i = f0.i - s3.i * .5f;
-  s0.r *= epi3.i;
-  s0.i *= epi3.i;
-  f0.r += s3.r;
-  f0.i += s3.i;
+  const pcx epi3 = tw[fstride * m];
+  const pcx s1 = asppk::cmul<false>(F[m], tw[u * fstride]), s2 = asppk::cmul<false>(F[m2], tw[2 * u * fstride]);
+  const pcx s3 = s1 + s2;
+  pcx s0 = s1 - s2;
+  pcx f0 = F[0];
+  const pcx f1 = f0 - s3 * .5f;  // HALF_OF
+  s0 = s0 * epi3.y;              // C_MULBYSCALAR
+  f0 = f0 + s3;
   F[0] = f0;
-  F[m2].r = f1.r + s0.i;
-  F[m2].i = f1.i - s0.r;
-  F[m].r = f1.r - s0.i;
-  F[m].i = f1.i + s0.r;
+  F[m2] = asppk::add_swap_sub_hi(f1, s0);  // {f1.r + s0.i, f1.i - s0.r}
+  F[m] = asppk::add_swap_sub_lo(f1, s0);   // {f1.r - s0.i, f1.i + s0.r}
 }
 
-__device__ __forceinline__ void any_bfly4(cpx* F, int M, const cpx* tw, int fstride, int k, bool inverse) {
-  const cpx s0 = cmul(F[M], tw[k * fstride]);
-  const cpx s1 = cmul(F[2 * M], tw[k * fstride * 2]);
-  const cpx s2 = cmul(F[3 * M], tw[k * fstride * 3]);
-  cpx f0 = F[0], s3, s4, s5;
-  s5.r = f0.r - s1.r;
-  s5.i = f0.i - s1.i;
-  f0.r += s1.r;
-  f0.i += s1.i;
-  s3.r = s0.r + s2.r;
-  s3.i = s0.i + s2.i;
-  s4.r = s0.r - s2.r;
-  s4.i = s0.i - s2.i;
-  F[2 * M].r = f0.r - s3.r;
-  F[2 * M].i = f0.i - s3.i;
-  f0.r += s3.r;
-  f0.i += s3.i;
-  F[0] = f0;
-  if (inverse) {
-    F[M].r = s5.r - s4.i;
-    F[M].i = s5.i + s4.r;
-    F[3 * M].r = s5.r + s4.i;
-    F[3 * M].i = s5.i - s4.r;
-  } else {
-    F[M].r = s5.r + s4.i;
-    F[M].i = s5.i - s4.r;
-    F[3 * M].r = s5.r - s4.i;
-    F[3 * M].i = s5.i + s4.r;
-  }
+__device__ __forceinline__ void any_bfly4(cpx* F_, int M, const cpx* tw_, int fstride, int k, bool inverse) {
+  pcx* F = as_pcx(F_);
+  const pcx* tw = as_pcx(tw_);
+  const pcx s0 = asppk::cmul<false>(F[M], tw[k * fstride]);
+  const pcx s1 = asppk::cmul<false>(F[2 * M], tw[k * fstride * 2]);
+  const pcx s2 = asppk::cmul<false>(F[3 * M], tw[k * fstride * 3]);
+  pcx f0 = F[0];
+  const pcx s5 = f0 - s1;
+  f0 = f0 + s1;
+  const pcx s3 = s0 + s2;
+  const pcx s4 = s0 - s2;
+  F[2 * M] = f0 - s3;
+  F[0] = f0 + s3;
+  const pcx hi = asppk::add_swap_sub_hi(s5, s4);  // {s5.r + s4.i, s5.i - s4.r}
+  const pcx lo = asppk::add_swap_sub_lo(s5, s4);  // {s5.r - s4.i, s5.i + s4.r}
+  F[M] = inverse ? lo : hi;
+  F[3 * M] = inverse ? hi : lo;
 }
 
-__device__ __forceinline__ void any_bfly5(cpx* F, int m, const cpx* tw, int fstride, int u) {  // kiss_fft.c:138-197
-  const cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
-  const cpx s0 = F[0];
-  const cpx s1 = cmul(F[m], tw[u * fstride]), s2 = cmul(F[2 * m], tw[2 * u * fstride]);
-  const cpx s3 = cmul(F[3 * m], tw[3 * u * fstride]), s4 = cmul(F[4 * m], tw[4 * u * fstride]);
-  cpx s7, s10, s8, s9, s5, s6, s11, s12;
-  s7.r = s1.r + s4.r;
-  s7.i = s1.i + s4.i;
-  s10.r = s1.r - s4.r;
-  s10.i = s1.i - s4.i;
-  s8.r = s2.r + s3.r;
-  s8.i = s2.i + s3.i;
-  s9.r = s2.r - s3.r;
-  s9.i = s2.i - s3.i;
-  F[0].r = s0.r + (s7.r + s8.r);
-  F[0].i = s0.i + (s7.i + s8.i);
-  s5.r = s0.r + s7.r * ya.r + s8.r * yb.r;
-  s5.i = s0.i + s7.i * ya.r + s8.i * yb.r;
-  s6.r = s10.i * ya.i + s9.i * yb.i;
-  s6.i = -(s10.r * ya.i) - s9.r * yb.i;
-  F[m].r = s5.r - s6.r;
-  F[m].i = s5.i - s6.i;
-  F[4 * m].r = s5.r + s6.r;
-  F[4 * m].i = s5.i + s6.i;
-  s11.r = s0.r + s7.r * yb.r + s8.r * ya.r;
-  s11.i = s0.i + s7.i * yb.r + s8.i * ya.r;
-  s12.r = -(s10.i * yb.i) + s9.i * ya.i;
-  s12.i = s10.r * yb.i - s9.r * ya.i;
-  F[2 * m].r = s11.r + s12.r;
-  F[2 * m].i = s11.i + s12.i;
-  F[3 * m].r = s11.r - s12.r;
-  F[3 * m].i = s11.i - s12.i;
+__device__ __forceinline__ void any_bfly5(cpx* F_, int m, const cpx* tw_, int fstride, int u) {  // kiss_fft.c:138-197
+  pcx* F = as_pcx(F_);
+  const pcx* tw = as_pcx(tw_);
+  const pcx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
+  const pcx s0 = F[0];
+  const pcx s1 = asppk::cmul<false>(F[m], tw[u * fstride]), s2 = asppk::cmul<false>(F[2 * m], tw[2 * u * fstride]);
+  const pcx s3 = asppk::cmul<false>(F[3 * m], tw[3 * u * fstride]), s4 = asppk::cmul<false>(F[4 * m], tw[4 * u * fstride]);
+  const pcx s7 = s1 + s4, s10 = s1 - s4, s8 = s2 + s3, s9 = s2 - s3;
+  F[0] = s0 + (s7 + s8);
+  const pcx s5 = s0 + s7 * ya.x + s8 * yb.x;
+  // scratch[6] = {s10.i ya.i + s9.i yb.i, -(s10.r ya.i) - s9.r yb.i} = {w.x, -w.y}: (-a) - b == -(a + b) bit for bit
+  const pcx w = s10.yx * ya.y + s9.yx * yb.y;
+  F[m] = asppk::add_sub_lo(s5, w);      // scratch[5] - scratch[6]
+  F[4 * m] = asppk::add_sub_hi(s5, w);  // scratch[5] + scratch[6]
+  const pcx s11 = s0 + s7 * yb.x + s8 * ya.x;
+  // scratch[12] = {-(s10.i yb.i) + s9.i ya.i, s10.r yb.i - s9.r ya.i} = {-d.x, d.y}: (-a) + b == -(a - b) bit for bit
+  const pcx d = s10.yx * yb.y - s9.yx * ya.y;
+  F[2 * m] = asppk::add_sub_lo(s11, d);  // scratch[11] + scratch[12]
+  F[3 * m] = asppk::add_sub_hi(s11, d);  // scratch[11] - scratch[12]
 }
 
 // kf_bfly_generic (kiss_fft.c:199-235), the unit u of the sub-transform starting at `base` (index into
 // the frame's array; the twiddle index runs on the position inside the sub-transform)
-__device__ __forceinline__ void any_bfly_generic(cpx* F, int m, int p, const cpx* tw, int fstride, int u, int norig) {
-  cpx scratch[kAnyMaxRadix];
+__device__ __forceinline__ void any_bfly_generic(cpx* F_, int m, int p, const cpx* tw_, int fstride, int u, int norig) {
+  pcx* F = as_pcx(F_);
+  const pcx* tw = as_pcx(tw_);
+  pcx scratch[kAnyMaxRadix];
   int k = u;
   for (int q1 = 0; q1 < p; ++q1, k += m) scratch[q1] = F[k];
   k = u;
   for (int q1 = 0; q1 < p; ++q1, k += m) {
     int twidx = 0;
-    cpx acc = scratch[0];
+    pcx acc = scratch[0];
     for (int q = 1; q < p; ++q) {
       twidx += fstride * k;
       if (twidx >= norig) twidx -= norig;
-      const cpx t = cmul(scratch[q], tw[twidx]);
-      acc.r += t.r;
-      acc.i += t.i;
+      acc = acc + asppk::cmul<false>(scratch[q], tw[twidx]);
     }
     F[k] = acc;
   }
