@@ -961,12 +961,14 @@ hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const fl
   }
   const size_t lds = macroblock_lds_bytes(n);
   if (n == 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the device's copy of the kernel
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bt_macroblock_kernel<1024>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      attr_set = true;
+      attr_set[dev] = true;
     }
     hipLaunchKernelGGL(bt_macroblock_kernel<1024>, dim3(num_streams), dim3(512), lds, s, state, T,
                        in, out, frames, threshold, in_stride, out_stride, stamps);
@@ -995,8 +997,10 @@ hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const fl
   const size_t tile = (size_t)8 * (A.nc + 1) * sizeof(cpx), sq = (size_t)128 * sqw * sizeof(float);
   const size_t lds = 2 * tile + (size_t)A.nc * sizeof(cpx) + (tile >= sq ? 0 : sq) +
                      (size_t)(A.ncol * 15 + 16 + (threads / 64) * (128 + 64) + A.nc) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {  // the longest window needs 151 KB
+  static bool attr_set[64] = {};  // per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {  // the longest window needs 151 KB
     const int max_lds = 156 * 1024;
     hipError_t e = hipSuccess;
     const void* big[] = {reinterpret_cast<const void*>(bt_macroblock_any_kernel<512, 64, false>),
@@ -1006,7 +1010,7 @@ hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const fl
     for (const void* f : big)
       if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev] = true;
   }
   bool generic = false;
   for (int q = 0; q < A.nfac; ++q) generic |= A.fac[2 * q] > 5;
