@@ -1,4 +1,5 @@
-// bt_kernels8.hip -- the BlockThresholding macroblock kernel for N = 1024, one wave per STFT frame.
+// bt_kernels8.hip -- the BlockThresholding macroblock kernel for N = 1024 (one stream-channel per workgroup) and
+// N = 256 (four stream-channels per workgroup, template parameter Q4: see the kernel), one wave per STFT frame.
 // Replaces, for many independent stream-channels per launch, one whole macroblock (8 hops) of
 //   blockThreshold_STFT / _core / _adaptive_block / blockTreshold_compute_thre /
 //   blockThreshold_wiener / blockThreshold_inverse_STFT
