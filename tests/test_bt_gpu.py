@@ -208,16 +208,19 @@ def test_flush_partial_macroblock(bt):
         g.close()
 
 
-def test_scale_2048_streams(bt):
-    S = 2048
-    g = bt.BtBatch(S, 1024)
+@pytest.mark.parametrize("n,S", [(1024, 2048), (256, 4098)])
+def test_scale_2048_streams(bt, n, S):
+    """A large batch: spot streams against the oracle and permutation invariance (a stream's result does not
+    depend on its place in the batch -- at n = 256 not on which workgroup of four, or the left-over pair, it
+    lands in)."""
+    g = bt.BtBatch(S, n)
     x = bt_samples(S, g.macro)
     y = g.denoise(x)
     assert np.isfinite(y).all()
-    for s in (0, 1, 17, 1023, 2047):
-        assert np.array_equal(y[s], OracleBt(1024).macroblock(x[s]))
+    for s in (0, 1, 17, 1023, 2047, S - 1):
+        assert np.array_equal(y[s], OracleBt(n).macroblock(x[s]))
     perm = np.random.default_rng(1).permutation(S)
-    g2 = bt.BtBatch(S, 1024)
+    g2 = bt.BtBatch(S, n)
     assert np.array_equal(g2.denoise(np.ascontiguousarray(x[perm])), y[perm])
     g.close()
     g2.close()
