@@ -26,7 +26,8 @@ hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const fl
 hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int inverse,
                           const BtTables* T, hipStream_t s);
 hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const float* in, float* out, int num_streams,
-                                    int frames, int threshold, int in_stride, int out_stride, hipStream_t s);
+                                    int frames, int threshold, int in_stride, int out_stride, hipStream_t s,
+                                    unsigned long long* stamps = nullptr);
 hipError_t launch_bt_fftr_any(const BtAnyTables& A, const float* src, float* dst, int count, int inverse, hipStream_t s);
 }  // namespace aspbt
 
@@ -313,7 +314,7 @@ static hipError_t bt_launch(AspBtBatch* b, float* state, const float* in, float*
                             unsigned long long* stamps = nullptr) {
   if (b->any)
     return launch_bt_macroblock_any(b->any_tables, state, in, out, num_streams, frames, threshold, in_stride,
-                                    out_stride, s);
+                                    out_stride, s, stamps);
   return launch_bt_macroblock(b->win, state, b->tables, in, out, num_streams, frames, threshold, in_stride, out_stride,
                               s, stamps);
 }

@@ -587,7 +587,10 @@ __device__ __forceinline__ void any_stages(cpx* work, const cpx* __restrict__ tw
 template <int THREADS, int SQW, bool GENERIC>
 __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
     float* __restrict__ state, BtAnyTables A, const float* __restrict__ in, float* __restrict__ out, int frames,
-    int threshold, int in_stride, int out_stride) {
+    int threshold, int in_stride, int out_stride, unsigned long long* __restrict__ stamps) {
+  // diagnostic phase stamps (never enabled by the product entry points): workgroup 0, thread 0
+#define BTA_STAMP(k) \
+  if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
   const int N = A.n, NC = A.nc, HALF = A.nc, NB = A.nc + 1, NCOL = A.ncol;
   extern __shared__ __align__(16) unsigned char smem[];
   cpx* coef = reinterpret_cast<cpx*>(smem);                 // [8][NB]
@@ -612,6 +615,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   const cpx* sup_f = reinterpret_cast<const cpx*>(A.sup_f);
   const cpx* sup_i = reinterpret_cast<const cpx*>(A.sup_i);
 
+  BTA_STAMP(0)
   for (int i = tid; i < NC; i += THREADS) twl[i] = tw_f[i];
   // ---- STFT (blockThreshold_STFT, .c:273-282)
   const int total = frames * HALF;
@@ -632,7 +636,9 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
       const int p = total + i;
       st[kOffInTail + i] = p < HALF ? st[kOffInTail + p] : x[p - HALF];
     }
+  BTA_STAMP(1)
   any_stages<THREADS, GENERIC>(work, twl, A, frames, false, tid);
+  BTA_STAMP(2)
   // kiss_fftr post-pass (kiss_fftr.c:92-120)
   for (int w = tid; w < frames * (NC / 2 + 1); w += THREADS) {
     const int fr = fast_div(w, r_nh), k = w - fr * (NC / 2 + 1);
@@ -666,6 +672,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   }
   __syncthreads();
 
+  BTA_STAMP(3)
   if (threshold) {
     for (int w = tid; w < 128 * SQW; w += THREADS) {  // squared normalised real parts (.c:365-375)
       const int m = w % SQW, e = w / SQW;
@@ -677,6 +684,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
       sq[w] = v2;
     }
     __syncthreads();
+    BTA_STAMP(4)
     {  // SURE of the 15 segmentations of every macro-column (.c:354-401): bt_sure.h (lane = column, the two
        // half-waves share a segmentation's blocks), 32 columns per pass, the segmentations dealt to eight slots
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = THREADS / 64;
@@ -685,6 +693,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
           aspbt_sure::sure_slot<SQW>(slot, sq + c0, sure + c0 * 15, P, lane, min(NCOL - c0, 32));
     }
     __syncthreads();
+    BTA_STAMP(5)
     // DC column and the bins past the last whole macro-column (.c:501-506, 518-532)
     for (int w = tid; w < 1 + (NB - (1 + NCOL * 16)); w += THREADS) {
       const int col = w == 0 ? 0 : (1 + NCOL * 16) + (w - 1);
@@ -745,6 +754,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
       }
     }
     __syncthreads();
+    BTA_STAMP(6)
     for (int w = tid; w < 8 * NC; w += THREADS) {  // empirical Wiener, Nyquist untouched (.c:469-486)
       const int t = fast_div(w, r_nc), f = w - t * NC;
       const float r = thre[t * NB + f].r, i = thre[t * NB + f].i;
@@ -756,6 +766,7 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
     __syncthreads();
   }
 
+  BTA_STAMP(7)
   // ---- inverse STFT + overlap-add (blockThreshold_inverse_STFT, .c:284-300); kiss_fftri pre-pass
   // (kiss_fftr.c:137-157) straight into kiss order
   for (int i = tid; i < NC; i += THREADS) twl[i] = tw_i[i];  // the forward stages ended at a barrier long ago
@@ -788,7 +799,9 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
     }
   }
   __syncthreads();
+  BTA_STAMP(8)
   any_stages<THREADS, GENERIC>(work, twl, A, frames, true, tid);
+  BTA_STAMP(9)
   const float* td = reinterpret_cast<const float*>(work);  // frame fr sample j at fr * N + j
   const float fn = (float)N;
   for (int q = tid; q < total + HALF; q += THREADS) {
@@ -803,6 +816,8 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
   }
   __syncthreads();
   for (int i = tid; i < HALF; i += THREADS) st[kAnyOffOutTail + i] = threshold ? stage[i] : 0.0f;
+  BTA_STAMP(10)
+#undef BTA_STAMP
 }
 
 // kiss_fftr / kiss_fftri seam for any even length: one workgroup per row
@@ -991,9 +1006,10 @@ hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int in
 
 // any even window of 4 .. kAnyMaxWin samples (bt_macroblock_any_kernel); `state` has kAnyStateFloats per stream
 hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const float* in, float* out, int num_streams,
-                                    int frames, int threshold, int in_stride, int out_stride, hipStream_t s) {
+                                    int frames, int threshold, int in_stride, int out_stride, hipStream_t s,
+                                    unsigned long long* stamps) {
   const int sqw = A.ncol <= 15 ? 16 : A.ncol <= 31 ? 32 : 64;  // narrow table: it fits inside the attenuated tile sooner
-  const int threads = A.nc >= 192 ? 512 : 256;  // measured: 320-sample windows prefer 256 threads, 480 and up 512
+  const int threads = A.nc >= 192 ? 512 : 256;  // measured: 320-sample windows prefer 256 threads (five workgroups per CU), 480 and up 512
   const size_t tile = (size_t)8 * (A.nc + 1) * sizeof(cpx), sq = (size_t)128 * sqw * sizeof(float);
   const size_t lds = 2 * tile + (size_t)A.nc * sizeof(cpx) + (tile >= sq ? 0 : sq) +
                      (size_t)(A.ncol * 15 + 16 + (threads / 64) * (128 + 64) + A.nc) * sizeof(float);
@@ -1018,10 +1034,10 @@ hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const fl
   do {                                                                                                         \
     if (generic)                                                                                               \
       hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ, true>), dim3(num_streams), dim3(TH), lds, s, state, A, in, \
-                         out, frames, threshold, in_stride, out_stride);                                       \
+                         out, frames, threshold, in_stride, out_stride, stamps);                               \
     else                                                                                                       \
       hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ, false>), dim3(num_streams), dim3(TH), lds, s, state, A, in, \
-                         out, frames, threshold, in_stride, out_stride);                                       \
+                         out, frames, threshold, in_stride, out_stride, stamps);                               \
   } while (0)
   if (threads == 512 && sqw == 64)
     BT_ANY_LAUNCH(512, 64);
