@@ -26,15 +26,13 @@ hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables
                            const float* in, float* out, int num_streams, hipStream_t s);
 hipError_t launch_ns_frame2_ilp(bool io16, float* state, int32_t* hist, const NsTables* T,
                                 const float* in, float* out, int num_streams, hipStream_t s,
-                                unsigned long long* stamps = nullptr, int stagger = 0);
+                                unsigned long long* stamps = nullptr);
 hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps = nullptr, int stagger = 0);
+                            unsigned long long* stamps = nullptr);
 hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps = nullptr, int stagger = 0);
-hipError_t launch_ns_frame4(bool io16, float* state, int32_t* hist, const NsTables* T,
-                            const float* in, float* out, int num_streams, hipStream_t s);
+                            unsigned long long* stamps = nullptr);
 hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_hb_live(const float* state, const NsTables* T, const float* in_low,
                              int32_t* live, int num_streams, int hist_off, hipStream_t s);
@@ -474,7 +472,6 @@ struct AspNsBatch {
   // fused step kernel: 1 = ns_frame_kernel (one stream per wave, bins q / q + 64), 2 = ns_frame2_kernel
   // (two streams per wave), 3 = ns_frame1_kernel (one stream per wave, pair layout: ns_kernels1.hip)
   int kernel = 0;  // 0 = by batch size: 3 up to kIlpMaxStreams streams per GPU, 2 above
-  int stagger = 0;  // ns_frame1_kernel: start delay per workgroup slot of a CU, shader cycles (ns_kernels1.hip)
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
   // A captured K-step replay (hipGraph): the launches of `g_steps` fused steps over the ring
@@ -489,12 +486,7 @@ struct AspNsBatch {
   bool g_io16 = false, g_dual = false;
   int g_kernel = 0;
   bool use_graph = false;  // plain launches measured 4-7 % faster per step than graph replay (round 2)
-  // TimedSteps gate: the K steps are enqueued behind a stream wait on this host-mapped word and
-  // released together, so the timed region holds no host enqueue latency (as a graph replay would)
-  volatile uint32_t* gate_host = nullptr;
-  uint32_t* gate_dev = nullptr;
-  uint32_t gate_seq = 0;
-  bool use_gate = false;  // measured: helps 2 % at K = 20, costs 10 % at K = 1000 (the launches queue up behind it)
+  unsigned long long* timeline = nullptr;  // diagnostic (AspNsBatch_DebugTimeline): [workgroup][4] real-time stamps
   // > 16 kHz: 1 or 2 high bands next to the low band (ns_core.c:1362-1414)
   uint32_t fs = 16000;
   int num_high = 0;
@@ -564,8 +556,6 @@ int AspNsBatch_Create(AspNsBatch** out, int num_streams, int device) {
   AspNsBatch* b = new AspNsBatch();
   b->S = num_streams;
   b->device = device;
-  if (const char* e = getenv("ASP_NS_STAGGER")) b->stagger = atoi(e);
-  if (const char* e = getenv("ASP_NS_STAGGER_MODE")) b->stagger |= atoi(e) << 24;
   rc = device_tables(device, &b->tables);
   if (rc) {
     delete b;
@@ -603,7 +593,6 @@ int AspNsBatch_Free(AspNsBatch* b) {
     if (b->gexec[p]) (void)hipGraphExecDestroy(b->gexec[p]);
     if (b->graph[p]) (void)hipGraphDestroy(b->graph[p]);
   }
-  if (b->gate_host) (void)hipHostFree((void*)b->gate_host);
   if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
   for (int i = 0; i < 3; ++i) {
     if (b->join_ev[i]) (void)hipEventDestroy(b->join_ev[i]);
@@ -679,14 +668,17 @@ static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float
   const float* in = din + (size_t)s0 * sper;
   float* out = dout + (size_t)s0 * sper;
   const int kernel = b->kernel ? b->kernel : (b->S <= kIlpMaxStreams ? 3 : 2);
-  if (kernel == 4) return launch_ns_frame4(io16, state, hist, b->tables, in, out, n, st);
-  if (kernel == 3) return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st, nullptr, b->stagger);
+  if (kernel == 3) {
+    unsigned long long* tl = nullptr;  // timeline mode: pointer bit 0 set, this sub-launch's first workgroup
+    if (b->timeline) tl = reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(b->timeline + (size_t)(s0 / 4) * 4) | 1);
+    return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st, tl);
+  }
   if (kernel == 1 || n < 2) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
   const int even = n & ~1;
   // two builds of the same kernel (ns_kernels2.hip): the ILP-scheduled one while the batch gives a
   // SIMD at most two waves to run, the 168-VGPR one (three resident waves) for larger batches
-  hipError_t e = b->S <= kIlpMaxStreams ? launch_ns_frame2_ilp(io16, state, hist, b->tables, in, out, even, st, nullptr, b->stagger)
-                                        : launch_ns_frame2(io16, state, hist, b->tables, in, out, even, st, nullptr, b->stagger);
+  hipError_t e = b->S <= kIlpMaxStreams ? launch_ns_frame2_ilp(io16, state, hist, b->tables, in, out, even, st)
+                                        : launch_ns_frame2(io16, state, hist, b->tables, in, out, even, st);
   if (e == hipSuccess && even != n)  // the odd last stream: one-stream-per-wave kernel
     e = launch_ns_frame(io16 ? 3 : 2, state + (size_t)even * kStreamDwords,
                         hist + (size_t)even * kHistDwords, b->tables, in + (size_t)even * sper,
@@ -1039,36 +1031,6 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
     rc = ensure_graph(b, in, out, frames_in_ring, steps, false);
     if (rc) return rc;
   }
-  // gate: everything below is enqueued while the stream waits on a host-mapped word; the host
-  // opens it once the last launch is queued (falls back to no gate where the wait is unsupported)
-  bool gated = false;
-  if (b->use_gate && b->stream != nullptr && steps > 0) {
-    if (!b->gate_host) {
-      void* hp = nullptr;
-      if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
-        void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
-          b->gate_host = (volatile uint32_t*)hp;
-          b->gate_dev = (uint32_t*)dp;
-          *b->gate_host = 0;
-        } else {
-          (void)hipHostFree(hp);
-          b->use_gate = false;
-        }
-      } else {
-        b->use_gate = false;
-      }
-    }
-    if (b->gate_host) {
-      b->gate_seq += 1;
-      if (hipStreamWaitValue32(b->stream, b->gate_dev, b->gate_seq, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess)
-        gated = true;
-      else {
-        (void)hipGetLastError();
-        b->use_gate = false;
-      }
-    }
-  }
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   const auto h0 = std::chrono::steady_clock::now();
   if (graph) {
@@ -1082,11 +1044,6 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
     fprintf(stderr, "TimedSteps: host enqueue of %d steps took %.1f us per step\n", steps,
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count() / (steps > 0 ? steps : 1));
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
-  if (gated) {
-    __sync_synchronize();
-    *b->gate_host = b->gate_seq;  // open the gate
-    __sync_synchronize();
-  }
   HIP_TRY(hipEventSynchronize(b->ev1));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
   return ASP_OK;
@@ -1170,7 +1127,7 @@ int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
   hipError_t e = hipMemset(d, 0, 16 * sizeof(unsigned long long));
   if (e == hipSuccess) {
     if ((b->kernel ? b->kernel : (b->S <= kIlpMaxStreams ? 3 : 2)) == 3)
-      e = launch_ns_frame1(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d, 0);
+      e = launch_ns_frame1(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d);
     else
       e = b->S <= kIlpMaxStreams  // the build the product path uses for this batch size
               ? launch_ns_frame2_ilp(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d)
@@ -1183,16 +1140,43 @@ int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
   return ASP_OK;
 }
 
+// Diagnostic: `steps` fused steps through the product launch path (chains as set by SetSplit) with every
+// workgroup of the pair-layout kernel recording four real-time stamps (100 MHz counter: start, first
+// loads in, before the last stores, end); out[num_workgroups][4] holds those of the last step.
+int AspNsBatch_DebugTimeline(AspNsBatch* b, const float* in_dev, float* out_dev, int frames_in_ring,
+                             int steps, unsigned long long* out, int num_workgroups) {
+  DeviceScope dev_scope_;
+  int rc = check(b);
+  if (rc) return rc;
+  const int kernel = b->kernel ? b->kernel : (b->S <= kIlpMaxStreams ? 3 : 2);
+  if (!in_dev || !out_dev || !out || steps <= 0 || frames_in_ring <= 0 || !b->paired || kernel != 3 ||
+      num_workgroups != (b->S + 3) / 4 || (b->S & 3))
+    return fail(ASP_ERR_PARAM, "DebugTimeline: bad argument (pair-layout kernel, stream count a multiple of 4)");
+  const size_t bytes = (size_t)num_workgroups * 4 * sizeof(unsigned long long);
+  HIP_TRY(hipMalloc((void**)&b->timeline, bytes));
+  hipError_t e = hipMemset(b->timeline, 0, bytes);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e == hipSuccess) {
+    rc = fused_steps(b, in_dev, out_dev, frames_in_ring, steps);
+    if (rc == ASP_OK) e = hipStreamSynchronize(b->stream);
+  }
+  if (e == hipSuccess && rc == ASP_OK) e = hipMemcpy(out, b->timeline, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(b->timeline);
+  b->timeline = nullptr;
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "DebugTimeline", e);
+  return ASP_OK;
+}
+
 int AspNsBatch_SetGraph(AspNsBatch* b, int on) {
   if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
   b->use_graph = (on & 1) != 0;
-  b->use_gate = (on & 2) != 0;  // bit 1: TimedSteps with the enqueue gate
   return ASP_OK;
 }
 
 int AspNsBatch_SetKernel(AspNsBatch* b, int streams_per_wave) {
-  if (!b || streams_per_wave < 0 || streams_per_wave > 4)
-    return fail(ASP_ERR_PARAM, "SetKernel: 0 (by batch size), 1 (one stream per wave, q / q + 64), 2 (two streams per wave), 3 (one stream per wave, pair layout) or 4 (pair layout, scalar section shared by the workgroup)");
+  if (!b || streams_per_wave < 0 || streams_per_wave > 3)
+    return fail(ASP_ERR_PARAM, "SetKernel: 0 (by batch size), 1 (one stream per wave, q / q + 64), 2 (two streams per wave) or 3 (one stream per wave, pair layout)");
   b->dual = streams_per_wave == 2;
   b->kernel = streams_per_wave;
   return ASP_OK;

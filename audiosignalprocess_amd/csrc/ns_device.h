@@ -10,6 +10,14 @@
 namespace aspns_dev {
 using namespace aspns;
 
+// instruction-budget builds (tools/ns_valu_budget.py, never shipped) assert that the rarely taken
+// libm fallbacks are not taken, so that they vanish from the straight-line code being counted
+#ifdef NS1_BUDGET
+#define ASP_NS_RARE(c) (__builtin_assume(!(c)), false)
+#else
+#define ASP_NS_RARE(c) __builtin_expect((c), 0)
+#endif
+
 // ns/defines.h:19-48, same (float)<double literal> spelling as the reference
 #define NS_QUANTILE (float)0.25
 #define NS_END_STARTUP_LONG 200
@@ -63,26 +71,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   const float r0 = lane_bcast(v, 0), r1 = lane_bcast(v, 16);
   const float r2 = lane_bcast(v, 32), r3 = lane_bcast(v, 48);
   return (r0 + r1) + (r2 + r3);
-}
-
-// The same sum with the four row sums combined by two row-broadcast DPP adds instead of four v_readlane,
-// two moves and two adds: row_bcast:15 (rows 1, 3 written) leaves r0 + r1 and r2 + r3 in rows 1 and 3,
-// row_bcast:31 (row 3 written) adds row 1's into row 3's: (r0 + r1) + (r2 + r3), read from lane 63.
-// Same operands, same association as wave_sum: bit-identical; five VALU issue slots fewer (the frame step
-// of ns_kernels1.hip is bound by VALU issue).  The s_nops cover the VALU-write -> DPP-read hazard.
-__device__ __forceinline__ float wave_sum_bcast(float v) {
-  v = v + dpp_move<0xB1>(v);   // xor 1
-  v = v + dpp_move<0x4E>(v);   // xor 2
-  v = v + dpp_move<0x141>(v);  // xor 4
-  v = v + dpp_move<0x140>(v);  // xor 8: every lane of a row holds the row's sum
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 1"
-      : "+v"(v));
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Correctly rounded a / d for a divisor shared by the whole wave: `rd` is the
@@ -244,52 +232,6 @@ __device__ __forceinline__ void fdiv3(const float (&n)[3], const float (&d)[3], 
   q[0] = a.x; q[1] = a.y;
   q[2] = fdiv(n[2], d[2]);
 }
-// The two bins a lane of ns_kernels4.hip owns, as one packed pair (F3 without the tail).
-struct B2 {
-  bool v[2];
-};
-struct P2 {
-  f32x2 p;
-  __device__ __forceinline__ P2() {}
-  __device__ __forceinline__ P2(f32x2 p_) : p(p_) {}
-  __device__ __forceinline__ explicit P2(float c) : p(f32x2{c, c}) {}
-  __device__ __forceinline__ explicit P2(const float (&x)[2]) : p(f32x2{x[0], x[1]}) {}
-  __device__ __forceinline__ void store(float (&x)[2]) const {
-    x[0] = p.x; x[1] = p.y;
-  }
-};
-__device__ __forceinline__ P2 operator+(const P2& x, const P2& y) { return P2(x.p + y.p); }
-__device__ __forceinline__ P2 operator-(const P2& x, const P2& y) { return P2(x.p - y.p); }
-__device__ __forceinline__ P2 operator*(const P2& x, const P2& y) { return P2(x.p * y.p); }
-__device__ __forceinline__ P2 operator*(float c, const P2& y) { return P2(c) * y; }
-__device__ __forceinline__ P2 operator+(const P2& x, float c) { return x + P2(c); }
-__device__ __forceinline__ P2 fma2(const P2& x, const P2& y, const P2& z) {
-  return P2(__builtin_elementwise_fma(x.p, y.p, z.p));
-}
-__device__ __forceinline__ P2 abs2(const P2& x) { return P2(f32x2{fabsf(x.p.x), fabsf(x.p.y)}); }
-__device__ __forceinline__ B2 gt2(const P2& x, const P2& y) {
-  B2 r;
-  r.v[0] = x.p.x > y.p.x; r.v[1] = x.p.y > y.p.y;
-  return r;
-}
-__device__ __forceinline__ B2 lt2(const P2& x, const P2& y) {
-  B2 r;
-  r.v[0] = x.p.x < y.p.x; r.v[1] = x.p.y < y.p.y;
-  return r;
-}
-__device__ __forceinline__ P2 sel2(const B2& c, const P2& x, const P2& y) {  // c ? x : y
-  return P2(f32x2{c.v[0] ? x.p.x : y.p.x, c.v[1] ? x.p.y : y.p.y});
-}
-__device__ __forceinline__ P2 div_by_uniform2(const P2& a, float d, float rd) {
-  const P2 q0 = a * P2(rd);
-  const P2 r = fma2(P2(-d), q0, a);
-  return fma2(r, P2(rd), q0);
-}
-__device__ __forceinline__ P2 fdiv2v(const P2& n, const P2& d) { return P2(fdiv2(n.p, d.p)); }
-__device__ __forceinline__ void fdiv2a(const float (&n)[2], const float (&d)[2], float (&q)[2]) {
-  const f32x2 a = fdiv2(f32x2{n[0], n[1]}, f32x2{d[0], d[1]});
-  q[0] = a.x; q[1] = a.y;
-}
 #define DIV129(a) div_by_uniform((a), 129.0f, 1.0f / 129.0f)
 
 // (float)log((double)x), the reference's idiom (ns_core.c:228,540,681,1096), for
@@ -366,7 +308,7 @@ __device__ __forceinline__ float exp_f32_via_f64(float x, const double* __restri
   const double y = exp_lean_f64(in_range ? x : 0.0f, t64);
   const bool ok = in_range && f64_rounds_safely_to_f32(y);
   float r = (float)y;
-  if (__builtin_expect(!ok, 0)) r = (float)exp((double)x);
+  if (ASP_NS_RARE(!ok)) r = (float)exp((double)x);
   return r;
 }
 
@@ -394,7 +336,7 @@ __device__ __forceinline__ float tanh_f32_via_f64(float a, const double* __restr
   const double t = ax < 0.03125f ? t_small : qv;
   const bool ok = finite_ok && f64_rounds_safely_to_f32(t);
   float r = __builtin_copysignf((float)t, a);
-  if (__builtin_expect(!ok, 0)) r = (float)tanh((double)a);
+  if (ASP_NS_RARE(!ok)) r = (float)tanh((double)a);
   return r;
 }
 
@@ -412,7 +354,7 @@ __device__ __forceinline__ float fsqrt(float x) {
   const float d = __builtin_fmaf(-g, g, x);
   g = __builtin_fmaf(d, h, g);
   float res = (x == 0.0f || x == __builtin_inff()) ? x : g;
-  if (__builtin_expect(x < 0x1p-100f && x > 0.0f, 0)) res = sqrtf(x);
+  if (ASP_NS_RARE(x < 0x1p-100f && x > 0.0f)) res = sqrtf(x);
   return res;
 }
 
@@ -484,7 +426,7 @@ __device__ __forceinline__ void log_f32_via_tab_n(const float (&x)[N], float (&o
     bad |= (normal_pos ^ 1u) | (f64_rounds_safely_to_f32(y) ? 0u : 1u);
     out[k] = (float)y;
   }
-  if (__builtin_expect(bad != 0, 0)) {
+  if (ASP_NS_RARE(bad != 0)) {
 #pragma unroll
     for (int k = 0; k < N; ++k) out[k] = log_f32_slow(x[k]);
   }
@@ -501,7 +443,7 @@ __device__ __forceinline__ void exp_f32_via_f64_n(const float (&x)[N], float (&o
     bad |= (in_range ^ 1u) | (f64_rounds_safely_to_f32(y) ? 0u : 1u);
     out[k] = (float)y;
   }
-  if (__builtin_expect(bad != 0, 0)) {
+  if (ASP_NS_RARE(bad != 0)) {
 #pragma unroll
     for (int k = 0; k < N; ++k) out[k] = exp_f32_slow(x[k]);
   }
@@ -525,7 +467,7 @@ __device__ __forceinline__ void fsqrt_n(const float (&x)[N], float (&out)[N]) {
     out[k] = (xv == 0.0f || xv == __builtin_inff()) ? xv : g;
     bad |= (xv < 0x1p-100f && xv > 0.0f) ? 1u : 0u;
   }
-  if (__builtin_expect(bad != 0, 0)) {
+  if (ASP_NS_RARE(bad != 0)) {
 #pragma unroll
     for (int k = 0; k < N; ++k)
       if (x[k] < 0x1p-100f && x[k] > 0.0f) out[k] = sqrt_f32_slow(x[k]);

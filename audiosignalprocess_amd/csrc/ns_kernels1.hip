@@ -29,20 +29,16 @@
 #include "ns_layout.h"
 #include "ns_pair_fft.h"
 
-// cross-bin sums: 1 = rows combined by row-broadcast DPP adds (ns_device.h: five VALU instructions fewer per sum,
-// bit-identical; measured: 13.2-13.3 us against 13.0-13.4 us, inside the run-to-run noise) -- kept selectable
-#ifndef NS1_BCAST_SUM
-#define NS1_BCAST_SUM 0
-#endif
-#if NS1_BCAST_SUM
-#define WAVE_SUM1 wave_sum_bcast
-#else
-#define WAVE_SUM1 wave_sum
-#endif
-
 namespace {
 using namespace aspns_dev;
 using namespace aspns_pair;
+
+// which CU a wave runs on, for the timeline diagnostic: HW_ID[15:8] (cu_id, sh_id, se_id) and XCC_ID[3:0]
+__device__ __forceinline__ unsigned long long ns_cu_tag() {
+  const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);    // HW_REG_HW_ID, bits 8..15
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID, bits 0..3
+  return (unsigned long long)((xcc << 8) | hw);
+}
 
 constexpr int NS3 = 3;  // 2 owned bins + the tail bin 128
 
@@ -57,31 +53,37 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
                                                            const float* __restrict__ in,
                                                            float* __restrict__ out,
                                                            int num_streams,
-                                                           unsigned long long* __restrict__ stamps,
-                                                           int stagger) {
+                                                           unsigned long long* __restrict__ stamps) {
+#ifdef NS1_BUDGET
+  // instruction-budget build (tools/ns_valu_budget.py, never shipped): the phase marks become
+  // assembly comments and the steady-state conditions are asserted, so that the straight-line
+  // code between two marks is what a wave executes per frame after start-up
 #define NS_STAMP(k)                                                                \
-  if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {                  \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    stamps[k] = __builtin_amdgcn_s_memtime();                                      \
-    __builtin_amdgcn_sched_barrier(0);                                             \
+  __builtin_amdgcn_sched_barrier(0);                                               \
+  asm volatile("; NS_PHASE " #k);                                                  \
+  __builtin_amdgcn_sched_barrier(0);
+#define NS_STEADY(x) __builtin_assume(x)
+#else
+  // diagnostic stamps (never passed by the product entry points).  Pointer bit 0 clear: the 16 phase
+  // stamps (shader clock) of workgroup 0's first wave.  Bit 0 set ("timeline"): every workgroup's
+  // first wave records the 100 MHz real-time counter at its start, after its first loads, before
+  // its last stores and at its end (4 values per workgroup) -- the launch-level picture.
+#define NS_STAMP(k)                                                                          \
+  if (stamps != nullptr && threadIdx.x == 0) {                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if ((reinterpret_cast<uintptr_t>(stamps) & 1) != 0) {                                    \
+      if ((k) == 0 || (k) == 1 || (k) == 14 || (k) == 15)                                    \
+        reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(stamps) & ~(uintptr_t)1)[ \
+            blockIdx.x * 4 + ((k) == 0 ? 0 : (k) == 1 ? 1 : (k) == 14 ? 2 : 3)] =                 \
+            __builtin_amdgcn_s_memrealtime() | ((k) == 0 ? ns_cu_tag() << 48 : 0ull);         \
+    } else if (blockIdx.x == 0) {                                                            \
+      stamps[k] = __builtin_amdgcn_s_memtime();                                              \
+    }                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
   }
+#define NS_STEADY(x)
+#endif
   NS_STAMP(0)
-  // Phase stagger: every workgroup of a launch starts at once, so without it all resident waves
-  // load together, compute together and store together -- the memory pipe idles while the SIMDs
-  // work and the other way round.  The workgroup in slot k of its CU (HW_ID.TG_ID) starts
-  // k * stagger shader cycles late, so that the four waves a SIMD holds are in different phases.
-  if (stagger > 0) {
-    const int mode = stagger >> 24;  // experiment selector in the top byte
-    const unsigned hwtg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);  // HW_REG_HW_ID[19:16]
-    const unsigned tg = mode == 0 ? (hwtg & 3u) : mode == 1 ? (hwtg & 1u)
-                        : mode == 2 ? (blockIdx.x >= gridDim.x / 2 ? 1u : 0u) : (blockIdx.x & 1u);
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long wait = (unsigned long long)tg * (unsigned)(stagger & 0xffffff);
-    for (int i = 0; i < 2048; ++i) {  // bounded: a wave always leaves the loop
-      if (__builtin_amdgcn_s_memtime() - t0 >= wait) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
   __shared__ float2 lds[4][128];
   // per-lane twiddles of the three passes (3 x 64 x 4), real-split factors (32 x 4 x 2) and the
   // window, staged in LDS once per workgroup behind the state loads
@@ -151,21 +153,11 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     SC_SET_F(S_TAIL0 + (f), srcv[2]);                                                          \
   }
 
-#ifndef NS1_FRONTLOAD
-#define NS1_FRONTLOAD 0
-#endif
-  // state rows: with NS1_FRONTLOAD every row of the step is requested here, before the first
-  // wait (a step of 4096 streams is bound by the memory pipe being busy from the first cycle of
-  // a launch to the last, not by one wave's registers); otherwise in two groups, just ahead of use
+  // state rows are requested in two groups, just ahead of their use (requesting all of them before
+  // the first wait measured slower: every wave of a launch starts at once, and a bigger
+  // start-of-kernel burst makes every wave wait longer)
   float LQ[3][NS3], DEN[3][NS3], quant[NS3];
   float smooth[NS3], noisePrev[NS3], magnPrevA[NS3], logLrt[NS3], avgPause[NS3];
-  if (NS1_FRONTLOAD) {
-    LOADV(LQ[0], V_LQ0) LOADV(LQ[1], V_LQ1) LOADV(LQ[2], V_LQ2)
-    LOADV(DEN[0], V_DEN0) LOADV(DEN[1], V_DEN1) LOADV(DEN[2], V_DEN2)
-    LOADV(quant, V_QUANT)
-    LOADV(magnPrevA, V_MAGNPREV_A) LOADV(logLrt, V_LOGLRT) LOADV(avgPause, V_AVGPAUSE)
-    LOADV(smooth, V_SMOOTH) LOADV(noisePrev, V_NOISEPREV)
-  }
   // syntBuf[0..95]: the lane's output samples 2E, 2E+1 that still carry overlap are those of
   // slot 0 when g == 0 (2q + 32h) and of slot 1 when g == 0 and h == 0 (2q + 64); every lane
   // loads (no branch), the overlap-add uses the owners' values only
@@ -189,11 +181,12 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   epart += wx1 * wx1;
   epart += wx2 * wx2;
   epart += wx3 * wx3;
-  const float energy1 = WAVE_SUM1(epart);
+  const float energy1 = wave_sum(epart);
 
   // the carried 96 samples of the next frame are this frame's last 96
   if (lane >= 40) *reinterpret_cast<float4*>(hbuf + 4 * (lane - 40)) = s4;
 
+  NS_STEADY(energy1 != 0.0f);
   if (energy1 == 0.0f) {
     // Analyze: nothing but the buffer slide (ns_core.c:1072-1082); Process: emit the synthesis
     // tail and clear it (ns_core.c:1239-1264)
@@ -211,11 +204,9 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 
   // the tracker rows are requested once the frame's samples are in; they are used after the
   // transform, the magnitudes and the logarithms
-  if (!NS1_FRONTLOAD) {
-    LOADV(LQ[0], V_LQ0) LOADV(LQ[1], V_LQ1) LOADV(LQ[2], V_LQ2)
-    LOADV(DEN[0], V_DEN0) LOADV(DEN[1], V_DEN1) LOADV(DEN[2], V_DEN2)
-    LOADV(quant, V_QUANT)
-  }
+  LOADV(LQ[0], V_LQ0) LOADV(LQ[1], V_LQ1) LOADV(LQ[2], V_LQ2)
+  LOADV(DEN[0], V_DEN0) LOADV(DEN[1], V_DEN1) LOADV(DEN[2], V_DEN2)
+  LOADV(quant, V_QUANT)
   LOADT(LQ[0], V_LQ0) LOADT(LQ[1], V_LQ1) LOADT(LQ[2], V_LQ2)
   LOADT(DEN[0], V_DEN0) LOADT(DEN[1], V_DEN1) LOADT(DEN[2], V_DEN2)
   LOADT(quant, V_QUANT)
@@ -230,10 +221,8 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 
   NS_STAMP(2)
   // second group of state rows (latency hides under magnitude / log / trackers)
-  if (!NS1_FRONTLOAD) {
-    LOADV(magnPrevA, V_MAGNPREV_A) LOADV(logLrt, V_LOGLRT) LOADV(avgPause, V_AVGPAUSE)
-    LOADV(smooth, V_SMOOTH) LOADV(noisePrev, V_NOISEPREV)
-  }
+  LOADV(magnPrevA, V_MAGNPREV_A) LOADV(logLrt, V_LOGLRT) LOADV(avgPause, V_AVGPAUSE)
+  LOADV(smooth, V_SMOOTH) LOADV(noisePrev, V_NOISEPREV)
   LOADT(magnPrevA, V_MAGNPREV_A) LOADT(logLrt, V_LOGLRT) LOADT(avgPause, V_AVGPAUSE)
   LOADT(smooth, V_SMOOTH) LOADT(noisePrev, V_NOISEPREV)
 
@@ -270,6 +259,14 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   const int updateParsFlag = SC_I(S_MUP0);
   int updates = SC_I(S_UPDATES);
   int counter[3] = {SC_I(S_COUNTER0), SC_I(S_COUNTER1), SC_I(S_COUNTER2)};
+  // steady state (budget build only): past both start-up windows, no tracker publishes, the
+  // histogram window stays open, gain compensation on
+  NS_STEADY(blockInd > NS_END_STARTUP_LONG + 1);
+  NS_STEADY(updates >= NS_END_STARTUP_LONG);
+  NS_STEADY(counter[0] < NS_END_STARTUP_LONG - 1 && counter[1] < NS_END_STARTUP_LONG - 1 && counter[2] < NS_END_STARTUP_LONG - 1);
+  NS_STEADY(counter[0] >= 0 && counter[1] >= 0 && counter[2] >= 0);
+  NS_STEADY(updateParsFlag >= 1);
+  NS_STEADY(gainmap == 1);
 
   float lmagn[NS3];
   log_f32_via_tab_n<NS3>(magn, lmagn, logts);
@@ -282,8 +279,8 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     for (int k = 0; k < NS3; ++k) se[k] = re[k] * re[k] + im[k] * im[k];
     PART3(t_se, se)
     PART3(t_sm, magn)
-    signalEnergy = WAVE_SUM1(t_se);
-    sumMagn = WAVE_SUM1(t_sm);
+    signalEnergy = wave_sum(t_se);
+    sumMagn = wave_sum(t_sm);
     signalEnergy = DIV129(signalEnergy);
   }
 
@@ -339,8 +336,8 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     }
     PART3(t_lm, lm3)
     PART3(t_lilm, lilm)
-    const float sum_log_magn = WAVE_SUM1(t_lm);
-    const float sum_log_i_log_magn = WAVE_SUM1(t_lilm);
+    const float sum_log_magn = wave_sum(t_lm);
+    const float sum_log_i_log_magn = wave_sum(t_lilm);
     const float sum_log_i = T->sum_log_i, sum_log_i_square = T->sum_log_i_square;
     whiteNoiseLevel += DIV129(sumMagn) * overdrive;
     float tmpFloat1 = sum_log_i_square * ((float)(kBins - NS_START_BAND));
@@ -414,7 +411,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 #pragma unroll
     for (int k = 0; k < NS3; ++k) fl3[k] = (k == 0 && lane == 0) ? 0.f : lmagn[k];
     PART3(t_fl, fl3)
-    float num = WAVE_SUM1(t_fl);
+    float num = wave_sum(t_fl);
     float den = sumMagn - lane_bcast(magn[0], 0);
     den = DIV129(den);
     num = DIV129(num);
@@ -424,7 +421,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   // ---- ComputeSpectralDifference (ns_core.c:595-634)
   {
     PART3(t_ap, avgPause)
-    float avgPauseMean = WAVE_SUM1(t_ap);
+    float avgPauseMean = wave_sum(t_ap);
     float avgMagn = sumMagn;
     avgPauseMean = DIV129(avgPauseMean);
     avgMagn = DIV129(avgMagn);
@@ -439,9 +436,9 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     PART3(t_cv, cv)
     PART3(t_vp, vp)
     PART3(t_vm, vm)
-    float covMagnPause = WAVE_SUM1(t_cv);
-    float varPause = WAVE_SUM1(t_vp);
-    float varMagn = WAVE_SUM1(t_vm);
+    float covMagnPause = wave_sum(t_cv);
+    float varPause = wave_sum(t_vp);
+    float varMagn = wave_sum(t_vm);
     covMagnPause = DIV129(covMagnPause);
     varPause = DIV129(varPause);
     varMagn = DIV129(varMagn);
@@ -464,6 +461,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   const float pmp2 = SC_F(S_PMP2);
   int mup0 = updateParsFlag, mup3 = SC_I(S_MUP3);
   const int mup1 = SC_I(S_MUP1);
+  NS_STEADY(mup3 > 2);
   bool window_closed = false;
   if (updateParsFlag >= 1) {
     mup3--;
@@ -513,7 +511,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     }
   }
   PART3(t_ll, logLrt)
-  float logLrtTimeAvgKsum = WAVE_SUM1(t_ll);
+  float logLrtTimeAvgKsum = wave_sum(t_ll);
   logLrtTimeAvgKsum = DIV129(logLrtTimeAvgKsum);
   fd3 = logLrtTimeAvgKsum;
   {
@@ -677,7 +675,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     e2 += td1 * td1;
     e2 += td2 * td2;
     e2 += td3s * td3s;
-    const float energy2 = WAVE_SUM1(e2);
+    const float energy2 = wave_sum(e2);
     float gain = fsqrt(fdiv(energy2, energy1 + 1.f));
     if (gain > NS_B_LIM) {
       factor1 = 1.f + 1.3f * (gain - NS_B_LIM);
@@ -765,14 +763,14 @@ namespace aspns {
 
 hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps, int stagger) {
+                            unsigned long long* stamps) {
   const dim3 grid((num_streams + 3) / 4), block(256);
   if (io16)
     hipLaunchKernelGGL(ns_frame1_kernel<true>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps, stagger);
+                       num_streams, stamps);
   else
     hipLaunchKernelGGL(ns_frame1_kernel<false>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps, stagger);
+                       num_streams, stamps);
   return hipGetLastError();
 }
 

@@ -207,8 +207,7 @@ __global__ __launch_bounds__(256, NS_MIN_WG_PER_CU) void ns_frame2_kernel(float*
                                                         const float* __restrict__ in,
                                                         float* __restrict__ out,
                                                         int num_streams,
-                                                        unsigned long long* __restrict__ stamps,
-                                                        int stagger) {
+                                                        unsigned long long* __restrict__ stamps) {
   // diagnostic phase stamps (never passed by the product entry points): wave 0, lane 0
 #ifndef NS_STAMP_BLOCK
 #define NS_STAMP_BLOCK 0
@@ -220,19 +219,6 @@ __global__ __launch_bounds__(256, NS_MIN_WG_PER_CU) void ns_frame2_kernel(float*
     __builtin_amdgcn_sched_barrier(0);                                             \
   }
   NS_STAMP(0)
-  // phase stagger between the waves that share a SIMD (see ns_kernels1.hip): experiment knob
-  if (stagger > 0) {
-    const int mode = stagger >> 24;
-    const unsigned hwtg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);  // HW_REG_HW_ID[19:16]
-    const unsigned tg = mode == 0 ? (hwtg & 3u) : mode == 1 ? (hwtg & 1u)
-                        : mode == 2 ? (blockIdx.x >= gridDim.x / 2 ? 1u : 0u) : (blockIdx.x & 1u);
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long wait = (unsigned long long)tg * (unsigned)(stagger & 0xffffff);
-    for (int i = 0; i < 2048; ++i) {
-      if (__builtin_amdgcn_s_memtime() - t0 >= wait) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
   __shared__ float2 lds[4][2][128];
   // FFT twiddles (3 passes x 32 lanes x 8) and real-split factors (32 x 4 x 2) staged in LDS once
   // per workgroup: the passes would otherwise stall on a table load from L2 each
@@ -929,15 +915,15 @@ namespace aspns {
 
 hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps, int stagger) {
+                            unsigned long long* stamps) {
   // num_streams must be even: 8 streams per 256-thread workgroup
   const dim3 grid((num_streams / 2 + 3) / 4), block(256);
   if (io16)
     hipLaunchKernelGGL(ns_frame2_kernel<true>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps, stagger);
+                       num_streams, stamps);
   else
     hipLaunchKernelGGL(ns_frame2_kernel<false>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps, stagger);
+                       num_streams, stamps);
   return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
-// ns_pair_fft.h -- device helpers shared by the one-stream-per-wave pair-layout frame kernels
-// (ns_kernels1.hip, ns_kernels4.hip): the 128-point complex transform with half a radix-4 butterfly
+// ns_pair_fft.h -- device helpers of the one-stream-per-wave pair-layout frame kernel
+// (ns_kernels1.hip): the 128-point complex transform with half a radix-4 butterfly
 // per lane, its radix-2 tail and real split, the PCM store and the scalar-row lane write.
 // Lane L = 2 lam + h (lam = q + 16 g) owns elements E = q + 64 g + 16 h and E + 32.
 #pragma once

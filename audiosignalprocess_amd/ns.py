@@ -232,10 +232,9 @@ class NsBatch:
                                                         frames_in_ring, steps),
                "AspNsBatch_AnalyzeProcessReplay")
 
-    def set_graph(self, on, gate=False):
-        """on: replay captured hipGraphs instead of plain launches; gate: TimedSteps enqueues the
-        K steps behind a host-opened stream gate (no host enqueue latency inside the timed region)."""
-        _check(self.lib.AspNsBatch_SetGraph(self.h, (1 if on else 0) | (2 if gate else 0)), "AspNsBatch_SetGraph")
+    def set_graph(self, on):
+        """on: replay captured hipGraphs instead of plain launches."""
+        _check(self.lib.AspNsBatch_SetGraph(self.h, 1 if on else 0), "AspNsBatch_SetGraph")
 
     def timed_steps(self, in_ptr, out_ptr, frames_in_ring, steps):
         """K fused frame steps bracketed by hipEvents on the launch stream -> ms."""

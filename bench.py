@@ -345,7 +345,7 @@ def ns_measure(args, S, rank, world, local_rank, dist):
     d_out = torch.empty_like(d_in)
     del x
     ns = NsBatch(S, device=local_rank, policy=1, streams_per_wave=args.streams_per_wave or None)
-    ns.set_graph(args.graph, gate=args.gate)
+    ns.set_graph(args.graph)
     if args.split > 1:
         ns.set_split(args.split)
 
@@ -425,11 +425,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the AEC / BT-1024 / config-5 lines of the N = 1 run")
     ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs (one linear graph per chain) instead of plain launches")
     ap.add_argument("--no-graph", action="store_true", help="(default) plain kernel launches")
-    ap.add_argument("--gate", action="store_true", help="enqueue the timed steps behind a host-opened stream gate (measured: no gain)")
     ap.add_argument("--secondary-steps", type=int, default=1000)
     ap.add_argument("--secondary-warmup", type=int, default=250)
     ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
-    ap.add_argument("--streams-per-wave", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--streams-per-wave", type=int, default=0, choices=[0, 1, 2, 3],
                     help="fused-step kernel: 0 = the library's choice by batch size (default: 3 up to 6144 streams per "
                          "GPU, 2 above), 2 = two streams per wave64, 1 = one (bins q / q + 64), "
                          "3 = one stream per wave, pair layout (ns_kernels1.hip)")
@@ -478,7 +477,7 @@ def main():
         achieved = ALGO_BYTES_PER_FRAME * S / step_s / 1e9
         kid = args.streams_per_wave or (3 if S <= 6144 else 2)
         kernel = {2: "ns_frame2_kernel_ilp<false>" if S <= 6144 else "ns_frame2_kernel<false>",
-                  1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>", 4: "ns_frame4_kernel<false>"}[kid]
+                  1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>"}[kid]
         line = {
             "metric": "audio frames/sec (10 ms @16 kHz) Wiener NS",
             "value": frames_per_region / (step_s * K),
@@ -502,8 +501,7 @@ def main():
                 "input_ring_frames": args.ring,
                 "primed_frames_in_setup": primed,
                 "sub_launches_per_step": args.split,
-                "launch": ("hipGraph replay (one linear graph per chain, kernel nodes only)" if args.graph else "plain launches")
-                          + (", the K steps enqueued behind a host-opened stream gate" if args.gate else ""),
+                "launch": ("hipGraph replay (one linear graph per chain, kernel nodes only)" if args.graph else "plain launches"),
                 "parallelism": "stream-sharded x%d, no collectives" % world,
             },
             # one clock for value, ms_per_step and roofline: the median over `regions` repeats of the

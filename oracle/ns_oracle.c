@@ -324,17 +324,15 @@ static float butterfly32(float* t) {
  * lane 0 additionally bin 128.  TREE32: lane l < 16 holds bins l, l+16, l+32, l+48, lane
  * 16+l holds 64+l, 80+l, 96+l, 112+l (summed in that order), lane 0 additionally bin 128. */
 static float sum_bins(const float* x, int mode) {
-  if (mode == ASP_NS_REDUCE_TREE64P || mode == ASP_NS_REDUCE_TREE64Q) {
-    /* ns_kernels1.hip / ns_kernels4.hip: lane l = 2 lam + h holds bins q + 64 g + 16 h and that
-     * + 32 (lam = q + 16 g); bin 128 joins lane 0's partial before the butterfly (64P) or is
-     * added to the butterfly's result (64Q) */
+  if (mode == ASP_NS_REDUCE_TREE64P) {
+    /* ns_kernels1.hip: lane l = 2 lam + h holds bins q + 64 g + 16 h and that + 32
+     * (lam = q + 16 g); bin 128 joins lane 0's partial before the butterfly */
     float t[64];
     for (int l = 0; l < 64; ++l) {
       const int lam = l >> 1, h = l & 1;
       const int b = (lam & 15) + 64 * (lam >> 4) + 16 * h;
       t[l] = x[b] + x[b + 32];
     }
-    if (mode == ASP_NS_REDUCE_TREE64Q) return butterfly64(t) + x[128];
     t[0] = t[0] + x[128];
     return butterfly64(t);
   }
@@ -363,7 +361,7 @@ static float sum_bins(const float* x, int mode) {
  * lane layout: 1 = lane l holds samples 4l..4l+3 (analysis side), 0 = lane l
  * holds samples 2l, 2l+1, 2l+128, 2l+129 (after the inverse FFT). */
 static float energy256(const float* x, int mode, int by4) {
-  if ((mode == ASP_NS_REDUCE_TREE64P || mode == ASP_NS_REDUCE_TREE64Q) && !by4) {
+  if (mode == ASP_NS_REDUCE_TREE64P && !by4) {
     /* synthesis side of ns_kernels1.hip: lane l = 2 lam + h holds complex elements
      * E = q + 64 g + 16 h and E + 32, i.e. samples 2E, 2E+1, 2E+64, 2E+65 (the analysis side
      * is the TREE layout: samples 4l .. 4l+3) */

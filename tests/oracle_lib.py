@@ -21,7 +21,6 @@ REDUCE_SEQ = 0
 REDUCE_TREE = 1
 REDUCE_TREE32 = 2
 REDUCE_TREE64P = 3   # ns_kernels1.hip: one stream per wave, pair layout
-REDUCE_TREE64Q = 4   # ns_kernels4.hip: the same with bin 128 added last
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 

@@ -17,7 +17,7 @@ import pytest
 
 from audiosignalprocess_amd.synth import ns_frames
 from tests.conftest import check_free_running, rel_l2_per_stream, state_diff, state_from_bytes
-from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P, REDUCE_TREE64Q, OracleNs
+from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P, OracleNs
 
 pytestmark = pytest.mark.gpu
 
@@ -593,11 +593,10 @@ def test_dual_then_unfused_continues(ns):
 
 
 # ---------------------------------------------------------------------------------------------
-# The one-stream-per-wave, two-bins-per-lane fused kernels: ns_kernels1.hip (kernel id 3, bin 128 on every
-# lane: ASP_NS_REDUCE_TREE64P) and ns_kernels4.hip (kernel id 4, the scalar section and bin 128 of a
-# workgroup's four streams on one wave: ASP_NS_REDUCE_TREE64Q): bit-exact against the oracle in the matching
-# association, outputs and every state array.
-PAIR_KERNELS = [(3, REDUCE_TREE64P), (4, REDUCE_TREE64Q)]
+# The one-stream-per-wave, two-bins-per-lane fused kernel: ns_kernels1.hip (kernel id 3, bin 128 on every
+# lane: ASP_NS_REDUCE_TREE64P): bit-exact against the oracle in the matching association, outputs and
+# every state array.
+PAIR_KERNELS = [(3, REDUCE_TREE64P)]
 
 @pytest.mark.parametrize("kid,mode", PAIR_KERNELS)
 def test_pair_kernel_free_running_bit_exact(ns, kid, mode):

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Per-phase instruction budget of the fused NS frame kernels (costs no GPU time).
+
+Compiles the kernel source with -DNS1_BUDGET (ns_kernels1.hip): the NS_STAMP marks become assembly
+comments and the steady-state conditions (past start-up, no tracker publish, histogram window open,
+no libm fallback) are asserted, so the code between two marks is what one wave executes per frame.
+Prints, per phase, the instruction classes of the <IO16 = false> instantiation; branch targets that
+survive are listed so that a cold block cannot hide inside a phase.
+
+usage: tools/ns_valu_budget.py [source.hip] [--dump out.s] [extra hipcc flags...]
+"""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ["in+energy", "fftF", "g2loads+magn+log", "sums1", "trackers", "startup", "snr", "flat+diff", "hist",
+         "speechprob", "noiseupd", "gain", "ifft", "gainfac", "ola", "scalars", "tail"]
+
+
+def classify(op):
+    if op.startswith("v_"):
+        if op.startswith(("v_mov_b", "v_accvgpr")):
+            return "mov"
+        if op.startswith("v_cndmask"):
+            return "cndmask"
+        if op.startswith(("v_readlane", "v_readfirstlane", "v_writelane")):
+            return "lane"
+        if op.startswith("v_permlane"):
+            return "permlane"
+        if op.startswith("v_cmp") or op.startswith("v_cmpx"):
+            return "cmp"
+        if "_dpp" in op:
+            return "dpp"
+        if op.startswith("v_pk_"):
+            return "pk_f32"
+        if op.endswith("_f64") or "_f64_" in op:
+            return "f64"
+        if op.startswith(("v_rcp", "v_rsq", "v_sqrt", "v_exp", "v_log", "v_sin", "v_cos")):
+            return "trans"
+        if op.startswith("v_cvt"):
+            return "cvt"
+        if re.match(r"v_(add|sub|subrev|mul|fma|fmac|mac|mad|max|min|med3|ldexp|rndne|fract|floor|trunc)_f32", op) or op.startswith("v_fma_f32"):
+            return "f32"
+        return "int/bit"
+    if op.startswith("s_nop"):
+        return "s_nop"
+    if op.startswith("s_waitcnt"):
+        return "waitcnt"
+    if op.startswith(("s_cbranch", "s_branch")):
+        return "branch"
+    if op.startswith("s_"):
+        return "salu"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        return "vmem"
+    return "other"
+
+
+VALU = ("mov", "cndmask", "lane", "permlane", "cmp", "dpp", "pk_f32", "f64", "trans", "cvt", "f32", "int/bit")
+
+
+def main():
+    args = sys.argv[1:]
+    src = os.path.join(ROOT, "audiosignalprocess_amd", "csrc", "ns_kernels1.hip")
+    dump = None
+    extra = []
+    i = 0
+    while i < len(args):
+        if args[i] == "--dump":
+            dump = args[i + 1]
+            i += 2
+        elif args[i].endswith(".hip"):
+            src = args[i]
+            i += 1
+        else:
+            extra.append(args[i])
+            i += 1
+    out = dump or os.path.join(tempfile.mkdtemp(), "k.s")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-mllvm",
+           "-amdgpu-kernarg-preload-count=8", "-DNS1_BUDGET", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "audiosignalprocess_amd", "csrc"), "-S", "--cuda-device-only", "-o", out, src] + extra
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    lines = open(out).read().split("\n")
+    # the <false> instantiation: from its label to its s_endpgm
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z.*kernelILb0E.*:", l))
+    body = []
+    for l in lines[start + 1:]:
+        body.append(l)
+        if l.strip().startswith(".Lfunc_end"):
+            break
+    phase = -1
+    per = collections.OrderedDict()
+    labels = collections.defaultdict(list)
+    for l in body:
+        t = l.strip()
+        m = re.match(r"; NS_PHASE (\d+)", t)
+        if m:
+            phase = int(m.group(1))
+            continue
+        if not t or t.startswith((";", ".")) and not re.match(r"^\.LBB", t):
+            continue
+        if re.match(r"^\.LBB\S+:", t):
+            labels[phase].append(t.split(":")[0])
+            continue
+        op = t.split()[0]
+        per.setdefault(phase, collections.Counter())[classify(op)] += 1
+    cols = list(VALU) + ["s_nop", "salu", "lds", "vmem", "waitcnt", "branch"]
+    print("%-18s %5s | " % ("phase", "VALU") + " ".join("%7s" % c for c in cols))
+    tot = collections.Counter()
+    for ph, c in per.items():
+        v = sum(c[k] for k in VALU)
+        name = "prologue" if ph < 0 else "%2d %s" % (ph, NAMES[ph] if ph < len(NAMES) else "")
+        print("%-18s %5d | " % (name, v) + " ".join("%7d" % c[k] for k in cols) + ("   labels: " + ",".join(labels[ph]) if labels[ph] else ""))
+        tot.update(c)
+    v = sum(tot[k] for k in VALU)
+    print("%-18s %5d | " % ("total", v) + " ".join("%7d" % tot[k] for k in cols))
+    m = re.search(r"\.vgpr_count:\s+(\d+)", "\n".join(lines[::-1]))
+    for l in lines:
+        if "vgpr_count" in l or "sgpr_count" in l or "vgpr_spill" in l:
+            print(l.strip())
+
+
+if __name__ == "__main__":
+    main()
