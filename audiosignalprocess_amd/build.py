@@ -8,8 +8,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
-LIB = os.path.join(LIBDIR, "libasp_amd.so")
-SOURCES = ["ns_kernels.hip", "ns_kernels1.hip", "ns_kernels2.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_kernels8.hip", "bt_api.hip",
+# ASP_AMD_LIB: load another build of the library (same-box A / B runs against an earlier build)
+LIB = os.environ.get("ASP_AMD_LIB") or os.path.join(LIBDIR, "libasp_amd.so")
+SOURCES = ["ns_kernels.hip", "ns_kernels1.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_kernels8.hip", "bt_api.hip",
            "aec_kernels.hip", "aec_api.hip", "qmf_kernels.hip", "qmf_api.hip", "sinc_kernels.hip", "sinc_api.hip"]
 C_SOURCES = ["wav_io.c"]  # host-only C (kept C, as in the reference)
 # -ffp-contract=off: parity with the reference depends on unfused mul/add.
@@ -22,15 +23,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 # with dependent scalar loads before the first vector load can issue (-0.5 us per NS step, measured);
 # the object carries a prologue for firmware without the feature
 _PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=8"]
-EXTRA = {"ns_kernels2.hip": list(_PRELOAD), "ns_kernels.hip": list(_PRELOAD), "ns_kernels1.hip": list(_PRELOAD),
+EXTRA = {"ns_kernels.hip": list(_PRELOAD), "ns_kernels1.hip": list(_PRELOAD),
          # the echo canceller's block is long straight-line code at 4 waves per SIMD: the compiler's ILP-first
          # scheduling measured 92.7-93.8 us per step against 95.5 us in one session (max-ilp: 97-99 us)
          "aec_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
-# second builds of a source under another object name: (source, object, extra flags).  The NS frame
-# kernel exists as the 168-VGPR / three-waves-per-SIMD build (large batches) and as an ILP-scheduled
-# build (ns_kernels2.hip explains; the library picks by batch size)
-VARIANTS = [("ns_kernels2.hip", "ns_kernels2_ilp.hip.o",
-             ["-DNS_VARIANT_ILP", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"])]
+# second builds of a source under another object name: (source, object, extra flags)
+VARIANTS = []
 for _item in filter(None, os.environ.get("ASP_HIPCC_EXTRA", "").split(";")):
     _f, _, _fl = _item.partition(":")
     EXTRA.setdefault(_f.strip(), []).extend(_fl.split())

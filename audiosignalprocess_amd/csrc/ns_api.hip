@@ -24,15 +24,9 @@ using namespace aspns;
 namespace aspns {
 hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables* T,
                            const float* in, float* out, int num_streams, hipStream_t s);
-hipError_t launch_ns_frame2_ilp(bool io16, float* state, int32_t* hist, const NsTables* T,
-                                const float* in, float* out, int num_streams, hipStream_t s,
-                                unsigned long long* stamps = nullptr);
 hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps = nullptr);
-hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTables* T,
-                            const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps = nullptr);
+                            unsigned long long* stamps = nullptr, int stamp_mode = 0);
 hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_hb_live(const float* state, const NsTables* T, const float* in_low,
                              int32_t* live, int num_streams, int hist_off, hipStream_t s);
@@ -136,8 +130,12 @@ void build_tables(NsTables* T) {
           tBr = 0.f;
           tBi = 1.f;
         } else {
+          // the reference's factored w[2] block: w (p.r - p.i), w (p.r + p.i) and -w (m.r + m.i),
+          // w (m.r - m.i).  The pair-layout kernel forms p + i p and m - i m under the diag bit and
+          // multiplies by (w, 0) / (-w, 0) (ns_pair_fft.h); ns_kernels.hip reads tAr only.
           diag = true;
           tAr = w[2];
+          tBr = -w[2];
         }
       } else if (B >= 2) {
         const int u = B >> 1;
@@ -203,34 +201,6 @@ void build_tables(NsTables* T) {
     T->logtab[i][0] = invc;
     T->logtab[i][1] = c == 1.0L ? 0.0 : (double)(-logl((long double)invc));
   }
-  // full-butterfly twiddles of the two-streams-per-wave kernel: block index B of pass 0/1/2 is
-  // lane, lane >> 2, lane >> 4 (same twiddle cases as above, fft4g.c:1008-1102 / 1114-1229)
-  for (int pass = 0; pass < 3; ++pass)
-    for (int lane = 0; lane < 32; ++lane) {
-      const int B = pass == 0 ? lane : (pass == 1 ? lane >> 2 : lane >> 4);
-      float* e = T->tw2[pass][lane];
-      e[0] = 1.f; e[1] = 0.f; e[2] = 1.f; e[3] = 0.f; e[4] = 1.f; e[5] = 0.f; e[6] = 0.f; e[7] = 0.f;
-      if (B == 1) {
-        e[0] = w[2];
-        e[2] = 0.f;
-        e[3] = 1.f;
-        e[6] = 1.f;
-      } else if (B >= 2) {
-        const int u = B >> 1;
-        const float wk2r = w[2 * u], wk2i = w[2 * u + 1];
-        if ((B & 1) == 0) {
-          const float w1r = w[4 * u], w1i = w[4 * u + 1];
-          e[0] = w1r; e[1] = w1i; e[2] = wk2r; e[3] = wk2i;
-          e[4] = w1r - 2 * wk2i * w1i;
-          e[5] = 2 * wk2i * w1r - w1i;
-        } else {
-          const float w1r = w[4 * u + 2], w1i = w[4 * u + 3];
-          e[0] = w1r; e[1] = w1i; e[2] = -wk2i; e[3] = wk2r;
-          e[4] = w1r - 2 * wk2r * w1i;
-          e[5] = 2 * wk2r * w1r - w1i;
-        }
-      }
-    }
   for (int lane = 0; lane < 32; ++lane)
     for (int t = 0; t < 4; ++t) {
       const int g = lane >> 4, pq = (lane & 15) + 16 * t;  // element E = pq + 64 g
@@ -468,10 +438,9 @@ struct AspNsBatch {
   // sub-launches on separate HIP streams, so one part's load/store phases
   // overlap another part's arithmetic (streams never interact).
   int split = 1;
-  bool dual = true;  // fused paired step through the two-streams-per-wave kernel
-  // fused step kernel: 1 = ns_frame_kernel (one stream per wave, bins q / q + 64), 2 = ns_frame2_kernel
-  // (two streams per wave), 3 = ns_frame1_kernel (one stream per wave, pair layout: ns_kernels1.hip)
-  int kernel = 0;  // 0 = by batch size: 3 up to kIlpMaxStreams streams per GPU, 2 above
+  // fused step kernel: 1 = ns_frame_kernel (one stream per wave, bins q / q + 64: ns_kernels.hip),
+  // 3 = ns_frame1_kernel (one stream per wave, pair layout: ns_kernels1.hip)
+  int kernel = 0;  // 0 = the default: 3 (measured faster than the others at every batch size, profiles/README.md)
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
   // A captured K-step replay (hipGraph): the launches of `g_steps` fused steps over the ring
@@ -483,7 +452,7 @@ struct AspNsBatch {
   const float* g_in = nullptr;
   float* g_out = nullptr;
   int g_ring = 0, g_steps = 0, g_split = 0;
-  bool g_io16 = false, g_dual = false;
+  bool g_io16 = false;
   int g_kernel = 0;
   bool use_graph = false;  // plain launches measured 4-7 % faster per step than graph replay (round 2)
   unsigned long long* timeline = nullptr;  // diagnostic (AspNsBatch_DebugTimeline): [workgroup][4] real-time stamps
@@ -657,8 +626,6 @@ int AspNsBatch_set_policy(AspNsBatch* b, int mode) {
   return ASP_OK;
 }
 
-constexpr int kIlpMaxStreams = 6144;  // streams per GPU up to which the ILP build of the frame kernel is used
-
 // One fused paired frame step over streams [s0, s0 + n) of the batch.
 static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float* dout, int s0, int n,
                                hipStream_t st) {
@@ -667,27 +634,13 @@ static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float
   int32_t* hist = b->hist + (size_t)s0 * kHistDwords;
   const float* in = din + (size_t)s0 * sper;
   float* out = dout + (size_t)s0 * sper;
-  const int kernel = b->kernel ? b->kernel : (b->S <= kIlpMaxStreams ? 3 : 2);
-  if (kernel == 3) {
-    unsigned long long* tl = nullptr;  // timeline mode: pointer bit 0 set, this sub-launch's first workgroup
-    if (b->timeline) tl = reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(b->timeline + (size_t)(s0 / 4) * 4) | 1);
-    return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st, tl);
-  }
-  if (kernel == 1 || n < 2) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
-  const int even = n & ~1;
-  // two builds of the same kernel (ns_kernels2.hip): the ILP-scheduled one while the batch gives a
-  // SIMD at most two waves to run, the 168-VGPR one (three resident waves) for larger batches
-  hipError_t e = b->S <= kIlpMaxStreams ? launch_ns_frame2_ilp(io16, state, hist, b->tables, in, out, even, st)
-                                        : launch_ns_frame2(io16, state, hist, b->tables, in, out, even, st);
-  if (e == hipSuccess && even != n)  // the odd last stream: one-stream-per-wave kernel
-    e = launch_ns_frame(io16 ? 3 : 2, state + (size_t)even * kStreamDwords,
-                        hist + (size_t)even * kHistDwords, b->tables, in + (size_t)even * sper,
-                        out + (size_t)even * sper, 1, st);
-  return e;
+  if (b->kernel == 1) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
+  // timeline diagnostic: this sub-launch's first workgroup's slot, stamp mode 1
+  unsigned long long* tl = b->timeline ? b->timeline + (size_t)(s0 / 4) * 4 : nullptr;
+  return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st, tl, tl ? 1 : 0);
 }
 
-// stream boundaries of the sub-launch chains: multiples of 8 streams (one workgroup = 8 streams in
-// the two-per-wave kernel, 4 in the one-per-wave kernels)
+// stream boundaries of the sub-launch chains: multiples of 8 streams (two workgroups of 4)
 static int chain_parts(const AspNsBatch* b, int base[5]) {
   const int parts = (b->split > 1 && b->S >= 8 * b->split) ? b->split : 1;
   for (int p = 0; p <= parts; ++p) base[p] = (int)(((long long)b->S * p / parts) / 8 * 8);
@@ -745,7 +698,7 @@ static void drop_graph(AspNsBatch* b) {
 static int ensure_graph(AspNsBatch* b, const float* din, float* dout, int ring, int steps, bool io16) {
   const bool hit = b->gexec[0] && b->g_in == din && b->g_out == dout && b->g_ring == ring &&
                    b->g_steps == steps && b->g_split == b->split && b->g_io16 == io16 &&
-                   b->g_dual == b->dual && b->g_kernel == b->kernel;
+                   b->g_kernel == b->kernel;
   if (hit) return ASP_OK;
   drop_graph(b);
   int base[5];
@@ -780,7 +733,6 @@ static int ensure_graph(AspNsBatch* b, const float* din, float* dout, int ring, 
   b->g_steps = steps;
   b->g_split = b->split;
   b->g_io16 = io16;
-  b->g_dual = b->dual;
   b->g_kernel = b->kernel;
   return ASP_OK;
 }
@@ -1114,25 +1066,19 @@ int AspNsBatch_SetSplit(AspNsBatch* b, int parts) {
   return ASP_OK;
 }
 
-// Diagnostic: one fused step of the two-per-wave kernel with phase stamps of wave 0 (16 values).
+// Diagnostic: one fused step of the pair-layout kernel with the phase stamps of workgroup 0's first wave (16 values).
 int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
                            unsigned long long* stamps16) {
   DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
-  if (!in_dev || !out_dev || !stamps16 || !b->paired || ((b->S & 1) && b->kernel == 2))
-    return fail(ASP_ERR_PARAM, "DebugStamps: bad argument");
+  if (!in_dev || !out_dev || !stamps16 || !b->paired || b->kernel == 1)
+    return fail(ASP_ERR_PARAM, "DebugStamps: bad argument (paired state, pair-layout kernel)");
   unsigned long long* d = nullptr;
   HIP_TRY(hipMalloc((void**)&d, 16 * sizeof(unsigned long long)));
   hipError_t e = hipMemset(d, 0, 16 * sizeof(unsigned long long));
-  if (e == hipSuccess) {
-    if ((b->kernel ? b->kernel : (b->S <= kIlpMaxStreams ? 3 : 2)) == 3)
-      e = launch_ns_frame1(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d);
-    else
-      e = b->S <= kIlpMaxStreams  // the build the product path uses for this batch size
-              ? launch_ns_frame2_ilp(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d)
-              : launch_ns_frame2(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d);
-  }
+  if (e == hipSuccess)
+    e = launch_ns_frame1(false, b->state, b->hist, b->tables, in_dev, out_dev, b->S, b->stream, d);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (e == hipSuccess) e = hipMemcpy(stamps16, d, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d);
@@ -1148,8 +1094,7 @@ int AspNsBatch_DebugTimeline(AspNsBatch* b, const float* in_dev, float* out_dev,
   DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
-  const int kernel = b->kernel ? b->kernel : (b->S <= kIlpMaxStreams ? 3 : 2);
-  if (!in_dev || !out_dev || !out || steps <= 0 || frames_in_ring <= 0 || !b->paired || kernel != 3 ||
+  if (!in_dev || !out_dev || !out || steps <= 0 || frames_in_ring <= 0 || !b->paired || b->kernel == 1 ||
       num_workgroups != (b->S + 3) / 4 || (b->S & 3))
     return fail(ASP_ERR_PARAM, "DebugTimeline: bad argument (pair-layout kernel, stream count a multiple of 4)");
   const size_t bytes = (size_t)num_workgroups * 4 * sizeof(unsigned long long);
@@ -1174,11 +1119,10 @@ int AspNsBatch_SetGraph(AspNsBatch* b, int on) {
   return ASP_OK;
 }
 
-int AspNsBatch_SetKernel(AspNsBatch* b, int streams_per_wave) {
-  if (!b || streams_per_wave < 0 || streams_per_wave > 3)
-    return fail(ASP_ERR_PARAM, "SetKernel: 0 (by batch size), 1 (one stream per wave, q / q + 64), 2 (two streams per wave) or 3 (one stream per wave, pair layout)");
-  b->dual = streams_per_wave == 2;
-  b->kernel = streams_per_wave;
+int AspNsBatch_SetKernel(AspNsBatch* b, int kernel) {
+  if (!b || (kernel != 0 && kernel != 1 && kernel != 3))
+    return fail(ASP_ERR_PARAM, "SetKernel: 0 (default), 1 (one stream per wave, bins q / q + 64) or 3 (one stream per wave, pair layout)");
+  b->kernel = kernel;
   return ASP_OK;
 }
 

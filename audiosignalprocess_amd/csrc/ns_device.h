@@ -1,5 +1,5 @@
 // ns_device.h -- device-side helpers shared by the NS kernels (ns_kernels.hip: one stream per
-// wave; ns_kernels2.hip: two streams per wave): the reference's constants, exact division /
+// wave, bins q / q + 64; ns_kernels1.hip: one stream per wave, pair layout): the reference's constants, exact division /
 // sqrt / log / exp / tanh forms (each verified exhaustively against its libm form on the device,
 // tests/test_ns_gpu.py), wave reductions, and the histogram-window close.
 #pragma once
@@ -73,6 +73,60 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// The same sum (same operands, same association: bit-identical) with the four row sums combined by two
+// row-broadcast DPP adds instead of four v_readlane, two moves and two adds: row_bcast:15 (rows 1, 3
+// written) leaves r0 + r1 and r2 + r3 in rows 1 and 3, row_bcast:31 (row 3 written) adds row 1's into
+// row 3's: (r0 + r1) + (r2 + r3), read from lane 63.  Seven 2.8-cycle issue slots instead of eight plus
+// five 1.7-cycle ones (profiles/r03_issue_probe3.txt).  A DPP read needs two wait states behind the VALU
+// write of its source: one sum alone pays them as s_nops, N sums reduced side by side (wave_sums_bcast)
+// fill each other's slots.
+#define ASP_DPP_STEP(r, ctl) "v_add_f32_dpp " r ", " r ", " r " " ctl "\n\t"
+#define ASP_DPP_Q1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define ASP_DPP_Q2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+#define ASP_DPP_HM "row_half_mirror row_mask:0xf bank_mask:0xf"
+#define ASP_DPP_RM "row_mirror row_mask:0xf bank_mask:0xf"
+#define ASP_DPP_B15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define ASP_DPP_B31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+__device__ __forceinline__ float wave_sum_bcast(float v) {
+  asm volatile("s_nop 1\n\t" ASP_DPP_STEP("%0", ASP_DPP_Q1) "s_nop 1\n\t" ASP_DPP_STEP("%0", ASP_DPP_Q2)
+               "s_nop 1\n\t" ASP_DPP_STEP("%0", ASP_DPP_HM) "s_nop 1\n\t" ASP_DPP_STEP("%0", ASP_DPP_RM)
+               "s_nop 1\n\t" ASP_DPP_STEP("%0", ASP_DPP_B15) "s_nop 1\n\t" ASP_DPP_STEP("%0", ASP_DPP_B31)
+               "s_nop 0"
+               : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// two / three / four independent sums, each with exactly wave_sum's association
+__device__ __forceinline__ void wave_sums_bcast(float& a, float& b) {
+#define ASP_S2(ctl) ASP_DPP_STEP("%0", ctl) ASP_DPP_STEP("%1", ctl) "s_nop 0\n\t"
+  asm volatile("s_nop 1\n\t" ASP_S2(ASP_DPP_Q1) ASP_S2(ASP_DPP_Q2) ASP_S2(ASP_DPP_HM) ASP_S2(ASP_DPP_RM)
+               ASP_S2(ASP_DPP_B15) ASP_S2(ASP_DPP_B31)
+               : "+v"(a), "+v"(b));
+#undef ASP_S2
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+}
+__device__ __forceinline__ void wave_sums_bcast(float& a, float& b, float& c) {
+#define ASP_S3(ctl) ASP_DPP_STEP("%0", ctl) ASP_DPP_STEP("%1", ctl) ASP_DPP_STEP("%2", ctl)
+  asm volatile("s_nop 1\n\t" ASP_S3(ASP_DPP_Q1) ASP_S3(ASP_DPP_Q2) ASP_S3(ASP_DPP_HM) ASP_S3(ASP_DPP_RM)
+               ASP_S3(ASP_DPP_B15) ASP_S3(ASP_DPP_B31) "s_nop 0"
+               : "+v"(a), "+v"(b), "+v"(c));
+#undef ASP_S3
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+  c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+}
+__device__ __forceinline__ void wave_sums_bcast(float& a, float& b, float& c, float& d) {
+#define ASP_S4(ctl) ASP_DPP_STEP("%0", ctl) ASP_DPP_STEP("%1", ctl) ASP_DPP_STEP("%2", ctl) ASP_DPP_STEP("%3", ctl)
+  asm volatile("s_nop 1\n\t" ASP_S4(ASP_DPP_Q1) ASP_S4(ASP_DPP_Q2) ASP_S4(ASP_DPP_HM) ASP_S4(ASP_DPP_RM)
+               ASP_S4(ASP_DPP_B15) ASP_S4(ASP_DPP_B31) "s_nop 0"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef ASP_S4
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+  c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+  d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63));
+}
+
 // Correctly rounded a / d for a divisor shared by the whole wave: `rd` is the
 // correctly rounded reciprocal of d (one exact division per wave), then
 // Markstein's q0 = a*rd, r = a - d*q0, q = q0 + r*rd is the rounded quotient
@@ -100,7 +154,7 @@ __device__ __forceinline__ float fdiv(float n, float d) {
   const float e2 = __builtin_fmaf(-d, q1, n);
   return __builtin_fmaf(e2, r1, q1);
 }
-// Two / five correctly rounded divisions at a time: the same arithmetic as fdiv with the seven
+// Two correctly rounded divisions at a time: the same arithmetic as fdiv with the seven
 // multiply-add steps issued as packed-f32 instructions (one issue slot for two quotients).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fdiv2(f32x2 n, f32x2 d) {
@@ -116,71 +170,9 @@ __device__ __forceinline__ f32x2 fdiv2(f32x2 n, f32x2 d) {
   const f32x2 e2 = __builtin_elementwise_fma(-d, q1, n);
   return __builtin_elementwise_fma(e2, r1, q1);
 }
-__device__ __forceinline__ void fdiv5(const float (&n)[5], const float (&d)[5], float (&q)[5]) {
-  const f32x2 a = fdiv2(f32x2{n[0], n[1]}, f32x2{d[0], d[1]});
-  const f32x2 b = fdiv2(f32x2{n[2], n[3]}, f32x2{d[2], d[3]});
-  q[0] = a.x; q[1] = a.y; q[2] = b.x; q[3] = b.y;
-  q[4] = fdiv(n[4], d[4]);
-}
-// Five bins of a lane (four owned + bin 128) as two packed pairs and a scalar: +, -, * and fma on
-// an F5 compile to v_pk_* for the pairs.  Every operation is the IEEE single operation of its
-// scalar spelling (no contraction), so results are bit-identical to the per-bin loops.
-struct B5 {
-  bool v[5];
-};
-struct F5 {
-  f32x2 a, b;
-  float t;
-  __device__ __forceinline__ F5() {}
-  __device__ __forceinline__ F5(f32x2 a_, f32x2 b_, float t_) : a(a_), b(b_), t(t_) {}
-  __device__ __forceinline__ explicit F5(float c) : a(f32x2{c, c}), b(f32x2{c, c}), t(c) {}
-  __device__ __forceinline__ explicit F5(const float (&x)[5]) : a(f32x2{x[0], x[1]}), b(f32x2{x[2], x[3]}), t(x[4]) {}
-  __device__ __forceinline__ void store(float (&x)[5]) const {
-    x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = t;
-  }
-  __device__ __forceinline__ float get(int k) const { return k == 0 ? a.x : k == 1 ? a.y : k == 2 ? b.x : k == 3 ? b.y : t; }
-};
-__device__ __forceinline__ F5 operator+(const F5& x, const F5& y) { return F5(x.a + y.a, x.b + y.b, x.t + y.t); }
-__device__ __forceinline__ F5 operator-(const F5& x, const F5& y) { return F5(x.a - y.a, x.b - y.b, x.t - y.t); }
-__device__ __forceinline__ F5 operator*(const F5& x, const F5& y) { return F5(x.a * y.a, x.b * y.b, x.t * y.t); }
-__device__ __forceinline__ F5 operator*(float c, const F5& y) { return F5(c) * y; }
-__device__ __forceinline__ F5 operator*(const F5& x, float c) { return x * F5(c); }
-__device__ __forceinline__ F5 operator+(const F5& x, float c) { return x + F5(c); }
-__device__ __forceinline__ F5 operator-(const F5& x, float c) { return x - F5(c); }
-__device__ __forceinline__ F5 operator-(float c, const F5& y) { return F5(c) - y; }
-__device__ __forceinline__ F5 operator-(const F5& x) { return F5(-x.a, -x.b, -x.t); }
-__device__ __forceinline__ F5 fma5(const F5& x, const F5& y, const F5& z) {
-  return F5(__builtin_elementwise_fma(x.a, y.a, z.a), __builtin_elementwise_fma(x.b, y.b, z.b),
-            __builtin_fmaf(x.t, y.t, z.t));
-}
-__device__ __forceinline__ F5 abs5(const F5& x) {
-  return F5(f32x2{fabsf(x.a.x), fabsf(x.a.y)}, f32x2{fabsf(x.b.x), fabsf(x.b.y)}, fabsf(x.t));
-}
-#define ASP_F5_CMP(name, op)                                                        \
-  __device__ __forceinline__ B5 name(const F5& x, const F5& y) {                    \
-    B5 r;                                                                           \
-    r.v[0] = x.a.x op y.a.x; r.v[1] = x.a.y op y.a.y; r.v[2] = x.b.x op y.b.x;      \
-    r.v[3] = x.b.y op y.b.y; r.v[4] = x.t op y.t;                                   \
-    return r;                                                                       \
-  }
-ASP_F5_CMP(gt5, >)
-ASP_F5_CMP(lt5, <)
-#undef ASP_F5_CMP
-__device__ __forceinline__ F5 sel5(const B5& c, const F5& x, const F5& y) {  // c ? x : y
-  return F5(f32x2{c.v[0] ? x.a.x : y.a.x, c.v[1] ? x.a.y : y.a.y},
-            f32x2{c.v[2] ? x.b.x : y.b.x, c.v[3] ? x.b.y : y.b.y}, c.v[4] ? x.t : y.t);
-}
-// div_by_uniform for five bins
-__device__ __forceinline__ F5 div_by_uniform5(const F5& a, float d, float rd) {
-  const F5 q0 = a * rd;
-  const F5 r = fma5(F5(-d), q0, a);
-  return fma5(r, F5(rd), q0);
-}
-__device__ __forceinline__ F5 fdiv5v(const F5& n, const F5& d) {
-  return F5(fdiv2(n.a, d.a), fdiv2(n.b, d.b), fdiv(n.t, d.t));
-}
 // Three bins of a lane of the one-stream-per-wave kernel (two owned + bin 128) as one packed pair
-// and a scalar; same contract as F5 (every operation is the IEEE single operation of its scalar spelling).
+// and a scalar: +, -, * and fma on an F3 compile to v_pk_* for the pair.  Every operation is the IEEE
+// single operation of its scalar spelling (no contraction), so results are bit-identical to per-bin loops.
 struct B3 {
   bool v[3];
 };
@@ -205,6 +197,24 @@ __device__ __forceinline__ F3 operator-(const F3& x, float c) { return x - F3(c)
 __device__ __forceinline__ F3 operator-(float c, const F3& y) { return F3(c) - y; }
 __device__ __forceinline__ F3 fma3(const F3& x, const F3& y, const F3& z) {
   return F3(__builtin_elementwise_fma(x.p, y.p, z.p), __builtin_fmaf(x.t, y.t, z.t));
+}
+// One v_max_f32 / v_min_f32 (the builtin forms put a canonicalising v_max x, x in front of each).  For a
+// quiet NaN they return the other operand, as `x > c ? x : c` / `x < c ? x : c` do.
+__device__ __forceinline__ float fmax_raw(float x, float c) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fmin_raw(float x, float c) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(c));
+  return r;
+}
+__device__ __forceinline__ F3 min3(const F3& x, const F3& y) {  // y < x ? y : x, NaN-free operands
+  return F3(f32x2{fmin_raw(x.p.x, y.p.x), fmin_raw(x.p.y, y.p.y)}, fmin_raw(x.t, y.t));
+}
+__device__ __forceinline__ F3 max3(const F3& x, float c) {
+  return F3(f32x2{fmax_raw(x.p.x, c), fmax_raw(x.p.y, c)}, fmax_raw(x.t, c));
 }
 __device__ __forceinline__ F3 abs3(const F3& x) {
   return F3(f32x2{fabsf(x.p.x), fabsf(x.p.y)}, fabsf(x.t));
@@ -420,9 +430,11 @@ __device__ __forceinline__ void log_f32_via_tab_n(const float (&x)[N], float (&o
   unsigned bad = 0;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
+    // an argument outside [2^-126, inf) runs through the lean form as it is (the table index is masked,
+    // nothing can fault) and is flagged: the fallback below recomputes the lane's values
     const unsigned ax = __float_as_uint(x[k]);
     const unsigned normal_pos = (ax - 0x00800000u) < 0x7f000000u ? 1u : 0u;  // [2^-126, inf)
-    const double y = log_tab_f64(normal_pos ? x[k] : 1.0f, tab);
+    const double y = log_tab_f64(x[k], tab);
     bad |= (normal_pos ^ 1u) | (f64_rounds_safely_to_f32(y) ? 0u : 1u);
     out[k] = (float)y;
   }
@@ -438,8 +450,9 @@ __device__ __forceinline__ void exp_f32_via_f64_n(const float (&x)[N], float (&o
   unsigned bad = 0;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
+    // out-of-range arguments run through the lean form as they are (masked table index) and are flagged
     const unsigned in_range = fabsf(x[k]) <= 87.0f ? 1u : 0u;  // false for NaN too
-    const double y = exp_lean_f64(in_range ? x[k] : 0.0f, t64);
+    const double y = exp_lean_f64(x[k], t64);
     bad |= (in_range ^ 1u) | (f64_rounds_safely_to_f32(y) ? 0u : 1u);
     out[k] = (float)y;
   }

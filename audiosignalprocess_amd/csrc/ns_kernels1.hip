@@ -1,14 +1,11 @@
 // ns_kernels1.hip -- the fused Analyze+Process frame step with ONE stream per wave64 and two
 // bins per lane: the low-latency build of the frame step.
 //
-// Same arithmetic as ns_frame2_kernel (ns_kernels2.hip) and ns_frame_kernel<true,true>
-// (ns_kernels.hip) -- every per-bin float operation of ns_core.c:1043-1359 in the reference's
-// order, Ooura-order FFT (fft4g.c), exact libm forms (ns_device.h) -- mapped so that a frame
-// step of 4096 streams is 4096 short waves (four per SIMD at <= 128 VGPRs) instead of 2048 long
-// ones: at that batch size a step is bound by the time ONE wave needs from its first load to its
-// last store (profiles/README.md, round 2), and a wave that carries one stream on 64 lanes has
-// about 0.6x the instructions of one that carries two streams on 32 lanes each, while four
-// resident waves per SIMD hide each other's LDS / memory / dependent-issue stalls.
+// Same arithmetic as ns_frame_kernel<true,true> (ns_kernels.hip) -- every per-bin float operation of
+// ns_core.c:1043-1359 in the reference's order, Ooura-order FFT (fft4g.c), exact libm forms
+// (ns_device.h) -- mapped so that a frame step of 4096 streams is 4096 short waves, all resident at
+// once (four per SIMD at <= 128 VGPRs): a step is bound by the time a wave needs from its first load
+// to its last store plus the launch boundary (profiles/README.md, rounds 2 and 3).
 //
 //   * lane L = 2 lam + h (lam = q + 16 g: the "dual lane" of ns_layout.h's row order) owns the
 //     FFT elements / bins E = q + 64 g + 16 t for t = h and t = h + 2: exactly the two outputs
@@ -53,7 +50,8 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
                                                            const float* __restrict__ in,
                                                            float* __restrict__ out,
                                                            int num_streams,
-                                                           unsigned long long* __restrict__ stamps) {
+                                                           unsigned long long* __restrict__ stamps,
+                                                           int stamp_mode) {
 #ifdef NS1_BUDGET
   // instruction-budget build (tools/ns_valu_budget.py, never shipped): the phase marks become
   // assembly comments and the steady-state conditions are asserted, so that the straight-line
@@ -64,18 +62,17 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   __builtin_amdgcn_sched_barrier(0);
 #define NS_STEADY(x) __builtin_assume(x)
 #else
-  // diagnostic stamps (never passed by the product entry points).  Pointer bit 0 clear: the 16 phase
-  // stamps (shader clock) of workgroup 0's first wave.  Bit 0 set ("timeline"): every workgroup's
-  // first wave records the 100 MHz real-time counter at its start, after its first loads, before
-  // its last stores and at its end (4 values per workgroup) -- the launch-level picture.
+  // diagnostic stamps (never passed by the product entry points).  stamp_mode 0: the 16 phase stamps
+  // (shader clock) of workgroup 0's first wave.  stamp_mode 1 ("timeline"): every workgroup's first
+  // wave records the 100 MHz real-time counter at its start, after its first loads, before its last
+  // stores and at its end (4 values per workgroup) -- the launch-level picture.
 #define NS_STAMP(k)                                                                          \
   if (stamps != nullptr && threadIdx.x == 0) {                                               \
     __builtin_amdgcn_sched_barrier(0);                                                       \
-    if ((reinterpret_cast<uintptr_t>(stamps) & 1) != 0) {                                    \
+    if (stamp_mode != 0) {                                                                   \
       if ((k) == 0 || (k) == 1 || (k) == 14 || (k) == 15)                                    \
-        reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(stamps) & ~(uintptr_t)1)[ \
-            blockIdx.x * 4 + ((k) == 0 ? 0 : (k) == 1 ? 1 : (k) == 14 ? 2 : 3)] =                 \
-            __builtin_amdgcn_s_memrealtime() | ((k) == 0 ? ns_cu_tag() << 48 : 0ull);         \
+        stamps[blockIdx.x * 4 + ((k) == 0 ? 0 : (k) == 1 ? 1 : (k) == 14 ? 2 : 3)] =        \
+            __builtin_amdgcn_s_memrealtime() | ((k) == 0 ? ns_cu_tag() << 48 : 0ull);       \
     } else if (blockIdx.x == 0) {                                                            \
       stamps[k] = __builtin_amdgcn_s_memtime();                                              \
     }                                                                                        \
@@ -84,7 +81,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 #define NS_STEADY(x)
 #endif
   NS_STAMP(0)
-  __shared__ float2 lds[4][128];
+  __shared__ __align__(16) float2 lds[4][130];  // 128 elements + the slot lane 0 reads past them (ns_pair_fft.h)
   // per-lane twiddles of the three passes (3 x 64 x 4), real-split factors (32 x 4 x 2) and the
   // window, staged in LDS once per workgroup behind the state loads
   __shared__ __align__(16) float tabs[3 * 64 * 4 + 32 * 4 * 2];
@@ -120,7 +117,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 #define SC_I(k) __builtin_amdgcn_readlane(__float_as_int(sv), (k))
 #define SC_F(k) __int_as_float(SC_I(k))
 #define SC_SET_I(k, val) sv = writelane_bits<(k)>(sv, (int)(val))
-#define SC_SET_F(k, val) sv = writelane_bits<(k)>(sv, __float_as_int(val))
+#define SC_SET_F(k, val) sv = setlane_vgpr<(k)>(sv, (val))
 
   // ---- sliding analysis buffer [96 carried | 160 new]: lane L owns samples 4L .. 4L+3
   float* hbuf = st + kOffAnaHist;
@@ -147,9 +144,21 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   }
 #define LOADT(dst, f) dst[2] = SC_F(S_TAIL0 + (f));
 #define LOAD3(dst, f) LOADV(dst, f) LOADT(dst, f)
+#ifndef NS1_NT_STORE
+#define NS1_NT_STORE 0
+#endif
+#if NS1_NT_STORE
+#define ROW_STORE2(ptr, a, b) __builtin_nontemporal_store(f32x2{(a), (b)}, reinterpret_cast<f32x2*>(ptr))
+#else
+#define ROW_STORE2(ptr, a, b) *reinterpret_cast<float2*>(ptr) = make_float2((a), (b))
+#endif
+#ifndef NS1_EXP_SKIPSTORE
+#define NS1_EXP_SKIPSTORE 0  // experiment: bit f set = row f is not written back (breaks the recurrence; timing only)
+#endif
 #define STORE3(f, srcv)                                                                        \
   {                                                                                            \
-    *reinterpret_cast<float2*>(vec + (f)*kVecStride + 2 * lane) = make_float2(srcv[0], srcv[1]); \
+    if (!((NS1_EXP_SKIPSTORE >> (f)) & 1))                                                     \
+      ROW_STORE2(vec + (f)*kVecStride + 2 * lane, srcv[0], srcv[1]);                           \
     SC_SET_F(S_TAIL0 + (f), srcv[2]);                                                          \
   }
 
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   epart += wx1 * wx1;
   epart += wx2 * wx2;
   epart += wx3 * wx3;
-  const float energy1 = wave_sum(epart);
+  const float energy1 = wave_sum_bcast(epart);
 
   // the carried 96 samples of the next frame are this frame's last 96
   if (lane >= 40) *reinterpret_cast<float4*>(hbuf + 4 * (lane - 40)) = s4;
@@ -214,10 +223,14 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   // ---- forward FFT (ns_core.c:886-911)
   *reinterpret_cast<float4*>(&tile[2 * lane]) = make_float4(wx0, wx1, wx2, wx3);
   lds_sync1();
-  float2 el[2];
-  cft128_passes1(tile, tws, diagbits, lane, el[0], el[1]);
-  radix2_tail1(el[0], el[1], gmask, false);
-  real_split1(tile, spls, lane, el, false);
+  const PairFftLane fl = pair_fft_lane(lane, diagbits);
+  f32x2 er, ei;  // the lane's two bins {slot 0, slot 1}: real parts, imaginary parts
+  {
+    f32x2 ea, eb;
+    cft128_passes1(tile, tws, fl, lane, ea, eb);
+    radix2_tail1(ea, eb, gmask, false, er, ei);
+  }
+  real_split1(tile, spls, lane, er, ei, false);
 
   NS_STAMP(2)
   // second group of state rows (latency hides under magnitude / log / trackers)
@@ -227,11 +240,11 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   LOADT(smooth, V_SMOOTH) LOADT(noisePrev, V_NOISEPREV)
 
   float re[NS3], im[NS3], magn[NS3];
-  re[0] = el[0].x;
-  im[0] = el[0].y;
-  re[1] = el[1].x;
-  im[1] = el[1].y;
-  re[2] = lane_bcast(el[0].y, 0);  // R128 sits in the imaginary slot of element 0 (lane 0, slot 0)
+  re[0] = er.x;
+  im[0] = ei.x;
+  re[1] = er.y;
+  im[1] = ei.y;
+  re[2] = lane_bcast(ei.x, 0);  // R128 sits in the imaginary slot of element 0 (lane 0, slot 0)
   im[2] = 0.f;
   if (lane == 0) im[0] = 0.f;
   {
@@ -243,10 +256,9 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   if (lane == 0) magn[0] = fabsf(re[0]) + 1.f;
   magn[2] = fabsf(re[2]) + 1.f;
 
-  // per-lane partial of a per-bin quantity: the two owned bins, then the tail on lane 0
-#define PART3(dst, v)                     \
-  float dst = v[0] + v[1];                \
-  if (lane == 0) dst = dst + v[2];
+  // sum over the 129 bins of a per-bin quantity: the lane's two owned bins, the wave64 butterfly over the
+  // 64 partials, then bin 128 (association ASP_NS_REDUCE_TREE64P of oracle/ns_oracle.c)
+#define SUM3(v) (wave_sum_bcast(v[0] + v[1]) + v[2])
 
   int blockInd = SC_I(S_BLOCKIND);
   const float overdrive = SC_F(S_OVERDRIVE);
@@ -272,34 +284,42 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   log_f32_via_tab_n<NS3>(magn, lmagn, logts);
 
   NS_STAMP(3)
-  float signalEnergy, sumMagn;
+  // the four cross-bin sums that need only this frame's spectrum and the loaded rows, reduced side by
+  // side: signal energy (ns_core.c:1089-1103), sum of magnitudes, the flatness numerator (bins 1..128,
+  // :535-541) and the mean of magnAvgPause (:603-607)
+  float signalEnergy, sumMagn, flatNum, avgPauseMean;
   {
-    float se[NS3];
-#pragma unroll
-    for (int k = 0; k < NS3; ++k) se[k] = re[k] * re[k] + im[k] * im[k];
-    PART3(t_se, se)
-    PART3(t_sm, magn)
-    signalEnergy = wave_sum(t_se);
-    sumMagn = wave_sum(t_sm);
+    float p_se = (re[0] * re[0] + im[0] * im[0]) + (re[1] * re[1] + im[1] * im[1]);
+    float p_sm = magn[0] + magn[1];
+    float p_fl = lane == 0 ? lmagn[1] : lmagn[0] + lmagn[1];
+    float p_ap = avgPause[0] + avgPause[1];
+    wave_sums_bcast(p_se, p_sm, p_fl, p_ap);
+    signalEnergy = p_se + (re[2] * re[2] + im[2] * im[2]);
+    sumMagn = p_sm + magn[2];
+    flatNum = p_fl + lmagn[2];
+    avgPauseMean = p_ap + avgPause[2];
     signalEnergy = DIV129(signalEnergy);
   }
 
   NS_STAMP(4)
   // ---- NoiseEstimation (ns_core.c:217-285)
   if (updates < NS_END_STARTUP_LONG) updates++;
+  bool quant_new = false;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     const float cnt = (float)counter[s];
     const float cnt1 = (float)(counter[s] + 1);
     const float rcnt1 = fdiv(1.f, cnt1);  // == 1.f / cnt1 (cnt1 = 1 .. 201)
     {
+      // ns_core.c:232-260 with two of its three branches folded into the arithmetic (same roundings):
+      // delta = FACTOR / max(density, 1) (the quotient by 1 is exact), and the step carries its sign,
+      // lq += (+QUANTILE delta) / n or (-(1 - QUANTILE) delta) / n (products, quotients and x + (-y)
+      // are sign-symmetric)
       F3 den(DEN[s]), lq(LQ[s]);
       const F3 lm(lmagn);
-      const F3 dq = fdiv3v(F3(NS_FACTOR * 1.f), den);  // used where density > 1
-      const F3 delta = sel3(gt3(den, F3(1.0f)), dq, F3(NS_FACTOR));
-      const B3 up = gt3(lm, lq);
-      const F3 step = div_by_uniform3(sel3(up, NS_QUANTILE * delta, (1.f - NS_QUANTILE) * delta), cnt1, rcnt1);
-      lq = sel3(up, lq + step, lq - step);
+      const F3 delta = fdiv3v(F3(NS_FACTOR * 1.f), max3(den, 1.0f));
+      const F3 coef = sel3(gt3(lm, lq), F3(NS_QUANTILE), F3(-(1.f - NS_QUANTILE)));
+      lq = lq + div_by_uniform3(coef * delta, cnt1, rcnt1);
       const F3 nd = div_by_uniform3(cnt * den + 1.f / (2.f * NS_WIDTH), cnt1, rcnt1);
       den = sel3(lt3(abs3(lm - lq), F3(NS_WIDTH)), nd, den);
       den.store(DEN[s]);
@@ -307,16 +327,24 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     }
     if (counter[s] >= NS_END_STARTUP_LONG) {
       counter[s] = 0;
-      if (updates >= NS_END_STARTUP_LONG) exp_f32_via_f64_n<NS3>(LQ[s], quant, exp2s);
+      if (updates >= NS_END_STARTUP_LONG) {
+        exp_f32_via_f64_n<NS3>(LQ[s], quant, exp2s);
+        quant_new = true;
+      }
     }
     counter[s]++;
   }
-  if (updates < NS_END_STARTUP_LONG) exp_f32_via_f64_n<NS3>(LQ[2], quant, exp2s);
+  if (updates < NS_END_STARTUP_LONG) {
+    exp_f32_via_f64_n<NS3>(LQ[2], quant, exp2s);
+    quant_new = true;
+  }
 #pragma unroll
   for (int k = 0; k < NS3; ++k) noise[k] = quant[k];
   STORE3(V_LQ0, LQ[0]) STORE3(V_LQ1, LQ[1]) STORE3(V_LQ2, LQ[2])
   STORE3(V_DEN0, DEN[0]) STORE3(V_DEN1, DEN[1]) STORE3(V_DEN2, DEN[2])
-  STORE3(V_QUANT, quant)
+  // the published quantile changes once in ~67 frames past start-up (a tracker publishes every 200
+  // frames, ns_core.c:262-270): its row is written back only then (wave-uniform branch)
+  if (quant_new) STORE3(V_QUANT, quant)
 
   NS_STAMP(5)
   // ---- startup noise model (ns_core.c:1091-1100, 1109-1162)
@@ -334,10 +362,8 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
       lm3[k] = bin >= NS_START_BAND ? lmagn[k] : 0.f;
       lilm[k] = bin >= NS_START_BAND ? li * lmagn[k] : 0.f;
     }
-    PART3(t_lm, lm3)
-    PART3(t_lilm, lilm)
-    const float sum_log_magn = wave_sum(t_lm);
-    const float sum_log_i_log_magn = wave_sum(t_lilm);
+    const float sum_log_magn = SUM3(lm3);
+    const float sum_log_i_log_magn = SUM3(lilm);
     const float sum_log_i = T->sum_log_i, sum_log_i_square = T->sum_log_i_square;
     whiteNoiseLevel += DIV129(sumMagn) * overdrive;
     float tmpFloat1 = sum_log_i_square * ((float)(kBins - NS_START_BAND));
@@ -407,11 +433,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   // ---- ComputeSpectralFlatness (ns_core.c:523-556)
   float fd0 = SC_F(S_FD0), fd4 = SC_F(S_FD4), fd6 = SC_F(S_FD6);
   {
-    float fl3[NS3];
-#pragma unroll
-    for (int k = 0; k < NS3; ++k) fl3[k] = (k == 0 && lane == 0) ? 0.f : lmagn[k];
-    PART3(t_fl, fl3)
-    float num = wave_sum(t_fl);
+    float num = flatNum;
     float den = sumMagn - lane_bcast(magn[0], 0);
     den = DIV129(den);
     num = DIV129(num);
@@ -420,8 +442,6 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   }
   // ---- ComputeSpectralDifference (ns_core.c:595-634)
   {
-    PART3(t_ap, avgPause)
-    float avgPauseMean = wave_sum(t_ap);
     float avgMagn = sumMagn;
     avgPauseMean = DIV129(avgPauseMean);
     avgMagn = DIV129(avgMagn);
@@ -433,12 +453,11 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
       vp[k] = dp * dp;
       vm[k] = dm * dm;
     }
-    PART3(t_cv, cv)
-    PART3(t_vp, vp)
-    PART3(t_vm, vm)
-    float covMagnPause = wave_sum(t_cv);
-    float varPause = wave_sum(t_vp);
-    float varMagn = wave_sum(t_vm);
+    float covMagnPause = cv[0] + cv[1], varPause = vp[0] + vp[1], varMagn = vm[0] + vm[1];
+    wave_sums_bcast(covMagnPause, varPause, varMagn);
+    covMagnPause += cv[2];
+    varPause += vp[2];
+    varMagn += vm[2];
     covMagnPause = DIV129(covMagnPause);
     varPause = DIV129(varPause);
     varMagn = DIV129(varMagn);
@@ -510,8 +529,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
       logLrt[k] += NS_LRT_TAVG * (besselTmp - lt1[k] - logLrt[k]);
     }
   }
-  PART3(t_ll, logLrt)
-  float logLrtTimeAvgKsum = wave_sum(t_ll);
+  float logLrtTimeAvgKsum = SUM3(logLrt);
   logLrtTimeAvgKsum = DIV129(logLrtTimeAvgKsum);
   fd3 = logLrtTimeAvgKsum;
   {
@@ -576,24 +594,21 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     prevProb[0] = a_from1 ? a1 : a0;
     prevProb[1] = b_from1 ? b1 : b0;
     prevProb[2] = lane_bcast(probSpeech[1], 63);  // bin 128 <- bin 127 (q = 15, g = 1, t = 3)
-#pragma unroll
-    for (int k = 0; k < NS3; ++k) {
-      float gammaOld = prevProb[k] > NS_PROB_RANGE ? NS_SPEECH_UPDATE : NS_NOISE_UPDATE;
-      if (k == 0 && lane == 0) gammaOld = NS_NOISE_UPDATE;  // bin 0 has no predecessor
-      const float ps = probSpeech[k], pns = 1.f - probSpeech[k];
-      const float noiseUpdateTmp =
-          gammaOld * noisePrev[k] + (1.f - gammaOld) * (pns * magn[k] + ps * noisePrev[k]);
-      float gammaNew = NS_NOISE_UPDATE;
-      if (ps > NS_PROB_RANGE) gammaNew = NS_SPEECH_UPDATE;
-      if (ps < NS_PROB_RANGE) avgPause[k] += NS_GAMMA_PAUSE * (magn[k] - avgPause[k]);
-      float nz;
-      if (gammaNew == gammaOld) {
-        nz = noiseUpdateTmp;
-      } else {
-        nz = gammaNew * noisePrev[k] + (1.f - gammaNew) * (pns * magn[k] + ps * noisePrev[k]);
-        if (noiseUpdateTmp < nz) nz = noiseUpdateTmp;
-      }
-      noise[k] = nz;
+    // ns_core.c:813-845.  The update with a time constant g is u(g) = g noisePrev + (1 - g) x, x = (1 -
+    // ps) magn + ps noisePrev; the reference computes u(gammaOld) and, when gammaNew differs, keeps the
+    // smaller of u(gammaOld) and u(gammaNew).  With both constants' updates at hand that is: the old
+    // bin's choice, the new bin's choice, their minimum (equal choices give the same value twice).
+    {
+      const F3 np(noisePrev), mg(magn), ps(probSpeech), ap(avgPause);
+      const F3 x = (1.f - ps) * mg + ps * np;
+      const F3 uS = NS_SPEECH_UPDATE * np + (1.f - NS_SPEECH_UPDATE) * x;
+      const F3 uN = NS_NOISE_UPDATE * np + (1.f - NS_NOISE_UPDATE) * x;
+      B3 oldSpeech = gt3(F3(prevProb), F3(NS_PROB_RANGE));
+      oldSpeech.v[0] = oldSpeech.v[0] && lane != 0;  // bin 0 has no predecessor: gamma = NOISE_UPDATE
+      const F3 uOld = sel3(oldSpeech, uS, uN);
+      const F3 uNew = sel3(gt3(ps, F3(NS_PROB_RANGE)), uS, uN);
+      min3(uOld, uNew).store(noise);
+      sel3(lt3(ps, F3(NS_PROB_RANGE)), ap + NS_GAMMA_PAUSE * (mg - ap), ap).store(avgPause);
     }
   }
   STORE3(V_LOGLRT, logLrt) STORE3(V_AVGPAUSE, avgPause)
@@ -627,9 +642,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   }
 #pragma unroll
   for (int k = 0; k < NS3; ++k) {
-    float gg = gq2[k];
-    if (gg < denoiseBound) gg = denoiseBound;
-    if (gg > 1.f) gg = 1.f;
+    float gg = fmin_raw(fmax_raw(gq2[k], denoiseBound), 1.f);  // ns_core.c:1001-1006
     if (startup) {
       float tmp = (initMagn[k] - overdrive * pnoise[k]);
       tmp /= (initMagn[k] + 0.0001f);
@@ -649,22 +662,28 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 
   NS_STAMP(12)
   // ---- IFFT (ns_core.c:923-944)
-  el[0] = make_float2(re[0], im[0]);
-  el[1] = make_float2(re[1], im[1]);
-  if (lane == 0) el[0].y = re[2];  // Ooura packing: a[1] = R128
-  real_split1(tile, spls, lane, el, true);
+  er = f32x2{re[0], re[1]};
+  ei = f32x2{im[0], im[1]};
+  if (lane == 0) ei.x = re[2];  // Ooura packing: a[1] = R128
+  real_split1(tile, spls, lane, er, ei, true);
   lds_sync1();
   {
     const int base = 64 * g + q + 16 * h;
-    tile[base] = el[0];
-    tile[base + 32] = el[1];
+    float* tf = reinterpret_cast<float*>(tile);
+    tf[2 * base] = er.x;
+    tf[2 * base + 1] = ei.x;
+    tf[2 * base + 64] = er.y;
+    tf[2 * base + 65] = ei.y;
   }
   lds_sync1();
-  cft128_passes1(tile, tws, diagbits, lane, el[0], el[1]);
-  radix2_tail1(el[0], el[1], gmask, true);
-  // samples 2E, 2E+1 of elements E = binA (slot 0) and binA + 32 (slot 1)
-  const float td0 = el[0].x * (2.f / kAnal), td1 = el[0].y * (2.f / kAnal);
-  const float td2 = el[1].x * (2.f / kAnal), td3s = el[1].y * (2.f / kAnal);
+  f32x2 tr, ti;  // samples 2E (tr) and 2E + 1 (ti) of elements E = binA (slot 0) and binA + 32 (slot 1)
+  {
+    f32x2 ea, eb;
+    cft128_passes1(tile, tws, fl, lane, ea, eb);
+    radix2_tail1(ea, eb, gmask, true, tr, ti);
+  }
+  const float td0 = tr.x * (2.f / kAnal), td1 = ti.x * (2.f / kAnal);
+  const float td2 = tr.y * (2.f / kAnal), td3s = ti.y * (2.f / kAnal);
 
   NS_STAMP(13)
   // ---- energy-based gain compensation (ns_core.c:1315-1342)
@@ -675,7 +694,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
     e2 += td1 * td1;
     e2 += td2 * td2;
     e2 += td3s * td3s;
-    const float energy2 = wave_sum(e2);
+    const float energy2 = wave_sum_bcast(e2);
     float gain = fsqrt(fdiv(energy2, energy1 + 1.f));
     if (gain > NS_B_LIM) {
       factor1 = 1.f + 1.3f * (gain - NS_B_LIM);
@@ -754,7 +773,7 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
 #undef LOADV
 #undef LOADT
 #undef STORE3
-#undef PART3
+#undef SUM3
 }
 
 }  // namespace
@@ -763,14 +782,14 @@ namespace aspns {
 
 hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
-                            unsigned long long* stamps) {
+                            unsigned long long* stamps, int stamp_mode) {
   const dim3 grid((num_streams + 3) / 4), block(256);
   if (io16)
     hipLaunchKernelGGL(ns_frame1_kernel<true>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps);
+                       num_streams, stamps, stamp_mode);
   else
     hipLaunchKernelGGL(ns_frame1_kernel<false>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps);
+                       num_streams, stamps, stamp_mode);
   return hipGetLastError();
 }
 

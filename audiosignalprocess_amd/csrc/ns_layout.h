@@ -19,7 +19,7 @@ constexpr int kBins = 129;     // ns/defines.h:16
 constexpr int kHist = 1000;    // ns/defines.h:45
 constexpr int kVecStride = 128;  // one state row = bins 0..127 (bin 128 lives with the scalars): 512 B, cache-line aligned
 // Position of bin b inside a state row.  Bins are grouped by (b & 15, b >> 6) = the "dual lane"
-// lam = (b & 15) + 16 (b >> 6) of the two-streams-per-wave kernel, which owns the four bins
+// lam = (b & 15) + 16 (b >> 6), which gathers the four bins
 // q + 16 t + 64 g (t = 0..3) as one 16-byte access; inside a group the order is t = 0, 2, 1, 3, so
 // that lane 2 lam + h of the one-stream-per-wave kernel (ns_kernels1.hip), which owns t = h and
 // t = h + 2 (the two outputs of its half of a radix-4 butterfly), moves them as one 8-byte access.
@@ -94,9 +94,7 @@ struct NsTables {
   float sum_log_i_square;
   float pad[2];
   double exp2_64[64];         // 2^(j/64), range-reduction table of the lean exp
-  // two-streams-per-wave kernel (ns_kernels2.hip): one full butterfly per lane and pass
-  float tw2[3][32][8];        // (w1r, w1i, w2r, w2i, w3r, w3i, diag, 0)
-  float spl[32][4][2];        // real-split (wkr, wki) of element (lane & 15) + 16 t + 64 (lane >> 4)
+  float spl[32][4][2];        // real-split (wkr, wki) of element (lam & 15) + 16 t + 64 (lam >> 4), lam = 0..31
   double logtab[128][2];      // {1/c, log c} of the table-driven log (ns_device.h: log_tab_f64)
 };
 

@@ -139,7 +139,7 @@ class DeviceBuffer:
 class NsBatch:
     """N independent 16 kHz noise-suppressor streams on one GPU."""
 
-    def __init__(self, num_streams, device=0, fs=16000, policy=None, streams_per_wave=None):
+    def __init__(self, num_streams, device=0, fs=16000, policy=None, kernel=None):
         self.lib = load_library()
         self.S = int(num_streams)
         self.device = device
@@ -149,8 +149,8 @@ class NsBatch:
         self.init(fs)
         if policy is not None:
             self.set_policy(policy)
-        if streams_per_wave is not None:
-            self.set_kernel(streams_per_wave)
+        if kernel is not None:
+            self.set_kernel(kernel)
 
     def init(self, fs=16000):
         _check(self.lib.AspNsBatch_Init(self.h, fs), "AspNsBatch_Init")
@@ -250,8 +250,9 @@ class NsBatch:
     def set_split(self, parts):
         _check(self.lib.AspNsBatch_SetSplit(self.h, parts), "AspNsBatch_SetSplit")
 
-    def set_kernel(self, streams_per_wave):
-        _check(self.lib.AspNsBatch_SetKernel(self.h, streams_per_wave), "AspNsBatch_SetKernel")
+    def set_kernel(self, kernel):
+        """0 / 3: the pair-layout fused kernel (default); 1: the bins q / q + 64 kernel."""
+        _check(self.lib.AspNsBatch_SetKernel(self.h, kernel), "AspNsBatch_SetKernel")
 
     def synchronize(self):
         _check(self.lib.AspNsBatch_Synchronize(self.h), "AspNsBatch_Synchronize")

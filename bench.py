@@ -344,7 +344,7 @@ def ns_measure(args, S, rank, world, local_rank, dist):
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.empty_like(d_in)
     del x
-    ns = NsBatch(S, device=local_rank, policy=1, streams_per_wave=args.streams_per_wave or None)
+    ns = NsBatch(S, device=local_rank, policy=1, kernel=args.kernel or None)
     ns.set_graph(args.graph)
     if args.split > 1:
         ns.set_split(args.split)
@@ -428,10 +428,9 @@ def main():
     ap.add_argument("--secondary-steps", type=int, default=1000)
     ap.add_argument("--secondary-warmup", type=int, default=250)
     ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
-    ap.add_argument("--streams-per-wave", type=int, default=0, choices=[0, 1, 2, 3],
-                    help="fused-step kernel: 0 = the library's choice by batch size (default: 3 up to 6144 streams per "
-                         "GPU, 2 above), 2 = two streams per wave64, 1 = one (bins q / q + 64), "
-                         "3 = one stream per wave, pair layout (ns_kernels1.hip)")
+    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 3],
+                    help="fused-step kernel: 0 / 3 = one stream per wave, pair layout (ns_kernels1.hip, the default), "
+                         "1 = one stream per wave, bins q / q + 64 (ns_kernels.hip)")
     ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256", "aec", "split48"],
                     help="ns = the headline metric (default); bt* / aec / split48 = secondary lines")
     args = ap.parse_args()
@@ -475,9 +474,7 @@ def main():
         step_s = float(np.median(ev)) / K            # THE clock of this line: hipEvents over the K-step region
         frames_per_region = S * world * args.steps
         achieved = ALGO_BYTES_PER_FRAME * S / step_s / 1e9
-        kid = args.streams_per_wave or (3 if S <= 6144 else 2)
-        kernel = {2: "ns_frame2_kernel_ilp<false>" if S <= 6144 else "ns_frame2_kernel<false>",
-                  1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>"}[kid]
+        kernel = {1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>"}[args.kernel or 3]
         line = {
             "metric": "audio frames/sec (10 ms @16 kHz) Wiener NS",
             "value": frames_per_region / (step_s * K),

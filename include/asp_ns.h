@@ -173,10 +173,11 @@ int AspNsBatch_SetStream(AspNsBatch* b, void* hip_stream);
  * sub-launches on separate HIP streams (streams never interact, so results are
  * unchanged); lets one part's memory phases overlap another part's arithmetic. */
 int AspNsBatch_SetSplit(AspNsBatch* b, int parts);
-/* Which fused-step kernel serves AnalyzeProcess: 2 (default) = two streams per wave64,
- * 1 = one stream per wave64.  Same arithmetic; the ~10 cross-bin sums per frame are
- * associated over 32 resp. 64 lanes, so outputs agree to reduction-order rounding. */
-int AspNsBatch_SetKernel(AspNsBatch* b, int streams_per_wave);
+/* Which fused-step kernel serves AnalyzeProcess: 0 / 3 (default) = one stream per wave64 in the pair
+ * layout (two bins per lane, ns_kernels1.hip), 1 = one stream per wave64 with bins q / q + 64
+ * (ns_kernels.hip, the kernel of the two-call Analyze / Process protocol).  Same arithmetic; the ~10
+ * cross-bin sums per frame are associated differently, so outputs agree to reduction-order rounding. */
+int AspNsBatch_SetKernel(AspNsBatch* b, int kernel);
 void* AspNsBatch_GetStream(AspNsBatch* b);
 int AspNsBatch_Synchronize(AspNsBatch* b);
 

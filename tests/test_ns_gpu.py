@@ -17,7 +17,7 @@ import pytest
 
 from audiosignalprocess_amd.synth import ns_frames
 from tests.conftest import check_free_running, rel_l2_per_stream, state_diff, state_from_bytes
-from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P, OracleNs
+from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE64P, OracleNs
 
 pytestmark = pytest.mark.gpu
 
@@ -62,7 +62,7 @@ def test_fft_linearity_and_roundtrip_large(ns):
 def test_fused_free_running_bit_exact_vs_tree_oracle(ns):
     S, F = 24, 1100  # crosses blockInd 50 / 200 and two 500-frame histogram windows
     x = ns_frames(S, F)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    g = ns.NsBatch(S, policy=1, kernel=1)
     y = g.analyze_process(x)
     o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE)
     yo = o.run(x, threads=8)
@@ -78,7 +78,7 @@ def test_fused_free_running_bit_exact_vs_tree_oracle(ns):
 def test_golden_reference_outputs_within_tolerance(ns, golden):
     x = golden["in_i16"].astype(np.float32)
     F, S, _ = x.shape
-    g = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    g = ns.NsBatch(S, policy=1, kernel=1)
     y = g.analyze_process(x)
     rel = rel_l2_per_stream(y, golden["out_f32"])
     check_free_running(rel)
@@ -99,7 +99,7 @@ def test_golden_teacher_forced_single_step(ns, golden):
     for k, f0 in enumerate(frames):
         if f0 >= x.shape[0]:
             continue
-        g = ns.NsBatch(S, policy=1, streams_per_wave=1)
+        g = ns.NsBatch(S, policy=1, kernel=1)
         for s in range(S):
             g.import_state(s, state_from_bytes(golden["snap_state"][k, s]))
         y = g.analyze_process(x[f0:f0 + 1])
@@ -127,9 +127,9 @@ def test_unfused_analyze_process_equals_fused(ns):
     including the paired -> unpaired transition mid-stream."""
     S, F = 7, 260  # ragged: not a multiple of the 4 streams per workgroup
     x = ns_frames(S, F, stream0=11)
-    g1 = ns.NsBatch(S, policy=2, streams_per_wave=1)
+    g1 = ns.NsBatch(S, policy=2, kernel=1)
     y1 = g1.analyze_process(x)
-    g2 = ns.NsBatch(S, policy=2, streams_per_wave=1)
+    g2 = ns.NsBatch(S, policy=2, kernel=1)
     y2 = np.empty_like(x)
     y2[:100] = g2.analyze_process(x[:100])  # fused / paired
     for f in range(100, F):                  # then the reference's two-call protocol
@@ -150,7 +150,7 @@ def test_analyze_and_process_on_different_frames(ns):
     S, F = 3, 120
     a = ns_frames(S, F, stream0=40)
     b = ns_frames(S, F, stream0=50)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    g = ns.NsBatch(S, policy=1, kernel=1)
     o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE)
     for f in range(F):
         g.analyze(a[f])
@@ -167,7 +167,7 @@ def test_zero_and_silence_edge_cases(ns):
     x[10:16, 1] = 0.0      # stream 1: silence long enough for energy == 0 frames
     x[:, 2] = 0.0          # stream 2: digital silence from the start
     x[30:, 3] = 32767.0    # stream 3: full-scale DC (saturation path)
-    g = ns.NsBatch(S, policy=3, streams_per_wave=1)
+    g = ns.NsBatch(S, policy=3, kernel=1)
     o = OracleNs(S, policy=3, reduce_mode=REDUCE_TREE)
     y, yo = g.analyze_process(x), o.run(x)
     assert np.isfinite(y).all()
@@ -184,7 +184,7 @@ def test_all_policies_bit_exact(ns):
     for policy in range(4):
         S, F = 4, 230
         x = ns_frames(S, F, stream0=20 * policy)
-        g = ns.NsBatch(S, policy=policy, streams_per_wave=1)
+        g = ns.NsBatch(S, policy=policy, kernel=1)
         o = OracleNs(S, policy=policy, reduce_mode=REDUCE_TREE)
         assert np.array_equal(g.analyze_process(x), o.run(x)), policy
         g.close()
@@ -194,11 +194,11 @@ def test_state_export_import_roundtrip(ns):
     """Checkpoint / restore: a restored batch continues bit-identically."""
     S, F = 4, 300
     x = ns_frames(S, F + 50, stream0=77)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    g = ns.NsBatch(S, policy=1, kernel=1)
     g.analyze_process(x[:F])
     saved = [g.export_state(s) for s in range(S)]
     y_a = g.analyze_process(x[F:])
-    g2 = ns.NsBatch(S, policy=0, streams_per_wave=1)
+    g2 = ns.NsBatch(S, policy=0, kernel=1)
     for s in range(S):
         g2.import_state(s, saved[s])
     y_b = g2.analyze_process(x[F:])
@@ -212,7 +212,7 @@ def test_config2_scale_4096_streams(ns):
     size-independent properties on all of them."""
     S, F = 4096, 60
     x = ns_frames(S, F)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    g = ns.NsBatch(S, policy=1, kernel=1)
     y = g.analyze_process(x)
     assert np.isfinite(y).all() and np.abs(y).max() <= 32768.0
     pick = [0, 1, 2, 3, 63, 64, 1023, 2048, 4093, 4094, 4095]
@@ -221,7 +221,7 @@ def test_config2_scale_4096_streams(ns):
     assert np.array_equal(y[:, pick], yo)
     # streams are independent: permuting the batch permutes the outputs
     perm = np.random.default_rng(0).permutation(S)
-    g2 = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    g2 = ns.NsBatch(S, policy=1, kernel=1)
     y2 = g2.analyze_process(np.ascontiguousarray(x[:, perm]))
     assert np.array_equal(y2, y[:, perm])
     # a noise suppressor never amplifies the frame energy by much after start-up
@@ -238,7 +238,7 @@ def test_device_pointer_path_in_place(ns):
     x = ns_frames(S, F, stream0=5)
     buf = ns.DeviceBuffer(x.nbytes)
     buf.upload(x)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    g = ns.NsBatch(S, policy=1, kernel=1)
     g.analyze_process_device(buf.ptr, buf.ptr, F)
     g.synchronize()
     y = buf.download(x.shape)
@@ -423,10 +423,10 @@ def test_split_launch_is_identical(ns):
     """The fused step issued as 2..4 sub-launches on separate HIP streams gives the same bits."""
     S, F = 256, 30
     x = ns_frames(S, F, stream0=900)
-    ref = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    ref = ns.NsBatch(S, policy=1, kernel=1)
     y_ref = ref.analyze_process(x)
     for parts in (2, 3, 4):
-        g = ns.NsBatch(S, policy=1, streams_per_wave=1)
+        g = ns.NsBatch(S, policy=1, kernel=1)
         g.set_split(parts)
         assert np.array_equal(g.analyze_process(x), y_ref), parts
         assert state_diff(g.export_state(S - 1), ref.export_state(S - 1)) == {}
@@ -439,9 +439,9 @@ def test_int16_pcm_path(ns, golden):
     and within 1 LSB of the reference driver's WAV output."""
     pcm = golden["in_i16"]
     F, S, _ = pcm.shape
-    g16 = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    g16 = ns.NsBatch(S, policy=1, kernel=1)
     y16 = g16.analyze_process_s16(pcm)
-    gf = ns.NsBatch(S, policy=1, streams_per_wave=1)
+    gf = ns.NsBatch(S, policy=1, kernel=1)
     yf = gf.analyze_process(pcm.astype(np.float32))
     pos = np.where(yf >= np.float32(32766.5), 32767, (yf + np.float32(0.5)).astype(np.int32))
     neg = np.where(yf <= np.float32(-32767.5), -32768, (yf - np.float32(0.5)).astype(np.int32))
@@ -489,110 +489,6 @@ def test_batched_wav_driver(ns, golden, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------
-# The two-streams-per-wave fused kernel (ns_kernels2.hip, the default for AnalyzeProcess):
-# bit-exact against the oracle's 32-lane association.
-
-def test_dual_kernel_free_running_bit_exact(ns):
-    S, F = 24, 1100  # crosses blockInd 50 / 200 and two 500-frame histogram windows
-    x = ns_frames(S, F, stream0=300)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=2)
-    y = g.analyze_process(x)
-    o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE32)
-    yo = o.run(x, threads=8)
-    assert np.isfinite(y).all()
-    bad = np.nonzero((y != yo).any(axis=2))
-    assert bad[0].size == 0, (bad[0][:5], bad[1][:5])
-    for s in range(0, S, 5):
-        assert state_diff(g.export_state(s), o.export_state(s)) == {}
-    g.close()
-
-
-def test_dual_kernel_edge_cases_policies_and_odd_count(ns):
-    S, F = 7, 260  # odd: stream 6 runs through the one-stream kernel (64-lane association)
-    x = ns_frames(S, F, stream0=40)
-    x[10:16, 1] = 0.0      # energy == 0 frames on one half of a wave only
-    x[:, 2] = 0.0          # digital silence from the start
-    x[30:, 3] = 32767.0    # full-scale DC
-    x[100:104, 4] = 0.0
-    x[100:104, 5] = 0.0    # both halves of a wave silent together
-    for policy in (0, 3):
-        g = ns.NsBatch(S, policy=policy, streams_per_wave=2)
-        y = g.analyze_process(x)
-        o32 = OracleNs(S - 1, policy=policy, reduce_mode=REDUCE_TREE32)
-        o64 = OracleNs(1, policy=policy, reduce_mode=REDUCE_TREE)
-        assert np.array_equal(y[:, :S - 1], o32.run(np.ascontiguousarray(x[:, :S - 1]))), policy
-        assert np.array_equal(y[:, S - 1:], o64.run(np.ascontiguousarray(x[:, S - 1:]))), policy
-        for s in range(S - 1):
-            assert state_diff(g.export_state(s), o32.export_state(s)) == {}, (policy, s)
-        assert state_diff(g.export_state(S - 1), o64.export_state(0)) == {}
-        g.close()
-
-
-def test_dual_kernel_golden_int16_split_and_scale(ns, golden):
-    pcm = golden["in_i16"]
-    F, S, _ = pcm.shape
-    g = ns.NsBatch(S, policy=1, streams_per_wave=2)
-    y = g.analyze_process(pcm.astype(np.float32))
-    rel = rel_l2_per_stream(y, golden["out_f32"])
-    check_free_running(rel)
-    g16 = ns.NsBatch(S, policy=1, streams_per_wave=2)
-    y16 = g16.analyze_process_s16(pcm)
-    ref = golden["wav_out_i16"][:F * 160].reshape(F, 160)
-    d = np.abs(y16[:, 0].astype(np.int32) - ref.astype(np.int32))
-    assert d.max() <= 1 and (d == 0).mean() >= 0.999
-    g.close()
-    g16.close()
-    # BASELINE config[1] size, 3 sub-launches, spot-checked against the oracle
-    S2, F2 = 4096, 40
-    x = ns_frames(S2, F2)
-    big = ns.NsBatch(S2, policy=1, streams_per_wave=2)
-    big.set_split(3)
-    yb = big.analyze_process(x)
-    assert np.isfinite(yb).all()
-    pick = [0, 1, 2, 3, 1364, 1365, 2730, 2731, 4094, 4095]
-    yo = OracleNs(len(pick), policy=1, reduce_mode=REDUCE_TREE32).run(np.ascontiguousarray(x[:, pick]))
-    assert np.array_equal(yb[:, pick], yo)
-    big.close()
-
-
-def test_large_batch_build_of_the_frame_kernel(ns):
-    """Batches above 6144 streams per GPU run the second build of the two-streams-per-wave kernel
-    (168 VGPRs, three waves per SIMD; csrc/ns_kernels2.hip, ns_api.hip: kIlpMaxStreams).  BASELINE
-    config 5 size (8192 streams): spot-checked bit for bit against the oracle through the start-up
-    phases, and equal to the small-batch build on the same streams."""
-    S, F = 8192, 230
-    base = ns_frames(16, F, stream0=40)
-    idx = np.arange(S) % 16
-    x = np.ascontiguousarray(base[:, idx])
-    big = ns.NsBatch(S, policy=2, streams_per_wave=2)
-    yb = big.analyze_process(x)
-    assert np.isfinite(yb).all()
-    yo = OracleNs(16, policy=2, reduce_mode=REDUCE_TREE32).run(base)
-    for k in (0, 5, 4095, 6143, 6144, 8190, 8191):
-        assert np.array_equal(yb[:, k], yo[:, idx[k]]), k
-    small = ns.NsBatch(16, policy=2, streams_per_wave=2)
-    assert np.array_equal(small.analyze_process(base), yo)
-    assert state_diff(big.export_state(8191), small.export_state(15)) == {}
-    big.close()
-    small.close()
-
-
-def test_dual_then_unfused_continues(ns):
-    """Fused two-per-wave steps, then the reference's two-call protocol on the same batch."""
-    S, F = 6, 130
-    x = ns_frames(S, F, stream0=77)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=2)
-    o = OracleNs(S, policy=1, reduce_mode=REDUCE_TREE32)
-    assert np.array_equal(g.analyze_process(x[:100]), o.run(x[:100]))
-    o.mode = REDUCE_TREE  # separate Analyze / Process launches use the one-stream kernels
-    for f in range(100, F):
-        g.analyze(x[f])
-        o.analyze(x[f])
-        assert np.array_equal(g.process(x[f]), o.process(x[f])), f
-    g.close()
-
-
-# ---------------------------------------------------------------------------------------------
 # The one-stream-per-wave, two-bins-per-lane fused kernel: ns_kernels1.hip (kernel id 3, bin 128 on every
 # lane: ASP_NS_REDUCE_TREE64P): bit-exact against the oracle in the matching association, outputs and
 # every state array.
@@ -602,7 +498,7 @@ PAIR_KERNELS = [(3, REDUCE_TREE64P)]
 def test_pair_kernel_free_running_bit_exact(ns, kid, mode):
     S, F = 24, 1100  # crosses blockInd 50 / 200 and two 500-frame histogram windows
     x = ns_frames(S, F, stream0=300)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=kid)
+    g = ns.NsBatch(S, policy=1, kernel=kid)
     y = g.analyze_process(x)
     o = OracleNs(S, policy=1, reduce_mode=mode)
     yo = o.run(x, threads=8)
@@ -623,7 +519,7 @@ def test_pair_kernel_edge_cases_policies_and_odd_count(ns, kid, mode):
     x[30:, 3] = 32767.0    # full-scale DC
     x[100:104, 4] = 0.0
     for policy in (0, 1, 2, 3):
-        g = ns.NsBatch(S, policy=policy, streams_per_wave=kid)
+        g = ns.NsBatch(S, policy=policy, kernel=kid)
         y = g.analyze_process(x)
         o = OracleNs(S, policy=policy, reduce_mode=mode)
         assert np.array_equal(y, o.run(x)), policy
@@ -636,11 +532,11 @@ def test_pair_kernel_edge_cases_policies_and_odd_count(ns, kid, mode):
 def test_pair_kernel_golden_int16_split_and_scale(ns, golden, kid, mode):
     pcm = golden["in_i16"]
     F, S, _ = pcm.shape
-    g = ns.NsBatch(S, policy=1, streams_per_wave=kid)
+    g = ns.NsBatch(S, policy=1, kernel=kid)
     y = g.analyze_process(pcm.astype(np.float32))
     rel = rel_l2_per_stream(y, golden["out_f32"])
     check_free_running(rel)
-    g16 = ns.NsBatch(S, policy=1, streams_per_wave=kid)
+    g16 = ns.NsBatch(S, policy=1, kernel=kid)
     y16 = g16.analyze_process_s16(pcm)
     ref = golden["wav_out_i16"][:F * 160].reshape(F, 160)
     d = np.abs(y16[:, 0].astype(np.int32) - ref.astype(np.int32))
@@ -653,7 +549,7 @@ def test_pair_kernel_golden_int16_split_and_scale(ns, golden, kid, mode):
         base = ns_frames(16, F2, stream0=11)
         idx = np.arange(S2) % 16
         x = np.ascontiguousarray(base[:, idx])
-        big = ns.NsBatch(S2, policy=1, streams_per_wave=kid)
+        big = ns.NsBatch(S2, policy=1, kernel=kid)
         big.set_split(parts)
         yb = big.analyze_process(x)
         assert np.isfinite(yb).all()
@@ -668,7 +564,7 @@ def test_pair_then_unfused_continues(ns, kid, mode):
     """Fused one-per-wave (pair layout) steps, then the reference's two-call protocol on the same batch."""
     S, F = 5, 130
     x = ns_frames(S, F, stream0=77)
-    g = ns.NsBatch(S, policy=1, streams_per_wave=kid)
+    g = ns.NsBatch(S, policy=1, kernel=kid)
     o = OracleNs(S, policy=1, reduce_mode=mode)
     assert np.array_equal(g.analyze_process(x[:100]), o.run(x[:100]))
     o.mode = REDUCE_TREE  # separate Analyze / Process launches use the q / q + 64 kernels
@@ -729,7 +625,7 @@ def _hb_frames(S, F, nh):
     return _band_frames(S, F, nh)
 
 
-@pytest.mark.parametrize("fs,nh,spw", [(32000, 1, 2), (48000, 2, 2), (32000, 1, 1)])
+@pytest.mark.parametrize("fs,nh,spw", [(32000, 1, 3), (48000, 2, 3), (32000, 1, 1)])
 def test_high_band_bit_exact_vs_oracle(ns, fs, nh, spw):
     """Low band as before (bit-exact vs the TREE oracle of the kernel in use); the high-band gain is
     computed from that state with the reference's own summation order, so the high-band outputs and
@@ -737,8 +633,8 @@ def test_high_band_bit_exact_vs_oracle(ns, fs, nh, spw):
     saturation."""
     S, F = 6, 560
     low, high = _hb_frames(S, F, nh)
-    g = ns.NsBatch(S, fs=fs, policy=2, streams_per_wave=spw)
-    o = OracleNs(S, policy=2, reduce_mode=REDUCE_TREE32 if spw == 2 else REDUCE_TREE, fs=fs)
+    g = ns.NsBatch(S, fs=fs, policy=2, kernel=spw)
+    o = OracleNs(S, policy=2, reduce_mode=REDUCE_TREE64P if spw == 3 else REDUCE_TREE, fs=fs)
     gl, gh = g.analyze_process_bands(low, high)
     ol, oh = o.run_bands(low, high)
     assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32))
@@ -760,8 +656,8 @@ def test_high_band_golden_and_unfused_protocol(ns):
     gl, gh = g.analyze_process_bands(low, high)
     assert rel_l2_per_stream(gl, gold["out_low"]).max() <= 1e-4
     assert rel_l2_per_stream(gh[:, 0], gold["out_high"]).max() <= 1e-4
-    u = ns.NsBatch(S, fs=32000, policy=2, streams_per_wave=1)
-    f = ns.NsBatch(S, fs=32000, policy=2, streams_per_wave=1)
+    u = ns.NsBatch(S, fs=32000, policy=2, kernel=1)
+    f = ns.NsBatch(S, fs=32000, policy=2, kernel=1)
     fl, fh = f.analyze_process_bands(low[:130], high[:130])
     for k in range(130):
         u.analyze(low[k])

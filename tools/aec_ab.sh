@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of aec_kernels.hip builds on the box: each argument is a flag set for that file
 export TMPDIR=/tmp
-O=gpurun_out/r02_aec_ab; mkdir -p $O
+O=gpurun_out/aec_ab; mkdir -p $O
 for FLAGS in "$@"; do
   export ASP_HIPCC_EXTRA="aec_kernels.hip:$FLAGS"
   touch audiosignalprocess_amd/csrc/aec_kernels.hip

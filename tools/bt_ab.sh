@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of bt_kernels8.hip builds on the box: each argument is a flag set for that file
 export TMPDIR=/tmp
-O=gpurun_out/r02_bt_ab; mkdir -p $O
+O=gpurun_out/bt_ab; mkdir -p $O
 for FLAGS in "$@"; do
   export ASP_HIPCC_EXTRA="bt_kernels8.hip:$FLAGS"
   touch audiosignalprocess_amd/csrc/bt_kernels8.hip

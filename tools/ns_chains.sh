@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: launch chains x graph replay matrix on the default kernel (host enqueue vs GPU step)
 set -u
-O=gpurun_out/r03_chains; mkdir -p $O
+O=gpurun_out/ns_chains; mkdir -p $O
 for split in 1 2 3 4; do
   for g in "" "--graph"; do
     for steps in 20 200; do

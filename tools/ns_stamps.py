@@ -5,9 +5,8 @@ import torch
 from audiosignalprocess_amd.ns import NsBatch
 from audiosignalprocess_amd.synth import ns_frames
 names = ["in+energy", "fftF", "g2loads+magn+log", "sums1", "trackers", "startup", "snr", "flat+diff", "hist", "speechprob", "noiseupd", "gain", "ifft", "gainfac", "ola", "scalars"]
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 for S in (8, 4096):
-    g = NsBatch(S, policy=1, streams_per_wave=K)
+    g = NsBatch(S, policy=1)
     x = torch.from_numpy(ns_frames(S, 260, frame0=0)).cuda()
     y = torch.empty_like(x)
     g.analyze_process_device(x.data_ptr(), y.data_ptr(), 259)

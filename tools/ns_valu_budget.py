@@ -43,7 +43,9 @@ def classify(op):
             return "trans"
         if op.startswith("v_cvt"):
             return "cvt"
-        if re.match(r"v_(add|sub|subrev|mul|fma|fmac|mac|mad|max|min|med3|ldexp|rndne|fract|floor|trunc)_f32", op) or op.startswith("v_fma_f32"):
+        if re.match(r"v_(max|min|med3)_", op):
+            return "cmp"  # v_max_f32 issues at the 2.8-cycle rate
+        if re.match(r"v_(add|sub|subrev|mul|fma|fmac|mac|mad|ldexp|rndne|fract|floor|trunc)_f32", op) or op.startswith("v_fma_f32"):
             return "f32"
         return "int/bit"
     if op.startswith("s_nop"):
@@ -62,6 +64,11 @@ def classify(op):
 
 
 VALU = ("mov", "cndmask", "lane", "permlane", "cmp", "dpp", "pk_f32", "f64", "trans", "cvt", "f32", "int/bit")
+# SIMD cycles per wave64 instruction with four waves per SIMD issuing (tools/probe/issue_probe3.hip,
+# profiles/r03_issue_probe3.txt): plain f32 / integer / move 1.7, packed f32 / f64 / compare / select /
+# lane / DPP / conversion 2.8, transcendental and v_permlane32_swap 5.3
+PRICE = {"mov": 1.73, "f32": 1.73, "int/bit": 1.75, "cndmask": 2.78, "lane": 2.8, "cmp": 2.78, "dpp": 2.78,
+         "pk_f32": 2.78, "f64": 2.77, "cvt": 2.7, "trans": 5.3, "permlane": 5.3}
 
 
 def main():
@@ -110,15 +117,16 @@ def main():
         op = t.split()[0]
         per.setdefault(phase, collections.Counter())[classify(op)] += 1
     cols = list(VALU) + ["s_nop", "salu", "lds", "vmem", "waitcnt", "branch"]
-    print("%-18s %5s | " % ("phase", "VALU") + " ".join("%7s" % c for c in cols))
+    print("%-18s %5s %6s | " % ("phase", "VALU", "cycles") + " ".join("%7s" % c for c in cols))
     tot = collections.Counter()
     for ph, c in per.items():
         v = sum(c[k] for k in VALU)
         name = "prologue" if ph < 0 else "%2d %s" % (ph, NAMES[ph] if ph < len(NAMES) else "")
-        print("%-18s %5d | " % (name, v) + " ".join("%7d" % c[k] for k in cols) + ("   labels: " + ",".join(labels[ph]) if labels[ph] else ""))
+        cyc = sum(c[k] * PRICE[k] for k in VALU)
+        print("%-18s %5d %6.0f | " % (name, v, cyc) + " ".join("%7d" % c[k] for k in cols) + ("   labels: %d" % len(labels[ph]) if labels[ph] else ""))
         tot.update(c)
     v = sum(tot[k] for k in VALU)
-    print("%-18s %5d | " % ("total", v) + " ".join("%7d" % tot[k] for k in cols))
+    print("%-18s %5d %6.0f | " % ("total", v, sum(tot[k] * PRICE[k] for k in VALU)) + " ".join("%7d" % tot[k] for k in cols))
     m = re.search(r"\.vgpr_count:\s+(\d+)", "\n".join(lines[::-1]))
     for l in lines:
         if "vgpr_count" in l or "sgpr_count" in l or "vgpr_spill" in l:
