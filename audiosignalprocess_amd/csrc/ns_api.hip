@@ -456,6 +456,7 @@ struct AspNsBatch {
   int g_kernel = 0;
   bool use_graph = false;  // plain launches measured 4-7 % faster per step than graph replay (round 2)
   unsigned long long* timeline = nullptr;  // diagnostic (AspNsBatch_DebugTimeline): [workgroup][4] real-time stamps
+  double last_enqueue_us = 0.0;  // host time the last TimedSteps call spent enqueuing its launches
   // > 16 kHz: 1 or 2 high bands next to the low band (ns_core.c:1362-1414)
   uint32_t fs = 16000;
   int num_high = 0;
@@ -992,9 +993,7 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
     rc = fused_steps(b, in, out, frames_in_ring, steps);
     if (rc) return rc;
   }
-  if (getenv("ASP_NS_DEBUG_TIMING"))
-    fprintf(stderr, "TimedSteps: host enqueue of %d steps took %.1f us per step\n", steps,
-            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count() / (steps > 0 ? steps : 1));
+  b->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
   HIP_TRY(hipEventSynchronize(b->ev1));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
@@ -1110,6 +1109,14 @@ int AspNsBatch_DebugTimeline(AspNsBatch* b, const float* in_dev, float* out_dev,
   b->timeline = nullptr;
   if (rc) return rc;
   if (e != hipSuccess) return fail(ASP_ERR_HIP, "DebugTimeline", e);
+  return ASP_OK;
+}
+
+// Host time (us) the last AspNsBatch_TimedSteps call spent enqueuing its launches (all steps): the
+// per-rank host budget of a multi-GPU node, printed by bench.py beside the device time.
+int AspNsBatch_LastEnqueueUs(AspNsBatch* b, double* us) {
+  if (!b || !us) return fail(ASP_ERR_PARAM, "LastEnqueueUs: bad argument");
+  *us = b->last_enqueue_us;
   return ASP_OK;
 }
 

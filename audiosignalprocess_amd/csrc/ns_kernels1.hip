@@ -39,12 +39,9 @@ __device__ __forceinline__ unsigned long long ns_cu_tag() {
 
 constexpr int NS3 = 3;  // 2 owned bins + the tail bin 128
 
-#ifndef NS1_MIN_WAVES
-#define NS1_MIN_WAVES 4
-#endif
 
 template <bool IO16>
-__global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __restrict__ state,
+__global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ state,
                                                            int32_t* __restrict__ hist_all,
                                                            const NsTables* __restrict__ T,
                                                            const float* __restrict__ in,
@@ -144,21 +141,9 @@ __global__ __launch_bounds__(256, NS1_MIN_WAVES) void ns_frame1_kernel(float* __
   }
 #define LOADT(dst, f) dst[2] = SC_F(S_TAIL0 + (f));
 #define LOAD3(dst, f) LOADV(dst, f) LOADT(dst, f)
-#ifndef NS1_NT_STORE
-#define NS1_NT_STORE 0
-#endif
-#if NS1_NT_STORE
-#define ROW_STORE2(ptr, a, b) __builtin_nontemporal_store(f32x2{(a), (b)}, reinterpret_cast<f32x2*>(ptr))
-#else
-#define ROW_STORE2(ptr, a, b) *reinterpret_cast<float2*>(ptr) = make_float2((a), (b))
-#endif
-#ifndef NS1_EXP_SKIPSTORE
-#define NS1_EXP_SKIPSTORE 0  // experiment: bit f set = row f is not written back (breaks the recurrence; timing only)
-#endif
 #define STORE3(f, srcv)                                                                        \
   {                                                                                            \
-    if (!((NS1_EXP_SKIPSTORE >> (f)) & 1))                                                     \
-      ROW_STORE2(vec + (f)*kVecStride + 2 * lane, srcv[0], srcv[1]);                           \
+    *reinterpret_cast<float2*>(vec + (f)*kVecStride + 2 * lane) = make_float2(srcv[0], srcv[1]); \
     SC_SET_F(S_TAIL0 + (f), srcv[2]);                                                          \
   }
 

@@ -61,6 +61,7 @@ def load_library():
         "AspNsBatch_SetKernel": [vp, ip],
         "AspNsBatch_Synchronize": [vp],
         "AspNsBatch_TimedSteps": [vp, vp, vp, ip, ip, fp],
+        "AspNsBatch_LastEnqueueUs": [vp, C.POINTER(C.c_double)],
         "AspNsBatch_AnalyzeProcessReplay": [vp, vp, vp, ip, ip],
         "AspNsBatch_SetGraph": [vp, ip],
         "AspNs_CopyCeiling": [C.c_size_t, ip, ip, C.POINTER(C.c_double)],
@@ -243,6 +244,12 @@ class NsBatch:
                                               frames_in_ring, steps, C.byref(ms)),
                "AspNsBatch_TimedSteps")
         return ms.value
+
+    def last_enqueue_us(self):
+        """Host microseconds the last timed_steps() call spent enqueuing its launches."""
+        us = C.c_double()
+        _check(self.lib.AspNsBatch_LastEnqueueUs(self.h, C.byref(us)), "AspNsBatch_LastEnqueueUs")
+        return us.value
 
     def set_stream(self, hip_stream):
         _check(self.lib.AspNsBatch_SetStream(self.h, C.c_void_p(hip_stream)), "AspNsBatch_SetStream")

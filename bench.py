@@ -372,7 +372,7 @@ def ns_measure(args, S, rank, world, local_rank, dist):
     # timed by hipEvents recorded on the launch stream around the K steps (the clock every number of
     # the line uses) and by the host's wall clock around the same region (reported beside it)
     R = args.regions if args.regions > 0 else max(5, min(200, -(-4000 // max(args.steps, 1))))
-    ev, wall = [], []
+    ev, wall, enq = [], [], []
     ns.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, args.steps)   # graph capture of the K-step region
     for _ in range(R):
         barrier()
@@ -381,10 +381,12 @@ def ns_measure(args, S, rank, world, local_rank, dist):
         barrier()
         wall.append(time.perf_counter() - t0)
         ev.append(ev_ms / 1e3)
+        enq.append(ns.last_enqueue_us() / max(args.steps, 1))
     if not torch.isfinite(d_out).all():
         raise SystemExit("non-finite output")
     ns.close()
     del d_in, d_out
+    ns_measure.host_enqueue_us_per_step = float(np.median(enq))  # this rank's host budget per step
     return np.array(ev), np.array(wall), S, primed
 
 
@@ -457,7 +459,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
+        # launched by torch.distributed.run: the same code shape at every N (a one-rank launch rehearses
+        # the RCCL initialisation, the barrier and the MAX over ranks of the N-rank run)
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -512,6 +516,7 @@ def main():
                 "ms_per_step_p90": 1e3 * float(np.percentile(ev, 90)) / K,
                 "ms_per_step_max": 1e3 * float(ev.max()) / K,
                 "wall_ms_per_step_median": 1e3 * float(np.median(wall)) / K,
+                "host_enqueue_us_per_step": ns_measure.host_enqueue_us_per_step,
                 "wall_value_median": frames_per_region / float(np.median(wall)),
             },
             "roofline": {
@@ -552,6 +557,8 @@ def main():
                 "workload": "8192 streams on 1 MI355X (the per-GPU share of BASELINE config 5)",
                 "value": S5 / s5, "unit": "frames/s", "ms_per_step": 1e3 * s5, "steps": a2.steps, "regions": int(len(ev5)),
                 "roofline_frac": ALGO_BYTES_PER_FRAME * S5 / s5 / 1e9 / HBM_PEAK_GBS,
+                # what one rank of the 8-GPU run needs from its host core per step, beside the device time
+                "host_enqueue_us_per_step": ns_measure.host_enqueue_us_per_step,
             }
         if world == 1 and not args.no_secondary:
             line["pcie_inclusive"] = pcie_inclusive(args.streams_per_gpu, local_rank)

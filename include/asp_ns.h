@@ -208,6 +208,8 @@ int AspNsBatch_SetGraph(AspNsBatch* b, int on);
  * that stream.  *elapsed_ms receives the event time for all steps. */
 int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out,
                           int frames_in_ring, int steps, float* elapsed_ms);
+/* Host time (microseconds) the last AspNsBatch_TimedSteps call spent enqueuing its launches. */
+int AspNsBatch_LastEnqueueUs(AspNsBatch* b, double* us);
 
 /* Number of HIP devices visible, or a negative error code. */
 int AspNs_device_count(void);

@@ -29,19 +29,41 @@ def built_lib():
     return LIB
 
 
-def check_free_running(rel, what=""):
+# the reference rebuilt with -O3 -ffp-contract=fast differs from its own -O2 build by up
+# to 3.6e-4 per stream (branch flips in the quantile tracker and the histogram thresholds).  A stream
+# that a test NAMES as such a flip may sit above the 1e-4 bar, never above this cap.
+CHAOS_CAP = 4e-4
+
+
+def check_free_running(rel, what="", known_flips=()):
     """SURVEY 8(c) item (3) for a free-running comparison with the reference: per-stream relative
-    L2 <= 1e-4 at the median and for all but at most one stream in eight, and never beyond 4e-4.
-    The suppressor is chaotic at the 1e-4 level against ITSELF: the reference rebuilt with
-    -O3 -ffp-contract=fast differs from its -O2 build by up to 3.6e-4 per stream (SURVEY 0.4,
-    branch flips in the quantile tracker and the histogram thresholds), so a reduction order other
-    than the reference's sequential one shows the same rare events (stream 6 of the eight-stream
-    fixture flips at frame 844 under the 32-lane and the 64-lane pair orders: 1.4e-4 over the run)."""
+    L2 <= 1e-5 at the median and <= 1e-4 for EVERY stream -- except the streams a caller names in
+    `known_flips` (stream indices with a recorded branch flip), which must stay below CHAOS_CAP.
+    With the device association of round 3 (ASP_NS_REDUCE_TREE64P: bin 128 added after the wave64
+    butterfly) no stream of the committed fixtures needs the allowance: the eight golden streams sit
+    at 1.5e-7 .. 4.9e-7."""
     rel = np.asarray(rel, np.float64)
     assert np.isfinite(rel).all(), (what, rel)
     assert np.median(rel) <= 1e-5, (what, rel)
-    assert (rel > 1e-4).sum() <= max(1, rel.size // 8), (what, rel)
-    assert rel.max() <= 4e-4, (what, rel)
+    for s, r in enumerate(rel):
+        assert r <= (CHAOS_CAP if s in known_flips else 1e-4), (what, s, r, rel)
+
+
+def free_running_report(y, ref, what=""):
+    """Per-stream relative L2 of [F][S][160] outputs against the reference-equal truth `ref`, printed
+    as SURVEY 8(c)(3) asks: median, 95th percentile, max with its stream, and the first frame whose own
+    relative L2 exceeds 1e-4 (-1: none).  Returns (rel, worst_stream, first_divergence_frame)."""
+    rel = rel_l2_per_stream(y, ref)
+    d = np.sqrt(((y - ref).astype(np.float64) ** 2).sum(axis=2))
+    n = np.sqrt((ref.astype(np.float64) ** 2).sum(axis=2))
+    frame_rel = d / np.maximum(n, 1e-30)
+    worst = int(np.argmax(rel))
+    over = np.nonzero((frame_rel > 1e-4).any(axis=1))[0]
+    first = int(over[0]) if over.size else -1
+    share = float((frame_rel > 1e-4).mean())
+    print("%s: per-stream rel-L2 median %.3g  p95 %.3g  max %.3g (stream %d); first frame beyond 1e-4: %d; "
+          "frames beyond 1e-4: %.4f %%" % (what, np.median(rel), np.percentile(rel, 95), rel.max(), worst, first, 100 * share))
+    return rel, worst, first
 
 
 def state_from_bytes(buf):

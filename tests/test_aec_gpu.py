@@ -263,6 +263,46 @@ def test_timed_steps_two_chains_equal_one_chain(aec, monkeypatch):
     assert np.array_equal(outs[1][:, 4:8].view(np.uint32), outs[1][:, 2044:2048].view(np.uint32))
 
 
+def test_timed_steps_equal_run_and_oracle(aec, monkeypatch):
+    """AspAecBatch_TimedSteps (the entry point bench.py times: K steps over device rings, one or two
+    launch chains) against AecBatch.run() on the same frames -- bit for bit, outputs and filter state --
+    and against the oracle with the bars of test_free_running_vs_oracle."""
+    from audiosignalprocess_amd.ns import DeviceBuffer
+
+    S, F, D = 2056, 220, 4
+    far4, near4 = aec_frames(D, F)
+    idx = np.arange(S) % D
+    far = np.ascontiguousarray(far4[:, idx])
+    near = np.ascontiguousarray(near4[:, idx])
+    per = S * 160 * 4
+    df, dn = DeviceBuffer(far.nbytes), DeviceBuffer(near.nbytes)
+    df.upload(far)
+    dn.upload(near)
+    gr = aec.AecBatch(S)
+    out_run = gr.run(far, near)
+    oras = [OracleAec() for _ in range(D)]
+    out_o = np.stack([oras[s].run(far4[:, s], near4[:, s]) for s in range(D)], axis=1)
+    for chains in ("1", "2"):
+        monkeypatch.setenv("ASP_AEC_CHAINS", chains)
+        g = aec.AecBatch(S)
+        do = DeviceBuffer(near.nbytes)
+        g.timed_steps(df.ptr, dn.ptr, do.ptr, 160, F, 100)
+        g.timed_steps(df.ptr + 100 * per, dn.ptr + 100 * per, do.ptr + 100 * per, 160, F - 100, F - 100)
+        g.synchronize()
+        out_t = do.download(near.shape)
+        assert np.array_equal(_bits(out_t), _bits(out_run)), chains
+        for s in (0, 1, 1027, 1028, S - 1):
+            rep = _state_report(g.export_state(s), gr.export_state(s))
+            assert all(v[0] for v in rep.values()), (chains, s, {k: v for k, v in rep.items() if not v[0]})
+            st_o, _ = oras[int(idx[s])].export()
+            rep = _state_report(g.export_state(s), st_o)
+            bad = [k for k in LINEAR_FIELDS if not rep[k][0]]
+            assert bad == [], (chains, s, {k: rep[k] for k in bad})
+            assert _rel_l2(out_t[:, s], out_o[:, idx[s]]) <= 1e-5, (chains, s)
+        g.close()
+    gr.close()
+
+
 def test_wav_driver_end_to_end(aec, aec_golden, tmp_path):
     """drivers/test_aec_module (the reference's test_aec_module.cpp loop in C over WebRtcAec_*):
     mic.wav + speaker.wav -> result.wav equals the reference's float output rounded by
