@@ -97,7 +97,8 @@ void fill_size(BtSize* S, int n, float* hann, float* tw_f, float* tw_i, float* s
     }
 }
 
-void build_bt_tables(BtTables* T) {
+// false: the inverse twiddles are not the exact conjugates bt_kernels8.hip assumes (an internal error)
+bool build_bt_tables(BtTables* T) {
   memset(T, 0, sizeof *T);
   fill_size(&T->s256, 256, T->hann256, T->tw256_f, T->tw256_i, T->sup256_f, T->sup256_i);
   fill_size(&T->s1024, 1024, T->hann1024, T->tw1024_f, T->tw1024_i, T->sup1024_f, T->sup1024_i);
@@ -112,9 +113,10 @@ void build_bt_tables(BtTables* T) {
   }
   // bt_kernels8.hip derives the inverse twiddles from the forward tables: they must be exact conjugates
   for (int i = 0; i < 512; ++i)
-    if (T->tw1024_i[2 * i] != T->tw1024_f[2 * i] || T->tw1024_i[2 * i + 1] != -T->tw1024_f[2 * i + 1]) abort();
+    if (T->tw1024_i[2 * i] != T->tw1024_f[2 * i] || T->tw1024_i[2 * i + 1] != -T->tw1024_f[2 * i + 1]) return false;
   for (int i = 0; i < 256; ++i)
-    if (T->sup1024_i[2 * i] != T->sup1024_f[2 * i] || T->sup1024_i[2 * i + 1] != -T->sup1024_f[2 * i + 1]) abort();
+    if (T->sup1024_i[2 * i] != T->sup1024_f[2 * i] || T->sup1024_i[2 * i + 1] != -T->sup1024_f[2 * i + 1]) return false;
+  return true;
 }
 
 // Tables of a window other than 256 / 1024 samples (bt_macroblock_any_kernel): one device block per batch.
@@ -197,7 +199,11 @@ int bt_tables(int device, BtTables** out) {
   std::lock_guard<std::mutex> lk(g_bt_mu);
   if (!g_bt_dev[device]) {
     BtTables* host = (BtTables*)malloc(sizeof(BtTables));
-    build_bt_tables(host);
+    if (!host) return bt_fail(ASP_ERR_STATE, "BT tables: out of host memory");
+    if (!build_bt_tables(host)) {
+      free(host);
+      return bt_fail(ASP_ERR_STATE, "BT tables: inverse twiddles are not the conjugates of the forward ones");
+    }
     BtTables* dev = nullptr;
     hipError_t e = hipMalloc((void**)&dev, sizeof(BtTables));
     if (e == hipSuccess) e = hipMemcpy(dev, host, sizeof(BtTables), hipMemcpyHostToDevice);
@@ -326,7 +332,13 @@ static int bt_run(AspBtBatch* b, const float* in, float* out, int frames, int th
   const int n = frames * b->half;
   const float* din = in;
   float* dout = out;
-  if (frames == 0) return ASP_OK;
+  if (frames == 0) {
+    // a flush with no pending hop emits nothing but still consumes the overlap tail, as the reference does
+    // (.c:656-659: outbuf is shifted and cleared whatever have_nblk_time is)
+    if (!threshold)
+      BT_TRY(hipMemset2DAsync(b->state + b->off_out, (size_t)b->state_floats * 4, 0, (size_t)b->half * 4, (size_t)b->S, b->stream));
+    return ASP_OK;
+  }
   if (mem == ASP_MEM_HOST) {
     BT_TRY(hipMemcpyAsync(b->stage_in, in, (size_t)b->S * n * 4, hipMemcpyHostToDevice, b->stream));
     din = b->stage_in;
@@ -453,14 +465,14 @@ static int bt_fft_seam(const float* src, float* dst, int n, int count, int inver
   if (rc) return rc;
   const size_t tb = (size_t)count * n * 4, fb = (size_t)count * (n + 2) * 4;
   float *ds = nullptr, *dd = nullptr;
-  BT_TRY(hipMalloc((void**)&ds, inverse ? fb : tb));
-  BT_TRY(hipMalloc((void**)&dd, inverse ? tb : fb));
-  hipError_t e = hipMemcpy(ds, src, inverse ? fb : tb, hipMemcpyHostToDevice);
+  hipError_t e = hipMalloc((void**)&ds, inverse ? fb : tb);  // every failure below frees ds, dd and any_block
+  if (e == hipSuccess) e = hipMalloc((void**)&dd, inverse ? tb : fb);
+  if (e == hipSuccess) e = hipMemcpy(ds, src, inverse ? fb : tb, hipMemcpyHostToDevice);
   if (e == hipSuccess)
     e = any ? launch_bt_fftr_any(A, ds, dd, count, inverse, nullptr) : launch_bt_fftr(n, ds, dd, count, inverse, T, nullptr);
   if (e == hipSuccess) e = hipMemcpy(dst, dd, inverse ? tb : fb, hipMemcpyDeviceToHost);
-  (void)hipFree(ds);
-  (void)hipFree(dd);
+  if (ds) (void)hipFree(ds);
+  if (dd) (void)hipFree(dd);
   if (any_block) (void)hipFree(any_block);
   if (e != hipSuccess) return bt_fail(ASP_ERR_HIP, "kiss_fftr seam", e);
   return ASP_OK;
@@ -565,18 +577,20 @@ int32_t blockThreshold_output_int16(MarsBlockThreshold_t* h, int16_t* out, int32
 int32_t blockThreshold_flush_float(MarsBlockThreshold_t* h, float* out, int32_t out_len) {
   const int32_t out_size = h->have_nblk_time * h->half_win_size;
   if (out_len < out_size) return -1;
-  if (out_size == 0) return 0;
-  if (AspBtBatch_Flush(h->batch, h->pending, h->have_nblk_time, out, ASP_MEM_HOST) != ASP_OK) abort();
+  // with no pending hop the reference still shifts the overlap tail out of outbuf and clears it
+  // (.c:656-659): the device call with hops = 0 does the same to the stream's tail
+  float none = 0.f;
+  if (AspBtBatch_Flush(h->batch, h->pending, h->have_nblk_time, out_size ? out : &none, ASP_MEM_HOST) != ASP_OK)
+    return -1;
   return out_size;
 }
 
 int32_t blockThreshold_flush_int16(MarsBlockThreshold_t* h, int16_t* out, int32_t out_len) {
   const int32_t out_size = h->have_nblk_time * h->half_win_size;
   if (out_len < out_size) return -1;
-  if (out_size == 0) return 0;
-  std::vector<float> tmp((size_t)out_size);
+  std::vector<float> tmp((size_t)out_size + 1);
   if (AspBtBatch_Flush(h->batch, h->pending, h->have_nblk_time, tmp.data(), ASP_MEM_HOST) != ASP_OK)
-    abort();
+    return -1;
   for (int32_t i = 0; i < out_size; i++) out[i] = bt_float_to_s16(tmp[i]);
   return out_size;
 }

@@ -2,7 +2,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BT_HD __host__ __device__
 #else
 #define BT_HD

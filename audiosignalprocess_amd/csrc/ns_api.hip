@@ -23,7 +23,7 @@ using namespace aspns;
 
 namespace aspns {
 hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables* T,
-                           const float* in, float* out, int num_streams, hipStream_t s);
+                           const float* in, float* out, int num_streams, hipStream_t s, bool g8 = false);
 hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
                             unsigned long long* stamps = nullptr, int stamp_mode = 0);
@@ -35,7 +35,7 @@ hipError_t launch_ns_hb_apply(const float* state, float* hb_tail, const int32_t*
                               int num_streams, int num_high, int paired, hipStream_t s);
 hipError_t launch_ns_set_policy(float* state, int num_streams, int mode, float overdrive,
                                 float denoiseBound, int gainmap, hipStream_t s);
-hipError_t launch_rdft256(float* data, int count, int isgn, const NsTables* T, hipStream_t s);
+hipError_t launch_rdft256(float* data, int count, int isgn, const NsTables* T, hipStream_t s, int n = 256);
 hipError_t launch_debug_eval(int fn, float* data, size_t n, const NsTables* T, hipStream_t s);
 hipError_t launch_debug_compare(int fn_a, int fn_b, unsigned start, unsigned count,
                                 unsigned* n_bad, unsigned* bad_bits, float param,
@@ -76,6 +76,110 @@ float window_entry(int i) {
   double s = sin(M_PI * (double)(i < 96 ? i : 256 - i) / 192.0);
   snprintf(buf, sizeof buf, "%.8f", s);
   return (float)strtod(buf, NULL);
+}
+
+// kBlocks80w128 (ns/windows_private.h:64-91): sin(pi*i/96) over the 48-sample ramps, same text round trip.
+float window8_entry(int i) {
+  if (i >= 48 && i <= 80) return 1.0f;
+  char buf[32];
+  double s = sin(M_PI * (double)(i < 48 ? i : 128 - i) / 96.0);
+  snprintf(buf, sizeof buf, "%.8f", s);
+  return (float)strtod(buf, NULL);
+}
+
+// The 8 kHz geometry: tables of WebRtc_rdft(128) -- makewt(32), makect(32) (fft4g.c:642-690) -- as the
+// per-lane twiddles of the 64-point transform of ns_kernels.hip (passes 1 and 2; pass 3 has none), the
+// real-split factors, kBlocks80w128 and the start-up sums over bins 5..64.
+void build_tables_8k(NsTables* T) {
+  float w[32], c[32], tmp[32];
+  const int nw = 32, nwh = 16;
+  float delta = (float)atan((double)1.0f) / nwh;
+  tmp[0] = 1;
+  tmp[1] = 0;
+  tmp[nwh] = (float)cos((double)(delta * nwh));
+  tmp[nwh + 1] = tmp[nwh];
+  for (int j = 2; j < nwh; j += 2) {
+    float x = (float)cos((double)(delta * j));
+    float y = (float)sin((double)(delta * j));
+    tmp[j] = x;
+    tmp[j + 1] = y;
+    tmp[nw - j] = y;
+    tmp[nw - j + 1] = x;
+  }
+  for (int j = 0; j < 16; ++j) {
+    unsigned r = bitrev((unsigned)j, 4);
+    w[2 * j] = tmp[2 * r];
+    w[2 * j + 1] = tmp[2 * r + 1];
+  }
+  c[0] = (float)cos((double)(delta * nwh));
+  c[nwh] = 0.5f * c[0];
+  for (int j = 1; j < nwh; j++) {
+    c[j] = 0.5f * (float)cos((double)(delta * j));
+    c[nw - j] = 0.5f * (float)sin((double)(delta * j));
+  }
+  for (int i = 0; i < 128; ++i) T->window8[i] = window8_entry(i);
+  for (int pass = 0; pass < 2; ++pass)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int b = (lane >> 1) & 15, h = lane & 1;
+      const int B = pass == 0 ? b : b >> 2;  // block index: same twiddle cases as the 128-point passes
+      float tAr = 1.f, tAi = 0.f, tBr = 1.f, tBi = 0.f;
+      bool diag = false;
+      if (B == 1) {
+        if (h == 0) {
+          tBr = 0.f;
+          tBi = 1.f;
+        } else {
+          diag = true;
+          tAr = w[2];
+        }
+      } else if (B >= 2) {
+        const int u = B >> 1;
+        const float wk2r = w[2 * u], wk2i = w[2 * u + 1];
+        float w1r, w1i, w3r, w3i, w2r, w2i;
+        if ((B & 1) == 0) {
+          w1r = w[4 * u];
+          w1i = w[4 * u + 1];
+          w3r = w1r - 2 * wk2i * w1i;
+          w3i = 2 * wk2i * w1r - w1i;
+          w2r = wk2r;
+          w2i = wk2i;
+        } else {
+          w1r = w[4 * u + 2];
+          w1i = w[4 * u + 3];
+          w3r = w1r - 2 * wk2r * w1i;
+          w3i = 2 * wk2r * w1r - w1i;
+          w2r = -wk2i;
+          w2i = wk2r;
+        }
+        if (h == 0) {
+          tBr = w2r;
+          tBi = w2i;
+        } else {
+          tAr = w1r;
+          tAi = w1i;
+          tBr = w3r;
+          tBi = w3i;
+        }
+      }
+      T->tw8[pass][lane][0] = tAr;
+      T->tw8[pass][lane][1] = tAi;
+      T->tw8[pass][lane][2] = tBr;
+      T->tw8[pass][lane][3] = tBi;
+      if (diag) T->diag8[lane] |= 1 << pass;
+    }
+  for (int lane = 0; lane < 64; ++lane) {
+    const int p = lane < 32 ? lane : 64 - lane;
+    T->c8a[lane] = (lane == 0 || lane == 32) ? 0.f : c[p];
+    T->c8b[lane] = (lane == 0 || lane == 32) ? 0.f : c[32 - p];
+  }
+  float sli = 0.f, slis = 0.f;  // ns_core.c:1094-1095 with magnLen 65, sequential over i = 5..64
+  for (int i = 5; i < 65; ++i) {
+    const float li = (float)log((double)(float)i);
+    sli += li;
+    slis += li * li;
+  }
+  T->sum_log_i8 = sli;
+  T->sum_log_i_square8 = slis;
 }
 
 // NOTE: this file is C++, where cos(float) would resolve to the float overload;
@@ -217,6 +321,7 @@ void build_tables(NsTables* T) {
       T->spl[lane][t][0] = wkr;
       T->spl[lane][t][1] = wki;
     }
+  build_tables_8k(T);
 }
 
 constexpr int kMaxDevices = 64;
@@ -275,13 +380,22 @@ inline int32_t f2i(float f) {
   return v;
 }
 
-void vec_put(float* blk, int f, const float* src) {
+// geometry of a stream (ns_core.c:89-98): 16 / 32 / 48 kHz 160 / 256 / 129, 8 kHz 80 / 128 / 65
+inline int geo_block(int fs) { return fs == 8000 ? 80 : kBlockL; }
+inline int geo_anal(int fs) { return fs == 8000 ? 128 : kAnal; }
+inline int geo_bins(int fs) { return geo_anal(fs) / 2 + 1; }
+
+// a per-bin array <-> its state row: bins 0 .. nb - 2 at their row positions, the last bin (128, or 64
+// at 8 kHz) in the row's scalar slot
+void vec_put(float* blk, int f, const float* src, int nb = kBins) {
   float* d = blk + kOffVec + f * kVecStride;
   for (int i = 128; i < kVecStride; ++i) d[i] = 0.f;
-  for (int i = 0; i < kBins; ++i) blk[row_dword(f, i)] = src[i];
+  for (int i = 0; i < nb - 1; ++i) blk[row_dword(f, i)] = src[i];
+  blk[row_dword(f, 128)] = src[nb - 1];
 }
-void vec_get(const float* blk, int f, float* dst) {
-  for (int i = 0; i < kBins; ++i) dst[i] = blk[row_dword(f, i)];
+void vec_get(const float* blk, int f, float* dst, int nb = kBins) {
+  for (int i = 0; i < nb - 1; ++i) dst[i] = blk[row_dword(f, i)];
+  dst[nb - 1] = blk[row_dword(f, 128)];
 }
 
 void pack_stream(const AspNsState* s, float* blk, int32_t* hist) {
@@ -307,23 +421,24 @@ void pack_stream(const AspNsState* s, float* blk, int32_t* hist) {
   for (int i = 0; i < 7; ++i) sc[S_PMP0 + i] = s->priorModelPars[i];
   for (int i = 0; i < 7; ++i) sc[S_FD0 + i] = s->featureData[i];
   sc[S_FS] = i2f(s->fs);
-  memcpy(blk + kOffAnaHist, s->analyzeBuf + kBlockL, sizeof(float) * kCarry);
-  memcpy(blk + kOffDataHist, s->dataBuf + kBlockL, sizeof(float) * kCarry);
-  memcpy(blk + kOffSynt, s->syntBuf, sizeof(float) * kCarry);
-  for (int k = 0; k < 3; ++k) {
-    vec_put(blk, V_LQ0 + k, s->lquantile + k * kBins);
-    vec_put(blk, V_DEN0 + k, s->density + k * kBins);
+  const int bl = geo_block(s->fs), carry = geo_anal(s->fs) - bl, nb = geo_bins(s->fs);
+  memcpy(blk + kOffAnaHist, s->analyzeBuf + bl, sizeof(float) * carry);
+  memcpy(blk + kOffDataHist, s->dataBuf + bl, sizeof(float) * carry);
+  memcpy(blk + kOffSynt, s->syntBuf, sizeof(float) * carry);
+  for (int k = 0; k < 3; ++k) {  // tracker k's bins start at k * magnLen (ns_core.c:224)
+    vec_put(blk, V_LQ0 + k, s->lquantile + k * nb, nb);
+    vec_put(blk, V_DEN0 + k, s->density + k * nb, nb);
   }
-  vec_put(blk, V_QUANT, s->quantile);
-  vec_put(blk, V_SMOOTH, s->smooth);
-  vec_put(blk, V_NOISEPREV, s->noisePrev);
-  vec_put(blk, V_MAGNPREV_A, s->magnPrevAnalyze);
-  vec_put(blk, V_LOGLRT, s->logLrtTimeAvg);
-  vec_put(blk, V_AVGPAUSE, s->magnAvgPause);
-  vec_put(blk, V_NOISE, s->noise);
-  vec_put(blk, V_MAGNPREV_P, s->magnPrevProcess);
-  vec_put(blk, V_INITMAGN, s->initMagnEst);
-  vec_put(blk, V_PARAMNOISE, s->parametricNoise);
+  vec_put(blk, V_QUANT, s->quantile, nb);
+  vec_put(blk, V_SMOOTH, s->smooth, nb);
+  vec_put(blk, V_NOISEPREV, s->noisePrev, nb);
+  vec_put(blk, V_MAGNPREV_A, s->magnPrevAnalyze, nb);
+  vec_put(blk, V_LOGLRT, s->logLrtTimeAvg, nb);
+  vec_put(blk, V_AVGPAUSE, s->magnAvgPause, nb);
+  vec_put(blk, V_NOISE, s->noise, nb);
+  vec_put(blk, V_MAGNPREV_P, s->magnPrevProcess, nb);
+  vec_put(blk, V_INITMAGN, s->initMagnEst, nb);
+  vec_put(blk, V_PARAMNOISE, s->parametricNoise, nb);
   memset(hist, 0, sizeof(int32_t) * kHistDwords);
   memcpy(hist, s->histLrt, sizeof(int32_t) * kHist);
   memcpy(hist + kHistStride, s->histSpecFlat, sizeof(int32_t) * kHist);
@@ -353,25 +468,31 @@ void unpack_stream(const float* blk, const int32_t* hist, bool paired, AspNsStat
   for (int i = 0; i < 7; ++i) s->priorModelPars[i] = sc[S_PMP0 + i];
   for (int i = 0; i < 7; ++i) s->featureData[i] = sc[S_FD0 + i];
   s->fs = f2i(sc[S_FS]);
-  // only the live 96 samples of each sliding buffer exist on the device
-  memcpy(s->analyzeBuf + kBlockL, blk + kOffAnaHist, sizeof(float) * kCarry);
-  memcpy(s->dataBuf + kBlockL, blk + (paired ? kOffAnaHist : kOffDataHist),
-         sizeof(float) * kCarry);
-  memcpy(s->syntBuf, blk + kOffSynt, sizeof(float) * kCarry);
-  for (int k = 0; k < 3; ++k) {
-    vec_get(blk, V_LQ0 + k, s->lquantile + k * kBins);
-    vec_get(blk, V_DEN0 + k, s->density + k * kBins);
+  // only the live 96 (8 kHz: 48) samples of each sliding buffer exist on the device
+  const int bl = geo_block(s->fs), carry = geo_anal(s->fs) - bl, nb = geo_bins(s->fs);
+  memcpy(s->analyzeBuf + bl, blk + kOffAnaHist, sizeof(float) * carry);
+  memcpy(s->dataBuf + bl, blk + (paired ? kOffAnaHist : kOffDataHist), sizeof(float) * carry);
+  memcpy(s->syntBuf, blk + kOffSynt, sizeof(float) * carry);
+  if (nb != kBins) {
+    // the reference's Init fills these arrays to their full length (ns_core.c:116-131, :152-155) and
+    // an 8 kHz stream never touches the part beyond its 3 x 65 / 65 bins
+    for (int i = 0; i < ASP_NS_SIMULT * kBins; ++i) s->lquantile[i] = 8.f, s->density[i] = 0.3f;
+    for (int i = 0; i < kBins; ++i) s->smooth[i] = 1.f, s->logLrtTimeAvg[i] = (float)0.5;
   }
-  vec_get(blk, V_QUANT, s->quantile);
-  vec_get(blk, V_SMOOTH, s->smooth);
-  vec_get(blk, V_NOISEPREV, s->noisePrev);
-  vec_get(blk, V_MAGNPREV_A, s->magnPrevAnalyze);
-  vec_get(blk, V_LOGLRT, s->logLrtTimeAvg);
-  vec_get(blk, V_AVGPAUSE, s->magnAvgPause);
-  vec_get(blk, paired ? V_NOISEPREV : V_NOISE, s->noise);
-  vec_get(blk, paired ? V_MAGNPREV_A : V_MAGNPREV_P, s->magnPrevProcess);
-  vec_get(blk, V_INITMAGN, s->initMagnEst);
-  vec_get(blk, V_PARAMNOISE, s->parametricNoise);
+  for (int k = 0; k < 3; ++k) {
+    vec_get(blk, V_LQ0 + k, s->lquantile + k * nb, nb);
+    vec_get(blk, V_DEN0 + k, s->density + k * nb, nb);
+  }
+  vec_get(blk, V_QUANT, s->quantile, nb);
+  vec_get(blk, V_SMOOTH, s->smooth, nb);
+  vec_get(blk, V_NOISEPREV, s->noisePrev, nb);
+  vec_get(blk, V_MAGNPREV_A, s->magnPrevAnalyze, nb);
+  vec_get(blk, V_LOGLRT, s->logLrtTimeAvg, nb);
+  vec_get(blk, V_AVGPAUSE, s->magnAvgPause, nb);
+  vec_get(blk, paired ? V_NOISEPREV : V_NOISE, s->noise, nb);
+  vec_get(blk, paired ? V_MAGNPREV_A : V_MAGNPREV_P, s->magnPrevProcess, nb);
+  vec_get(blk, V_INITMAGN, s->initMagnEst, nb);
+  vec_get(blk, V_PARAMNOISE, s->parametricNoise, nb);
   memcpy(s->histLrt, hist, sizeof(int32_t) * kHist);
   memcpy(s->histSpecFlat, hist + kHistStride, sizeof(int32_t) * kHist);
   memcpy(s->histSpecDiff, hist + 2 * kHistStride, sizeof(int32_t) * kHist);
@@ -411,7 +532,8 @@ void init_state(AspNsState* s, uint32_t fs) {
 }
 
 bool state_is_paired(const AspNsState* s) {
-  return memcmp(s->analyzeBuf + kBlockL, s->dataBuf + kBlockL, sizeof(float) * kCarry) == 0 &&
+  const int bl = geo_block(s->fs), carry = geo_anal(s->fs) - bl;
+  return memcmp(s->analyzeBuf + bl, s->dataBuf + bl, sizeof(float) * carry) == 0 &&
          memcmp(s->magnPrevAnalyze, s->magnPrevProcess, sizeof s->magnPrevAnalyze) == 0 &&
          memcmp(s->noise, s->noisePrev, sizeof s->noise) == 0;
 }
@@ -459,6 +581,7 @@ struct AspNsBatch {
   double last_enqueue_us = 0.0;  // host time the last TimedSteps call spent enqueuing its launches
   // > 16 kHz: 1 or 2 high bands next to the low band (ns_core.c:1362-1414)
   uint32_t fs = 16000;
+  int block = kBlockL;  // samples per frame and stream: 160, or 80 at 8 kHz (ns_core.c:89-98)
   int num_high = 0;
   float* hb_tail = nullptr;    // [S][2][96]: dataBufHB[b][160..255]
   int32_t* hb_live = nullptr;  // [S]: energy1 != 0 of the frame being processed
@@ -473,7 +596,7 @@ int ensure_stage(AspNsBatch* b, size_t frames) {
   if (b->stage_out) (void)hipFree(b->stage_out);
   b->stage_in = b->stage_out = nullptr;
   b->stage_frames = 0;
-  const size_t bytes = frames * (size_t)b->S * kBlockL * sizeof(float);
+  const size_t bytes = frames * (size_t)b->S * b->block * sizeof(float);
   HIP_TRY(hipMalloc((void**)&b->stage_in, bytes));
   HIP_TRY(hipMalloc((void**)&b->stage_out, bytes));
   b->stage_frames = frames;
@@ -577,12 +700,21 @@ int AspNsBatch_num_streams(const AspNsBatch* b) { return b ? b->S : ASP_ERR_PARA
 
 int AspNsBatch_Init(AspNsBatch* b, uint32_t fs) {
   if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
-  // ns_core.c:82-86 accepts 8/16/32/48 kHz; the 160 / 256 / 129 geometry (16, 32, 48 kHz) is built
-  if (fs != 16000 && fs != 32000 && fs != 48000)
-    return fail(ASP_ERR_PARAM, "AspNsBatch_Init: fs must be 16000, 32000 or 48000");
+  // ns_core.c:82-86: 8 kHz (80 / 128 / 65: ns_kernels.hip's G8 instantiation serves every entry point)
+  // and 16 / 32 / 48 kHz (160 / 256 / 129)
+  if (fs != 8000 && fs != 16000 && fs != 32000 && fs != 48000)
+    return fail(ASP_ERR_PARAM, "AspNsBatch_Init: fs must be 8000, 16000, 32000 or 48000");
   HIP_TRY(hipSetDevice(b->device));
+  if (b->fs != fs && b->stage_frames) {  // the staging buffers are sized in frames of the old length
+    if (b->stream) HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->stage_in) (void)hipFree(b->stage_in);
+    if (b->stage_out) (void)hipFree(b->stage_out);
+    b->stage_in = b->stage_out = nullptr;
+    b->stage_frames = 0;
+  }
   b->fs = fs;
-  b->num_high = (int)(fs / 16000) - 1;
+  b->block = geo_block((int)fs);
+  b->num_high = fs >= 32000 ? (int)(fs / 16000) - 1 : 0;
   if (b->num_high > 0) {
     if (!b->hb_tail) HIP_TRY(hipMalloc((void**)&b->hb_tail, (size_t)b->S * 2 * kCarry * sizeof(float)));
     if (!b->hb_live) HIP_TRY(hipMalloc((void**)&b->hb_live, (size_t)b->S * sizeof(int32_t)));
@@ -630,12 +762,13 @@ int AspNsBatch_set_policy(AspNsBatch* b, int mode) {
 // One fused paired frame step over streams [s0, s0 + n) of the batch.
 static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float* dout, int s0, int n,
                                hipStream_t st) {
-  const size_t sper = io16 ? kBlockL / 2 : kBlockL;  // one stream's frame in float units
+  const size_t sper = io16 ? b->block / 2 : b->block;  // one stream's frame in float units
   float* state = b->state + (size_t)s0 * kStreamDwords;
   int32_t* hist = b->hist + (size_t)s0 * kHistDwords;
   const float* in = din + (size_t)s0 * sper;
   float* out = dout + (size_t)s0 * sper;
-  if (b->kernel == 1) return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st);
+  if (b->kernel == 1 || b->fs == 8000)  // the pair-layout kernel is built for the 129-bin geometry only
+    return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st, b->fs == 8000);
   // timeline diagnostic: this sub-launch's first workgroup's slot, stamp mode 1
   unsigned long long* tl = b->timeline ? b->timeline + (size_t)(s0 / 4) * 4 : nullptr;
   return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st, tl, tl ? 1 : 0);
@@ -653,7 +786,7 @@ static int chain_parts(const AspNsBatch* b, int base[5]) {
 static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, int steps,
                        bool io16 = false) {
   // offsets below are in float units; int16 frames are half as wide
-  const size_t per = (size_t)b->S * kBlockL / (io16 ? 2 : 1);
+  const size_t per = (size_t)b->S * b->block / (io16 ? 2 : 1);
 
   int base[5];
   const int parts = chain_parts(b, base);
@@ -704,7 +837,7 @@ static int ensure_graph(AspNsBatch* b, const float* din, float* dout, int ring, 
   drop_graph(b);
   int base[5];
   const int parts = chain_parts(b, base);
-  const size_t per = (size_t)b->S * kBlockL / (io16 ? 2 : 1);
+  const size_t per = (size_t)b->S * b->block / (io16 ? 2 : 1);
   for (int p = 0; p < parts; ++p) {
     hipStream_t st = p == 0 ? b->stream : b->side[p - 1];
     HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -755,7 +888,8 @@ static int launch_graphs(AspNsBatch* b) {
 
 static int run_frames(AspNsBatch* b, int kmode, const float* in, float* out, int num_frames,
                       int mem) {
-  const size_t per = (size_t)b->S * kBlockL;
+  const size_t per = (size_t)b->S * b->block;
+  const bool g8 = b->fs == 8000;
   const float* din = in;
   float* dout = out;
   if (mem == ASP_MEM_HOST) {
@@ -776,10 +910,10 @@ static int run_frames(AspNsBatch* b, int kmode, const float* in, float* out, int
     const float* fi = din + per * f;
     float* fo = dout ? dout + per * f : nullptr;
     if (kmode == 2 && !b->paired) {
-      HIP_TRY(launch_ns_frame(0, b->state, b->hist, b->tables, fi, fo, b->S, b->stream));
-      HIP_TRY(launch_ns_frame(1, b->state, b->hist, b->tables, fi, fo, b->S, b->stream));
+      HIP_TRY(launch_ns_frame(0, b->state, b->hist, b->tables, fi, fo, b->S, b->stream, g8));
+      HIP_TRY(launch_ns_frame(1, b->state, b->hist, b->tables, fi, fo, b->S, b->stream, g8));
     } else {
-      HIP_TRY(launch_ns_frame(kmode, b->state, b->hist, b->tables, fi, fo, b->S, b->stream));
+      HIP_TRY(launch_ns_frame(kmode, b->state, b->hist, b->tables, fi, fo, b->S, b->stream, g8));
     }
   }
   if (mem == ASP_MEM_HOST) {
@@ -932,7 +1066,7 @@ int AspNsBatch_AnalyzeProcessS16(AspNsBatch* b, const int16_t* in, int16_t* out,
   if (b->num_high > 0)
     return fail(ASP_ERR_STATE, "AnalyzeProcessS16: one-band entry point on a batch initialised at 32 / 48 kHz");
   if (num_frames == 0) return ASP_OK;
-  const size_t bytes = (size_t)b->S * kBlockL * sizeof(int16_t) * (size_t)num_frames;
+  const size_t bytes = (size_t)b->S * b->block * sizeof(int16_t) * (size_t)num_frames;
   const float* din = reinterpret_cast<const float*>(in);
   float* dout = reinterpret_cast<float*>(out);
   if (mem == ASP_MEM_HOST) {
@@ -1021,11 +1155,11 @@ int AspNsBatch_ImportState(AspNsBatch* b, int stream, const AspNsState* in) {
   int rc = check(b);
   if (rc) return rc;
   if (!in || stream < 0 || stream >= b->S) return fail(ASP_ERR_PARAM, "ImportState: bad argument");
-  if (in->fs != 16000 && in->fs != 32000 && in->fs != 48000)
-    return fail(ASP_ERR_PARAM, "ImportState: fs must be 16000, 32000 or 48000");
-  for (int i = kCarry; i < kAnal; ++i)
+  if ((uint32_t)in->fs != b->fs)
+    return fail(ASP_ERR_PARAM, "ImportState: the state's fs differs from the batch's (AspNsBatch_Init)");
+  for (int i = geo_anal(in->fs) - geo_block(in->fs); i < geo_anal(in->fs); ++i)
     if (in->syntBuf[i] != 0.f)
-      return fail(ASP_ERR_PARAM, "ImportState: syntBuf[96..255] must be zero (between frames)");
+      return fail(ASP_ERR_PARAM, "ImportState: syntBuf beyond the carried overlap must be zero (between frames)");
   if (!state_is_paired(in)) {
     rc = ensure_unpaired(b);
     if (rc) return rc;
@@ -1071,7 +1205,7 @@ int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
   DeviceScope dev_scope_;
   int rc = check(b);
   if (rc) return rc;
-  if (!in_dev || !out_dev || !stamps16 || !b->paired || b->kernel == 1)
+  if (!in_dev || !out_dev || !stamps16 || !b->paired || b->kernel == 1 || b->fs == 8000)
     return fail(ASP_ERR_PARAM, "DebugStamps: bad argument (paired state, pair-layout kernel)");
   unsigned long long* d = nullptr;
   HIP_TRY(hipMalloc((void**)&d, 16 * sizeof(unsigned long long)));
@@ -1094,7 +1228,7 @@ int AspNsBatch_DebugTimeline(AspNsBatch* b, const float* in_dev, float* out_dev,
   int rc = check(b);
   if (rc) return rc;
   if (!in_dev || !out_dev || !out || steps <= 0 || frames_in_ring <= 0 || !b->paired || b->kernel == 1 ||
-      num_workgroups != (b->S + 3) / 4 || (b->S & 3))
+      b->fs == 8000 || num_workgroups != (b->S + 3) / 4 || (b->S & 3))
     return fail(ASP_ERR_PARAM, "DebugTimeline: bad argument (pair-layout kernel, stream count a multiple of 4)");
   const size_t bytes = (size_t)num_workgroups * 4 * sizeof(unsigned long long);
   HIP_TRY(hipMalloc((void**)&b->timeline, bytes));
@@ -1227,27 +1361,37 @@ int AspNs_MemcpyD2H(void* dst, const void* src, size_t bytes) {
   return ASP_OK;
 }
 
-int AspNs_rdft256_batch(float* data, int count, int isgn, int mem, int device) {
-  if (!data || count <= 0) return fail(ASP_ERR_PARAM, "rdft256_batch: bad argument");
+static int rdft_batch(float* data, int count, int isgn, int mem, int device, int n) {
+  if (!data || count <= 0) return fail(ASP_ERR_PARAM, "rdft batch: bad argument");
   int rc = select_device(device);
   if (rc) return rc;
   NsTables* T = nullptr;
   rc = device_tables(device, &T);
   if (rc) return rc;
   float* d = data;
-  const size_t bytes = (size_t)count * kAnal * sizeof(float);
+  const size_t bytes = (size_t)count * n * sizeof(float);
   if (mem == ASP_MEM_HOST) {
     HIP_TRY(hipMalloc((void**)&d, bytes));
-    HIP_TRY(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice));
+    hipError_t e0 = hipMemcpy(d, data, bytes, hipMemcpyHostToDevice);
+    if (e0 != hipSuccess) {
+      (void)hipFree(d);
+      return fail(ASP_ERR_HIP, "rdft batch: upload", e0);
+    }
   }
-  hipError_t e = launch_rdft256(d, count, isgn, T, nullptr);
+  hipError_t e = launch_rdft256(d, count, isgn, T, nullptr, n);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (mem == ASP_MEM_HOST) {
     if (e == hipSuccess) e = hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(d);
   }
-  if (e != hipSuccess) return fail(ASP_ERR_HIP, "rdft256_batch", e);
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "rdft batch", e);
   return ASP_OK;
+}
+int AspNs_rdft256_batch(float* data, int count, int isgn, int mem, int device) {
+  return rdft_batch(data, count, isgn, mem, device, 256);
+}
+int AspNs_rdft128_batch(float* data, int count, int isgn, int mem, int device) {
+  return rdft_batch(data, count, isgn, mem, device, 128);
 }
 
 // Test seams for the device math (see debug_fn in ns_kernels.hip).

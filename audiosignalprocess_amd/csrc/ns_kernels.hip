@@ -1,6 +1,7 @@
 // ns_kernels.hip -- hand-written gfx950 kernels of the batched noise suppressor.
 //
-// Replaces, for N independent 16 kHz streams per launch, the reference's
+// Replaces, for N independent streams per launch (16 kHz geometry: 160 / 256 / 129; template flag G8:
+// the 8 kHz geometry 80 / 128 / 65 of ns_core.c:89-98), the reference's
 //   WebRtcNs_AnalyzeCore  (ns/ns_core.c:1043-1181)
 //   WebRtcNs_ProcessCore  (ns/ns_core.c:1183-1359)
 //   WebRtc_rdft(256, +-1) (utility/fft4g.c:324-362)
@@ -172,6 +173,102 @@ __device__ __forceinline__ void rdft256_inv(float2* buf, const FftLane& L, int l
   hi = make_float2(a.x - c.x, -a.y + c.y);
 }
 
+// ---- 8 kHz: WebRtc_rdft(128, +-1) = a 64-point complex transform (fft4g.c:902-937, 952-987: cft1st,
+// cftmdl(l = 8), then ONE twiddle-free radix-4 stage since 4 l == n) + rftfsub / rftbsub with nc = 32.
+// Lane = half butterfly as above; 16 butterflies per pass, so lanes 32..63 repeat the work of lanes
+// 0..31 (same addresses, same values).  Element q of the result sits on lane q.
+struct FftLane8 {
+  float4 tw0, tw1;  // passes 1 and 2; pass 3 has no twiddles
+  int diag;
+  float ca, cb;     // makect(32): c[p], c[32 - p] for p = min(lane, 64 - lane)
+};
+__device__ __forceinline__ FftLane8 load_fft_lane8(const NsTables* __restrict__ T, int lane) {
+  FftLane8 L;
+  L.tw0 = *reinterpret_cast<const float4*>(T->tw8[0][lane]);
+  L.tw1 = *reinterpret_cast<const float4*>(T->tw8[1][lane]);
+  L.diag = T->diag8[lane];
+  L.ca = T->c8a[lane];
+  L.cb = T->c8b[lane];
+  return L;
+}
+__device__ __forceinline__ void cft64_passes(float2* buf, const FftLane8& L, int lane, bool backward) {
+  const int b = (lane >> 1) & 15;
+  const bool h = (lane & 1) != 0;
+  {
+    const int rb = (int)(__brev((unsigned)b) >> 28);  // bitrv2 of 64 complex points
+    cft_half_pass(buf, rb, rb + 32, rb + 16, rb + 48, 4 * b + (h ? 1 : 0), 4 * b + (h ? 3 : 2), h,
+                  L.tw0, (L.diag & 1) != 0);
+  }
+  wave_lds_fence();
+  {
+    const int base = 16 * (b >> 2) + (b & 3);
+    cft_half_pass(buf, base, base + 4, base + 8, base + 12, base + (h ? 4 : 0),
+                  base + (h ? 12 : 8), h, L.tw1, (L.diag & 2) != 0);
+  }
+  wave_lds_fence();
+  {
+    // the last stage, twiddle-free: forward fft4g.c:918-937, backward :968-987 (which carries the
+    // conjugation of the inverse transform).  With s = -1 on odd lanes (outputs 1 / 3) and +1 on even
+    // ones (outputs 0 / 2), every line below is the reference's own sum or difference: x - y == x + (-y).
+    const float2 c0 = buf[b], c1 = buf[b + 16], c2 = buf[b + 32], c3 = buf[b + 48];
+    const uint32_t sm = h ? 0x80000000u : 0u;
+    const float ur = c0.x + xorf(c1.x, sm);
+    const float vr = c2.x + xorf(c3.x, sm), vi = c2.y + xorf(c3.y, sm);
+    if (!backward) {
+      const float ui = c0.y + xorf(c1.y, sm);
+      const float vr2 = h ? -vi : vr;
+      const float vi2 = h ? vr : vi;
+      buf[b + (h ? 16 : 0)] = make_float2(ur + vr2, ui + vi2);
+      buf[b + (h ? 48 : 32)] = make_float2(ur - vr2, ui - vi2);
+    } else {
+      // x0i = -a[j+1] - a[j1+1] (even lanes), x1i = -a[j+1] + a[j1+1] (odd lanes)
+      const float ui = -c0.y + xorf(c1.y, sm ^ 0x80000000u);
+      // even: (x0r + x2r, x0i - x2i) -> j, (x0r - x2r, x0i + x2i) -> j2;
+      // odd:  (x1r + x3i, x1i + x3r) -> j3, (x1r - x3i, x1i - x3r) -> j1
+      const float A = h ? vi : vr;
+      const float B = h ? vr : -vi;
+      buf[b + (h ? 48 : 0)] = make_float2(ur + A, ui + B);
+      buf[b + (h ? 16 : 32)] = make_float2(ur - A, ui - B);
+    }
+  }
+  wave_lds_fence();
+}
+// WebRtc_rdft(128, +1): buf holds the 64 complex inputs (x[2n], x[2n+1]); returns element `lane` of the
+// Ooura-packed spectrum (lane 0: (R0, R64)).
+__device__ __forceinline__ float2 rdft128_fwd(float2* buf, const FftLane8& L, int lane) {
+  cft64_passes(buf, L, lane, false);
+  const float2 a = buf[lane], pa = buf[(64 - lane) & 63];
+  const bool jside = lane < 32;  // rftfsub (fft4g.c:1234-1256): pair (j = p, k = 64 - p), p = 1..31
+  const float2 J = jside ? a : pa, K = jside ? pa : a;
+  const float wkr = 0.5f - L.cb, wki = L.ca;
+  const float xr = J.x - K.x, xi = J.y + K.y;
+  const float yr = wkr * xr - wki * xi, yi = wkr * xi + wki * xr;
+  float2 r = make_float2(jside ? a.x - yr : a.x + yr, a.y - yi);
+  if (lane == 32) r = a;                                       // element m / 2 is left alone
+  if (lane == 0) r = make_float2(a.x + a.y, a.x - a.y);        // fft4g.c:347-349
+  return r;
+}
+// WebRtc_rdft(128, -1), unscaled: in = element `lane` of the packed spectrum, out = (x[2 lane], x[2 lane + 1]).
+__device__ __forceinline__ float2 rdft128_inv(float2* buf, const FftLane8& L, int lane, float2 a) {
+  const int src = (64 - lane) & 63;
+  const float2 pa = make_float2(__shfl(a.x, src, 64), __shfl(a.y, src, 64));
+  const bool jside = lane < 32;  // rftbsub (fft4g.c:1259-1283)
+  const float2 J = jside ? a : pa, K = jside ? pa : a;
+  const float wkr = 0.5f - L.cb, wki = L.ca;
+  const float xr = J.x - K.x, xi = J.y + K.y;
+  const float yr = wkr * xr + wki * xi, yi = wkr * xi - wki * xr;
+  float2 r = make_float2(jside ? a.x - yr : a.x + yr, yi - a.y);
+  if (lane == 32) r = make_float2(a.x, -a.y);                  // a[m + 1] = -a[m + 1]
+  if (lane == 0) {                                             // fft4g.c:351-352, :1264
+    const float t = 0.5f * (a.x - a.y);
+    r = make_float2(a.x - t, -t);
+  }
+  buf[lane] = r;
+  wave_lds_fence();
+  cft64_passes(buf, L, lane, true);
+  return buf[lane];
+}
+
 // --------------------------------------------------------------------------
 // One 10 ms frame of one stream per wave.
 //   DO_A && DO_P : Analyze(frame) then Process(frame) on the same frame with
@@ -202,7 +299,10 @@ __device__ __forceinline__ void store_pair(float* y, int idx, float a, float b) 
   }
 }
 
-template <bool DO_A, bool DO_P, bool IO16 = false>
+// G8: the 8 kHz geometry (blockLen 80, anaLen 128, 65 bins: ns_core.c:89-98).  Lane q owns bin q, the
+// "q + 64" slot is dead (it runs on constants and is neither loaded, summed nor stored) and the tail
+// slot is bin 64; lane l owns samples 2l, 2l+1 of the 128-sample buffers.
+template <bool DO_A, bool DO_P, bool IO16 = false, bool G8 = false>
 __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ state,
                                                        int32_t* __restrict__ hist_all,
                                                        const NsTables* __restrict__ T,
@@ -217,6 +317,13 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
   float* __restrict__ vec = st + kOffVec;
   int32_t* __restrict__ hist = hist_all + (size_t)stream * kHistDwords;
   float2* buf = lds[wv];
+  constexpr int BL = G8 ? 80 : kBlockL;      // samples per frame
+  constexpr int AN = G8 ? 128 : kAnal;       // analysis window
+  constexpr int NB = AN / 2 + 1;             // bins
+  // x / NB, correctly rounded (DIV129's form for either bin count)
+#define DIVB(a) div_by_uniform((a), (float)NB, 1.0f / (float)NB)
+  // the lane's partial of a cross-bin sum: its q slot, plus its q + 64 slot where that exists
+#define P2(a0, a1) (G8 ? (a0) : (a0) + (a1))
 
   // ---- per-stream scalars: lane k holds scalar k
   float sv = st[kOffScalars + lane];
@@ -227,8 +334,30 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
 
   // ---- sliding analysis buffer: [96 carried samples | 160 new], lane l owns 4l..4l+3
   float* hbuf = st + ((DO_A) ? kOffAnaHist : kOffDataHist);
-  float4 s4;
-  if (IO16) {
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = s4;
+  if (G8) {
+    // [48 carried | 80 new]: lanes 0..23 the carried samples, lanes 24..63 the frame (s4.z / .w unused)
+    if (IO16) {
+      const short* in16 = reinterpret_cast<const short*>(in) + (size_t)stream * BL;
+      if (lane < 24) {
+        const float2 c2 = *reinterpret_cast<const float2*>(hbuf + 2 * lane);
+        s4.x = c2.x;
+        s4.y = c2.y;
+      } else {
+        const short2 q = *reinterpret_cast<const short2*>(in16 + 2 * (lane - 24));
+        s4.x = (float)q.x;
+        s4.y = (float)q.y;
+      }
+    } else {
+      const float* src = lane < 24 ? hbuf + 2 * lane : in + (size_t)stream * BL + 2 * (lane - 24);
+      const float2 c2 = *reinterpret_cast<const float2*>(src);
+      s4.x = c2.x;
+      s4.y = c2.y;
+    }
+    const float2 w2 = *reinterpret_cast<const float2*>(T->window8 + 2 * lane);
+    w4.x = w2.x;
+    w4.y = w2.y;
+  } else if (IO16) {
     const short* in16 = reinterpret_cast<const short*>(in) + (size_t)stream * kBlockL;
     if (lane < 24) {
       s4 = *reinterpret_cast<const float4*>(hbuf + 4 * lane);
@@ -241,40 +370,44 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
         lane < 24 ? hbuf + 4 * lane : in + (size_t)stream * kBlockL + 4 * (lane - 24);
     s4 = *reinterpret_cast<const float4*>(src);
   }
-  const float4 w4 = *reinterpret_cast<const float4*>(T->window + 4 * lane);
+  if (!G8) w4 = *reinterpret_cast<const float4*>(T->window + 4 * lane);
 
   // ---- state rows (issued early; consumed after the FFT); bins lane and 64 + lane sit at
   // row_pos(lane) and 64 + row_pos(lane) (ns_layout.h)
   const int rpos = 4 * (lane & 15) + 2 * ((lane >> 4) & 1) + (lane >> 5);  // row_pos(lane)
   float LQ[3][3], DEN[3][3], quant[3], smooth[3], noisePrev[3], magnPrevA[3], logLrt[3],
       avgPause[3], noiseSt[3], magnPrevP[3];
-#define LOAD_ROW(dst, f)                          \
-  {                                               \
-    dst[0] = vec[(f)*kVecStride + rpos];          \
-    dst[1] = vec[(f)*kVecStride + 64 + rpos];     \
-    dst[2] = SC_F(S_TAIL0 + (f));                 \
+#define LOAD_ROW(dst, f)                                          \
+  {                                                               \
+    dst[0] = vec[(f)*kVecStride + rpos];                          \
+    dst[1] = G8 ? 1.f : vec[(f)*kVecStride + 64 + rpos];          \
+    dst[2] = SC_F(S_TAIL0 + (f));                                 \
   }
-#define STORE_ROW(f, srcv)                                  \
-  {                                                         \
-    vec[(f)*kVecStride + rpos] = srcv[0];                   \
-    vec[(f)*kVecStride + 64 + rpos] = srcv[1];              \
-    SC_SET_F(S_TAIL0 + (f), srcv[2]);                       \
+#define STORE_ROW(f, srcv)                                        \
+  {                                                               \
+    vec[(f)*kVecStride + rpos] = srcv[0];                         \
+    if (!G8) vec[(f)*kVecStride + 64 + rpos] = srcv[1];           \
+    SC_SET_F(S_TAIL0 + (f), srcv[2]);                             \
   }
   if (DO_A) {
     LOAD_ROW(LQ[0], V_LQ0) LOAD_ROW(LQ[1], V_LQ1) LOAD_ROW(LQ[2], V_LQ2)
     LOAD_ROW(DEN[0], V_DEN0) LOAD_ROW(DEN[1], V_DEN1) LOAD_ROW(DEN[2], V_DEN2)
     LOAD_ROW(quant, V_QUANT)
   }
-  float2 carry = make_float2(0.f, 0.f);  // syntBuf[0..95], lane l owns 2l, 2l+1
-  if (DO_P && lane < 48) carry = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * lane);
-  const FftLane L = load_fft_lane(T, lane);
+  float2 carry = make_float2(0.f, 0.f);  // syntBuf[0..95] (8 kHz: [0..47]), lane l owns 2l, 2l+1
+  if (DO_P && lane < (AN - BL) / 2) carry = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * lane);
+  FftLane L;
+  FftLane8 L8;
+  if (G8) L8 = load_fft_lane8(T, lane); else L = load_fft_lane(T, lane);
 
   // Windowing + Energy (ns_core.c:969-978, 951-960)
   const float wx0 = w4.x * s4.x, wx1 = w4.y * s4.y, wx2 = w4.z * s4.z, wx3 = w4.w * s4.w;
   float epart = wx0 * wx0;
   epart += wx1 * wx1;
-  epart += wx2 * wx2;
-  epart += wx3 * wx3;
+  if (!G8) {
+    epart += wx2 * wx2;
+    epart += wx3 * wx3;
+  }
   const float energy1 = wave_sum(epart);
 
   int blockInd = SC_I(S_BLOCKIND);
@@ -282,32 +415,46 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
   const float denoiseBound = SC_F(S_DENOISEBOUND);
   float priorSpeechProb = SC_F(S_PRIORSPEECHPROB);
 
-  // the carried 96 samples for the next frame are this frame's last 96
-  if (lane >= 40) *reinterpret_cast<float4*>(hbuf + 4 * (lane - 40)) = s4;
+  // the carried 96 (48) samples for the next frame are this frame's last 96 (48)
+  if (G8) {
+    if (lane >= 40) *reinterpret_cast<float2*>(hbuf + 2 * (lane - 40)) = make_float2(s4.x, s4.y);
+  } else if (lane >= 40) {
+    *reinterpret_cast<float4*>(hbuf + 4 * (lane - 40)) = s4;
+  }
 
   if (energy1 == 0.0f) {
     // Analyze: nothing but the buffer slide (ns_core.c:1072-1082).
     // Process: emit the synthesis tail (ns_core.c:1239-1264).
     if (DO_P) {
       float* sy = st + kOffSynt;
-      float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * kBlockL)
-                      : out + (size_t)stream * kBlockL;
+      float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * BL)
+                      : out + (size_t)stream * BL;
       float2 o01 = carry;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       o01.x = o01.x > 32767 ? 32767 : (o01.x < -32768 ? -32768 : o01.x);
       o01.y = o01.y > 32767 ? 32767 : (o01.y < -32768 ? -32768 : o01.y);
-      store_pair<IO16>(y, 2 * lane, o01.x, o01.y);
-      if (lane < 16) store_pair<IO16>(y, 128 + 2 * lane, 0.f, 0.f);
-      if (lane < 48) *reinterpret_cast<float2*>(sy + 2 * lane) = make_float2(0.f, 0.f);
+      if (G8) {
+        if (lane < 40) store_pair<IO16>(y, 2 * lane, o01.x, o01.y);  // the carry, then zeros
+      } else {
+        store_pair<IO16>(y, 2 * lane, o01.x, o01.y);
+        if (lane < 16) store_pair<IO16>(y, 128 + 2 * lane, 0.f, 0.f);
+      }
+      if (lane < (AN - BL) / 2) *reinterpret_cast<float2*>(sy + 2 * lane) = make_float2(0.f, 0.f);
     }
     return;
   }
 
   // ---- forward FFT (ns_core.c:886-911)
-  *reinterpret_cast<float4*>(&buf[2 * lane]) = make_float4(wx0, wx1, wx2, wx3);
-  wave_lds_fence();
-  float2 lo, hi;
-  rdft256_fwd(buf, L, lane, lo, hi);
+  float2 lo, hi = make_float2(0.f, 0.f);
+  if (G8) {
+    buf[lane] = make_float2(wx0, wx1);
+    wave_lds_fence();
+    lo = rdft128_fwd(buf, L8, lane);
+  } else {
+    *reinterpret_cast<float4*>(&buf[2 * lane]) = make_float4(wx0, wx1, wx2, wx3);
+    wave_lds_fence();
+    rdft256_fwd(buf, L, lane, lo, hi);
+  }
   // second group of state rows: issued after the FFT so they do not hold
   // registers across it; their latency hides under the magnitude / log / trackers
   asm volatile("" ::: "memory");
@@ -347,15 +494,15 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     for (int k = 0; k < 3; ++k) lmagn[k] = log_f32_via_f64(magn[k]);
 
     // signalEnergy, sumMagn (ns_core.c:1088-1104)
-    float t_se = (re[0] * re[0] + im[0] * im[0]) + (re[1] * re[1] + im[1] * im[1]);
-    float t_sm = magn[0] + magn[1];
+    float t_se = P2(re[0] * re[0] + im[0] * im[0], re[1] * re[1] + im[1] * im[1]);
+    float t_sm = P2(magn[0], magn[1]);
     if (lane == 0) {
       t_se = t_se + (re[2] * re[2] + im[2] * im[2]);
       t_sm = t_sm + magn[2];
     }
     float signalEnergy = wave_sum(t_se);
     const float sumMagn = wave_sum(t_sm);
-    signalEnergy = DIV129(signalEnergy);
+    signalEnergy = DIVB(signalEnergy);
 
     // ---- NoiseEstimation (ns_core.c:217-285)
     if (updates < NS_END_STARTUP_LONG) updates++;
@@ -401,26 +548,27 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     if (blockInd < NS_END_STARTUP_SHORT) {
       float logi[3];
       logi[0] = T->logi[lane];
-      logi[1] = T->logi[64 + lane];
-      logi[2] = T->logi[128];
-      float t_lm = (lane >= NS_START_BAND ? lmagn[0] : 0.f) + lmagn[1];
-      float t_lilm = (lane >= NS_START_BAND ? logi[0] * lmagn[0] : 0.f) + logi[1] * lmagn[1];
+      logi[1] = G8 ? 0.f : T->logi[64 + lane];
+      logi[2] = T->logi[NB - 1];
+      float t_lm = P2(lane >= NS_START_BAND ? lmagn[0] : 0.f, lmagn[1]);
+      float t_lilm = P2(lane >= NS_START_BAND ? logi[0] * lmagn[0] : 0.f, logi[1] * lmagn[1]);
       if (lane == 0) {
         t_lm = t_lm + lmagn[2];
         t_lilm = t_lilm + logi[2] * lmagn[2];
       }
       const float sum_log_magn = wave_sum(t_lm);
       const float sum_log_i_log_magn = wave_sum(t_lilm);
-      const float sum_log_i = T->sum_log_i, sum_log_i_square = T->sum_log_i_square;
-      whiteNoiseLevel += DIV129(sumMagn) * overdrive;
-      float tmpFloat1 = sum_log_i_square * ((float)(kBins - NS_START_BAND));
+      const float sum_log_i = G8 ? T->sum_log_i8 : T->sum_log_i;
+      const float sum_log_i_square = G8 ? T->sum_log_i_square8 : T->sum_log_i_square;
+      whiteNoiseLevel += DIVB(sumMagn) * overdrive;
+      float tmpFloat1 = sum_log_i_square * ((float)(NB - NS_START_BAND));
       tmpFloat1 -= (sum_log_i * sum_log_i);
       float tmpFloat2 = (sum_log_i_square * sum_log_magn - sum_log_i * sum_log_i_log_magn);
       float tmpFloat3 = tmpFloat2 / tmpFloat1;
       if (tmpFloat3 < 0.f) tmpFloat3 = 0.f;
       pinkNoiseNumerator += tmpFloat3;
       tmpFloat2 = (sum_log_i * sum_log_magn);
-      tmpFloat2 -= ((float)(kBins - NS_START_BAND)) * sum_log_i_log_magn;
+      tmpFloat2 -= ((float)(NB - NS_START_BAND)) * sum_log_i_log_magn;
       tmpFloat3 = tmpFloat2 / tmpFloat1;
       if (tmpFloat3 < 0.f) tmpFloat3 = 0.f;
       if (tmpFloat3 > 1.f) tmpFloat3 = 1.f;
@@ -434,7 +582,7 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
       float pn[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const int bin = k == 0 ? lane : (k == 1 ? 64 + lane : 128);
+        const int bin = k == 0 ? lane : (k == 1 ? 64 + lane : NB - 1);
         if (pinkNoiseExp == 0.f) {
           pn[k] = whiteNoiseLevel;
         } else {
@@ -468,8 +616,8 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
 
     // ---- ComputeSpectralFlatness (ns_core.c:523-556)
     float fd0 = SC_F(S_FD0), fd4 = SC_F(S_FD4), fd6 = SC_F(S_FD6);
-    float t_fl = (lane >= 1 ? lmagn[0] : 0.f) + lmagn[1];
-    float t_ap = avgPause[0] + avgPause[1];
+    float t_fl = P2(lane >= 1 ? lmagn[0] : 0.f, lmagn[1]);
+    float t_ap = P2(avgPause[0], avgPause[1]);
     if (lane == 0) {
       t_fl = t_fl + lmagn[2];
       t_ap = t_ap + avgPause[2];
@@ -477,8 +625,8 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     {
       float num = wave_sum(t_fl);
       float den = sumMagn - lane_bcast(magn[0], 0);
-      den = DIV129(den);
-      num = DIV129(num);
+      den = DIVB(den);
+      num = DIVB(num);
       const float spectralTmp = fdiv(exp_f32_via_f64(num, T->exp2_64), den);
       fd0 += NS_SPECT_FL_TAVG * (spectralTmp - fd0);
     }
@@ -486,17 +634,17 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     {
       float avgPauseMean = wave_sum(t_ap);
       float avgMagn = sumMagn;
-      avgPauseMean = DIV129(avgPauseMean);
-      avgMagn = DIV129(avgMagn);
+      avgPauseMean = DIVB(avgPauseMean);
+      avgMagn = DIVB(avgMagn);
       float dm[3], dp[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         dm[k] = magn[k] - avgMagn;
         dp[k] = avgPause[k] - avgPauseMean;
       }
-      float t_cov = dm[0] * dp[0] + dm[1] * dp[1];
-      float t_vp = dp[0] * dp[0] + dp[1] * dp[1];
-      float t_vm = dm[0] * dm[0] + dm[1] * dm[1];
+      float t_cov = P2(dm[0] * dp[0], dm[1] * dp[1]);
+      float t_vp = P2(dp[0] * dp[0], dp[1] * dp[1]);
+      float t_vm = P2(dm[0] * dm[0], dm[1] * dm[1]);
       if (lane == 0) {
         t_cov = t_cov + dm[2] * dp[2];
         t_vp = t_vp + dp[2] * dp[2];
@@ -505,9 +653,9 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
       float covMagnPause = wave_sum(t_cov);
       float varPause = wave_sum(t_vp);
       float varMagn = wave_sum(t_vm);
-      covMagnPause = DIV129(covMagnPause);
-      varPause = DIV129(varPause);
-      varMagn = DIV129(varMagn);
+      covMagnPause = DIVB(covMagnPause);
+      varPause = DIVB(varPause);
+      varMagn = DIVB(varMagn);
       fd6 += signalEnergy;
       float avgDiffNormMagn = varMagn - fdiv(covMagnPause * covMagnPause, varPause + 0.0001f);
       avgDiffNormMagn = fdiv(avgDiffNormMagn, fd5 + 0.0001f);
@@ -559,10 +707,10 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
       const float besselTmp = (snrLocPost[k] + 1.f) * t2;
       logLrt[k] += NS_LRT_TAVG * (besselTmp - log_f32_via_f64(t1) - logLrt[k]);
     }
-    float t_ll = logLrt[0] + logLrt[1];
+    float t_ll = P2(logLrt[0], logLrt[1]);
     if (lane == 0) t_ll = t_ll + logLrt[2];
     float logLrtTimeAvgKsum = wave_sum(t_ll);
-    logLrtTimeAvgKsum = DIV129(logLrtTimeAvgKsum);
+    logLrtTimeAvgKsum = DIVB(logLrtTimeAvgKsum);
     fd3 = logLrtTimeAvgKsum;
     {
       const float widthPrior0 = NS_WIDTH_PR_MAP, widthPrior1 = 2.f * NS_WIDTH_PR_MAP,
@@ -608,7 +756,7 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
       const float a63 = lane_bcast(probSpeech[0], 63);
       const float b63 = lane_bcast(probSpeech[1], 63);
       if (lane == 0) upB = a63;
-      float prevProb[3] = {upA, upB, b63};
+      float prevProb[3] = {upA, upB, G8 ? a63 : b63};  // the last bin follows bin 63 (8 kHz) / 127
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         float gammaOld = prevProb[k] > NS_PROB_RANGE ? NS_SPEECH_UPDATE : NS_NOISE_UPDATE;
@@ -722,14 +870,16 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     // ---- IFFT (ns_core.c:923-944)
     float2 tlo = make_float2(re[0], lane == 0 ? re[2] : im[0]);
     float2 thi = make_float2(re[1], im[1]);
-    {
+    if (G8) {
+      tlo = rdft128_inv(buf, L8, lane, tlo);
+    } else {
       int lane_o = lane;  // opaque copy: keeps the compiler from holding the forward tables live
       asm volatile("" : "+v"(lane_o));
       const FftLane Li = load_fft_lane(T, lane_o);
       rdft256_inv(buf, Li, lane, tlo, thi);
     }
-    float td0 = tlo.x * (2.f / kAnal), td1 = tlo.y * (2.f / kAnal);
-    float td2 = thi.x * (2.f / kAnal), td3 = thi.y * (2.f / kAnal);
+    float td0 = tlo.x * (2.f / AN), td1 = tlo.y * (2.f / AN);
+    float td2 = thi.x * (2.f / AN), td3 = thi.y * (2.f / AN);
 
     // ---- energy-based gain compensation (ns_core.c:1315-1342)
     float factor = 1.f;
@@ -737,8 +887,10 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
       float factor1 = 1.f, factor2 = 1.f;
       float e2 = td0 * td0;
       e2 += td1 * td1;
-      e2 += td2 * td2;
-      e2 += td3 * td3;
+      if (!G8) {
+        e2 += td2 * td2;
+        e2 += td3 * td3;
+      }
       const float energy2 = wave_sum(e2);
       float gain = fsqrt(fdiv(energy2, energy1 + 1.f));
       if (gain > NS_B_LIM) {
@@ -753,26 +905,34 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
     }
 
     // ---- synthesis window, overlap-add, emit 160, carry 96 (ns_core.c:1344-1359)
-    const float2 wlo = *reinterpret_cast<const float2*>(T->window + 2 * lane);
-    const float2 whi = *reinterpret_cast<const float2*>(T->window + 128 + 2 * lane);
+    const float2 wlo = *reinterpret_cast<const float2*>((G8 ? T->window8 : T->window) + 2 * lane);
     float* sy = st + kOffSynt;
-    float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * kBlockL)
-                    : out + (size_t)stream * kBlockL;
+    float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * BL)
+                    : out + (size_t)stream * BL;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // carry was read long ago; keep it so
     float o0 = carry.x + factor * (wlo.x * td0);
     float o1 = carry.y + factor * (wlo.y * td1);
-    float o2 = 0.f + factor * (whi.x * td2);
-    float o3 = 0.f + factor * (whi.y * td3);
-    if (lane >= 16) {  // samples 160..255 become the next carry
-      *reinterpret_cast<float2*>(sy + 2 * lane - 32) = make_float2(o2, o3);
-    }
-    o0 = o0 > 32767 ? 32767 : (o0 < -32768 ? -32768 : o0);
-    o1 = o1 > 32767 ? 32767 : (o1 < -32768 ? -32768 : o1);
-    store_pair<IO16>(y, 2 * lane, o0, o1);
-    if (lane < 16) {
-      o2 = o2 > 32767 ? 32767 : (o2 < -32768 ? -32768 : o2);
-      o3 = o3 > 32767 ? 32767 : (o3 < -32768 ? -32768 : o3);
-      store_pair<IO16>(y, 128 + 2 * lane, o2, o3);
+    if (G8) {
+      // samples 0..79 leave, samples 80..127 (lanes 40..63) become the next carry
+      if (lane >= 40) *reinterpret_cast<float2*>(sy + 2 * (lane - 40)) = make_float2(o0, o1);
+      o0 = o0 > 32767 ? 32767 : (o0 < -32768 ? -32768 : o0);
+      o1 = o1 > 32767 ? 32767 : (o1 < -32768 ? -32768 : o1);
+      if (lane < 40) store_pair<IO16>(y, 2 * lane, o0, o1);
+    } else {
+      const float2 whi = *reinterpret_cast<const float2*>(T->window + 128 + 2 * lane);
+      float o2 = 0.f + factor * (whi.x * td2);
+      float o3 = 0.f + factor * (whi.y * td3);
+      if (lane >= 16) {  // samples 160..255 become the next carry
+        *reinterpret_cast<float2*>(sy + 2 * lane - 32) = make_float2(o2, o3);
+      }
+      o0 = o0 > 32767 ? 32767 : (o0 < -32768 ? -32768 : o0);
+      o1 = o1 > 32767 ? 32767 : (o1 < -32768 ? -32768 : o1);
+      store_pair<IO16>(y, 2 * lane, o0, o1);
+      if (lane < 16) {
+        o2 = o2 > 32767 ? 32767 : (o2 < -32768 ? -32768 : o2);
+        o3 = o3 > 32767 ? 32767 : (o3 < -32768 ? -32768 : o3);
+        store_pair<IO16>(y, 128 + 2 * lane, o2, o3);
+      }
     }
   }
 
@@ -783,6 +943,8 @@ __global__ __launch_bounds__(256, 4) void ns_frame_kernel(float* __restrict__ st
 #undef SC_SET_F
 #undef LOAD_ROW
 #undef STORE_ROW
+#undef DIVB
+#undef P2
 }
 
 // Leaves the paired representation: materialises dataBuf / magnPrevProcess /
@@ -913,33 +1075,57 @@ __global__ __launch_bounds__(256) void rdft256_kernel(float* __restrict__ data, 
   *reinterpret_cast<float2*>(a + 2 * lane) = lo;
   *reinterpret_cast<float2*>(a + 128 + 2 * lane) = hi;
 }
+// The same seam for WebRtc_rdft(128, isgn) (the 8 kHz transform) on each 128-float row.
+__global__ __launch_bounds__(256) void rdft128_kernel(float* __restrict__ data, int count,
+                                                      int isgn,
+                                                      const NsTables* __restrict__ T) {
+  __shared__ float2 lds[4][128];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= count) return;
+  float* a = data + (size_t)row * 128;
+  float2* buf = lds[wv];
+  const FftLane8 L = load_fft_lane8(T, lane);
+  float2 v = *reinterpret_cast<const float2*>(a + 2 * lane);
+  if (isgn >= 0) {
+    buf[lane] = v;
+    wave_lds_fence();
+    v = rdft128_fwd(buf, L, lane);
+  } else {
+    v = rdft128_inv(buf, L, lane, v);
+  }
+  *reinterpret_cast<float2*>(a + 2 * lane) = v;
+}
 
 }  // namespace
 
 // ------------------------------------------------------------ launch wrappers
 namespace aspns {
 
+// mode: 0 Analyze, 1 Process, 2 fused, 3 fused with int16 frames; g8: the 8 kHz geometry
 hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables* T,
-                           const float* in, float* out, int num_streams, hipStream_t s) {
+                           const float* in, float* out, int num_streams, hipStream_t s, bool g8) {
   const dim3 grid((num_streams + 3) / 4), block(256);
-  switch (mode) {
-    case 0:
-      hipLaunchKernelGGL((ns_frame_kernel<true, false>), grid, block, 0, s, state, hist, T, in,
-                         out, num_streams);
-      break;
-    case 1:
-      hipLaunchKernelGGL((ns_frame_kernel<false, true>), grid, block, 0, s, state, hist, T, in,
-                         out, num_streams);
-      break;
-    case 3:
-      hipLaunchKernelGGL((ns_frame_kernel<true, true, true>), grid, block, 0, s, state, hist, T,
-                         in, out, num_streams);
-      break;
-    default:
-      hipLaunchKernelGGL((ns_frame_kernel<true, true>), grid, block, 0, s, state, hist, T, in,
-                         out, num_streams);
-      break;
+#define NS_LAUNCH(A, P, I16, G)                                                                   \
+  hipLaunchKernelGGL((ns_frame_kernel<A, P, I16, G>), grid, block, 0, s, state, hist, T, in, out, \
+                     num_streams)
+  if (g8) {
+    switch (mode) {
+      case 0: NS_LAUNCH(true, false, false, true); break;
+      case 1: NS_LAUNCH(false, true, false, true); break;
+      case 3: NS_LAUNCH(true, true, true, true); break;
+      default: NS_LAUNCH(true, true, false, true); break;
+    }
+  } else {
+    switch (mode) {
+      case 0: NS_LAUNCH(true, false, false, false); break;
+      case 1: NS_LAUNCH(false, true, false, false); break;
+      case 3: NS_LAUNCH(true, true, true, false); break;
+      default: NS_LAUNCH(true, true, false, false); break;
+    }
   }
+#undef NS_LAUNCH
   return hipGetLastError();
 }
 
@@ -969,9 +1155,11 @@ hipError_t launch_debug_compare(int fn_a, int fn_b, unsigned start, unsigned cou
   return hipGetLastError();
 }
 
-hipError_t launch_rdft256(float* data, int count, int isgn, const NsTables* T, hipStream_t s) {
-  hipLaunchKernelGGL(rdft256_kernel, dim3((count + 3) / 4), dim3(256), 0, s, data, count, isgn,
-                     T);
+hipError_t launch_rdft256(float* data, int count, int isgn, const NsTables* T, hipStream_t s, int n) {
+  if (n == 128)
+    hipLaunchKernelGGL(rdft128_kernel, dim3((count + 3) / 4), dim3(256), 0, s, data, count, isgn, T);
+  else
+    hipLaunchKernelGGL(rdft256_kernel, dim3((count + 3) / 4), dim3(256), 0, s, data, count, isgn, T);
   return hipGetLastError();
 }
 

@@ -96,6 +96,15 @@ struct NsTables {
   double exp2_64[64];         // 2^(j/64), range-reduction table of the lean exp
   float spl[32][4][2];        // real-split (wkr, wki) of element (lam & 15) + 16 t + 64 (lam >> 4), lam = 0..31
   double logtab[128][2];      // {1/c, log c} of the table-driven log (ns_device.h: log_tab_f64)
+  // 8 kHz geometry (ns_kernels.hip, G8): WebRtc_rdft(128) and kBlocks80w128
+  float window8[128];         // kBlocks80w128 (ns/windows_private.h:64-91)
+  float tw8[2][64][4];        // passes 1 and 2 of the 64-point transform, per lane (lanes 32..63 repeat 0..31)
+  int32_t diag8[64];
+  float c8a[64];              // makect(32): c[p], p = min(lane, 64 - lane) (0 on lanes 0 and 32)
+  float c8b[64];              //             c[32 - p]
+  float sum_log_i8;           // sequential sums over i = 5..64, ns_core.c:1094-1095 with magnLen 65
+  float sum_log_i_square8;
+  float pad8[2];
 };
 
 static_assert(__builtin_offsetof(NsTables, logtab) % 16 == 0, "logtab is read as double2");

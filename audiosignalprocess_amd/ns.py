@@ -70,6 +70,7 @@ def load_library():
         "AspNs_MemcpyH2D": [vp, vp, C.c_size_t],
         "AspNs_MemcpyD2H": [vp, vp, C.c_size_t],
         "AspNs_rdft256_batch": [vp, ip, ip, ip, ip],
+        "AspNs_rdft128_batch": [vp, ip, ip, ip, ip],
         "AspNs_device_count": [],
     }
     for name, args in sig.items():
@@ -138,7 +139,8 @@ class DeviceBuffer:
 
 
 class NsBatch:
-    """N independent 16 kHz noise-suppressor streams on one GPU."""
+    """N independent noise-suppressor streams on one GPU (fs = 8000: 80-sample frames; 16000 and up:
+    160-sample frames of the 0-8 kHz band)."""
 
     def __init__(self, num_streams, device=0, fs=16000, policy=None, kernel=None):
         self.lib = load_library()
@@ -155,6 +157,7 @@ class NsBatch:
 
     def init(self, fs=16000):
         _check(self.lib.AspNsBatch_Init(self.h, fs), "AspNsBatch_Init")
+        self.block = 80 if fs == 8000 else BLOCKL   # ns_core.c:89-98
 
     def set_policy(self, mode):
         _check(self.lib.AspNsBatch_set_policy(self.h, mode), "AspNsBatch_set_policy")
@@ -162,12 +165,12 @@ class NsBatch:
     # -- host-array convenience (copies in/out, synchronous)
     def analyze(self, frames):
         frames = np.ascontiguousarray(frames, np.float32)
-        assert frames.shape == (self.S, BLOCKL)
+        assert frames.shape == (self.S, self.block)
         _check(self.lib.AspNsBatch_Analyze(self.h, _ptr(frames), MEM_HOST), "AspNsBatch_Analyze")
 
     def process(self, frames):
         frames = np.ascontiguousarray(frames, np.float32)
-        assert frames.shape == (self.S, BLOCKL)
+        assert frames.shape == (self.S, self.block)
         out = np.empty_like(frames)
         _check(self.lib.AspNsBatch_Process(self.h, _ptr(frames), _ptr(out), MEM_HOST),
                "AspNsBatch_Process")
@@ -177,7 +180,7 @@ class NsBatch:
         """frames [F][S][160] -> denoised [F][S][160] (fused step per frame)."""
         frames = np.ascontiguousarray(frames, np.float32)
         F = frames.shape[0]
-        assert frames.shape == (F, self.S, BLOCKL)
+        assert frames.shape == (F, self.S, self.block)
         out = np.empty_like(frames)
         _check(self.lib.AspNsBatch_AnalyzeProcess(self.h, _ptr(frames), _ptr(out), F, MEM_HOST),
                "AspNsBatch_AnalyzeProcess")
@@ -215,7 +218,7 @@ class NsBatch:
         """pcm [F][S][160] int16 -> denoised int16 of the same shape (fused step, PCM in/out)."""
         pcm = np.ascontiguousarray(pcm, np.int16)
         F = pcm.shape[0]
-        assert pcm.shape == (F, self.S, BLOCKL)
+        assert pcm.shape == (F, self.S, self.block)
         out = np.empty_like(pcm)
         _check(self.lib.AspNsBatch_AnalyzeProcessS16(self.h, _ptr(pcm), _ptr(out), F, MEM_HOST),
                "AspNsBatch_AnalyzeProcessS16")
@@ -289,6 +292,16 @@ class NsBatch:
             self.close()
         except Exception:
             pass
+
+
+def rdft128(rows, isgn, device=0):
+    """WebRtc_rdft(128, isgn), the 8 kHz transform, on every row of `rows` ([count][128] float32)."""
+    lib = load_library()
+    rows = np.ascontiguousarray(rows, np.float32).copy()
+    flat = rows.reshape(-1, 128)
+    _check(lib.AspNs_rdft128_batch(_ptr(flat), flat.shape[0], isgn, MEM_HOST, device),
+           "AspNs_rdft128_batch")
+    return rows
 
 
 def rdft256(rows, isgn, device=0):

@@ -41,11 +41,14 @@ ALGO_BYTES_PER_FRAME = 15716  # frame-synchronous NS mod
 BT_TRAFFIC_BYTES_PER_MACROBLOCK = (2 * 10.0948 + 20.0) * 1024
 AEC_TRAFFIC_BYTES_PER_FRAME = (2 * 33.4001 + 32.9825) * 1024
 
+# ns_frame1_kernel<false> (the benched kernel, round 3: profiles/r03_ns_traffic.txt): FETCH_SIZE 3.8648 /
+# WRITE_SIZE 7.2188 KB per stream and launch at 4096 streams against 3.8233 / 7.2188 KB at 32768 streams, where
+# the kernel's known traffic is all HBM traffic: 7 808 B read (12 rows of 512 B, two 384-B sliding buffers, 256 B
+# of scalars, 640 B of samples) -- the calibration of its 8-byte-per-lane reads -- and 7 392 B written (the
+# quantile row is written back only when it changes: 7 296 B, + 96 B of histogram atomics), which WRITE_SIZE
+# reports exactly.  The one-stream kernel of the two-call protocol keeps its round-1 constant.
 PMC_TRAFFIC_BYTES_PER_FRAME = (4.832 * 1.638 + 9.158 / 1.09) * 1024      # ns_frame_kernel<true,true>
-# ns_frame2_kernel[_ilp] (default, end of round 1): FETCH_SIZE 3.8785 / WRITE_SIZE 7.7188 KB per stream at 4096
-# streams against 3.8269 / 7.7188 KB at 32768 streams, where the kernel's known 7 808 B each way (12 rows of
-# 512 B, two 384-B sliding buffers, 256 B of scalars, 640 B of samples) are all HBM traffic
-PMC_TRAFFIC_BYTES_PER_FRAME_DUAL = 7808 * (3.8785 / 3.8269 + 7.7188 / 7.7188)
+PMC_TRAFFIC_BYTES_PER_FRAME_PAIR = 7808 * (3.8648 / 3.8233) + 7.21875 * 1024
 NS_PRIME_FRAMES = 250  # untimed set-up frames + warm-up >= this (start-up phase of ns_core.c is 200)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -525,9 +528,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": PMC_TRAFFIC_BYTES_PER_FRAME_DUAL * S,
-                "traffic_source": "stored constant: PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE, "
-                                  "calibrated; not measured in this run), per frame step of all streams",
+                "traffic": (PMC_TRAFFIC_BYTES_PER_FRAME_PAIR if (args.kernel or 3) == 3 else PMC_TRAFFIC_BYTES_PER_FRAME) * S,
+                "traffic_source": "stored constant for the kernel named in this line: PMC passes kept under "
+                                  "profiles/r03_ns_traffic.txt (FETCH_SIZE / WRITE_SIZE in separate passes, reads "
+                                  "calibrated at 32768 streams; not measured in this run), per frame step of all streams",
                 "kernel": kernel,
                 # one frame step = `concurrent_launches` launches of this kernel side by side (one per HIP
                 # stream, S / concurrent_launches streams each); achieved = algorithmic bytes of the step /

@@ -52,13 +52,13 @@ int main(int argc, char* argv[]) {
   }
   const uint32_t frequency = (uint32_t)header.format.sample_per_sec;
   const int length = (int)(frequency / 100);
-  /* This driver feeds ONE band of ONE channel per 10 ms (the 16 kHz mono case of
-   * test_ns_module.cpp:59-113).  At 32 / 48 kHz the reference driver goes through
+  /* This driver feeds ONE band of ONE channel per 10 ms (the 8 and 16 kHz mono cases of
+   * test_ns_module.cpp:59-113: 80 / 160 samples per frame).  At 32 / 48 kHz the reference driver goes through
    * AudioBuffer::SplitIntoFrequencyBands / MergeFrequencyBands (test_ns_module.cpp:92-104): that
    * chain is include/apm_ns.h (APM_NS at 32 / 48 kHz) and drivers/apm_ns_raw.cpp here, so other
    * rates and channel counts are refused instead of being processed wrongly. */
-  if (frequency != 16000 || header.format.channels != 1) {
-    printf("test_ns_module: %u Hz / %d channel(s) not supported by this driver (16000 Hz mono only; "
+  if ((frequency != 16000 && frequency != 8000) || header.format.channels != 1) {
+    printf("test_ns_module: %u Hz / %d channel(s) not supported by this driver (8000 / 16000 Hz mono only; "
            "use drivers/apm_ns_raw for 32 / 48 kHz or multi-channel input)\n",
            frequency, (int)header.format.channels);
     return 2;

@@ -123,13 +123,15 @@ enum {
  * (sharding hint: one batch per GPU, streams are never exchanged). */
 int AspNsBatch_Create(AspNsBatch** out, int num_streams, int device);
 int AspNsBatch_Free(AspNsBatch* b);
-/* WebRtcNs_Init for every stream (ns_core.c:74-214). */
+/* WebRtcNs_Init for every stream (ns_core.c:74-214): fs = 8000 (frames of 80 samples, 128-sample
+ * window, 65 bins), 16000, or 32000 / 48000 (the 0-8 kHz band of the band split plus 1 / 2 high
+ * bands); frames are 160 samples per stream except at 8000. */
 int AspNsBatch_Init(AspNsBatch* b, uint32_t fs);
 /* WebRtcNs_set_policy for every stream (ns_core.c:1013-1041). */
 int AspNsBatch_set_policy(AspNsBatch* b, int mode);
 int AspNsBatch_num_streams(const AspNsBatch* b);
 
-/* frames: [num_streams][160] float.  Asynchronous on the batch's HIP stream
+/* frames: [num_streams][160] float ([num_streams][80] at 8 kHz, here and below).  Asynchronous on the batch's HIP stream
  * for ASP_MEM_DEVICE; ASP_MEM_HOST copies in/out and returns when done. */
 int AspNsBatch_Analyze(AspNsBatch* b, const float* frames, int mem);
 int AspNsBatch_Process(AspNsBatch* b, const float* in, float* out, int mem);
@@ -197,7 +199,8 @@ int AspNs_MemcpyD2H(void* dst, const void* src, size_t bytes);
  * (kernel nodes only, one launch per frame step and sub-launch, exactly the launches
  * AspNsBatch_AnalyzeProcess would issue).  The capture is cached while the arguments stay the
  * same, so a caller that feeds the same ring repeatedly pays one graph launch per call.
- * AspNsBatch_SetGraph(b, 0) turns replay off (plain launches). */
+ * Replay must be enabled with AspNsBatch_SetGraph(b, 1); it is off by default (plain launches measured
+ * faster), and with it off this call enqueues the same launches one by one. */
 int AspNsBatch_AnalyzeProcessReplay(AspNsBatch* b, const float* in, float* out,
                                     int frames_in_ring, int steps);
 int AspNsBatch_SetGraph(AspNsBatch* b, int on);
@@ -238,6 +241,8 @@ int AspNs_debug_compare(int fn_a, int fn_b, uint32_t start, uint32_t count,
  * what WebRtc_rdft(256, isgn, a, ip, w) (fft4g.c:324-362) does to each row.
  * data: [count][256] float, in place; isgn = +1 forward, -1 inverse (unscaled). */
 int AspNs_rdft256_batch(float* data, int count, int isgn, int mem, int device);
+/* The same seam for WebRtc_rdft(128, isgn), the transform of the 8 kHz geometry: data [count][128]. */
+int AspNs_rdft128_batch(float* data, int count, int isgn, int mem, int device);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 /*
  * ns_oracle.c -- CPU restatement of the reference's float noise suppressor
- * (WebRTC NS, 16 kHz, one band).  TEST INFRASTRUCTURE ONLY -- see ns_oracle.h.
+ * (WebRTC NS: the 160 / 256 / 129 geometry of 16, 32 and 48 kHz and the 80 / 128 / 65 geometry of
+ * 8 kHz, ns_core.c:89-98).  TEST INFRASTRUCTURE ONLY -- see ns_oracle.h.
  *
  * Parity status: PINNED against the reference C compiled from /root/reference
  * (oracle/Makefile -> oracle/_ref/libns_ref.so) and the committed golden
@@ -19,10 +20,18 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define BINS ASP_NS_BINS
-#define ANAL ASP_NS_ANAL
-#define BLOCKL ASP_NS_BLOCKL
+#define MAXBINS ASP_NS_BINS
+#define MAXANAL ASP_NS_ANAL
+#define MAXBLOCKL ASP_NS_BLOCKL
 #define SIMULT ASP_NS_SIMULT
+/* the geometry of a stream (ns_core.c:89-98): block / analysis window / bins, as locals of that name */
+#define GEO_FS(fs_)                                       \
+  const int BLOCKL = (fs_) == 8000 ? 80 : 160;            \
+  const int ANAL = (fs_) == 8000 ? 128 : 256;             \
+  const int BINS = ANAL / 2 + 1;                          \
+  (void)BLOCKL;                                           \
+  (void)BINS
+#define GEO(s_) GEO_FS((s_)->fs)
 #define HIST ASP_NS_HIST
 
 /* ns/defines.h:19-48 -- written with the same (float)<double literal> casts */
@@ -48,10 +57,13 @@
 
 /* ------------------------------------------------------------------ tables */
 
-static float g_window[ANAL]; /* kBlocks160w256, ns/windows_private.h:94-147 */
-static float g_w[64];        /* makewt(64), utility/fft4g.c:642-669          */
-static float g_c[64];        /* makect(64), utility/fft4g.c:671-690          */
-static float g_logi[BINS];   /* (float)log((float)i), ns_core.c:1093         */
+static float g_window[MAXANAL]; /* kBlocks160w256, ns/windows_private.h:94-147 */
+static float g_window8[128];    /* kBlocks80w128, ns/windows_private.h:64-91    */
+static float g_w[64];           /* makewt(64), utility/fft4g.c:642-669          */
+static float g_c[64];           /* makect(64), utility/fft4g.c:671-690          */
+static float g_w8[32];          /* makewt(32): the tables of WebRtc_rdft(128)   */
+static float g_c8[32];          /* makect(32)                                   */
+static float g_logi[MAXBINS];   /* (float)log((float)i), ns_core.c:1093         */
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
 
 static unsigned bitrev(unsigned x, int bits) {
@@ -71,6 +83,47 @@ static float window_entry(int i) {
   s = sin(M_PI * (double)(i < 96 ? i : 256 - i) / 192.0);
   snprintf(buf, sizeof buf, "%.8f", s);
   return (float)strtod(buf, NULL);
+}
+/* kBlocks80w128: sin(pi*i/96) over the 48-sample ramps, the same text round trip (every entry equals the
+ * header's, checked when this was written and by tests/test_ns_oracle.py against the compiled reference) */
+static float window8_entry(int i) {
+  char buf[32];
+  double s;
+  if (i >= 48 && i <= 80) return 1.0f;
+  s = sin(M_PI * (double)(i < 48 ? i : 128 - i) / 96.0);
+  snprintf(buf, sizeof buf, "%.8f", s);
+  return (float)strtod(buf, NULL);
+}
+/* makewt(nw) + its bitrv2, and makect(nc) (fft4g.c:642-690) for nw = nc = N: N/2 complex entries */
+static void make_wt_ct(int N, float* w, float* c) {
+  float tmp[64];
+  const int nwh = N >> 1;
+  int j, bits = 0;
+  float delta = (float)atan(1.0f) / nwh;
+  while ((1 << bits) < nwh) ++bits;
+  tmp[0] = 1;
+  tmp[1] = 0;
+  tmp[nwh] = (float)cos(delta * nwh);
+  tmp[nwh + 1] = tmp[nwh];
+  for (j = 2; j < nwh; j += 2) {
+    float x = (float)cos(delta * j);
+    float y = (float)sin(delta * j);
+    tmp[j] = x;
+    tmp[j + 1] = y;
+    tmp[N - j] = y;
+    tmp[N - j + 1] = x;
+  }
+  for (j = 0; j < nwh; ++j) {
+    unsigned r = bitrev((unsigned)j, bits);
+    w[2 * j] = tmp[2 * r];
+    w[2 * j + 1] = tmp[2 * r + 1];
+  }
+  c[0] = (float)cos(delta * nwh);
+  c[nwh] = 0.5f * c[0];
+  for (j = 1; j < nwh; j++) {
+    c[j] = 0.5f * (float)cos(delta * j);
+    c[N - j] = 0.5f * (float)sin(delta * j);
+  }
 }
 
 static void build_tables(void) {
@@ -110,9 +163,11 @@ static void build_tables(void) {
       g_c[nc - j] = 0.5f * (float)sin(delta * j);
     }
   }
-  for (j = 0; j < ANAL; ++j) g_window[j] = window_entry(j);
+  for (j = 0; j < MAXANAL; ++j) g_window[j] = window_entry(j);
+  for (j = 0; j < 128; ++j) g_window8[j] = window8_entry(j);
+  make_wt_ct(32, g_w8, g_c8);
   g_logi[0] = 0.f;
-  for (j = 1; j < BINS; ++j) g_logi[j] = (float)log((float)j);
+  for (j = 1; j < MAXBINS; ++j) g_logi[j] = (float)log((float)j);
 }
 
 static void ensure_tables(void) { pthread_once(&g_once, build_tables); }
@@ -120,6 +175,9 @@ static void ensure_tables(void) { pthread_once(&g_once, build_tables); }
 const float* asp_ns_oracle_window(void) { ensure_tables(); return g_window; }
 const float* asp_ns_oracle_fft_w(void) { ensure_tables(); return g_w; }
 const float* asp_ns_oracle_fft_c(void) { ensure_tables(); return g_c; }
+const float* asp_ns_oracle_window8(void) { ensure_tables(); return g_window8; }
+const float* asp_ns_oracle_fft_w8(void) { ensure_tables(); return g_w8; }
+const float* asp_ns_oracle_fft_c8(void) { ensure_tables(); return g_c8; }
 
 /* --------------------------------------------------------------------- FFT */
 
@@ -222,16 +280,43 @@ static void bit_reverse(float* a, int N, int bits) {
   }
 }
 
-/* cftfsub / cftbsub for n = 256 floats (N = 128 complex): three radix-4
- * passes then the radix-2 tail (fft4g.c:902-949, 952-999). */
-static void cft128(float* a, const float* w, int backward) {
-  const int N = 128;
-  cft_pass(a, N, 1, w);
-  cft_pass(a, N, 4, w);
-  cft_pass(a, N, 16, w);
-  for (int q = 0; q < 64; ++q) {
+/* cftfsub / cftbsub (fft4g.c:902-949, 952-999) for N complex points (n = 2N floats), N = 128 or 64:
+ * radix-4 passes at complex strides 1, 4, .. while 4 l < N, then
+ *   N = 128 (n = 256): the radix-2 tail at stride 64 (:939-947 / :989-997);
+ *   N = 64  (n = 128): one twiddle-free radix-4 stage at stride 16 (:918-937 / :968-987; forward it is
+ *                      the B = 0 case of the general pass, backward it carries the conjugation). */
+static void cftN(float* a, int N, const float* w, int backward) {
+  int l = 1;
+  cft_pass(a, N, l, w);
+  for (l = 4; 4 * l < N; l *= 4) cft_pass(a, N, l, w);
+  if (4 * l == N) {
+    if (!backward) {
+      cft_pass(a, N, l, w); /* a single block, B = 0: no twiddles */
+    } else {
+      for (int q = 0; q < l; ++q) { /* :968-987 */
+        float* e0 = a + 2 * q;
+        float* e1 = e0 + 2 * l;
+        float* e2 = e1 + 2 * l;
+        float* e3 = e2 + 2 * l;
+        float x0r = e0[0] + e1[0], x0i = -e0[1] - e1[1];
+        float x1r = e0[0] - e1[0], x1i = -e0[1] + e1[1];
+        float x2r = e2[0] + e3[0], x2i = e2[1] + e3[1];
+        float x3r = e2[0] - e3[0], x3i = e2[1] - e3[1];
+        e0[0] = x0r + x2r;
+        e0[1] = x0i - x2i;
+        e2[0] = x0r - x2r;
+        e2[1] = x0i + x2i;
+        e1[0] = x1r - x3i;
+        e1[1] = x1i - x3r;
+        e3[0] = x1r + x3i;
+        e3[1] = x1i + x3r;
+      }
+    }
+    return;
+  }
+  for (int q = 0; q < l; ++q) { /* 2 l == N */
     float* lo = a + 2 * q;
-    float* hi = a + 2 * (q + 64);
+    float* hi = a + 2 * (q + l);
     if (!backward) { /* :939-947 */
       float x0r = lo[0] - hi[0];
       float x0i = lo[1] - hi[1];
@@ -250,17 +335,20 @@ static void cft128(float* a, const float* w, int backward) {
   }
 }
 
-void asp_ns_oracle_rdft256(float* a, int isgn) {
-  const int n = 256, m = 128, nc = 64;
+/* WebRtc_rdft(n, isgn, a, ip, w) for n = 256 or 128 (fft4g.c:324-362; ks = 1 in rftfsub / rftbsub) */
+static void rdft_n(float* a, int n, int isgn) {
+  const int m = n >> 1, nc = n >> 2, bits = n == 256 ? 7 : 6;
+  const float* w = n == 256 ? g_w : g_w8;
+  const float* c = n == 256 ? g_c : g_c8;
   ensure_tables();
   if (isgn >= 0) { /* fft4g.c:339-349 */
     float xi;
-    bit_reverse(a, 128, 7);
-    cft128(a, g_w, 0);
-    for (int p = 1; p < 64; ++p) { /* rftfsub, fft4g.c:1234-1256 (ks = 1) */
+    bit_reverse(a, m, bits);
+    cftN(a, m, w, 0);
+    for (int p = 1; p < nc; ++p) { /* rftfsub, fft4g.c:1234-1256 */
       const int j = 2 * p, k = n - j;
-      float wkr = 0.5f - g_c[nc - p];
-      float wki = g_c[p];
+      float wkr = 0.5f - c[nc - p];
+      float wki = c[p];
       float xr = a[j] - a[k];
       float xim = a[j + 1] + a[k + 1];
       float yr = wkr * xr - wki * xim;
@@ -277,10 +365,10 @@ void asp_ns_oracle_rdft256(float* a, int isgn) {
     a[1] = 0.5f * (a[0] - a[1]);
     a[0] -= a[1];
     a[1] = -a[1]; /* rftbsub, fft4g.c:1259-1283 */
-    for (int p = 1; p < 64; ++p) {
+    for (int p = 1; p < nc; ++p) {
       const int j = 2 * p, k = n - j;
-      float wkr = 0.5f - g_c[nc - p];
-      float wki = g_c[p];
+      float wkr = 0.5f - c[nc - p];
+      float wki = c[p];
       float xr = a[j] - a[k];
       float xim = a[j + 1] + a[k + 1];
       float yr = wkr * xr + wki * xim;
@@ -291,10 +379,13 @@ void asp_ns_oracle_rdft256(float* a, int isgn) {
       a[k + 1] = yi - a[k + 1];
     }
     a[m + 1] = -a[m + 1];
-    bit_reverse(a, 128, 7);
-    cft128(a, g_w, 1);
+    bit_reverse(a, m, bits);
+    cftN(a, m, w, 1);
   }
 }
+
+void asp_ns_oracle_rdft256(float* a, int isgn) { rdft_n(a, 256, isgn); }
+void asp_ns_oracle_rdft128(float* a, int isgn) { rdft_n(a, 128, isgn); }
 
 /* -------------------------------------------------------------- reductions */
 
@@ -309,9 +400,16 @@ static float butterfly64(float* t) {
   return t[0];
 }
 
-/* Sum of x[0..128] (one value per bin).  TREE: lane l holds bins l and l+64,
- * lane 0 additionally bin 128.  TREE64P: see below. */
-static float sum_bins(const float* x, int mode) {
+/* Sum of x[0..BINS-1] (one value per bin).  TREE: lane l holds bins l and l+64,
+ * lane 0 additionally bin 128.  TREE64P: see below.  With 65 bins (8 kHz) every device association is
+ * the one of ns_kernels.hip's 8 kHz instantiation: lane l holds bin l, lane 0 additionally bin 64. */
+static float sum_bins(const float* x, int mode, int BINS) {
+  if (BINS == 65 && mode != ASP_NS_REDUCE_SEQ) {
+    float t[64];
+    for (int l = 0; l < 64; ++l) t[l] = x[l];
+    t[0] = t[0] + x[64];
+    return butterfly64(t);
+  }
   if (mode == ASP_NS_REDUCE_TREE64P) {
     /* ns_kernels1.hip: lane l = 2 lam + h holds bins q + 64 g + 16 h and that + 32
      * (lam = q + 16 g); bin 128 is added to the butterfly's result */
@@ -335,10 +433,20 @@ static float sum_bins(const float* x, int mode) {
   }
 }
 
-/* Energy of a 256-sample buffer (ns_core.c:951-960).  TREE: `by4` selects the
+/* Energy of an ANAL-sample buffer (ns_core.c:951-960).  TREE: `by4` selects the
  * lane layout: 1 = lane l holds samples 4l..4l+3 (analysis side), 0 = lane l
- * holds samples 2l, 2l+1, 2l+128, 2l+129 (after the inverse FFT). */
-static float energy256(const float* x, int mode, int by4) {
+ * holds samples 2l, 2l+1, 2l+128, 2l+129 (after the inverse FFT).  128 samples (8 kHz): lane l holds
+ * samples 2l, 2l+1 on both sides. */
+static float energy256(const float* x, int mode, int by4, int ANAL) {
+  if (ANAL == 128 && mode != ASP_NS_REDUCE_SEQ) {
+    float t[64];
+    for (int l = 0; l < 64; ++l) {
+      float s = x[2 * l] * x[2 * l];
+      s += x[2 * l + 1] * x[2 * l + 1];
+      t[l] = s;
+    }
+    return butterfly64(t);
+  }
   if (mode == ASP_NS_REDUCE_TREE64P && !by4) {
     /* synthesis side of ns_kernels1.hip: lane l = 2 lam + h holds complex elements
      * E = q + 64 g + 16 h and E + 32, i.e. samples 2E, 2E+1, 2E+64, 2E+65 (the analysis side
@@ -402,20 +510,21 @@ int asp_ns_oracle_set_policy(AspNsState* s, int mode) { /* ns_core.c:1013-1041 *
 int asp_ns_oracle_init(AspNsState* s, uint32_t fs) { /* ns_core.c:74-214 */
   int i;
   if (s == NULL) return -1;
-  if (fs != 16000 && fs != 32000 && fs != 48000) return -1; /* only the 160/256/129 geometry is restated */
+  if (fs != 8000 && fs != 16000 && fs != 32000 && fs != 48000) return -1; /* :82-86 */
+  GEO_FS(fs);
   ensure_tables();
   memset(s, 0, sizeof *s);
   s->fs = (int32_t)fs;
-  for (i = 0; i < SIMULT * BINS; i++) { /* :116-119 */
+  for (i = 0; i < SIMULT * MAXBINS; i++) { /* :116-119: the whole arrays, whatever magnLen is */
     s->lquantile[i] = 8.f;
     s->density[i] = 0.3f;
   }
   for (i = 0; i < SIMULT; i++) /* :121-124 */
     s->counter[i] = (int)floor((float)(END_STARTUP_LONG * (i + 1)) / (float)SIMULT);
   s->updates = 0;
-  for (i = 0; i < BINS; i++) s->smooth[i] = 1.f;          /* :129-131 */
+  for (i = 0; i < MAXBINS; i++) s->smooth[i] = 1.f;       /* :129-131 */
   s->priorSpeechProb = 0.5f;                               /* :137 */
-  for (i = 0; i < BINS; i++) s->logLrtTimeAvg[i] = LRT_FEATURE_THR; /* :152-155 */
+  for (i = 0; i < MAXBINS; i++) s->logLrtTimeAvg[i] = LRT_FEATURE_THR; /* :152-155 */
   s->featureData[0] = SF_FEATURE_THR;                      /* :159-168 */
   s->featureData[3] = LRT_FEATURE_THR;
   s->featureData[4] = SF_FEATURE_THR;
@@ -571,19 +680,22 @@ static void update_histograms(AspNsState* s) {
 /* ---------------------------------------------------------------- analysis */
 
 /* UpdateBuffer + Windowing (ns_core.c:855-873, 969-978). */
-static void slide_and_window(float* buf, const float* frame, float* win) {
+static void slide_and_window(float* buf, const float* frame, float* win, int fs) {
+  GEO_FS(fs);
+  const float* g_win = fs == 8000 ? g_window8 : g_window;
   memmove(buf, buf + BLOCKL, sizeof(float) * (ANAL - BLOCKL));
   if (frame)
     memcpy(buf + ANAL - BLOCKL, frame, sizeof(float) * BLOCKL);
   else
     memset(buf + ANAL - BLOCKL, 0, sizeof(float) * BLOCKL);
   if (win)
-    for (int i = 0; i < ANAL; ++i) win[i] = g_window[i] * buf[i];
+    for (int i = 0; i < ANAL; ++i) win[i] = g_win[i] * buf[i];
 }
 
 /* FFT(), ns_core.c:886-911. */
-static void forward_spectrum(float* td, float* re, float* im, float* magn) {
-  asp_ns_oracle_rdft256(td, 1);
+static void forward_spectrum(float* td, float* re, float* im, float* magn, int fs) {
+  GEO_FS(fs);
+  rdft_n(td, ANAL, 1);
   im[0] = 0;
   re[0] = td[0];
   magn[0] = (float)(fabs(re[0]) + 1.f);
@@ -598,6 +710,7 @@ static void forward_spectrum(float* td, float* re, float* im, float* magn) {
 }
 
 void asp_ns_oracle_analyze(AspNsState* s, const float* frame, int mode) {
+  GEO(s);
   int i, k, offset = 0;
   int updateParsFlag;
   float energy, signalEnergy, sumMagn;
@@ -607,19 +720,19 @@ void asp_ns_oracle_analyze(AspNsState* s, const float* frame, int mode) {
 
   ensure_tables();
   updateParsFlag = s->modelUpdatePars[0]; /* :1065 */
-  slide_and_window(s->analyzeBuf, frame, win); /* :1068-1070 */
-  energy = energy256(win, mode, 1);
+  slide_and_window(s->analyzeBuf, frame, win, s->fs); /* :1068-1070 */
+  energy = energy256(win, mode, 1, ANAL);
   if (energy == 0.0) return; /* :1072-1082 */
   s->blockInd++;
-  forward_spectrum(win, re, im, magn); /* :1086 */
+  forward_spectrum(win, re, im, magn, s->fs); /* :1086 */
 
   /* lmagn is needed three times with the same value: NoiseEstimation :228,
    * the startup fit :1096 and the flatness numerator :540. */
   for (i = 0; i < BINS; i++) lmagn[i] = (float)log(magn[i]);
 
   for (i = 0; i < BINS; i++) tmpv[i] = re[i] * re[i] + im[i] * im[i]; /* :1089 */
-  signalEnergy = sum_bins(tmpv, mode);
-  sumMagn = sum_bins(magn, mode); /* :1090 */
+  signalEnergy = sum_bins(tmpv, mode, BINS);
+  sumMagn = sum_bins(magn, mode, BINS); /* :1090 */
   signalEnergy = signalEnergy / ((float)BINS); /* :1102-1104 */
   s->signalEnergy = signalEnergy;
   s->sumMagn = sumMagn;
@@ -666,9 +779,9 @@ void asp_ns_oracle_analyze(AspNsState* s, const float* frame, int mode) {
       sum_log_i_square += g_logi[i] * g_logi[i];
     }
     for (i = 0; i < BINS; i++) tmpv[i] = i >= K_START_BAND ? lmagn[i] : 0.f;
-    sum_log_magn = sum_bins(tmpv, mode);
+    sum_log_magn = sum_bins(tmpv, mode, BINS);
     for (i = 0; i < BINS; i++) tmpv[i] = i >= K_START_BAND ? g_logi[i] * lmagn[i] : 0.f;
-    sum_log_i_log_magn = sum_bins(tmpv, mode);
+    sum_log_i_log_magn = sum_bins(tmpv, mode, BINS);
 
     s->whiteNoiseLevel += sumMagn / ((float)BINS) * s->overdrive; /* :1111 */
     tmpFloat1 = sum_log_i_square * ((float)(BINS - K_START_BAND));
@@ -720,7 +833,7 @@ void asp_ns_oracle_analyze(AspNsState* s, const float* frame, int mode) {
   { /* ComputeSpectralFlatness :523-556 (magn >= 1 so the log(0) exit is dead) */
     float num, den, spectralTmp;
     for (i = 0; i < BINS; i++) tmpv[i] = i >= 1 ? lmagn[i] : 0.f;
-    num = sum_bins(tmpv, mode);
+    num = sum_bins(tmpv, mode, BINS);
     den = s->sumMagn - magn[0];
     den = den / BINS;
     num = num / BINS;
@@ -729,17 +842,17 @@ void asp_ns_oracle_analyze(AspNsState* s, const float* frame, int mode) {
   }
   { /* ComputeSpectralDifference :595-634 */
     float avgPause, avgMagn, covMagnPause, varPause, varMagn, avgDiffNormMagn;
-    avgPause = sum_bins(s->magnAvgPause, mode);
+    avgPause = sum_bins(s->magnAvgPause, mode, BINS);
     avgMagn = s->sumMagn;
     avgPause = avgPause / ((float)BINS);
     avgMagn = avgMagn / ((float)BINS);
     for (i = 0; i < BINS; i++) tmpv[i] = (magn[i] - avgMagn) * (s->magnAvgPause[i] - avgPause);
-    covMagnPause = sum_bins(tmpv, mode);
+    covMagnPause = sum_bins(tmpv, mode, BINS);
     for (i = 0; i < BINS; i++)
       tmpv[i] = (s->magnAvgPause[i] - avgPause) * (s->magnAvgPause[i] - avgPause);
-    varPause = sum_bins(tmpv, mode);
+    varPause = sum_bins(tmpv, mode, BINS);
     for (i = 0; i < BINS; i++) tmpv[i] = (magn[i] - avgMagn) * (magn[i] - avgMagn);
-    varMagn = sum_bins(tmpv, mode);
+    varMagn = sum_bins(tmpv, mode, BINS);
     covMagnPause = covMagnPause / ((float)BINS);
     varPause = varPause / ((float)BINS);
     varMagn = varMagn / ((float)BINS);
@@ -780,7 +893,7 @@ void asp_ns_oracle_analyze(AspNsState* s, const float* frame, int mode) {
       float besselTmp = (snrLocPost[i] + 1.f) * t2;
       s->logLrtTimeAvg[i] += LRT_TAVG * (besselTmp - (float)log(t1) - s->logLrtTimeAvg[i]);
     }
-    logLrtTimeAvgKsum = sum_bins(s->logLrtTimeAvg, mode);
+    logLrtTimeAvgKsum = sum_bins(s->logLrtTimeAvg, mode, BINS);
     logLrtTimeAvgKsum = (float)logLrtTimeAvgKsum / (BINS);
     s->featureData[3] = logLrtTimeAvgKsum;
     widthPrior = widthPrior0; /* :690-698 */
@@ -847,20 +960,21 @@ static float sat16(float x) { /* WEBRTC_SPL_SAT(32767, x, -32768), ns_core.c:135
 
 /* returns 0 for the zero-energy early exit (ns_core.c:1239-1264), 1 otherwise */
 static int process_low(AspNsState* s, const float* in, float* out, int mode) {
+  GEO(s);
   int i;
   float energy1, energy2, gain, factor, factor1, factor2;
   float fout[BLOCKL], win[ANAL], magn[BINS], theFilter[BINS], re[BINS], im[BINS];
 
   ensure_tables();
-  slide_and_window(s->dataBuf, in, win); /* :1225, :1237 */
-  energy1 = energy256(win, mode, 1);
+  slide_and_window(s->dataBuf, in, win, s->fs); /* :1225, :1237 */
+  energy1 = energy256(win, mode, 1, ANAL);
   if (energy1 == 0.0) { /* :1239-1264 */
     for (i = 0; i < BLOCKL; i++) fout[i] = s->syntBuf[i];
-    slide_and_window(s->syntBuf, NULL, NULL);
+    slide_and_window(s->syntBuf, NULL, NULL, s->fs);
     for (i = 0; i < BLOCKL; ++i) out[i] = sat16(fout[i]);
     return 0;
   }
-  forward_spectrum(win, re, im, magn); /* :1266 */
+  forward_spectrum(win, re, im, magn, s->fs); /* :1266 */
   if (s->blockInd < END_STARTUP_SHORT) /* :1268-1272 */
     for (i = 0; i < BINS; i++) s->initMagnEst[i] += magn[i];
 
@@ -898,14 +1012,14 @@ static int process_low(AspNsState* s, const float* in, float* out, int mode) {
     win[2 * i] = re[i];
     win[2 * i + 1] = im[i];
   }
-  asp_ns_oracle_rdft256(win, -1);
+  rdft_n(win, ANAL, -1);
   for (i = 0; i < ANAL; ++i) win[i] *= 2.f / ANAL;
 
   factor = 1.f; /* :1315-1342 */
   if (s->gainmap == 1 && s->blockInd > END_STARTUP_LONG) {
     factor1 = 1.f;
     factor2 = 1.f;
-    energy2 = energy256(win, mode, 0);
+    energy2 = energy256(win, mode, 0, ANAL);
     gain = (float)sqrt(energy2 / (energy1 + 1.f));
     if (gain > B_LIM) {
       factor1 = 1.f + 1.3f * (gain - B_LIM);
@@ -917,10 +1031,10 @@ static int process_low(AspNsState* s, const float* in, float* out, int mode) {
     }
     factor = s->priorSpeechProb * factor1 + (1.f - s->priorSpeechProb) * factor2;
   }
-  for (i = 0; i < ANAL; ++i) win[i] = g_window[i] * win[i]; /* :1344 */
+  for (i = 0; i < ANAL; ++i) win[i] = (s->fs == 8000 ? g_window8 : g_window)[i] * win[i]; /* :1344 */
   for (i = 0; i < ANAL; i++) s->syntBuf[i] += factor * win[i]; /* :1347-1349 */
   for (i = 0; i < BLOCKL; i++) fout[i] = s->syntBuf[i];
-  slide_and_window(s->syntBuf, NULL, NULL); /* :1355 */
+  slide_and_window(s->syntBuf, NULL, NULL, s->fs); /* :1355 */
   for (i = 0; i < BLOCKL; ++i) out[i] = sat16(fout[i]);
   return 1;
 }
@@ -932,13 +1046,14 @@ void asp_ns_oracle_process(AspNsState* s, const float* in, float* out, int mode)
 void asp_ns_oracle_process_bands(AspNsState* s, AspNsHbState* hb, const float* in_low,
                                  const float* in_high, int num_high, float* out_low,
                                  float* out_high, int mode) {
+  GEO(s);
   int i, j, live;
   const int deltaBweHB = BINS / 4, deltaGainHB = BINS / 4; /* :1221-1223 */
   float avgProbSpeechHB, avgProbSpeechHBTmp, avgFilterGainHB, gainModHB, gainTimeDomainHB;
   float sumMagnAnalyze, sumMagnProcess;
   const float decayBweHB = 1.0, gainMapParHB = 1.0; /* :1202-1203 */
   for (i = 0; i < num_high; ++i) /* UpdateBuffer of the high bands, :1227-1235 */
-    slide_and_window(hb->dataBufHB[i], in_high + (size_t)i * BLOCKL, NULL);
+    slide_and_window(hb->dataBufHB[i], in_high + (size_t)i * BLOCKL, NULL, s->fs);
   live = process_low(s, in_low, out_low, mode);
   if (!live) { /* :1252-1261 */
     for (i = 0; i < num_high; ++i)
@@ -975,6 +1090,7 @@ void asp_ns_oracle_process_bands(AspNsState* s, AspNsHbState* hb, const float* i
 
 void asp_ns_oracle_run(AspNsState* states, int num_streams, const float* in,
                        float* out, int num_frames, int mode) {
+  GEO(&states[0]); /* one geometry per batch */
   for (int f = 0; f < num_frames; ++f)
     for (int st = 0; st < num_streams; ++st) {
       const float* x = in + ((size_t)f * num_streams + st) * BLOCKL;
@@ -995,6 +1111,7 @@ typedef struct {
 
 static void* shard_main(void* p) {
   Shard* sh = (Shard*)p;
+  GEO(&sh->states[0]);
   for (int f = 0; f < sh->num_frames; ++f)
     for (int st = sh->s0; st < sh->s1; ++st) {
       const float* x = sh->in + ((size_t)f * sh->num_streams + st) * BLOCKL;

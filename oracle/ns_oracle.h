@@ -58,6 +58,7 @@ void asp_ns_oracle_run_mt(AspNsState* states, int num_streams, const float* in,
 /* 256-point real FFT in Ooura packing, in place; WebRtc_rdft(256, isgn, ...)
  * (fft4g.c:324-362).  isgn=+1 forward, -1 inverse (unscaled). */
 void asp_ns_oracle_rdft256(float* a, int isgn);
+void asp_ns_oracle_rdft128(float* a, int isgn);   /* WebRtc_rdft(128, isgn): the 8 kHz transform */
 
 /* (float)fn((double)x) with the host libm, in place: fn 1 = log, 2 = exp, 3 = tanh. */
 void asp_oracle_libm_f32(int fn, float* data, size_t n);
@@ -66,6 +67,9 @@ void asp_oracle_libm_f32(int fn, float* data, size_t n);
 const float* asp_ns_oracle_window(void);      /* kBlocks160w256, windows_private.h:94-147 */
 const float* asp_ns_oracle_fft_w(void);       /* makewt(64) table, fft4g.c:642-669        */
 const float* asp_ns_oracle_fft_c(void);       /* makect(64) table, fft4g.c:671-690        */
+const float* asp_ns_oracle_window8(void);     /* kBlocks80w128, windows_private.h:64-91   */
+const float* asp_ns_oracle_fft_w8(void);      /* makewt(32): WebRtc_rdft(128)             */
+const float* asp_ns_oracle_fft_c8(void);      /* makect(32)                               */
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,21 @@ void ref_rdft256(float* a, int isgn) {
   WebRtc_rdft(256, isgn, a, ip, w);
 }
 
+/* WebRtc_rdft on one 128-float row (the 8 kHz transform) with freshly initialised work arrays. */
+void ref_rdft128(float* a, int isgn) {
+  static __thread int ip[128];
+  static __thread float w[128];
+  static __thread int ready;
+  if (!ready) {
+    float z[128];
+    memset(z, 0, sizeof z);
+    ip[0] = 0;
+    WebRtc_rdft(128, 1, z, ip, w);
+    ready = 1;
+  }
+  WebRtc_rdft(128, isgn, a, ip, w);
+}
+
 /* Batch loop of the reference entry points: frames [F][S][160], Analyze then
  * Process on the same frame per stream (test_ns_module.cpp:97-99). */
 typedef struct {
@@ -133,15 +148,16 @@ typedef struct {
 
 static void* ref_shard_main(void* p) {
   RefShard* sh = (RefShard*)p;
+  const size_t bl = (size_t)sh->inst[0].blockLen; /* 160, or 80 at 8 kHz: frames are [F][S][blockLen] */
   for (int f = 0; f < sh->F; ++f)
     for (int st = sh->s0; st < sh->s1; ++st) {
       float tmp[160], o[160];
       const float* ip[1] = {tmp};
       float* op[1] = {o};
-      memcpy(tmp, sh->in + ((size_t)f * sh->S + st) * 160, sizeof tmp);
+      memcpy(tmp, sh->in + ((size_t)f * sh->S + st) * bl, sizeof(float) * bl);
       WebRtcNs_AnalyzeCore(&sh->inst[st], tmp);
       WebRtcNs_ProcessCore(&sh->inst[st], ip, 1, op);
-      memcpy(sh->out + ((size_t)f * sh->S + st) * 160, o, sizeof o);
+      memcpy(sh->out + ((size_t)f * sh->S + st) * bl, o, sizeof(float) * bl);
     }
   return NULL;
 }

@@ -43,7 +43,8 @@ def _load_oracle():
     lib.asp_ns_oracle_analyze.argtypes = [sp, _f32p, C.c_int]
     lib.asp_ns_oracle_process.argtypes = [sp, _f32p, _f32p, C.c_int]
     lib.asp_ns_oracle_rdft256.argtypes = [_f32p, C.c_int]
-    for n in ("window", "fft_w", "fft_c"):
+    lib.asp_ns_oracle_rdft128.argtypes = [_f32p, C.c_int]
+    for n in ("window", "fft_w", "fft_c", "window8", "fft_w8", "fft_c8"):
         getattr(lib, "asp_ns_oracle_" + n).restype = C.POINTER(C.c_float)
     return lib
 
@@ -75,6 +76,7 @@ def ref_lib():
         lib.ref_ns_import.argtypes = [C.c_void_p, C.POINTER(AspNsState)]
         lib.ref_ns_run.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.c_int, C.c_int]
         lib.ref_rdft256.argtypes = [_f32p, C.c_int]
+        lib.ref_rdft128.argtypes = [_f32p, C.c_int]
         lib.ref_ns_fft_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _ref = lib
     return _ref
@@ -92,16 +94,17 @@ class OracleNs:
         self.lib = oracle_lib()
         self.S = num_streams
         self.mode = reduce_mode
+        self.block = 80 if fs == 8000 else BLOCKL   # ns_core.c:89-98
         self.states = (AspNsState * num_streams)()
         for i in range(num_streams):
             assert self.lib.asp_ns_oracle_init(C.byref(self.states[i]), fs) == 0
             assert self.lib.asp_ns_oracle_set_policy(C.byref(self.states[i]), policy) == 0
 
     def run(self, frames, threads=1):
-        """frames [F][S][160] float32 -> output of the same shape."""
+        """frames [F][S][160] float32 ([F][S][80] at 8 kHz) -> output of the same shape."""
         frames = np.ascontiguousarray(frames, dtype=np.float32)
         F = frames.shape[0]
-        assert frames.shape == (F, self.S, BLOCKL)
+        assert frames.shape == (F, self.S, self.block)
         out = np.empty_like(frames)
         if threads > 1:
             self.lib.asp_ns_oracle_run_mt(self.states, self.S, frames, out, F, self.mode, threads)
@@ -118,7 +121,7 @@ class OracleNs:
         frames = np.ascontiguousarray(frames, dtype=np.float32)
         out = np.empty_like(frames)
         for i in range(self.S):
-            o = np.empty(BLOCKL, np.float32)
+            o = np.empty(self.block, np.float32)
             self.lib.asp_ns_oracle_process(C.byref(self.states[i]), frames[i].copy(), o, self.mode)
             out[i] = o
         return out
@@ -161,6 +164,12 @@ class OracleNs:
             self.lib.asp_ns_oracle_rdft256(r, isgn)
         return rows
 
+    def rdft128(self, rows, isgn):
+        rows = np.ascontiguousarray(rows, dtype=np.float32).copy()
+        for r in rows.reshape(-1, 128):
+            self.lib.asp_ns_oracle_rdft128(r, isgn)
+        return rows
+
 
 class RefNs:
     """Batch of streams driven through the compiled reference (ns_core.c)."""
@@ -168,6 +177,7 @@ class RefNs:
     def __init__(self, num_streams, policy=1, fs=16000):
         self.lib = ref_lib()
         self.S = num_streams
+        self.block = 80 if fs == 8000 else BLOCKL
         self.size = self.lib.ref_ns_sizeof()
         self.buf = C.create_string_buffer(self.size * num_streams)
         self.base = C.addressof(self.buf)
@@ -181,7 +191,7 @@ class RefNs:
     def run(self, frames, threads=1):
         frames = np.ascontiguousarray(frames, dtype=np.float32)
         F = frames.shape[0]
-        assert frames.shape == (F, self.S, BLOCKL)
+        assert frames.shape == (F, self.S, self.block)
         out = np.empty_like(frames)
         self.lib.ref_ns_run(C.c_void_p(self.base), self.S, frames, out, F, threads)
         return out
@@ -224,6 +234,12 @@ class RefNs:
         rows = np.ascontiguousarray(rows, dtype=np.float32).copy()
         for r in rows.reshape(-1, 256):
             self.lib.ref_rdft256(r, isgn)
+        return rows
+
+    def rdft128(self, rows, isgn):
+        rows = np.ascontiguousarray(rows, dtype=np.float32).copy()
+        for r in rows.reshape(-1, 128):
+            self.lib.ref_rdft128(r, isgn)
         return rows
 
     def fft_tables(self):

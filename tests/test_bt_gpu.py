@@ -321,6 +321,16 @@ def test_layer1_reference_protocol(bt, built_lib):
         assert rc == o.denoise_float(hop) == (0x20 if k == 4 else 0x10)
     assert lib.blockThreshold_output_float(h, out.ctypes.data, 1024) == 1024
     assert np.array_equal(out, o.output_float()[1])
+    # a flush with no pending hop returns 0 samples and still consumes the overlap tail (.c:656-659):
+    # the next macroblock starts from a cleared tail, in the library as in the oracle
+    assert lib.blockThreshold_flush_float(h, fl.ctypes.data, 384) == 0
+    assert o.flush_float(0)[0] == 0
+    last = bt_samples(1, 1024, stream0=9)[0]
+    for k, hop in enumerate(np.ascontiguousarray(last).reshape(8, 128)):
+        hop = np.ascontiguousarray(hop)
+        assert lib.blockThreshold_denoise_float(h, hop.ctypes.data, 128) == o.denoise_float(hop)
+    assert lib.blockThreshold_output_float(h, out.ctypes.data, 1024) == 1024
+    assert np.array_equal(out, o.output_float()[1])
     lib.blockThreshold_free(h)
     # int16 path: S16ToFloat in, FloatToS16 out (.c:259-271)
     h = lib.blockThreshold_init(16, 16000, C.byref(err))

@@ -298,6 +298,31 @@ def test_wav_driver_end_to_end(ns, golden, tmp_path):
     assert (d == 0).mean() >= 0.999
 
 
+def test_wav_driver_8khz(ns, golden8k, tmp_path):
+    """drivers/test_ns_module on an 8 kHz mono WAV (test_ns_module.cpp:59-60: 80 samples per frame):
+    the committed reference outputs of stream 0, rounded by FloatS16ToS16, within 1 LSB; the trailing
+    frame of the `while (!feof)` loop (the stale last frame processed again) is present."""
+    from audiosignalprocess_amd.build import build_drivers
+
+    exe = build_drivers()[0]
+    pcm = np.ascontiguousarray(golden8k["in_i16"][:, 0, :]).reshape(-1)
+    hdr = b"RIFF" + struct.pack("<i", 36 + pcm.nbytes) + b"WAVE" + \
+        struct.pack("<4sihhiihh", b"fmt ", 16, 1, 1, 8000, 16000, 2, 16) + \
+        b"data" + struct.pack("<i", pcm.nbytes)
+    src, dst = tmp_path / "in8k.wav", tmp_path / "out8k.wav"
+    src.write_bytes(hdr + pcm.tobytes())
+    subprocess.run([exe, str(src), str(dst), "-q"], check=True, stdout=subprocess.DEVNULL)
+    raw = dst.read_bytes()
+    assert raw[:44] == hdr
+    out = np.frombuffer(raw[44:], dtype=np.int16)
+    assert out.size == pcm.size + 80
+    ref = golden8k["out_f32"][:, 0, :].reshape(-1)
+    want = np.where(ref > 0, np.where(ref >= 32766.5, 32767, (ref + np.float32(0.5)).astype(np.int32)),
+                    np.where(ref <= -32767.5, -32768, (ref - np.float32(0.5)).astype(np.int32)))
+    d = np.abs(out[:pcm.size].astype(np.int32) - want)
+    assert d.max() <= 1 and (d == 0).mean() >= 0.999
+
+
 def _debug_compare(lib, fn_a, fn_b, start, count, param=1.0):
     n_bad = C.c_uint32()
     bad = (C.c_uint32 * 64)()
@@ -574,6 +599,98 @@ def test_pair_then_unfused_continues(ns, kid, mode):
         o.analyze(x[f])
         assert np.array_equal(g.process(x[f]), o.process(x[f])), f
     g.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# 8 kHz (ns_core.c:89-98: blockLen 80, anaLen 128, 65 bins, kBlocks80w128, WebRtc_rdft(128)): the G8
+# instantiation of ns_kernels.hip behind every entry point of a batch initialised at fs = 8000.
+@pytest.fixture(scope="module")
+def golden8k():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "ns8k_golden.npz")))
+
+
+def test_8khz_rdft128_bit_exact(ns, golden8k):
+    from audiosignalprocess_amd.ns import rdft128
+
+    # value equality, as for the 256-point seam: an exact zero may carry the other sign where a
+    # twiddle-free butterfly multiplies by (1, 0) instead of skipping the product (impulse inputs only)
+    fwd = rdft128(golden8k["fft_in"], 1)
+    assert np.array_equal(fwd, golden8k["fft_fwd"])
+    assert np.array_equal(rdft128(golden8k["fft_fwd"], -1), golden8k["fft_inv"])
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal((300, 128)) * 5000).astype(np.float32)
+    o = OracleNs(1, fs=8000)
+    for isgn in (1, -1):
+        assert np.array_equal(rdft128(x, isgn).view(np.uint32), o.rdft128(x, isgn).view(np.uint32)), isgn
+
+
+def test_8khz_free_running_bit_exact_all_policies(ns):
+    S, F = 13, 560   # crosses blockInd 50 / 200 and a 500-frame histogram window
+    x = ns_frames(S, F, stream0=90)[:, :, ::2].copy()
+    x[20:24, 1] = 0.0
+    x[:, 2] = 0.0
+    x[60:, 3] = 32767.0
+    for policy in (1, 0, 3):
+        g = ns.NsBatch(S, fs=8000, policy=policy)
+        o = OracleNs(S, policy=policy, reduce_mode=REDUCE_TREE, fs=8000)
+        y, yo = g.analyze_process(x), o.run(x, threads=4)
+        bad = np.nonzero((y != yo).any(axis=2))
+        assert bad[0].size == 0, (policy, bad[0][:5], bad[1][:5])
+        for s in range(S):
+            assert state_diff(g.export_state(s), o.export_state(s)) == {}, (policy, s)
+        g.close()
+
+
+def test_8khz_golden_protocols_and_pcm(ns, golden8k):
+    """The reference's own 8 kHz outputs within the 1e-4 bar; Analyze + Process as two calls equals the
+    fused step; the int16 entry point within 1 LSB of FloatS16ToS16 of the reference's floats; state
+    import / export round trip; the reference's layer-1 symbols at fs = 8000."""
+    x = golden8k["in_i16"].astype(np.float32)
+    F, S, _ = x.shape
+    g = ns.NsBatch(S, fs=8000, policy=1)
+    y = g.analyze_process(x)
+    check_free_running(rel_l2_per_stream(y, golden8k["out_f32"]), "8 kHz HIP vs reference golden")
+    # two-call protocol on a second batch, switching over mid-run
+    u = ns.NsBatch(S, fs=8000, policy=1)
+    assert np.array_equal(u.analyze_process(x[:120]), y[:120])
+    for f in range(120, 260):
+        u.analyze(x[f])
+        assert np.array_equal(u.process(x[f]), y[f]), f
+    # checkpoint: export from one batch, import into a fresh one, continue
+    v = ns.NsBatch(S, fs=8000, policy=1)
+    for s in range(S):
+        v.import_state(s, u.export_state(s))
+    assert np.array_equal(v.analyze_process(x[260:300]), y[260:300])
+    # PCM in / out
+    g16 = ns.NsBatch(S, fs=8000, policy=1)
+    y16 = g16.analyze_process_s16(golden8k["in_i16"])
+    ref = golden8k["out_f32"]
+    want = np.where(ref > 0, np.where(ref >= 32766.5, 32767, (ref + np.float32(0.5)).astype(np.int32)),
+                    np.where(ref <= -32767.5, -32768, (ref - np.float32(0.5)).astype(np.int32)))
+    d = np.abs(y16.astype(np.int32) - want)
+    assert d.max() <= 1 and (d == 0).mean() >= 0.999
+    for b in (g, u, v, g16):
+        b.close()
+    # layer 1: WebRtcNs_Create / _Init(8000) / _set_policy / _Analyze / _Process (noise_suppression.h:35-123)
+    lib = ns.load_library()
+    h = C.c_void_p()
+    assert lib.WebRtcNs_Create(C.byref(h)) == 0
+    lib.WebRtcNs_Init.argtypes = [C.c_void_p, C.c_uint32]
+    assert lib.WebRtcNs_Init(h, 8000) == 0 and lib.WebRtcNs_set_policy(h, 1) == 0
+    lib.WebRtcNs_Analyze.argtypes = [C.c_void_p, C.c_void_p]
+    lib.WebRtcNs_Process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.WebRtcNs_Analyze.restype = lib.WebRtcNs_Process.restype = None
+    o = OracleNs(1, policy=1, reduce_mode=REDUCE_TREE, fs=8000)
+    for f in range(60):
+        fr = np.ascontiguousarray(x[f, 0])
+        out = np.empty(80, np.float32)
+        pin, pout = (C.c_void_p * 1)(fr.ctypes.data), (C.c_void_p * 1)(out.ctypes.data)
+        lib.WebRtcNs_Analyze(h, fr.ctypes.data)
+        lib.WebRtcNs_Process(h, pin, 1, pout)
+        o.analyze(fr[None])
+        assert np.array_equal(out, o.process(fr[None])[0]), f
+    lib.WebRtcNs_Free.argtypes = [C.c_void_p]
+    lib.WebRtcNs_Free(h)
 
 
 # ---------------------------------------------------------------------------------------------

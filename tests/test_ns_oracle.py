@@ -17,6 +17,7 @@ from tests import oracle_lib
 from tests.conftest import check_free_running, rel_l2_per_stream, state_diff, state_from_bytes
 from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE64P, OracleNs
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 needs_ref = pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built here")
 
 
@@ -203,3 +204,53 @@ def test_high_band_branch_equals_reference(fs, nh):
         assert np.array_equal(ref.export_hb(s)[:nh], hb[:nh])
     # the branch does something: the high band is attenuated during noise-only stretches
     assert np.abs(rh[450:600]).mean() < 0.9 * np.abs(high[450:600]).mean()
+
+
+# ---------------------------------------------------------------------------------------------
+# 8 kHz: blockLen 80, anaLen 128, 65 bins, window kBlocks80w128, WebRtc_rdft(128) (ns_core.c:89-98)
+@pytest.fixture(scope="module")
+def golden8k():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "ns8k_golden.npz")))
+
+
+def test_8khz_oracle_equals_reference_golden(golden8k):
+    """Outputs of the reference at fs = 8000 (committed fixture) bit for bit, full state at the
+    snapshots (start-up boundaries 50 / 200, a 500-frame histogram window, a zero-energy stretch),
+    and the 128-point transform's known answers."""
+    from audiosignalprocess_amd._abi import AspNsState
+
+    x = golden8k["in_i16"].astype(np.float32)
+    F, S, n = x.shape
+    assert n == 80
+    o = OracleNs(S, policy=1, fs=8000)
+    done = 0
+    for k, snap in zip(golden8k["snap_frames"], golden8k["snap_state"]):
+        y = o.run(x[done:k])
+        assert np.array_equal(y.view(np.uint32), golden8k["out_f32"][done:k].view(np.uint32)), k
+        done = int(k)
+        for s in range(S):
+            assert state_diff(o.export_state(s), AspNsState.from_buffer_copy(bytes(snap[s])), skip=set()) == {}, (k, s)
+    assert done == F
+    fwd = o.rdft128(golden8k["fft_in"], 1)
+    assert np.array_equal(fwd.view(np.uint32), golden8k["fft_fwd"].view(np.uint32))
+    assert np.array_equal(o.rdft128(fwd, -1).view(np.uint32), golden8k["fft_inv"].view(np.uint32))
+
+
+@needs_ref
+def test_8khz_oracle_equals_live_reference_all_policies():
+    x = ns_frames(5, 420, stream0=9)[:, :, ::2].copy()
+    x[100:104, 3] = 0.0
+    x[200:, 4] = 32767.0
+    for policy in (0, 1, 2, 3):
+        o, r = OracleNs(5, policy=policy, fs=8000), oracle_lib.RefNs(5, policy=policy, fs=8000)
+        assert np.array_equal(o.run(x).view(np.uint32), r.run(x).view(np.uint32)), policy
+        for s in range(5):
+            assert state_diff(o.export_state(s), r.export_state(s), skip=set()) == {}, (policy, s)
+
+
+def test_8khz_tree_association_within_tolerance(golden8k):
+    """The device association at 8 kHz (lane l holds bin l, bin 64 joins lane 0) against the
+    reference's outputs: every stream inside the 1e-4 bar."""
+    x = golden8k["in_i16"].astype(np.float32)
+    y = OracleNs(x.shape[1], policy=1, reduce_mode=REDUCE_TREE, fs=8000).run(x)
+    check_free_running(rel_l2_per_stream(y, golden8k["out_f32"]), "8 kHz TREE")
