@@ -108,9 +108,9 @@ class AspAecState(C.Structure):
         ("dBuf", C.c_float * 128), ("eBuf", C.c_float * 128),
         ("xPow", C.c_float * 65), ("dPow", C.c_float * 65), ("dMinPow", C.c_float * 65),
         ("dInitMinPow", C.c_float * 65),
-        ("xfBuf", C.c_float * (2 * 12 * 65)), ("wfBuf", C.c_float * (2 * 12 * 65)),
+        ("xfBuf", C.c_float * (2 * 32 * 65)), ("wfBuf", C.c_float * (2 * 32 * 65)),
         ("sde", C.c_float * (65 * 2)), ("sxd", C.c_float * (65 * 2)),
-        ("xfwBuf", C.c_float * (12 * 65 * 2)),
+        ("xfwBuf", C.c_float * (32 * 65 * 2)),
         ("sx", C.c_float * 65), ("sd", C.c_float * 65), ("se", C.c_float * 65),
         ("outBuf", C.c_float * 64),
         ("hNlFbMin", C.c_float), ("hNlFbLocalMin", C.c_float), ("hNlXdAvgMin", C.c_float),

@@ -88,7 +88,9 @@ struct AecCore* WebRtcAec_aec_core(void* handle);                               
 #define ASP_AEC_PART_LEN1 65   /* aec_core.h:22 */
 #define ASP_AEC_PART_LEN2 128  /* aec_core.h:23 */
 #define ASP_AEC_FRAME_LEN 80   /* aec_core.h:20 */
-#define ASP_AEC_PARTITIONS 12  /* kNormalNumPartitions, aec_core_internal.h:25 */
+#define ASP_AEC_PARTITIONS 12      /* kNormalNumPartitions, aec_core_internal.h:25 */
+#define ASP_AEC_PARTITIONS_MAX 32  /* kExtendedNumPartitions, aec_core_internal.h:23: the length of the reference's
+                                    * arrays whatever the filter length (extended filter: all 32 live) */
 #define ASP_AEC_FAR_SLOTS 250  /* kBufSizePartitions, aec_core.c:37 */
 
 /* ---------------------------------------------------------------- layer 2 */
@@ -103,11 +105,11 @@ typedef struct AspAecState {
   float dPow[65];
   float dMinPow[65];
   float dInitMinPow[65];
-  float xfBuf[2][12 * 65];
-  float wfBuf[2][12 * 65];
+  float xfBuf[2][ASP_AEC_PARTITIONS_MAX * 65];  /* partition p at [.][p * 65 ..] */
+  float wfBuf[2][ASP_AEC_PARTITIONS_MAX * 65];
   float sde[65][2];
   float sxd[65][2];
-  float xfwBuf[12 * 65][2];
+  float xfwBuf[ASP_AEC_PARTITIONS_MAX * 65][2];
   float sx[65];
   float sd[65];
   float se[65];

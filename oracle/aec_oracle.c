@@ -23,7 +23,8 @@
 #define PART_LEN1 65
 #define PART_LEN2 128
 #define FRAME_LEN 80
-#define NPART 12
+#define NPART_NORMAL 12   /* kNormalNumPartitions, core_internal:25 */
+#define NPART_MAX 32      /* kExtendedNumPartitions, core_internal:23: the arrays are always this long */
 #define FAR_SLOTS 250
 #define PRE_LEN (PART_LEN2 + 4 * FRAME_LEN) /* ec:146-147, aec_resampler.h:20 */
 #define FRBUF_LEN (FRAME_LEN + PART_LEN)     /* core:1299 */
@@ -381,6 +382,7 @@ struct AspAecOracle {
   /* integer part of AecCore */
   int system_delay, core_knownDelay, mult, nlp_mode, metricsMode, delay_logging;
   float normal_mu, normal_error_threshold;
+  int extended_filter_enabled, num_partitions; /* WebRtcAec_enable_delay_correction, core:1876-1881 */
   int blocks_processed;
   RingPos pre_pos, far_pos, near_pos, out_pos;
   float pre[PRE_LEN];
@@ -568,7 +570,17 @@ static void init_core(AspAecOracle* o, int sampFreq) { /* WebRtcAec_InitAec, cor
   o->metricsMode = 0;
   init_metrics(&o->met);
   o->blocks_processed = 0;
+  o->extended_filter_enabled = 0; /* core:1522-1523 */
+  o->num_partitions = NPART_NORMAL;
 }
+
+/* WebRtcAec_enable_delay_correction / _delay_correction_enabled, core:1876-1885 (reached through
+ * WebRtcAec_aec_core(handle)).  The delay estimator's allowed offset is outside the restated path. */
+void asp_aec_oracle_enable_delay_correction(AspAecOracle* o, int enable) {
+  o->extended_filter_enabled = enable;
+  o->num_partitions = enable ? NPART_MAX : NPART_NORMAL;
+}
+int asp_aec_oracle_delay_correction_enabled(const AspAecOracle* o) { return o->extended_filter_enabled; }
 
 int asp_aec_oracle_set_config(AspAecOracle* o, AecConfig config) { /* ec:410-438 */
   if (o->initFlag != kInitCheck) {
@@ -688,10 +700,10 @@ static void buffer_farend_partition(AspAecOracle* o, const float* farend) { /* c
   ring_write(&o->far_pos, &o->farw[0][0], 2 * PART_LEN1, &xf[0][0], 1);
 }
 
-static int partition_delay(const AspAecState* s) { /* core:294-318 */
+static int partition_delay(const AspAecState* s, int num_partitions) { /* core:294-318 */
   float wfEnMax = 0;
   int delay = 0;
-  for (int i = 0; i < NPART; i++) {
+  for (int i = 0; i < num_partitions; i++) {
     const int pos = i * PART_LEN1;
     float wfEn = 0;
     for (int j = 0; j < PART_LEN1; j++)
@@ -726,10 +738,13 @@ static void nonlinear_processing(AspAecOracle* o, float* output, float* outputH,
   float hNlDeAvg, hNlXdAvg, hNlFb = 0, hNlFbLow = 0;
   const float prefBandQuant = 0.75f, prefBandQuantLow = 0.5f;
   const int prefBandSize = 24 / o->mult, minPrefBand = 4 / o->mult;
-  static const float kMinOverDrive[3] = {1.0f, 2.0f, 5.0f}; /* kNormalMinOverDrive, core:108 */
+  static const float kNormalMinOverDrive[3] = {1.0f, 2.0f, 5.0f};    /* core:110 */
+  static const float kExtendedMinOverDrive[3] = {3.0f, 6.0f, 15.0f}; /* core:109 */
+  const float* kMinOverDrive = o->extended_filter_enabled ? kExtendedMinOverDrive : kNormalMinOverDrive; /* core:872-874 */
   static const float kTargetSupp[3] = {-6.9f, -11.5f, -18.4f}; /* core:104 */
-  static const float kCoef[2][2] = {{0.9f, 0.1f}, {0.93f, 0.07f}}; /* core:111-112 */
-  const float* gc = kCoef[o->mult - 1];
+  static const float kCoef[2][2] = {{0.9f, 0.1f}, {0.93f, 0.07f}};    /* kNormalSmoothingCoefficients, core:113-114 */
+  static const float kCoefExt[2][2] = {{0.9f, 0.1f}, {0.92f, 0.08f}}; /* kExtendedSmoothingCoefficients, core:111-112 */
+  const float* gc = (o->extended_filter_enabled ? kCoefExt : kCoef)[o->mult - 1]; /* core:337-339 */
   const int delayEstInterval = 10 * o->mult;
   float* xfw_raw = &s->xfwBuf[0][0];
   float sdSum = 0, seSum = 0;
@@ -741,7 +756,7 @@ static void nonlinear_processing(AspAecOracle* o, float* output, float* outputH,
   /* partition 0 of xfwBuf was filled by process_block (core:886-891) */
 
   /* SubbandCoherence, core:411-449 */
-  if (s->delayEstCtr == 0) s->delayIdx = partition_delay(s);
+  if (s->delayEstCtr == 0) s->delayIdx = partition_delay(s, o->num_partitions);
   memcpy(xfw, xfw_raw + (size_t)s->delayIdx * 2 * PART_LEN1, sizeof xfw);
   memcpy(fft, s->dBuf, sizeof fft);
   window128(fft);
@@ -782,7 +797,7 @@ static void nonlinear_processing(AspAecOracle* o, float* output, float* outputH,
   }
   s->divergeState = (s->divergeState ? 1.05f : 1.0f) * seSum > sdSum;
   if (s->divergeState) memcpy(efw, dfw, sizeof efw);
-  if (seSum > (19.95f * sdSum)) memset(s->wfBuf, 0, sizeof s->wfBuf);
+  if (!o->extended_filter_enabled && seSum > (19.95f * sdSum)) memset(s->wfBuf, 0, sizeof s->wfBuf); /* core:383 */
 
   for (i = 0; i < PART_LEN1; i++) { /* core:439-448 */
     cohde[i] = (s->sde[i][0] * s->sde[i][0] + s->sde[i][1] * s->sde[i][1]) / (s->sd[i] * s->se[i] + 1e-10f);
@@ -976,7 +991,8 @@ static void nonlinear_processing(AspAecOracle* o, float* output, float* outputH,
   /* core:1069-1081 */
   memcpy(s->dBuf, s->dBuf + PART_LEN, sizeof(float) * PART_LEN);
   memcpy(s->eBuf, s->eBuf + PART_LEN, sizeof(float) * PART_LEN);
-  memmove(xfw_raw + 2 * PART_LEN1, xfw_raw, sizeof(float) * 2 * PART_LEN1 * (NPART - 1));
+  /* the whole 32-partition array moves whatever the filter length is (core:1079-1081: sizeof(aec->xfwBuf)) */
+  memmove(xfw_raw + 2 * PART_LEN1, xfw_raw, sizeof(float) * 2 * PART_LEN1 * (NPART_MAX - 1));
 }
 
 static void process_block(AspAecOracle* o) { /* core:1084-1287 */
@@ -1019,7 +1035,7 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
   for (i = 0; i < PART_LEN1; i++) { /* core:1144-1156 */
     const float far_spectrum = (xf[0][i] * xf[0][i]) + (xf[1][i] * xf[1][i]);
     const float near_spectrum = df[0][i] * df[0][i] + df[1][i] * df[1][i];
-    s->xPow[i] = gPow[0] * s->xPow[i] + gPow[1] * NPART * far_spectrum;
+    s->xPow[i] = gPow[0] * s->xPow[i] + gPow[1] * o->num_partitions * far_spectrum;
     s->dPow[i] = gPow[0] * s->dPow[i] + gPow[1] * near_spectrum;
   }
   if (s->noiseEstCtr > 50) { /* core:1159-1168 */
@@ -1044,15 +1060,15 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
   }
 
   s->xfBufBlockPos--; /* core:1203-1214 */
-  if (s->xfBufBlockPos == -1) s->xfBufBlockPos = NPART - 1;
+  if (s->xfBufBlockPos == -1) s->xfBufBlockPos = o->num_partitions - 1;
   memcpy(s->xfBuf[0] + s->xfBufBlockPos * PART_LEN1, xf[0], sizeof(float) * PART_LEN1);
   memcpy(s->xfBuf[1] + s->xfBufBlockPos * PART_LEN1, xf[1], sizeof(float) * PART_LEN1);
 
   memset(yf, 0, sizeof yf);
-  for (i = 0; i < NPART; i++) { /* FilterFar, core:147-169 */
+  for (i = 0; i < o->num_partitions; i++) { /* FilterFar, core:147-169 */
     int xPos = (i + s->xfBufBlockPos) * PART_LEN1;
     const int pos = i * PART_LEN1;
-    if (i + s->xfBufBlockPos >= NPART) xPos -= NPART * PART_LEN1;
+    if (i + s->xfBufBlockPos >= o->num_partitions) xPos -= o->num_partitions * PART_LEN1;
     for (int j = 0; j < PART_LEN1; j++) {
       yf[0][j] += s->xfBuf[0][xPos + j] * s->wfBuf[0][pos + j] - s->xfBuf[1][xPos + j] * s->wfBuf[1][pos + j];
       yf[1][j] += s->xfBuf[0][xPos + j] * s->wfBuf[1][pos + j] + s->xfBuf[1][xPos + j] * s->wfBuf[0][pos + j];
@@ -1081,7 +1097,9 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
   if (o->metricsMode == 1) update_level(&o->met.linoutlevel, ef); /* core:1258-1263 */
 
   { /* ScaleErrorSignal, core:171-193 */
-    const float mu = o->normal_mu, error_threshold = o->normal_error_threshold;
+    /* core:172-175, core_internal:39-40 */
+    const float mu = o->extended_filter_enabled ? 0.4f : o->normal_mu;
+    const float error_threshold = o->extended_filter_enabled ? 1.0e-6f : o->normal_error_threshold;
     for (i = 0; i < PART_LEN1; i++) {
       float abs_ef;
       ef[0][i] /= (s->xPow[i] + 1e-10f);
@@ -1097,11 +1115,11 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
     }
   }
 
-  for (i = 0; i < NPART; i++) { /* FilterAdaptation, core:221-269 */
+  for (i = 0; i < o->num_partitions; i++) { /* FilterAdaptation, core:221-269 */
     int xPos = (i + s->xfBufBlockPos) * PART_LEN1;
     const int pos = i * PART_LEN1;
     int j;
-    if (i + s->xfBufBlockPos >= NPART) xPos -= NPART * PART_LEN1;
+    if (i + s->xfBufBlockPos >= o->num_partitions) xPos -= o->num_partitions * PART_LEN1;
     for (j = 0; j < PART_LEN; j++) {
       const float aRe = s->xfBuf[0][xPos + j], aIm = -s->xfBuf[1][xPos + j];
       fft[2 * j] = aRe * ef[0][j] - aIm * ef[1][j];
@@ -1203,6 +1221,69 @@ static void est_buf_delay_normal(AspAecOracle* o) { /* EstBufDelayNormal, ec:816
   if (o->timeForDelayChange > 25) {
     const int v = (int)o->filtDelay - 160;
     o->knownDelay = v > 0 ? v : 0;
+  }
+}
+
+static void est_buf_delay_extended(AspAecOracle* o) { /* EstBufDelayExtended, ec:869-922 */
+  const int reported_delay = o->msInSndCardBuf * kSampMsNb * o->rate_factor;
+  int current_delay = reported_delay - o->system_delay;
+  int delay_difference;
+  current_delay += FRAME_LEN * o->rate_factor;
+  /* skewMode is off in the restated configuration (ec:885-887) */
+  if (current_delay < PART_LEN) current_delay += far_move_read(o, 2) * PART_LEN;
+  if (o->filtDelay == -1) {
+    const double v = 0.5 * current_delay; /* WEBRTC_SPL_MAX(0, 0.5 * current_delay) -> short */
+    o->filtDelay = (int16_t)(v > 0 ? v : 0);
+  } else {
+    const int16_t v = (int16_t)(0.95 * o->filtDelay + 0.05 * current_delay);
+    o->filtDelay = v > 0 ? v : 0;
+  }
+  delay_difference = o->filtDelay - o->knownDelay;
+  if (delay_difference > 384) {
+    if (o->lastDelayDiff < 128) {
+      o->timeForDelayChange = 0;
+    } else {
+      o->timeForDelayChange++;
+    }
+  } else if (delay_difference < 128 && o->knownDelay > 0) {
+    if (o->lastDelayDiff > 384) {
+      o->timeForDelayChange = 0;
+    } else {
+      o->timeForDelayChange++;
+    }
+  } else {
+    o->timeForDelayChange = 0;
+  }
+  o->lastDelayDiff = (int16_t)delay_difference;
+  if (o->timeForDelayChange > 25) {
+    const int v = (int)o->filtDelay - 256;
+    o->knownDelay = v > 0 ? v : 0;
+  }
+}
+
+/* ProcessExtended, ec:744-814 (WEBRTC_UNTRUSTED_DELAY and WEBRTC_MAC undefined: the trusted-delay branch,
+ * kFixedDelayMs = 50, kMinTrustedDelayMs = 20, kDelayDiffOffsetSamples = 0, ec:70-84) */
+static void process_extended(AspAecOracle* o, const float* nearend, const float* nearendH, float* out,
+                             float* outH, int nrOfSamples, int16_t reported_delay_ms) {
+  const int kFixedDelayMs = 50, kMinTrustedDelayMs = 20, delay_diff_offset = 0;
+  reported_delay_ms = reported_delay_ms < kMinTrustedDelayMs ? kMinTrustedDelayMs : reported_delay_ms;
+  reported_delay_ms = reported_delay_ms >= kMaxTrustedDelayMs ? kFixedDelayMs : reported_delay_ms;
+  o->msInSndCardBuf = reported_delay_ms;
+  if (!o->farend_started) {
+    if (nearend != out) memcpy(out, nearend, sizeof(float) * nrOfSamples);
+    if (o->num_bands > 1 && nearendH != outH) memcpy(outH, nearendH, sizeof(float) * nrOfSamples);
+    return;
+  }
+  if (o->startup_phase) {
+    const int startup_size_ms = reported_delay_ms < kFixedDelayMs ? kFixedDelayMs : reported_delay_ms;
+    const int overhead_elements = (o->system_delay - startup_size_ms / 2 * o->rate_factor * 8) / PART_LEN;
+    far_move_read(o, overhead_elements);
+    o->startup_phase = 0;
+  }
+  est_buf_delay_extended(o); /* reported_delay_enabled is 1 off Android, core:1517-1521 */
+  {
+    const int adjusted = o->knownDelay + delay_diff_offset;
+    process_frames(o, nearend, nearendH, nrOfSamples, adjusted > 0 ? adjusted : 0, out, outH);
   }
 }
 
@@ -1317,7 +1398,10 @@ int asp_aec_oracle_process_bands(AspAecOracle* o, const float* nearend, const fl
     o->lastError = AEC_NULL_POINTER_ERROR;
     return -1;
   }
-  if (process_normal(o, nearend, nearendH, out, outH, nrOfSamples, (int16_t)msInSndCardBuf) != 0) retVal = -1;
+  if (o->extended_filter_enabled) /* ec:377-394 */
+    process_extended(o, nearend, nearendH, out, outH, nrOfSamples, (int16_t)msInSndCardBuf);
+  else if (process_normal(o, nearend, nearendH, out, outH, nrOfSamples, (int16_t)msInSndCardBuf) != 0)
+    retVal = -1;
   return retVal;
 }
 

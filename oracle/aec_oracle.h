@@ -24,6 +24,9 @@ AspAecOracle* asp_aec_oracle_create(void);
 void asp_aec_oracle_free(AspAecOracle* o);
 int asp_aec_oracle_init(AspAecOracle* o, int32_t sampFreq, int32_t scSampFreq);
 int asp_aec_oracle_set_config(AspAecOracle* o, AecConfig config);
+/* WebRtcAec_enable_delay_correction on the core (aec_core.c:1876-1885): the extended filter, 32 partitions */
+void asp_aec_oracle_enable_delay_correction(AspAecOracle* o, int enable);
+int asp_aec_oracle_delay_correction_enabled(const AspAecOracle* o);
 int asp_aec_oracle_buffer_farend(AspAecOracle* o, const float* farend, int nrOfSamples);
 int asp_aec_oracle_process(AspAecOracle* o, const float* nearend, float* out, int nrOfSamples,
                            int msInSndCardBuf, int32_t skew);

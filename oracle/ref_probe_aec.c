@@ -114,6 +114,13 @@ int ref_aec_set_nlp(void* h, int mode) {
   return WebRtcAec_set_config(h, c);
 }
 
+/* the extended filter (32 partitions) is switched on the core, as audio_processing does
+ * (WebRtcAec_enable_delay_correction(WebRtcAec_aec_core(handle), 1), aec_core.c:1876-1881) */
+void ref_aec_enable_delay_correction(void* h, int enable) {
+  WebRtcAec_enable_delay_correction(WebRtcAec_aec_core(h), enable);
+}
+int ref_aec_delay_correction_enabled(void* h) { return WebRtcAec_delay_correction_enabled(WebRtcAec_aec_core(h)); }
+
 void ref_aec_export(void* h, AspAecState* st, AspAecControl* c) {
   const Aec* a = (const Aec*)h;
   const AecCore* k = a->aec;

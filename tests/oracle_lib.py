@@ -405,6 +405,11 @@ class RefAec:
         self.lib.ref_aec_set_config.argtypes = [C.c_void_p, C.c_int, C.c_int]
         return self.lib.ref_aec_set_config(self.h, mode, metrics)
 
+    def enable_delay_correction(self, enable=1):
+        self.lib.ref_aec_enable_delay_correction.argtypes = [C.c_void_p, C.c_int]
+        self.lib.ref_aec_enable_delay_correction.restype = None
+        self.lib.ref_aec_enable_delay_correction(self.h, enable)
+
     def metrics_state(self):
         from audiosignalprocess_amd._abi import AspAecMetricsState
         m = AspAecMetricsState()
@@ -501,6 +506,12 @@ class OracleAec:
     def set_nlp(self, mode, skew=0, metrics=0, delay_logging=0):
         from audiosignalprocess_amd._abi import AecConfig
         return self.lib.asp_aec_oracle_set_config(self.h, AecConfig(mode, skew, metrics, delay_logging))
+
+    def enable_delay_correction(self, enable=1):
+        """WebRtcAec_enable_delay_correction on the core: the extended filter (32 partitions)."""
+        self.lib.asp_aec_oracle_enable_delay_correction.argtypes = [C.c_void_p, C.c_int]
+        self.lib.asp_aec_oracle_enable_delay_correction.restype = None
+        self.lib.asp_aec_oracle_enable_delay_correction(self.h, enable)
 
     def metrics_state(self):
         from audiosignalprocess_amd._abi import AspAecMetricsState

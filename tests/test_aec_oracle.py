@@ -5,6 +5,7 @@ against (a) the reference build oracle/_ref/libaec_ref.so run live (when present
 container), bit for bit on outputs, float state and control-plane integers, and (b) the committed
 golden vectors tests/golden/aec_golden.npz (outputs of that same reference build), which travel."""
 import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import numpy as np
 import pytest
@@ -24,6 +25,11 @@ TABLES = [(0, "rdft_w", 64), (1, "rdft_wk3ri_first", 16), (2, "rdft_wk3ri_second
 def aec_golden():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     return dict(np.load(os.path.join(root, "tests", "golden", "aec_golden.npz")))
+
+
+@pytest.fixture(scope="module")
+def aec_ext_golden():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "aec_ext_golden.npz")))
 
 
 def _bits(a):
@@ -159,6 +165,58 @@ def test_oracle_equals_reference_live(fs, n, delay, nlp):
             assert ca.pre_read == wrap(cb.pre_read, cb.pre_write, cb.pre_wrap, 448)
             assert ca.near_read == wrap(cb.near_read, cb.near_write, cb.near_wrap, 144)
             assert ca.out_read == wrap(cb.out_read, cb.out_write, cb.out_wrap, 144)
+
+
+@needs_ref
+@pytest.mark.parametrize("fs,n,nlp", [(16000, 160, 1), (16000, 80, 2), (8000, 80, 0)])
+def test_oracle_extended_filter_equals_reference_live(fs, n, nlp):
+    """WebRtcAec_enable_delay_correction(core, 1) -- the extended filter: 32 partitions, kExtendedMu /
+    kExtendedErrorThreshold, the extended smoothing coefficients and minimum overdrive, no filter reset,
+    ProcessExtended / EstBufDelayExtended (aec_core.c:172-174, 337-338, 383, 872-873, 1876-1881,
+    echo_cancellation.c:744-814, 869-922): outputs, float state over all 32 partitions and the
+    control-plane integers bit-equal frame by frame, through delay changes and out-of-range reports."""
+    F = 460
+    far, near = aec_frames(3, F * 160 // n if n == 80 else F)
+    far = far.reshape(-1, 3, 160)[:, 1].reshape(-1, n)[:F]
+    near = near.reshape(-1, 3, 160)[:, 1].reshape(-1, n)[:F]
+    ref, ora = oracle_lib.RefAec(fs), oracle_lib.OracleAec(fs)
+    assert ref.set_nlp(nlp) == 0 and ora.set_nlp(nlp) == 0
+    ref.enable_delay_correction(1)
+    ora.enable_delay_correction(1)
+    for f in range(F):
+        d = 30
+        if f in (150, 151):
+            d = 700         # >= kMaxTrustedDelayMs: replaced by kFixedDelayMs (ec:766-768)
+        if f == 200:
+            d = -5
+        if 250 <= f < 330:
+            d = 180         # a sustained change: EstBufDelayExtended's knownDelay update
+        if f >= 400:
+            d = 5           # below kMinTrustedDelayMs
+        o_ref, rc_ref = ref.frame(far[f], near[f], d)
+        o_ora, rc_ora = ora.frame(far[f], near[f], d)
+        assert rc_ref == rc_ora, f
+        assert np.array_equal(_bits(o_ref), _bits(o_ora)), f
+        if f % 40 == 0 or f == F - 1:
+            _compare_states(ref, ora)
+    # switching the mode off again returns to the 12-partition filter (aec_core.c:1878)
+    ref.enable_delay_correction(0)
+    ora.enable_delay_correction(0)
+    for f in range(40):
+        o_ref, _ = ref.frame(far[f], near[f], 30)
+        o_ora, _ = ora.frame(far[f], near[f], 30)
+        assert np.array_equal(_bits(o_ref), _bits(o_ora)), f
+    _compare_states(ref, ora)
+
+
+def test_oracle_extended_filter_reproduces_golden(aec_ext_golden):
+    """The reference's own extended-filter outputs (committed fixture) from the restatement, bit for bit."""
+    far, near = aec_ext_golden["far_i16"].astype(np.float32), aec_ext_golden["near_i16"].astype(np.float32)
+    for s in range(far.shape[1]):
+        o = oracle_lib.OracleAec(16000)
+        o.enable_delay_correction(1)
+        out = o.run(far[:, s], near[:, s], int(aec_ext_golden["delay_ms"]))
+        assert np.array_equal(_bits(out), _bits(aec_ext_golden["out_f32"][:, s])), s
 
 
 def test_oracle_error_behaviour():
