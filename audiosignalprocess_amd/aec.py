@@ -21,6 +21,8 @@ def _lib():
             "AspAecBatch_Init": [vp, C.c_int32, C.c_int32],
             "AspAecBatch_set_config": [vp, AecConfig],
             "AspAecBatch_num_streams": [vp],
+            "AspAecBatch_enable_delay_correction": [vp, ip],
+            "AspAecBatch_delay_correction_enabled": [vp],
             "AspAecBatch_BufferFarend": [vp, vp, ip, ip],
             "AspAecBatch_Process": [vp, vp, vp, ip, ip, C.c_int32, ip],
             "AspAecBatch_ProcessBands": [vp, vp, vp, vp, vp, ip, ip, C.c_int32, ip],
@@ -67,6 +69,14 @@ class AecBatch:
 
     def set_config(self, nlp_mode, skew=0, metrics=0, delay_logging=0):
         return self.lib.AspAecBatch_set_config(self.h, AecConfig(nlp_mode, skew, metrics, delay_logging))
+
+    def enable_delay_correction(self, enable=1):
+        """WebRtcAec_enable_delay_correction for every stream (aec_core.c:1876-1881): the 32-partition extended
+        filter and the ProcessExtended delay handling.  Call after construction (Init switches it off)."""
+        _check(self.lib.AspAecBatch_enable_delay_correction(self.h, int(enable)), "AspAecBatch_enable_delay_correction")
+
+    def delay_correction_enabled(self):
+        return int(self.lib.AspAecBatch_delay_correction_enabled(self.h))
 
     def error_code(self):
         return self.lib.AspAecBatch_get_error_code(self.h)

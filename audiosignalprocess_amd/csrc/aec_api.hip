@@ -22,13 +22,13 @@ using namespace aspaec;
 namespace aspaec {
 hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, const float* farend,
                              int num_streams, const FarOps& ops, hipStream_t s, int stream0 = 0,
-                             int stream_end = -1);
+                             int stream_end = -1, int num_part = kNumPartNormal);
 hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
                               const float* near_high, float* out_high, float* metrics,
                               hipStream_t s, unsigned long long* stamps = nullptr, int stream0 = 0,
-                              int stream_end = -1);
+                              int stream_end = -1, int num_part = kNumPartNormal);
 hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
                               hipStream_t s);
 }  // namespace aspaec
@@ -201,7 +201,9 @@ struct AspAecBatch {
   int S = 0, device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  float* state = nullptr;     // [S][kStateDwords]
+  float* state = nullptr;     // [S][AecRows(num_part).state_dwords]
+  // WebRtcAec_enable_delay_correction (aec_core.c:1876-1881): the extended filter, 32 partitions instead of 12
+  int extended = 0, num_part = kNumPartNormal;
   float* far_ring = nullptr;  // [kFarSlots][S][kFarSlotDwords]
   AecTables* tables = nullptr;
   float *stage_far = nullptr, *stage_near = nullptr, *stage_out = nullptr;  // [S][160]
@@ -243,10 +245,11 @@ struct AspAecBatch {
 namespace {
 // every device launch of a batch goes through these two: one launch, or one per half on the two chains
 hipError_t batch_launch_farend(AspAecBatch* b, const float* far_dev, const FarOps& ops) {
-  if (!b->dual) return launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream);
+  if (!b->dual) return launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream, 0, -1, b->num_part);
   const int half = ((b->S / 2 + 3) / 4) * 4;
-  hipError_t e = launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream, 0, half);
-  if (e == hipSuccess) e = launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->side, half, b->S);
+  hipError_t e = launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream, 0, half, b->num_part);
+  if (e == hipSuccess)
+    e = launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->side, half, b->S, b->num_part);
   return e;
 }
 hipError_t batch_launch_process(AspAecBatch* b, const float* near_dev, float* out_dev, int n, const ProcOps& ops,
@@ -254,13 +257,13 @@ hipError_t batch_launch_process(AspAecBatch* b, const float* near_dev, float* ou
                                 float* metrics, unsigned long long* stamps) {
   if (!b->dual)
     return launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops, near_high,
-                              out_high, metrics, b->stream, stamps);
+                              out_high, metrics, b->stream, stamps, 0, -1, b->num_part);
   const int half = ((b->S / 2 + 3) / 4) * 4;
   hipError_t e = launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
-                                    near_high, out_high, metrics, b->stream, stamps, 0, half);
+                                    near_high, out_high, metrics, b->stream, stamps, 0, half, b->num_part);
   if (e == hipSuccess)
     e = launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops, near_high,
-                           out_high, metrics, b->side, nullptr, half, b->S);
+                           out_high, metrics, b->side, nullptr, half, b->S, b->num_part);
   return e;
 }
 }  // namespace
@@ -293,14 +296,17 @@ int init_metrics_device(AspAecBatch* b) {
   return 0;
 }
 
-size_t state_bytes(const AspAecBatch* b) { return (size_t)b->S * kStateDwords * sizeof(float); }
+int state_dwords(const AspAecBatch* b) { return AecRows(b->num_part).state_dwords; }
+size_t state_bytes(const AspAecBatch* b) { return (size_t)b->S * state_dwords(b) * sizeof(float); }
 size_t far_bytes(const AspAecBatch* b) {
   return (size_t)kFarSlots * b->S * kFarSlotDwords * sizeof(float);
 }
 
 // ---- AspAecState <-> device block
 void pack_stream(const AspAecBatch* b, const AspAecState* s, float* blk) {
-  memset(blk, 0, kStateDwords * sizeof(float));
+  const AecRows rw(b->num_part);
+  const int kNumPart = rw.NP, R_XF_IM = rw.R_XF_IM, R_WF_RE = rw.R_WF_RE, R_WF_IM = rw.R_WF_IM, R_XFW = rw.R_XFW;
+  memset(blk, 0, rw.state_dwords * sizeof(float));
   float* rows = blk + kOffRows;
   auto put_row = [&](int r, const float* src) {
     memcpy(rows + r * kRowS, src, 64 * sizeof(float));
@@ -326,7 +332,7 @@ void pack_stream(const AspAecBatch* b, const AspAecState* s, float* blk) {
     put_row(R_SXD_RE, tmp[2]);
     put_row(R_SXD_IM, tmp[3]);
   }
-  for (int a = 0; a < kNumPart; ++a) {  // logical age a: canonical (c + a) % 12 -> physical (h + a) % 12
+  for (int a = 0; a < kNumPart; ++a) {  // logical age a: canonical (c + a) % NP -> physical (h + a) % NP
     const int pc = (s->xfBufBlockPos + a) % kNumPart, ph = (b->xf_pos + a) % kNumPart;
     put_row(R_XF_RE + ph, s->xfBuf[0] + pc * 65);
     put_row(R_XF_IM + ph, s->xfBuf[1] + pc * 65);
@@ -337,10 +343,11 @@ void pack_stream(const AspAecBatch* b, const AspAecState* s, float* blk) {
   }
   {
     // canonical partition a >= 1 holds the block of age a - 1 (aec_core.c:1079-1081); physical
-    // age g sits at (xfw_head + g) % 12
+    // age g sits at (xfw_head + g) % 32: all 32 blocks of history whatever the filter length, as the
+    // reference shifts them (aec_core.c:1079-1081)
     const float* raw = &s->xfwBuf[0][0];
-    for (int a = 1; a < kNumPart; ++a) {
-      const int ph = (b->xfw_head + a - 1) % kNumPart;
+    for (int a = 1; a < kNumPartMax; ++a) {
+      const int ph = (b->xfw_head + a - 1) % kNumPartMax;
       put_row(R_XFW + 2 * ph, raw + a * 130);
       put_row(R_XFW + 2 * ph + 1, raw + a * 130 + 65);
     }
@@ -368,6 +375,8 @@ void pack_stream(const AspAecBatch* b, const AspAecState* s, float* blk) {
 }
 
 void unpack_stream(const AspAecBatch* b, const float* blk, AspAecState* s) {
+  const AecRows rw(b->num_part);
+  const int kNumPart = rw.NP, R_XF_IM = rw.R_XF_IM, R_WF_RE = rw.R_WF_RE, R_WF_IM = rw.R_WF_IM, R_XFW = rw.R_XFW;
   memset(s, 0, sizeof *s);
   const float* rows = blk + kOffRows;
   auto get_row = [&](int r, float* dst) {
@@ -403,8 +412,8 @@ void unpack_stream(const AspAecBatch* b, const float* blk, AspAecState* s) {
   s->xfBufBlockPos = b->xf_pos;
   {
     float* raw = &s->xfwBuf[0][0];
-    for (int a = 0; a < kNumPart; ++a) {
-      const int ph = (b->xfw_head + (a == 0 ? 0 : a - 1)) % kNumPart;
+    for (int a = 0; a < kNumPartMax; ++a) {
+      const int ph = (b->xfw_head + (a == 0 ? 0 : a - 1)) % kNumPartMax;
       get_row(R_XFW + 2 * ph, raw + a * 130);
       get_row(R_XFW + 2 * ph + 1, raw + a * 130 + 65);
     }
@@ -432,6 +441,13 @@ void unpack_stream(const AspAecBatch* b, const float* blk, AspAecState* s) {
   s->noiseEstCtr = sci[S_NOISEESTCTR];
   s->delayEstCtr = sci[S_DELAYESTCTR];
   s->seed = reinterpret_cast<const uint32_t*>(sc)[S_SEED];
+}
+
+// the far-end pre-buffer and the near / out rings of both bands: device-only data between kOffPre and the rows
+// (dBufH, in their middle, belongs to AspAecState)
+void keep_rings(float* blk, const float* cur) {
+  memcpy(blk + kOffPre, cur + kOffPre, (kOffDBufH - kOffPre) * sizeof(float));
+  memcpy(blk + kOffNearFrH, cur + kOffNearFrH, (kOffRows - kOffNearFrH) * sizeof(float));
 }
 
 void init_canonical(AspAecState* s) {  // WebRtcAec_InitAec float state, aec_core.c:1562-1610
@@ -532,20 +548,22 @@ void est_buf_delay_normal(AspAecBatch* b) {  // echo_cancellation.c:816-867
 }
 
 // WebRtcAec_ProcessFrames control plane (aec_core.c:1647-1778) -> one launch.
-int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n) {
+// `knownDelay`: the delay ProcessNormal / ProcessExtended hand over (echo_cancellation.c:735-741, 803-812)
+int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n, int knownDelay) {
   ProcOps ops;
   memset(&ops, 0, sizeof ops);
+  const int kNumPart = b->num_part;
   ops.mult = b->mult;
   ops.nlp_mode = b->nlp_mode;
   ops.num_high = b->num_high;
-  ops.mu = b->normal_mu;
-  ops.error_threshold = b->normal_error_threshold;
+  ops.mu = b->extended ? 0.4f : b->normal_mu;                                 // kExtendedMu, aec_core.c:172
+  ops.error_threshold = b->extended ? 1.0e-6f : b->normal_error_threshold;    // kExtendedErrorThreshold, :173-175
   for (int j = 0; j < n; j += kFrameLen) {
     SubFrame& sf = ops.sub[ops.nsub++];
     rp_write(&b->near_pos, kFrameLen, &sf.near_wpos);
     if (b->system_delay < kFrameLen) far_move_read(b, -(b->mult + 1));
     {
-      const int move_elements = (b->core_knownDelay - b->knownDelay - 32) / kPartLen;
+      const int move_elements = (b->core_knownDelay - knownDelay - 32) / kPartLen;
       const int moved_elements = rp_move_read(&b->far_pos, move_elements);
       b->core_knownDelay -= moved_elements * kPartLen;
     }
@@ -557,7 +575,7 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
       rp_read(&b->far_pos, 1, &slot);
       op.far_slot = slot >= kFarSlots ? slot - kFarSlots : slot;
       b->xf_pos = b->xf_pos == 0 ? kNumPart - 1 : b->xf_pos - 1;  // aec_core.c:1203-1207
-      b->xfw_head = (b->xfw_head + kNumPart - 1) % kNumPart;
+      b->xfw_head = (b->xfw_head + kNumPartMax - 1) % kNumPartMax;
       op.xf_pos = b->xf_pos;
       op.xfw_head = b->xfw_head;
       rp_write(&b->out_pos, kPartLen, &op.out_wpos);
@@ -636,7 +654,69 @@ int process_normal_device(AspAecBatch* b, const float* near_dev, float* out_dev,
     return 0;
   }
   est_buf_delay_normal(b);
-  return process_frames_device(b, near_dev, out_dev, n);
+  return process_frames_device(b, near_dev, out_dev, n, b->knownDelay);
+}
+
+void est_buf_delay_extended(AspAecBatch* b) {  // EstBufDelayExtended, echo_cancellation.c:869-922
+  const int reported_delay = b->msInSndCardBuf * kSampMsNb * b->rate_factor;
+  int current_delay = reported_delay - b->system_delay;
+  current_delay += kFrameLen * b->rate_factor;
+  // (skew compensation, :885-887: skewMode is refused by set_config)
+  if (current_delay < kPartLen) current_delay += far_move_read(b, 2) * kPartLen;
+  if (b->filtDelay == -1) {
+    const double v = 0.5 * current_delay;
+    b->filtDelay = (int16_t)(v > 0 ? v : 0);
+  } else {
+    const int16_t v = (int16_t)(0.95 * b->filtDelay + 0.05 * current_delay);
+    b->filtDelay = v > 0 ? v : 0;
+  }
+  const int delay_difference = b->filtDelay - b->knownDelay;
+  if (delay_difference > 384) {
+    if (b->lastDelayDiff < 128) {
+      b->timeForDelayChange = 0;
+    } else {
+      b->timeForDelayChange++;
+    }
+  } else if (delay_difference < 128 && b->knownDelay > 0) {
+    if (b->lastDelayDiff > 384) {
+      b->timeForDelayChange = 0;
+    } else {
+      b->timeForDelayChange++;
+    }
+  } else {
+    b->timeForDelayChange = 0;
+  }
+  b->lastDelayDiff = (int16_t)delay_difference;
+  if (b->timeForDelayChange > 25) {
+    const int v = (int)b->filtDelay - 256;
+    b->knownDelay = v > 0 ? v : 0;
+  }
+}
+
+// ProcessExtended (echo_cancellation.c:744-814) on device buffers: the trusted-delay build (neither
+// WEBRTC_UNTRUSTED_DELAY nor WEBRTC_MAC: kFixedDelayMs 50, kMinTrustedDelayMs 20, kDelayDiffOffsetSamples 0, :70-84).
+int process_extended_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n, int16_t reported_delay_ms) {
+  const int kFixedDelayMs = 50, kMinTrustedDelayMs = 20, kDelayDiffOffsetSamples = 0;
+  reported_delay_ms = reported_delay_ms < kMinTrustedDelayMs ? kMinTrustedDelayMs : reported_delay_ms;
+  reported_delay_ms = reported_delay_ms >= kMaxTrustedDelayMs ? kFixedDelayMs : reported_delay_ms;
+  b->msInSndCardBuf = reported_delay_ms;
+  if (!b->farend_started) {  // pass the near end through until the far end starts (:768-776)
+    if (near_dev != out_dev && !b->sim)
+      AEC_TRY(hipMemcpyAsync(out_dev, near_dev, (size_t)b->S * n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    if (b->num_high > 0 && b->cur_near_high != b->cur_out_high && !b->sim)
+      AEC_TRY(hipMemcpyAsync(b->cur_out_high, b->cur_near_high, (size_t)b->S * n * sizeof(float),
+                             hipMemcpyDeviceToDevice, b->stream));
+    return 0;
+  }
+  if (b->startup_phase) {  // :777-794
+    const int startup_size_ms = reported_delay_ms < kFixedDelayMs ? kFixedDelayMs : reported_delay_ms;
+    const int overhead_elements = (b->system_delay - startup_size_ms / 2 * b->rate_factor * 8) / kPartLen;
+    far_move_read(b, overhead_elements);
+    b->startup_phase = 0;
+  }
+  est_buf_delay_extended(b);  // reported_delay_enabled is on off Android (aec_core.c:1517-1521)
+  const int adjusted = b->knownDelay + kDelayDiffOffsetSamples;
+  return process_frames_device(b, near_dev, out_dev, n, adjusted > 0 ? adjusted : 0);
 }
 
 // WebRtcAec_Process checks (echo_cancellation.c:341-375); *rc is the reference's return value.
@@ -651,6 +731,7 @@ int process_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n,
     b->lastError = AEC_BAD_PARAMETER_WARNING;
     *rc = -1;
   }
+  if (b->extended) return process_extended_device(b, near_dev, out_dev, n, (int16_t)msInSndCardBuf);  // :377-394
   return process_normal_device(b, near_dev, out_dev, n, (int16_t)msInSndCardBuf);
 }
 
@@ -829,15 +910,23 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
   b->xf_pos = 0;
   b->xfw_head = 0;
   b->blocks_processed = 0;
+  b->extended = 0;  // aec_core.c:1522-1523
   if (!b->sim) {
     AEC_TRY(hipSetDevice(b->device));
-    AspAecState s0;
+    AEC_TRY(hipStreamSynchronize(b->stream));
+    if (b->num_part != kNumPartNormal) {  // back to the 12-partition blocks
+      b->num_part = kNumPartNormal;
+      AEC_TRY(hipFree(b->state));
+      b->state = nullptr;
+      AEC_TRY(hipMalloc((void**)&b->state, state_bytes(b)));
+    }
+    const int kStateDwords = state_dwords(b);
+    static AspAecState s0;  // ~50 KB
     init_canonical(&s0);
     std::vector<float> blk(kStateDwords);
     pack_stream(b, &s0, blk.data());
     std::vector<float> all((size_t)b->S * kStateDwords);
     for (int s = 0; s < b->S; ++s) memcpy(all.data() + (size_t)s * kStateDwords, blk.data(), kStateDwords * sizeof(float));
-    AEC_TRY(hipStreamSynchronize(b->stream));
     AEC_TRY(hipMemcpy(b->state, all.data(), state_bytes(b), hipMemcpyHostToDevice));
     // on the batch's own (non-blocking) stream: a null-stream memset is not ordered with its kernels
     AEC_TRY(hipMemsetAsync(b->far_ring, 0, far_bytes(b), b->stream));  // WebRtc_InitBuffer zeroes the rings
@@ -845,6 +934,7 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
     const int err = init_metrics_device(b);  // aec_core.c:1612-1613
     if (err) return err;
   }
+  b->num_part = kNumPartNormal;
   rp_init(&b->pre_pos, kPreLen);
   rp_move_read(&b->pre_pos, -kPartLen);  // start overlap, echo_cancellation.c:226
   b->initFlag = kInitCheck;
@@ -1077,6 +1167,7 @@ int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out) {
   if (!b || !out || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ExportState: bad argument");
   AEC_TRY(hipSetDevice(b->device));
   AEC_TRY(hipStreamSynchronize(b->stream));
+  const int kStateDwords = state_dwords(b);
   std::vector<float> blk(kStateDwords);
   AEC_TRY(hipMemcpy(blk.data(), b->state + (size_t)stream * kStateDwords, kStateDwords * sizeof(float), hipMemcpyDeviceToHost));
   unpack_stream(b, blk.data(), out);
@@ -1088,14 +1179,59 @@ int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in) {
   if (!b || !in || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ImportState: bad argument");
   AEC_TRY(hipSetDevice(b->device));
   AEC_TRY(hipStreamSynchronize(b->stream));
+  const int kStateDwords = state_dwords(b);
   std::vector<float> blk(kStateDwords), cur(kStateDwords);
   AEC_TRY(hipMemcpy(cur.data(), b->state + (size_t)stream * kStateDwords, kStateDwords * sizeof(float), hipMemcpyDeviceToHost));
   pack_stream(b, in, blk.data());
   // the time-domain rings are not part of AspAecState: keep the stream's own
-  memcpy(blk.data() + kOffPre, cur.data() + kOffPre, (kStateDwords - kOffPre) * sizeof(float));
+  keep_rings(blk.data(), cur.data());
   AEC_TRY(hipMemcpy(b->state + (size_t)stream * kStateDwords, blk.data(), kStateDwords * sizeof(float), hipMemcpyHostToDevice));
   return ASP_OK;
 }
+
+// WebRtcAec_enable_delay_correction(WebRtcAec_aec_core(inst), enable) for every stream of the batch
+// (aec_core.c:1876-1881): 32 partitions and the extended constants; WebRtcAec_Process then takes the
+// ProcessExtended path (echo_cancellation.c:377-394).  Like the reference call it belongs right after Init; used
+// mid-stream, the streams' states are carried over (re-packed into blocks of the new size) and behave as the
+// reference's do, except that the far-spectrum and filter partitions 12..31 are dropped when the filter is
+// shortened (the reference leaves them in place, stale, for a later re-enable).
+int AspAecBatch_enable_delay_correction(AspAecBatch* b, int enable) {
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  const int np = enable ? kNumPartMax : kNumPartNormal;
+  if (np != b->num_part) {
+    if (b->xf_pos >= np) return aec_fail(ASP_ERR_STATE, "enable_delay_correction: xfBufBlockPos beyond the shorter filter");
+    if (b->far_pending) {
+      const int rc = flush_pending_farend(b);
+      if (rc != 0) return rc;
+    }
+    if (!b->sim) {
+      AEC_TRY(hipSetDevice(b->device));
+      AEC_TRY(hipStreamSynchronize(b->stream));
+      const int od = state_dwords(b), nd = AecRows(np).state_dwords;
+      std::vector<float> old_all((size_t)b->S * od), new_all((size_t)b->S * nd);
+      AEC_TRY(hipMemcpy(old_all.data(), b->state, old_all.size() * sizeof(float), hipMemcpyDeviceToHost));
+      std::vector<AspAecState> canon(1);
+      const int old_np = b->num_part;
+      for (int s = 0; s < b->S; ++s) {
+        b->num_part = old_np;
+        unpack_stream(b, old_all.data() + (size_t)s * od, canon.data());
+        b->num_part = np;
+        pack_stream(b, canon.data(), new_all.data() + (size_t)s * nd);
+        keep_rings(new_all.data() + (size_t)s * nd, old_all.data() + (size_t)s * od);
+      }
+      AEC_TRY(hipFree(b->state));
+      b->state = nullptr;
+      b->num_part = np;
+      AEC_TRY(hipMalloc((void**)&b->state, state_bytes(b)));
+      AEC_TRY(hipMemcpy(b->state, new_all.data(), new_all.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    b->num_part = np;
+  }
+  b->extended = enable;  // the reference stores the argument as given
+  return 0;
+}
+
+int AspAecBatch_delay_correction_enabled(const AspAecBatch* b) { return b ? b->extended : 0; }
 
 int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* c) {
   if (!b || !c) return aec_fail(ASP_ERR_PARAM, "GetControl: bad argument");
@@ -1143,7 +1279,7 @@ int AspAecBatch_get_echo_status(AspAecBatch* b, int* status) {
   AEC_TRY(hipStreamSynchronize(b->stream));
   for (int s = 0; s < b->S; ++s) {
     int32_t v = 0;
-    AEC_TRY(hipMemcpy(&v, b->state + (size_t)s * kStateDwords + kOffScalars + S_ECHOSTATE, sizeof v, hipMemcpyDeviceToHost));
+    AEC_TRY(hipMemcpy(&v, b->state + (size_t)s * state_dwords(b) + kOffScalars + S_ECHOSTATE, sizeof v, hipMemcpyDeviceToHost));
     status[s] = v;
   }
   return 0;
@@ -1360,6 +1496,15 @@ int32_t WebRtcAec_get_error_code(void* aecInst) {
 
 struct AecCore* WebRtcAec_aec_core(void* handle) {
   return reinterpret_cast<struct AecCore*>(handle);
+}
+
+// aec_core.h:129-133 / aec_core.c:1876-1885: `self` is the token WebRtcAec_aec_core returned
+void WebRtcAec_enable_delay_correction(struct AecCore* self, int enable) {
+  (void)AspAecBatch_enable_delay_correction(reinterpret_cast<AspAecBatch*>(self), enable);
+}
+
+int WebRtcAec_delay_correction_enabled(struct AecCore* self) {
+  return AspAecBatch_delay_correction_enabled(reinterpret_cast<AspAecBatch*>(self));
 }
 
 }  // extern "C"

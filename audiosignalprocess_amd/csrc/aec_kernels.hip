@@ -56,13 +56,19 @@ enum LRow { L_XFR = 0, L_XFI, L_DFR, L_DFI, L_YFR, L_YFI, L_EFR, L_EFI, L_XPOW, 
 constexpr int kLRow = 66;
 constexpr int kLdsDbuf = kLdsRows + L_NROWS * kLRow;  // 128
 constexpr int kLdsEbuf = kLdsDbuf + 128;              // 128
-constexpr int kLdsMisc = kLdsEbuf + 128;              // 16
-constexpr int kLdsC64 = kLdsMisc + 16;                // bin 64 of every state row (84)
-constexpr int kLdsWave = kLdsC64 + 84;                // 1940 floats = 7 760 B per wave
+constexpr int kLdsMisc = kLdsEbuf + 128;              // 16: the four NLP sums / 12 partition energies
+constexpr int kLdsC64 = kLdsMisc + 16;                // bin 64 of every state row: 124 floats with 12 partitions, the
+                                                      // whole padded column (256) with 32
+constexpr int lds_c64_len(int np) { return np == kNumPartNormal ? 124 : kC64Len; }
+// 12 partitions: 1980 floats = 7 920 B per wave, four workgroups per CU (40 432 B each); 32: 2112 floats, three
+constexpr int lds_wave(int np, bool metrics) { return kLdsC64 + lds_c64_len(np) + (metrics ? 4 * kLRow : 0); }
+constexpr int lds_met(int np) { return kLdsC64 + lds_c64_len(np); }
+constexpr int kLdsWave = lds_wave(kNumPartNormal, false);  // the far-end / transform-seam kernels (tiles only)
+constexpr int kPeScratch = 208;  // 32 partitions: the partition energies sit in the pad of the bin-64 column
+static_assert(kPeScratch >= AecRows(kNumPartMax).R_COUNT && kPeScratch + kNumPartMax <= kC64Len, "energy scratch");
 // metrics mode appends 4 rows of per-bin energy terms (far / near / linear-out / NLP-out) to each wave's region
-constexpr int kLdsMet = kLdsWave;
-constexpr int kLdsWaveMet = kLdsWave + 4 * kLRow;
-static_assert(kNumPart * kLRow <= kLdsRows + 9 * kLRow, "partition-energy rows overlay");
+constexpr int kPeChunk = 12;  // partitions whose per-bin energies overlay the tiles and the dead rows at a time
+static_assert(kPeChunk * kLRow <= kLdsRows + 9 * kLRow, "partition-energy rows overlay");
 
 struct SharedTables {
   double exp2_64[64];
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(256) void aec_farend_kernel(int stream0, int stream
                                                          float* __restrict__ far_ring,
                                                          const AecTables* __restrict__ G,
                                                          const float* __restrict__ farend,
-                                                         int num_streams, FarOps ops) {
+                                                         int num_streams, FarOps ops, int state_dwords) {
   __shared__ SharedTables T;
   __shared__ float lds[4 * kLdsWave];
   stage_tables(T, G);
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(256) void aec_farend_kernel(int stream0, int stream
   const int stream = stream0 + blockIdx.x * 4 + wave;  // this launch covers streams stream0 .. stream_end - 1
   if (stream >= stream_end) return;
   float* wl = lds + wave * kLdsWave;
-  float* st = state + (size_t)stream * kStateDwords;
+  float* st = state + (size_t)stream * state_dwords;
   farend_work(st, far_ring, wl, T, farend, num_streams, stream, ops, lane);
 }
 
@@ -502,7 +508,7 @@ __device__ __attribute__((noinline)) void high_band_block(float* __restrict__ st
 // left in the wave's kLdsMet rows: lanes 0..3 each sum one level in the reference's order (bin 0, bin 64,
 // bins 1..63) and update its PowerLevel; lane 0 then updates the ERL / A_NLP / ERLE statistics.
 // `met` is this stream's AspAecMetricsState image (include/asp_aec.h).
-__device__ __attribute__((noinline)) void metrics_block(float* __restrict__ met, float* __restrict__ wl,
+__device__ __attribute__((noinline)) void metrics_block(float* __restrict__ met, float* __restrict__ metrows,
                                                         int lane, int echoState) {
   constexpr int subCountLen = 4, countLen = 50;  // aec_core.c:47-48
   int32_t* meti = reinterpret_cast<int32_t*>(met);
@@ -510,7 +516,7 @@ __device__ __attribute__((noinline)) void metrics_block(float* __restrict__ met,
   float minlevel = 0.f, averagelevel = 0.f;
   int frcounter = 0, sfrcounter = 0;
   if (lane < 4) {
-    const float* src = wl + kLdsMet + lane * kLRow;
+    const float* src = metrows + lane * kLRow;
     float energy = src[0];
     energy += src[64];
 #pragma unroll
@@ -626,9 +632,9 @@ __device__ __forceinline__ float set_lane(float row, int bits) {
 struct StateBuf {
   __amdgpu_buffer_rsrc_t r;
 };
-__device__ __forceinline__ StateBuf state_buf(float* st) {
+__device__ __forceinline__ StateBuf state_buf(float* st, int dwords) {
   StateBuf b;
-  b.r = __builtin_amdgcn_make_buffer_rsrc(st, 0, kStateDwords * 4, 0x00020000);
+  b.r = __builtin_amdgcn_make_buffer_rsrc(st, 0, dwords * 4, 0x00020000);
   return b;
 }
 // dword `uni + vec` of the block: uni wave-uniform, vec per lane
@@ -639,7 +645,8 @@ __device__ __forceinline__ void sst(const StateBuf& b, int uni, int vec, float v
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, vec * 4, uni * 4, 0);
 }
 
-template <bool kMetrics>
+// NP = 12 partitions, or 32: the extended filter (aec_core_internal.h:23-25, WebRtcAec_enable_delay_correction)
+template <bool kMetrics, int NP>
 __device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
                                               const float* __restrict__ far_slot,
                                               const SharedTables& T, const BlockOp& op, int mult,
@@ -652,7 +659,13 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   if (stamps != nullptr) stamps[k] = __builtin_amdgcn_s_memtime();
   AEC_STAMP(0)
   asm volatile("" : "+v"(lane));  // lane masks are recomputed per block instead of living in SGPR pairs across the block loop
-  const StateBuf sb = state_buf(st);
+  constexpr AecRows RW(NP);
+  constexpr int kNumPart = NP, R_XF_IM = RW.R_XF_IM, R_WF_RE = RW.R_WF_RE, R_WF_IM = RW.R_WF_IM, R_XFW = RW.R_XFW,
+                R_COUNT = RW.R_COUNT;
+  constexpr bool kExtended = NP == kNumPartMax;
+  constexpr int kC64Chunks = (R_COUNT + 63) / 64, kC64Lds = lds_c64_len(NP);
+  static_assert(R_COUNT <= kC64Lds, "bin-64 column in LDS");
+  const StateBuf sb = state_buf(st, RW.state_dwords);
   // the stream's 32 scalars: one row load, lane k holds scalar k (wave-uniform values read with v_readlane),
   // one row store at the end -- a scalar address apiece had cost an SGPR pair each across the block loop
   float scrow = sld(sb, kOffScalars, lane & 31);
@@ -683,23 +696,25 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   float* DWI = lrow(wl, L_DWI);
   float* EWR = lrow(wl, L_EWR);  // windowed error spectrum (NLP)
   float* EWI = lrow(wl, L_EWI);
-  [[maybe_unused]] float* MET = wl + kLdsMet;  // [4][kLRow], metrics mode only
+  [[maybe_unused]] float* MET = wl + lds_met(NP);  // [4][kLRow], metrics mode only
   const float scale = 2.0f / 128;
   // State rows: trip 0 (bin = lane) goes to HBM, trip 1 (bin 64) to a per-wave LDS copy of the
   // bin-64 column that is gathered once per block and scattered back at its end.
   float* c64 = wl + kLdsC64;
-#define ROW_LD(r) (t_ == 0 ? sld(sb, (r) * kRowS, lane) : c64[r])
+#define ROWO(r) (kOffRows + (r) * kRowS)
+#define ROW_LD(r) (t_ == 0 ? sld(sb, ROWO(r), lane) : c64[r])
 #define ROW_ST(r, v)                         \
   do {                                       \
     if (t_ == 0) {                           \
-      sst(sb, (r) * kRowS, lane, (v));       \
+      sst(sb, ROWO(r), lane, (v));       \
     } else {                                 \
       c64[r] = (v);                          \
     }                                        \
   } while (0)
   // loads return in order: the few the first FFT round waits for go first
-  const float c64_a = sld(sb, kOffC64, lane);
-  const float c64_b = lane < R_COUNT - 64 ? sld(sb, kOffC64 + 64, lane) : 0.f;
+  float c64_in[kC64Chunks];
+#pragma unroll
+  for (int k = 0; k < kC64Chunks; ++k) c64_in[k] = sld(sb, kOffC64 + 64 * k, lane);  // the column is padded to 256
   float fs_lane[4], fs_64[4];  // this block's far spectra (plain re/im, windowed re/im)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -711,28 +726,31 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   dbuf[lane] = sld(sb, kOffDBuf, lane);
   dbuf[64 + lane] = ne;
   ebuf[lane] = sld(sb, kOffEBuf, lane);
-  c64[lane] = c64_a;
-  if (lane < R_COUNT - 64) c64[64 + lane] = c64_b;
+#pragma unroll
+  for (int k = 0; k < kC64Chunks; ++k)
+    if (64 * (k + 1) <= kC64Lds || 64 * k + lane < kC64Lds) c64[64 * k + lane] = c64_in[k];
   // The lane's bins of the far-spectrum history and of the filter, for FilterFar only (logical partition
   // order; partition 0 is this block's spectrum).  FilterFar depends on nothing but these, so it runs
   // ahead of the near FFT and the 46 registers are free again before the ten FFT rounds of the block;
   // FilterAdaptation streams its partitions again, four at a time.
-  float xr[kNumPart], xi[kNumPart], wr[kNumPart], wi[kNumPart];
+  // (the 32 partitions of the extended filter do not fit in registers: their FilterFar loads row by row)
+  constexpr int kFarRegs = kExtended ? 1 : kNumPart, kFarUnroll = kExtended ? 8 : kNumPart;
+  float xr[kFarRegs], xi[kFarRegs], wr[kFarRegs], wi[kFarRegs];
 #pragma unroll
-  for (int i = 0; i < kNumPart; ++i) {
+  for (int i = 0; i < kFarRegs; ++i) {
     int px = i + op.xf_pos;
     if (px >= kNumPart) px -= kNumPart;
     if (i > 0) {
-      xr[i] = sld(sb, ((R_XF_RE + px)) * kRowS, lane);
-      xi[i] = sld(sb, ((R_XF_IM + px)) * kRowS, lane);
+      xr[i] = sld(sb, ROWO((R_XF_RE + px)), lane);
+      xi[i] = sld(sb, ROWO((R_XF_IM + px)), lane);
     }
-    wr[i] = sld(sb, ((R_WF_RE + i)) * kRowS, lane);
-    wi[i] = sld(sb, ((R_WF_IM + i)) * kRowS, lane);
+    wr[i] = sld(sb, ROWO((R_WF_RE + i)), lane);
+    wi[i] = sld(sb, ROWO((R_WF_IM + i)), lane);
   }
 
   // rows of the power / noise-floor update and the overlap-add tail: in flight during the first FFT
-  const float p_xpow = sld(sb, (R_XPOW) * kRowS, lane), p_dpow = sld(sb, (R_DPOW) * kRowS, lane);
-  const float p_dmin = sld(sb, (R_DMINPOW) * kRowS, lane), p_dinit = sld(sb, (R_DINITMINPOW) * kRowS, lane);
+  const float p_xpow = sld(sb, ROWO(R_XPOW), lane), p_dpow = sld(sb, ROWO(R_DPOW), lane);
+  const float p_dmin = sld(sb, ROWO(R_DMINPOW), lane), p_dinit = sld(sb, ROWO(R_DINITMINPOW), lane);
   const float p_outbuf = sld(sb, kOffOutBuf, lane);
   wave_fence();
 
@@ -753,14 +771,22 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
   BINS_2TRIPS {
     float yr = 0.f, yi = 0.f;
-#pragma unroll
+#pragma unroll kFarUnroll
     for (int i = 0; i < kNumPart; ++i) {
       int px = i + op.xf_pos;
       if (px >= kNumPart) px -= kNumPart;
-      const float ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
-      const float ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
-      const float br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
-      const float bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
+      float ar, ai, br, bi;
+      if constexpr (kExtended) {
+        ar = i == 0 ? XFR[bin] : ROW_LD((R_XF_RE + px));
+        ai = i == 0 ? XFI[bin] : ROW_LD((R_XF_IM + px));
+        br = ROW_LD((R_WF_RE + i));
+        bi = ROW_LD((R_WF_IM + i));
+      } else {
+        ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
+        ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
+        br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
+        bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
+      }
       yr += ar * br - ai * bi;
       yi += ar * bi + ai * br;
     }
@@ -817,14 +843,22 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
   BINS_2TRIPS {
     float yr = 0.f, yi = 0.f;
-#pragma unroll
+#pragma unroll kFarUnroll
     for (int i = 0; i < kNumPart; ++i) {
       int px = i + op.xf_pos;
       if (px >= kNumPart) px -= kNumPart;
-      const float ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
-      const float ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
-      const float br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
-      const float bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
+      float ar, ai, br, bi;
+      if constexpr (kExtended) {
+        ar = i == 0 ? XFR[bin] : ROW_LD((R_XF_RE + px));
+        ai = i == 0 ? XFI[bin] : ROW_LD((R_XF_IM + px));
+        br = ROW_LD((R_WF_RE + i));
+        bi = ROW_LD((R_WF_IM + i));
+      } else {
+        ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
+        ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
+        br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
+        bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
+      }
       yr += ar * br - ai * bi;
       yi += ar * bi + ai * br;
     }
@@ -944,10 +978,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 
   AEC_STAMP(7)
   // the PSD rows of the NLP: in flight during the six FFT rounds of the filter update
-  const float q_sd = sld(sb, (R_SD) * kRowS, lane), q_se = sld(sb, (R_SE) * kRowS, lane);
-  const float q_sx = sld(sb, (R_SX) * kRowS, lane);
-  const float q_sde_r = sld(sb, (R_SDE_RE) * kRowS, lane), q_sde_i = sld(sb, (R_SDE_IM) * kRowS, lane);
-  const float q_sxd_r = sld(sb, (R_SXD_RE) * kRowS, lane), q_sxd_i = sld(sb, (R_SXD_IM) * kRowS, lane);
+  const float q_sd = sld(sb, ROWO(R_SD), lane), q_se = sld(sb, ROWO(R_SE), lane);
+  const float q_sx = sld(sb, ROWO(R_SX), lane);
+  const float q_sde_r = sld(sb, ROWO(R_SDE_RE), lane), q_sde_i = sld(sb, ROWO(R_SDE_IM), lane);
+  const float q_sxd_r = sld(sb, ROWO(R_SXD_RE), lane), q_sxd_i = sld(sb, ROWO(R_SXD_IM), lane);
   // ---- FilterAdaptation (aec_core.c:221-269): four partitions per round, streamed: a group's far
   // spectra and filter rows are requested one group ahead (partition 0 = this block's spectrum, still in
   // registers), the updated filter rows go straight back
@@ -957,10 +991,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     const int i_ = 4 * (g_) + k;                                                    \
     int px_ = i_ + op.xf_pos;                                                       \
     if (px_ >= kNumPart) px_ -= kNumPart;                                           \
-    gx[buf][2 * k] = i_ == 0 ? fs_lane[0] : sld(sb, ((R_XF_RE + px_)) * kRowS, lane);   \
-    gx[buf][2 * k + 1] = i_ == 0 ? fs_lane[1] : sld(sb, ((R_XF_IM + px_)) * kRowS, lane); \
-    gw[buf][2 * k] = sld(sb, ((R_WF_RE + i_)) * kRowS, lane);                           \
-    gw[buf][2 * k + 1] = sld(sb, ((R_WF_IM + i_)) * kRowS, lane);                       \
+    gx[buf][2 * k] = i_ == 0 ? fs_lane[0] : sld(sb, ROWO((R_XF_RE + px_)), lane);   \
+    gx[buf][2 * k + 1] = i_ == 0 ? fs_lane[1] : sld(sb, ROWO((R_XF_IM + px_)), lane); \
+    gw[buf][2 * k] = sld(sb, ROWO((R_WF_RE + i_)), lane);                           \
+    gw[buf][2 * k + 1] = sld(sb, ROWO((R_WF_IM + i_)), lane);                       \
   }
   AEC_LOAD_GROUP(0, 0)
 #pragma unroll
@@ -998,8 +1032,8 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       const float wi_sum = gw[cb][2 * k + 1] + v.y;
       const float wi_new = lane == 0 ? gw[cb][2 * k + 1] : wi_sum;
       if (lane == 0) c64[R_WF_RE + i] += v.y;
-      sst(sb, ((R_WF_RE + i)) * kRowS, lane, wr_new);
-      sst(sb, ((R_WF_IM + i)) * kRowS, lane, wi_new);
+      sst(sb, ROWO((R_WF_RE + i)), lane, wr_new);
+      sst(sb, ROWO((R_WF_IM + i)), lane, wi_new);
     }
     wave_fence();
   }
@@ -1012,23 +1046,27 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   int delayIdx = SCI(S_DELAYIDX);
   if (delayEstCtr == 0) {  // PartitionDelay (aec_core.c:294-318)
     float* pe = wl + kLdsTile;  // 12 rows of 66 overlaying the tiles and the dead rows
-    for (int i = 0; i < kNumPart; ++i)
-      BINS_2TRIPS {
-        const float wr = ROW_LD((R_WF_RE + i)), wi = ROW_LD((R_WF_IM + i));
-        pe[i * kLRow + bin] = wr * wr + wi * wi;
-      }
-    wave_fence();
-    if (lane < kNumPart) {
-      float wfEn = 0.f;
+    float* pen = kExtended ? c64 + kPeScratch : misc;  // the partitions' energies
+    for (int c0 = 0; c0 < kNumPart; c0 += kPeChunk) {
+      const int nc = kNumPart - c0 < kPeChunk ? kNumPart - c0 : kPeChunk;
+      for (int i = 0; i < nc; ++i)
+        BINS_2TRIPS {
+          const float wr = ROW_LD((R_WF_RE + c0 + i)), wi = ROW_LD((R_WF_IM + c0 + i));
+          pe[i * kLRow + bin] = wr * wr + wi * wi;
+        }
+      wave_fence();
+      if (lane < nc) {
+        float wfEn = 0.f;
 #pragma unroll
-      for (int j = 0; j < 65; ++j) wfEn += pe[lane * kLRow + j];
-      misc[lane] = wfEn;
+        for (int j = 0; j < 65; ++j) wfEn += pe[lane * kLRow + j];
+        pen[c0 + lane] = wfEn;
+      }
+      wave_fence();
     }
-    wave_fence();
     float wfEnMax = 0.f;
     delayIdx = 0;
     for (int i = 0; i < kNumPart; ++i) {
-      const float v = misc[i];
+      const float v = pen[i];
       if (v > wfEnMax) {
         wfEnMax = v;
         delayIdx = i;
@@ -1042,9 +1080,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 
   AEC_STAMP(10)
   // ---- SmoothedPSD + coherence (aec_core.c:332-385, 438-448)
-  const float g0 = mult == 1 ? 0.9f : 0.93f, g1 = mult == 1 ? 0.1f : 0.07f;  // aec_core.c:111-112
-  int pd = op.xfw_head + delayIdx;
-  if (pd >= kNumPart) pd -= kNumPart;
+  // aec_core.c:111-114, 337-339: WebRtcAec_kNormal / kExtendedSmoothingCoefficients[mult - 1]
+  const float g0 = mult == 1 ? 0.9f : kExtended ? 0.92f : 0.93f, g1 = mult == 1 ? 0.1f : kExtended ? 0.08f : 0.07f;
+  int pd = op.xfw_head + delayIdx;  // the history ring is 32 deep whatever the filter length
+  if (pd >= kNumPartMax) pd -= kNumPartMax;
   BINS_2TRIPS {
     const float dr = DWR[bin], di = DWI[bin], er = EWR[bin], ei = EWI[bin];
     const float xr = delayIdx == 0 ? XWR[bin] : ROW_LD((R_XFW + 2 * pd));
@@ -1094,7 +1133,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       EWI[bin] = DWI[bin];
     }
   }
-  if (seSum > (19.95f * sdSum)) {
+  if (!kExtended && seSum > (19.95f * sdSum)) {  // aec_core.c:383
     for (int i = 0; i < 2 * kNumPart; ++i)
       BINS_2TRIPS ROW_ST((R_WF_RE + i), 0.f);
   }
@@ -1114,7 +1153,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   } else if (hNlDeAvg < 0.95f || hNlXdAvg < 0.8f) {
     stNearState = 0;
   }
-  const float minOverDrive = nlp_mode == 0 ? 1.0f : nlp_mode == 1 ? 2.0f : 5.0f;
+  // kNormalMinOverDrive / kExtendedMinOverDrive (aec_core.c:108-109, 872-874)
+  const float minOverDrive = kExtended ? (nlp_mode == 0 ? 3.0f : nlp_mode == 1 ? 6.0f : 15.0f)
+                                       : (nlp_mode == 0 ? 1.0f : nlp_mode == 1 ? 2.0f : 5.0f);
   const float targetSupp = nlp_mode == 0 ? -6.9f : nlp_mode == 1 ? -11.5f : -18.4f;
   float hNlFb, hNlFbLow;
   int hnl_kind;  // 0: cohde, 1: 1 - cohxd, 2: min of both
@@ -1272,7 +1313,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     sst(sb, kOffOutFr, ring_idx(op.out_wpos, lane, kFrBufLen), o);
   }
   if (num_high > 0) high_band_block(st, wl, T, op.near_rpos, op.out_wpos, lane);
-  if constexpr (kMetrics) metrics_block(met, wl, lane, echoState);
+  if constexpr (kMetrics) metrics_block(met, MET, lane, echoState);
   AEC_STAMP(14)
   // ---- carry the block (aec_core.c:1069-1081; the xfwBuf shift is the host's circular head)
   sst(sb, kOffDBuf, lane, ne);
@@ -1295,11 +1336,13 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     if (lane < 32) sst(sb, kOffScalars, lane, scrow);
   }
   wave_fence();
-  sst(sb, kOffC64, lane, c64[lane]);
-  if (lane < R_COUNT - 64) sst(sb, kOffC64 + 64, lane, c64[64 + lane]);
+#pragma unroll
+  for (int k = 0; k < kC64Chunks; ++k)
+    if (64 * (k + 1) <= kC64Lds || 64 * k + lane < kC64Lds) sst(sb, kOffC64 + 64 * k, lane, c64[64 * k + lane]);
   AEC_STAMP(15)
 #undef AEC_STAMP
 #undef ROW_LD
+#undef ROWO
 #undef ROW_ST
 #undef SCI
 #undef SCF
@@ -1312,8 +1355,8 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #ifndef AEC_WAVES
 #define AEC_WAVES 4  // waves per SIMD the register allocation aims at (4: every stream of a 4096-stream batch is resident at once)
 #endif
-template <bool kMetrics>
-__global__ __launch_bounds__(256, kMetrics ? 2 : AEC_WAVES) void aec_process_kernel(int stream0, int stream_end, float* __restrict__ state,
+template <bool kMetrics, int NP>
+__global__ __launch_bounds__(256, kMetrics ? 2 : NP == kNumPartNormal ? AEC_WAVES : 3) void aec_process_kernel(int stream0, int stream_end, float* __restrict__ state,
                                                           float* far_ring,
                                                           const AecTables* __restrict__ G,
                                                           const float* __restrict__ nearend,
@@ -1324,7 +1367,7 @@ __global__ __launch_bounds__(256, kMetrics ? 2 : AEC_WAVES) void aec_process_ker
                                                           float* metrics,
                                                           unsigned long long* __restrict__ stamps) {
   __shared__ SharedTables T;
-  constexpr int kWaveLds = kMetrics ? kLdsWaveMet : kLdsWave;
+  constexpr int kWaveLds = lds_wave(NP, kMetrics);
   __shared__ float lds[4 * kWaveLds];
   stage_tables(T, G);
   const int lane = threadIdx.x & 63;
@@ -1332,7 +1375,7 @@ __global__ __launch_bounds__(256, kMetrics ? 2 : AEC_WAVES) void aec_process_ker
   const int stream = stream0 + blockIdx.x * 4 + wave;  // this launch covers streams stream0 .. stream_end - 1
   if (stream >= stream_end) return;
   float* wl = lds + wave * kWaveLds;
-  float* st = state + (size_t)stream * kStateDwords;
+  float* st = state + (size_t)stream * AecRows(NP).state_dwords;
   const float* nin = nearend + (size_t)stream * nrOfSamples;
   float* o = out + (size_t)stream * nrOfSamples;
   float* met = kMetrics ? metrics + (size_t)stream * kMetDwords : nullptr;
@@ -1364,7 +1407,7 @@ __global__ __launch_bounds__(256, kMetrics ? 2 : AEC_WAVES) void aec_process_ker
     for (int k = 0; k < sf.nblocks; ++k) {
       const BlockOp& op = sf.blk[k];
       const float* slot = far_ring + ((size_t)op.far_slot * num_streams + stream) * kFarSlotDwords;
-      process_block<kMetrics>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
+      process_block<kMetrics, NP>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
                     ops.num_high, met,
                     (stamps != nullptr && stream == 0 && s == 0 && k == 0) ? stamps : nullptr);  // wave-uniform; every lane stores the same scalar time
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1423,10 +1466,11 @@ __global__ __launch_bounds__(256) void aec_rdft128_kernel(const float* __restric
 namespace aspaec {
 
 hipError_t launch_aec_farend(float* state, float* far_ring, const AecTables* T, const float* farend,
-                             int num_streams, const FarOps& ops, hipStream_t s, int stream0, int stream_end) {
+                             int num_streams, const FarOps& ops, hipStream_t s, int stream0, int stream_end,
+                             int num_part) {
   if (stream_end < 0) stream_end = num_streams;
   hipLaunchKernelGGL(aec_farend_kernel, dim3((stream_end - stream0 + 3) / 4), dim3(256), 0, s, stream0,
-                     stream_end, state, far_ring, T, farend, num_streams, ops);
+                     stream_end, state, far_ring, T, farend, num_streams, ops, AecRows(num_part).state_dwords);
   return hipGetLastError();
 }
 
@@ -1434,18 +1478,21 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const float* nearend, float* out, int num_streams, int nrOfSamples,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
                               const float* near_high, float* out_high, float* metrics,
-                              hipStream_t s, unsigned long long* stamps, int stream0, int stream_end) {
+                              hipStream_t s, unsigned long long* stamps, int stream0, int stream_end,
+                              int num_part) {
   if (stream_end < 0) stream_end = num_streams;
+  if (num_part != kNumPartNormal && num_part != kNumPartMax) return hipErrorInvalidValue;
   const dim3 grid((stream_end - stream0 + 3) / 4);
-  if (metrics != nullptr) {
-    hipLaunchKernelGGL(aec_process_kernel<true>, grid, dim3(256), 0, s, stream0, stream_end, state,
-                       far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,
-                       out_high, metrics, stamps);
+#define ASP_AEC_LAUNCH(MET, NP)                                                                              \
+  hipLaunchKernelGGL((aec_process_kernel<MET, NP>), grid, dim3(256), 0, s, stream0, stream_end, state,        \
+                     far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,      \
+                     out_high, metrics, stamps)
+  if (num_part == kNumPartNormal) {
+    if (metrics != nullptr) ASP_AEC_LAUNCH(true, kNumPartNormal); else ASP_AEC_LAUNCH(false, kNumPartNormal);
   } else {
-    hipLaunchKernelGGL(aec_process_kernel<false>, grid, dim3(256), 0, s, stream0, stream_end, state,
-                       far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,
-                       out_high, metrics, stamps);
+    if (metrics != nullptr) ASP_AEC_LAUNCH(true, kNumPartMax); else ASP_AEC_LAUNCH(false, kNumPartMax);
   }
+#undef ASP_AEC_LAUNCH
   return hipGetLastError();
 }
 

@@ -1,16 +1,21 @@
 // aec_layout.h -- HBM layout of the batched echo canceller and the launch descriptors shared by
 // aec_kernels.hip (device) and aec_api.hip (host control plane).
 //
-// Per stream (all float / int32 dwords, one contiguous block of kStateDwords):
-//   rows of kRowS = 64 dwords (256-byte aligned) holding bins 0..63 (lane q <-> bin q); bin 64 of
-//   every row lives in one contiguous column c64[R_COUNT] so a wave gathers it with two loads:
-//     xPow dPow dMinPow dInitMinPow sx sd se sde.re sde.im sxd.re sxd.im           (11 rows)
-//     xfBuf  re[12] im[12]   -- partition p at physical index p (circular, xfBufBlockPos on host)
-//     wfBuf  re[12] im[12]
-//     xfwBuf [12] x {re, im} -- circular, newest at physical index `xfw_head` (host)
+// Per stream (all float / int32 dwords, one contiguous block of state_dwords(NP)), NP = 12 partitions, or
+// 32 with the extended filter (aec_core_internal.h:23-25).  The blocks whose size does not depend on NP
+// come first, at the same offsets for both filter lengths:
+//   c64[256]: bin 64 of every state row, one contiguous column a wave gathers with 2 (NP = 12) / 4 loads
 //   dBuf[128] eBuf[128] outBuf[64]
 //   scalars[32]: see S_* below
-//   rings: far_pre[448] nearFr[144] outFr[144]   (positions live on the host)
+//   rings: far_pre[448] nearFr[144] outFr[144]   (positions live on the host), the 32 kHz high band's
+//   delay line and rings
+// then the rows of kRowS = 64 dwords (256-byte aligned) holding bins 0..63 (lane q <-> bin q):
+//     xPow dPow dMinPow dInitMinPow sx sd se sde.re sde.im sxd.re sxd.im           (11 rows)
+//     xfBuf  re[NP] im[NP]   -- partition p at physical index p (circular, xfBufBlockPos on host)
+//     wfBuf  re[NP] im[NP]
+//     xfwBuf [32] x {re, im} -- circular, newest at physical index `xfw_head` (host); all 32 blocks of
+//                               history whatever NP, as the reference keeps them (aec_core.c:1079-1081):
+//                               switching the filter length mid-stream then reads what the reference reads
 // Far-end spectra ring: separate allocation [250 slots][stream][4 rows of kRow]:
 //   plain re, plain im, windowed re, windowed im  (far_buf / far_buf_windowed, aec_core.c:1330-1341)
 #pragma once
@@ -18,27 +23,29 @@
 
 namespace aspaec {
 
-constexpr int kPartLen = 64, kPartLen1 = 65, kPartLen2 = 128, kFrameLen = 80, kNumPart = 12;
+constexpr int kPartLen = 64, kPartLen1 = 65, kPartLen2 = 128, kFrameLen = 80;
+constexpr int kNumPartNormal = 12, kNumPartMax = 32;  // kNormalNumPartitions / kExtendedNumPartitions
 constexpr int kFarSlots = 250;              // kBufSizePartitions, aec_core.c:37
 constexpr int kPreLen = 128 + 4 * 80;       // far_pre_buf, echo_cancellation.c:146-147
 constexpr int kFrBufLen = 80 + 64;          // nearFrBuf / outFrBuf, aec_core.c:1299-1305
 constexpr int kRow = 68;    // far-ring rows: 65 bins + pad
 constexpr int kRowS = 64;   // state rows: bins 0..63 (bin 64 in the c64 column)
 
+// rows that exist once, whatever the filter length; the partition rows follow from R_XF_RE on
 enum Row {
   R_XPOW = 0, R_DPOW, R_DMINPOW, R_DINITMINPOW, R_SX, R_SD, R_SE, R_SDE_RE, R_SDE_IM, R_SXD_RE,
   R_SXD_IM,
-  R_XF_RE,                          // 12 rows
-  R_XF_IM = R_XF_RE + kNumPart,     // 12 rows
-  R_WF_RE = R_XF_IM + kNumPart,
-  R_WF_IM = R_WF_RE + kNumPart,
-  R_XFW = R_WF_IM + kNumPart,       // 24 rows: partition p -> rows R_XFW + 2p (re), + 2p + 1 (im)
-  R_COUNT = R_XFW + 2 * kNumPart    // 83
+  R_XF_RE                           // NP rows, then R_XF_IM, R_WF_RE, R_WF_IM (NP each), R_XFW (2 x 32)
+};
+// row indices that depend on the number of partitions
+struct AecRows {
+  int NP, R_XF_IM, R_WF_RE, R_WF_IM, R_XFW, R_COUNT, state_dwords;
+  constexpr explicit AecRows(int np);
 };
 
-constexpr int kOffRows = 0;
-constexpr int kOffC64 = R_COUNT * kRowS;          // bin 64 of every row: 84 dwords
-constexpr int kOffDBuf = kOffC64 + 84 + 12;       // keeps the sample buffers 256-byte aligned
+constexpr int kC64Len = 256;                      // >= R_COUNT of 32 partitions (203)
+constexpr int kOffC64 = 0;
+constexpr int kOffDBuf = kOffC64 + kC64Len;       // the sample buffers are 256-byte aligned
 constexpr int kOffEBuf = kOffDBuf + 128;
 constexpr int kOffOutBuf = kOffEBuf + 128;
 constexpr int kOffScalars = kOffOutBuf + 64;
@@ -49,7 +56,13 @@ constexpr int kOffOutFr = kOffNearFr + kFrBufLen;
 constexpr int kOffDBufH = kOffOutFr + kFrBufLen;   // dBufH[0][0..63]
 constexpr int kOffNearFrH = kOffDBufH + 64;
 constexpr int kOffOutFrH = kOffNearFrH + kFrBufLen;
-constexpr int kStateDwords = ((kOffOutFrH + kFrBufLen + 63) / 64) * 64;
+constexpr int kOffRows = ((kOffOutFrH + kFrBufLen + 63) / 64) * 64;
+
+constexpr AecRows::AecRows(int np)
+    : NP(np), R_XF_IM(R_XF_RE + np), R_WF_RE(R_XF_RE + 2 * np), R_WF_IM(R_XF_RE + 3 * np),
+      R_XFW(R_XF_RE + 4 * np), R_COUNT(R_XF_RE + 4 * np + 2 * kNumPartMax),
+      state_dwords(kOffRows + (R_XF_RE + 4 * np + 2 * kNumPartMax) * kRowS) {}
+static_assert(AecRows(kNumPartMax).R_COUNT <= kC64Len, "the bin-64 column holds every row of the extended filter");
 
 enum Scalar {
   S_HNLFBMIN = 0, S_HNLFBLOCALMIN, S_HNLXDAVGMIN, S_OVERDRIVE, S_OVERDRIVESM,  // float

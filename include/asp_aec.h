@@ -82,6 +82,10 @@ int32_t WebRtcAec_get_error_code(void* aecInst);                                
 /* The reference returns its internal AecCore; here it is an opaque token that is only
  * valid as an argument of the layer-1 functions of this library. */
 struct AecCore* WebRtcAec_aec_core(void* handle);                               /* .h:247 */
+/* The extended filter (32 partitions, ProcessExtended delay handling): aec_core.h:129-133,
+ * aec_core.c:1876-1885.  As in the reference, Init switches it off again. */
+void WebRtcAec_enable_delay_correction(struct AecCore* self, int enable);
+int WebRtcAec_delay_correction_enabled(struct AecCore* self);
 #endif /* reference header not included */
 
 #define ASP_AEC_PART_LEN 64    /* aec_core.h:21 */
@@ -193,6 +197,13 @@ int AspAecBatch_get_echo_status(AspAecBatch* b, int* status /* [num_streams] */)
 int AspAecBatch_GetMetrics(AspAecBatch* b, AecMetrics* out);
 int AspAecBatch_ExportMetricsState(AspAecBatch* b, int stream, AspAecMetricsState* out);
 int AspAecBatch_get_error_code(const AspAecBatch* b);
+/* WebRtcAec_enable_delay_correction for every stream of the batch: the extended filter (32 partitions,
+ * kExtendedMu / kExtendedErrorThreshold, the extended smoothing coefficients and overdrive floors, no filter
+ * reset on divergence) and the ProcessExtended / EstBufDelayExtended delay handling of
+ * echo_cancellation.c:744-814, 869-922 (trusted-delay build).  Call it after Init (Init switches it off, as
+ * aec_core.c:1522-1523 does); the per-stream blocks are re-packed to the new filter length. */
+int AspAecBatch_enable_delay_correction(AspAecBatch* b, int enable);
+int AspAecBatch_delay_correction_enabled(const AspAecBatch* b);
 int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out);
 int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in);
 int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* out);

@@ -120,6 +120,136 @@ def test_free_running_vs_oracle(aec, fs, n, nlp):
     assert frac_exact > 0.9
 
 
+@pytest.mark.parametrize("fs,n,nlp", [(16000, 160, 1), (16000, 80, 2), (8000, 80, 0)])
+def test_extended_filter_vs_oracle(aec, fs, n, nlp):
+    """AspAecBatch_enable_delay_correction(b, 1): the extended filter (32 partitions, kExtendedMu, the extended
+    smoothing coefficients and overdrive floors, no divergence reset) and the ProcessExtended /
+    EstBufDelayExtended control plane (aec_core.c:172-174, 337-338, 383, 872-873, 1876-1881;
+    echo_cancellation.c:744-814, 869-922) against the oracle (== reference build, tests/test_aec_oracle.py):
+    return codes and control plane equal, linear state over all 32 partitions bit-exact, outputs within 1e-5
+    per-stream rel-L2; then switched off again mid-stream (back to 12 partitions, state carried over)."""
+    S, F = 6, 460
+    far, near = aec_frames(S, F if n == 160 else F // 2)
+    far = far.reshape(-1, S, 160 // n, n).transpose(0, 2, 1, 3).reshape(-1, S, n)[:F]
+    near = near.reshape(-1, S, 160 // n, n).transpose(0, 2, 1, 3).reshape(-1, S, n)[:F]
+    g = aec.AecBatch(S, fs, nlp_mode=nlp)
+    assert g.delay_correction_enabled() == 0
+    g.enable_delay_correction(1)
+    assert g.delay_correction_enabled() == 1
+    oras = [OracleAec(fs, nlp_mode=nlp) for _ in range(S)]
+    for o in oras:
+        o.enable_delay_correction(1)
+    out_g = np.empty((F, S, n), np.float32)
+    out_o = np.empty((F, S, n), np.float32)
+
+    def delay(f):
+        if f in (150, 151):
+            return 700       # >= kMaxTrustedDelayMs: replaced by kFixedDelayMs (ec:766-768)
+        if f == 200:
+            return -5
+        if 250 <= f < 330:
+            return 180       # a sustained change: EstBufDelayExtended moves knownDelay
+        return 5 if f >= 400 else 30   # 5: below kMinTrustedDelayMs
+
+    def compare(f):
+        cg = g.control()
+        _, co = oras[0].export()
+        for name, _t in cg._fields_:
+            assert getattr(cg, name) == getattr(co, name), (f, name)
+        for s in range(S):
+            st_o, _ = oras[s].export()
+            rep = _state_report(g.export_state(s), st_o)
+            bad = [k for k in LINEAR_FIELDS if not rep[k][0]]
+            assert bad == [], (f, s, {k: rep[k] for k in bad})
+            assert rep["outBuf"][1] <= 1e-5 and rep["overDrive"][1] <= 1e-6 and rep["overDriveSm"][1] <= 1e-6
+
+    for f in range(F):
+        out_g[f], rc_g = g.frame(far[f], near[f], delay(f))
+        for s in range(S):
+            out_o[f, s], rc_o = oras[s].frame(far[f, s], near[f, s], delay(f))
+        assert rc_g == rc_o, f
+        if f % 115 == 114:
+            compare(f)
+    compare(F)
+    worst = max(_rel_l2(out_g[:, s], out_o[:, s]) for s in range(S))
+    frac_exact = (_bits(out_g) == _bits(out_o)).mean()
+    print("AEC extended fs=%d n=%d: %.4f of output samples bit-equal to the oracle, worst rel-L2 %.2e" % (fs, n, frac_exact, worst))
+    assert worst <= 1e-5 and frac_exact > 0.9
+    assert np.abs(aec_state_arrays(g.export_state(0))["wfBuf"].reshape(2, 32 * 65)[:, 12 * 65:]).max() > 0   # the long filter is live
+    # off again, mid-stream (legal where xfBufBlockPos lies inside the short filter, as in the reference): the
+    # 12-partition path then reads the 32-deep far-spectrum history the extended run left, delayIdx included
+    k = 0
+    while g.export_state(0).xfBufBlockPos >= 12:
+        _, rc_g = g.frame(far[k], near[k], 30)
+        for s in range(S):
+            _, rc_o = oras[s].frame(far[k, s], near[k, s], 30)
+        k += 1
+    g.enable_delay_correction(0)
+    for o in oras:
+        o.enable_delay_correction(0)
+    for f in range(k, k + 60):
+        og, rc_g = g.frame(far[f], near[f], 30)
+        for s in range(S):
+            oo, rc_o = oras[s].frame(far[f, s], near[f, s], 30)
+            assert rc_g == rc_o and _rel_l2(og[s], oo) <= 1e-5, (f, s)
+    for s in range(S):   # partitions 12..31 of xfBuf / wfBuf stay (stale) in the reference; the device drops them
+        st_o, _ = oras[s].export()
+        da, db = aec_state_arrays(g.export_state(s)), aec_state_arrays(st_o)
+        for name in ("xfBuf", "wfBuf"):
+            assert np.array_equal(_bits(da[name].reshape(2, 32 * 65)[:, :12 * 65]), _bits(db[name].reshape(2, 32 * 65)[:, :12 * 65])), (s, name)
+        for name in ("xfwBuf", "sd", "se", "sx", "sde", "sxd", "xPow", "dPow", "delayIdx", "xfBufBlockPos", "seed"):
+            assert np.array_equal(_bits(np.asarray(da[name], np.float32)) if isinstance(da[name], np.ndarray) else da[name],
+                                  _bits(np.asarray(db[name], np.float32)) if isinstance(db[name], np.ndarray) else db[name]), (s, name)
+
+
+def test_extended_filter_golden_and_layer1(aec):
+    """The reference's own extended-filter outputs (tests/golden/aec_ext_golden.npz, written by the reference
+    build): batch path and the per-stream WebRtcAec_enable_delay_correction(WebRtcAec_aec_core(h), 1) path,
+    <= 1e-5 per-stream rel-L2 (bar 1e-4); Init switches the mode off again (aec_core.c:1522-1523)."""
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "aec_ext_golden.npz")))
+    far, near = gold["far_i16"].astype(np.float32), gold["near_i16"].astype(np.float32)
+    F, S = far.shape[:2]
+    d = int(gold["delay_ms"])
+    g = aec.AecBatch(S, 16000)
+    g.enable_delay_correction(1)
+    out = g.run(far, near, d)
+    for s in range(S):
+        assert _rel_l2(out[:, s], gold["out_f32"][:, s]) <= 1e-5, s
+    lib = g.lib
+    f32p = C.POINTER(C.c_float)
+    lib.WebRtcAec_Create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.WebRtcAec_Init.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.WebRtcAec_BufferFarend.argtypes = [C.c_void_p, f32p, C.c_int16]
+    lib.WebRtcAec_Process.argtypes = [C.c_void_p, C.POINTER(f32p), C.c_int, C.POINTER(f32p), C.c_int16,
+                                      C.c_int16, C.c_int32]
+    lib.WebRtcAec_Free.argtypes = [C.c_void_p]
+    lib.WebRtcAec_aec_core.restype = C.c_void_p
+    lib.WebRtcAec_aec_core.argtypes = [C.c_void_p]
+    lib.WebRtcAec_enable_delay_correction.restype = None
+    lib.WebRtcAec_enable_delay_correction.argtypes = [C.c_void_p, C.c_int]
+    lib.WebRtcAec_delay_correction_enabled.argtypes = [C.c_void_p]
+    h = C.c_void_p()
+    assert lib.WebRtcAec_Create(C.byref(h)) == 0 and lib.WebRtcAec_Init(h, 16000, 48000) == 0
+    core = lib.WebRtcAec_aec_core(h)
+    assert lib.WebRtcAec_delay_correction_enabled(core) == 0
+    lib.WebRtcAec_enable_delay_correction(core, 1)
+    assert lib.WebRtcAec_delay_correction_enabled(core) == 1
+    F1 = 200
+    got = np.empty((F1, 160), np.float32)
+    for f in range(F1):
+        fr = np.ascontiguousarray(far[f, 2])
+        nr = np.ascontiguousarray(near[f, 2])
+        assert lib.WebRtcAec_BufferFarend(h, fr.ctypes.data_as(C.POINTER(C.c_float)), 160) == 0
+        o = np.empty(160, np.float32)
+        pin = (C.POINTER(C.c_float) * 1)(nr.ctypes.data_as(C.POINTER(C.c_float)))
+        pout = (C.POINTER(C.c_float) * 1)(o.ctypes.data_as(C.POINTER(C.c_float)))
+        assert lib.WebRtcAec_Process(h, pin, 1, pout, 160, d, 0) == 0
+        got[f] = o
+    assert _rel_l2(got, gold["out_f32"][:F1, 2]) <= 1e-5
+    assert lib.WebRtcAec_Init(h, 16000, 48000) == 0 and lib.WebRtcAec_delay_correction_enabled(core) == 0
+    assert lib.WebRtcAec_Free(h) == 0
+
+
 def test_golden_reference_outputs(aec, aec_golden):
     """The reference's own outputs (committed fixture): <= 1e-5 per-stream rel-L2 (bar 1e-4),
     start-up frames passed through untouched, echo cancelled by > 15 dB."""

@@ -297,11 +297,15 @@ def test_host_control_plane_matches_oracle():
 
     lib = aec_mod._lib()
     lib.AspAecBatch_CreateControlOnly.argtypes = [C.POINTER(C.c_void_p), C.c_int]
-    for fs, n in [(16000, 160), (16000, 80), (8000, 80)]:
+    for fs, n, ext in [(16000, 160, 0), (16000, 80, 0), (8000, 80, 0), (16000, 160, 1), (8000, 80, 1)]:
         h = C.c_void_p()
         assert lib.AspAecBatch_CreateControlOnly(C.byref(h), 7) == 0
         assert lib.AspAecBatch_Init(h, fs, 48000) == 0
         ora = oracle_lib.OracleAec(fs)
+        if ext:     # ProcessExtended / EstBufDelayExtended (echo_cancellation.c:744-814, 869-922)
+            assert lib.AspAecBatch_enable_delay_correction(h, 1) == 0
+            assert lib.AspAecBatch_delay_correction_enabled(h) == 1
+            ora.enable_delay_correction(1)
         dummy = np.zeros(7 * 160, np.float32)
         z = np.zeros(n, np.float32)
         for f in range(900):
@@ -317,12 +321,12 @@ def test_host_control_plane_matches_oracle():
             rc_o = ora.frame(z, z, d)[1]
             rc_b = lib.AspAecBatch_BufferFarend(h, dummy.ctypes.data, n, 1)
             rc_b |= lib.AspAecBatch_Process(h, dummy.ctypes.data, dummy.ctypes.data, n, d, 0, 1)
-            assert (rc_b != 0) == (rc_o != 0), (fs, n, f)
+            assert (rc_b != 0) == (rc_o != 0), (fs, n, ext, f)
             cb = AspAecControl()
             assert lib.AspAecBatch_GetControl(h, C.byref(cb)) == 0
             _, co = ora.export()
             for name, _t in cb._fields_:
-                assert getattr(cb, name) == getattr(co, name), (fs, n, f, name)
+                assert getattr(cb, name) == getattr(co, name), (fs, n, ext, f, name)
         assert lib.AspAecBatch_get_error_code(h) == ora.error_code()
         # data-touching entry points refuse a control-only handle
         lib.AspAecBatch_Synchronize.argtypes = [C.c_void_p]
