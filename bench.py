@@ -243,6 +243,9 @@ def bench_aec(args):
     d_near = torch.from_numpy(np.ascontiguousarray(near1[:, idx])).cuda()
     d_out = torch.empty_like(d_near)
     g = AecBatch(S, 16000)
+    ext = bool(getattr(args, "aec_extended", False))
+    if ext:     # WebRtcAec_enable_delay_correction: the 32-partition extended filter
+        g.enable_delay_correction(1)
     steps, warm = max(args.steps // 4, 10), max(args.warmup // 2, 80)   # warm-up passes the start-up phase
     g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, warm)
     torch.cuda.synchronize()
@@ -252,7 +255,9 @@ def bench_aec(args):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     assert bool(torch.isfinite(d_out).all())
-    algo = 71400                        # 2.5 blocks x 28 560 B per 10 ms frame
+    # 2.5 blocks x 28 560 B per 10 ms frame; the same accounting with 32 partitions:
+    # read X, W 2 x 32 x 130 + 1 229 floats, write W 32 x 130 + 1 231 floats = 59 760 B per block
+    algo = 149400 if ext else 71400
     step_s = ev_ms / 1e3 / steps
     achieved = algo * S / step_s / 1e9
     line = {
@@ -262,10 +267,10 @@ def bench_aec(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "WebRTC AEC (test_aec_module): 10 ms/16 kHz far+near frames, %d concurrent "
-                               "streams on 1 MI355X, 12 partitions, the far-end work fused into the process "
-                               "launch of each frame" % S},
+                               "streams on 1 MI355X, %d partitions, the far-end work fused into the process "
+                               "launch of each frame" % (S, 32 if ext else 12)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": AEC_TRAFFIC_BYTES_PER_FRAME * S,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if ext else AEC_TRAFFIC_BYTES_PER_FRAME * S,
                      "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE; 4-byte-per-lane accesses, a width MI355X_MICROARCH.md does not calibrate), per frame step of all streams; not measured in this run",
                      "kernel": "aec_process_kernel (the far-end work of the frame inside it)",
                      "launch_chains": 2 if S >= 2048 else 1,
@@ -436,6 +441,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 3],
                     help="fused-step kernel: 0 / 3 = one stream per wave, pair layout (ns_kernels1.hip, the default), "
                          "1 = one stream per wave, bins q / q + 64 (ns_kernels.hip)")
+    ap.add_argument("--aec-extended", action="store_true", help="--workload aec: the 32-partition extended filter")
     ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256", "aec", "split48"],
                     help="ns = the headline metric (default); bt* / aec / split48 = secondary lines")
     args = ap.parse_args()
