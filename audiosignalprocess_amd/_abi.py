@@ -170,6 +170,50 @@ class AspAecControl(C.Structure):
         "blocks_processed")]
 
 
+class AspAecDelayState(C.Structure):
+    """include/asp_aec.h: AspAecDelayState (the delay estimator of one stream and the AecCore fields around it)."""
+
+    _fields_ = [("mean_far_spectrum", C.c_float * 65), ("far_spectrum_initialized", C.c_int32),
+                ("binary_far_history", C.c_uint32 * 125), ("far_bit_counts", C.c_int32 * 125),
+                ("mean_near_spectrum", C.c_float * 65), ("near_spectrum_initialized", C.c_int32),
+                ("binary_near_history", C.c_uint32 * 126), ("mean_bit_counts", C.c_int32 * 126),
+                ("bit_counts", C.c_int32 * 125), ("histogram", C.c_float * 126),
+                ("minimum_probability", C.c_int32), ("last_delay_probability", C.c_int32), ("last_delay", C.c_int32),
+                ("last_candidate_delay", C.c_int32), ("compare_delay", C.c_int32), ("candidate_hits", C.c_int32),
+                ("last_delay_histogram", C.c_float), ("lookahead", C.c_int32), ("allowed_offset", C.c_int32),
+                ("delay_histogram", C.c_int32 * 125),
+                ("previous_delay", C.c_int32), ("delay_correction_count", C.c_int32), ("shift_offset", C.c_int32),
+                ("delay_quality_threshold", C.c_float),
+                ("far_read", C.c_int32), ("far_write", C.c_int32), ("far_wrap", C.c_int32), ("system_delay", C.c_int32)]
+
+    def far_available(self):
+        """readable partitions of the stream's far buffer (ring_buffer.c:231-240); a reference export carries the
+        count itself in far_read (far_write = -1)"""
+        if self.far_write < 0:
+            return self.far_read
+        return self.far_write - self.far_read if self.far_wrap == 0 else 250 - self.far_read + self.far_write
+
+    def diff(self, other, skip=("far_read", "far_write", "far_wrap")):
+        """names of the fields that differ bitwise (ring positions compared as the readable count)"""
+        import numpy as np
+        bad = []
+        for name, _t in self._fields_:
+            if name in skip:
+                continue
+            a, b = getattr(self, name), getattr(other, name)
+            if hasattr(a, "_length_"):
+                if not np.array_equal(np.frombuffer(bytes(a), np.uint32), np.frombuffer(bytes(b), np.uint32)):
+                    bad.append(name)
+            elif isinstance(a, float):
+                if np.float32(a).view(np.uint32) != np.float32(b).view(np.uint32):
+                    bad.append(name)
+            elif a != b:
+                bad.append(name)
+        if self.far_available() != other.far_available():
+            bad.append("far_available")
+        return bad
+
+
 def aec_state_arrays(st):
     """AspAecState -> {field: numpy array / scalar} for comparisons."""
     import numpy as np

@@ -146,6 +146,38 @@ typedef struct AspAecMetricsState {
   int32_t stateCounter;
 } AspAecMetricsState;
 
+/* Delay estimation of one stream (set_config with delay_logging = kAecTrue; also what the
+ * delay-agnostic mode steers by): the binary-spectrum delay estimator of utility/delay_estimator.c /
+ * delay_estimator_wrapper.c (float path) with the sizes aec_core.c:1356-1377 creates it with, and the
+ * AecCore fields around it (aec_core_internal.h:129-142). */
+#define ASP_AEC_DELAY_HISTORY 125   /* kHistorySizeBlocks, aec_core_internal.h:34 */
+#define ASP_AEC_DELAY_LOOKAHEAD 15  /* kLookaheadBlocks, aec_core_internal.h:30   */
+typedef struct AspAecDelayState {
+  /* far end: DelayEstimatorFarend + BinaryDelayEstimatorFarend */
+  float mean_far_spectrum[65];
+  int32_t far_spectrum_initialized;
+  uint32_t binary_far_history[ASP_AEC_DELAY_HISTORY];
+  int32_t far_bit_counts[ASP_AEC_DELAY_HISTORY];
+  /* near end: DelayEstimator + BinaryDelayEstimator */
+  float mean_near_spectrum[65];
+  int32_t near_spectrum_initialized;
+  uint32_t binary_near_history[ASP_AEC_DELAY_HISTORY + 1]; /* max_lookahead = kHistorySizeBlocks, aec_core.c:1363-1366 */
+  int32_t mean_bit_counts[ASP_AEC_DELAY_HISTORY + 1];
+  int32_t bit_counts[ASP_AEC_DELAY_HISTORY];
+  float histogram[ASP_AEC_DELAY_HISTORY + 1];
+  int32_t minimum_probability, last_delay_probability, last_delay;
+  int32_t last_candidate_delay, compare_delay, candidate_hits;
+  float last_delay_histogram;
+  int32_t lookahead, allowed_offset;
+  /* AecCore: the logging histogram and the signal-based correction of the delay-agnostic mode */
+  int32_t delay_histogram[ASP_AEC_DELAY_HISTORY];
+  int32_t previous_delay, delay_correction_count, shift_offset;
+  float delay_quality_threshold;
+  /* the stream's own far-buffer read side and system delay (identical for all streams of a batch until
+   * the delay-agnostic mode moves them apart) */
+  int32_t far_read, far_write, far_wrap, system_delay;
+} AspAecDelayState;
+
 /* Integer control plane shared by all streams of a batch (one Aec + the integer part of
  * AecCore), exposed for the parity tests. */
 typedef struct AspAecControl {

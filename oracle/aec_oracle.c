@@ -5,10 +5,13 @@
  *
  * Paths below are relative to WebRtc_AMP_Port/webrtc/ ; "core" = modules/audio_processing/aec/
  * aec_core.c, "ec" = .../aec/echo_cancellation.c, "rdft" = .../aec/aec_rdft.c,
- * "ring" = common_audio/ring_buffer.c.
+ * "ring" = common_audio/ring_buffer.c, "de" / "dw" = modules/audio_processing/utility/delay_estimator.c /
+ * delay_estimator_wrapper.c, "rs" = .../aec/aec_resampler.c.
  *
- * Covered configuration (what test_aec_module.cpp:60-88 runs): one band (8 / 16 kHz), 12
- * partitions, reported-delay mode, no skew resampling, no delay logging, metrics off.
+ * Covered configuration: what test_aec_module.cpp:60-88 runs (one band at 8 / 16 kHz, 12 partitions,
+ * reported-delay mode) plus the second band at 32 kHz, echo metrics, the extended filter, delay logging with
+ * WebRtcAec_GetDelayMetrics, the delay-agnostic mode (reported delays off) and skew compensation -- each pinned
+ * to the reference build by its own test in tests/test_aec_oracle.py.
  * Compile with -ffp-contract=off.
  */
 #include "aec_oracle.h"
@@ -372,6 +375,7 @@ static int ring_read(RingPos* r, const float* data, int ef, float* dst, int n) {
 }
 
 /* ------------------------------------------------------------------ object */
+enum { RS_BUF = 4 * FRAME_LEN, RS_EST = 400, RS_DELAY = 1 }; /* kResamplerBufferSize, kEstimateLengthFrames, kResamplingDelay */
 struct AspAecOracle {
   AspAecState st;
   /* Aec (ec, echo_cancellation_internal.h:17-65) */
@@ -383,6 +387,18 @@ struct AspAecOracle {
   int system_delay, core_knownDelay, mult, nlp_mode, metricsMode, delay_logging;
   float normal_mu, normal_error_threshold;
   int extended_filter_enabled, num_partitions; /* WebRtcAec_enable_delay_correction, core:1876-1881 */
+  int reported_delay_enabled;                  /* WebRtcAec_enable_reported_delay, core:1868-1874 */
+  AspAecDelayState de;                         /* delay estimator + AecCore's fields around it */
+  /* skew compensation (ec:304-315, 606-645; aec_resampler.c) */
+  int16_t skewFrCtr;
+  int resample, highSkewCtr;
+  float skew, sampFactor;
+  float rs_buffer[RS_BUF];
+  float rs_position;
+  int rs_deviceSampleRateHz;
+  int rs_skewData[RS_EST];
+  int rs_skewDataIndex;
+  float rs_skewEstimate;
   int blocks_processed;
   RingPos pre_pos, far_pos, near_pos, out_pos;
   float pre[PRE_LEN];
@@ -408,6 +424,7 @@ AspAecOracle* asp_aec_oracle_create(void) { /* ec:121-168 */
   if (o) {
     o->initFlag = 0;
     o->lastError = 0;
+    o->de.lookahead = ASP_AEC_DELAY_LOOKAHEAD; /* WebRtc_set_lookahead at Create, core:1374-1378 (not Android) */
   }
   return o;
 }
@@ -524,6 +541,188 @@ static void update_metrics(AspAecMetricsState* m, int echoState) { /* core:644-7
   }
 }
 
+/* ------------------------------------------------------------ delay estimator
+ * utility/delay_estimator.c (de:) and delay_estimator_wrapper.c (dw:), float path, robust validation on
+ * (core:1534), history 125 blocks, near history 126 (max_lookahead = kHistorySizeBlocks), lookahead 15
+ * (core:1356-1377). */
+enum { DE_HIST = ASP_AEC_DELAY_HISTORY, DE_NEAR = ASP_AEC_DELAY_HISTORY + 1, DE_BAND_FIRST = 12, DE_BAND_LAST = 43 };
+static const int32_t kMaxBitCountsQ9 = (32 << 9); /* de.h */
+
+static void de_init(AspAecDelayState* d) { /* dw:175-191, 305-322; de:303-307, 476-498; core:1502-1516 */
+  const int lookahead = d->lookahead, allowed = d->allowed_offset;
+  memset(d, 0, sizeof *d);
+  d->lookahead = lookahead; /* not touched by the Init functions */
+  d->allowed_offset = allowed;
+  for (int i = 0; i <= DE_HIST; ++i) d->mean_bit_counts[i] = (20 << 9);
+  d->minimum_probability = kMaxBitCountsQ9;
+  d->last_delay_probability = (int)kMaxBitCountsQ9;
+  d->last_delay = -2;
+  d->last_candidate_delay = -2;
+  d->compare_delay = DE_HIST;
+  d->previous_delay = -2;
+  d->shift_offset = 5; /* kInitialShiftOffset, core:102 */
+}
+
+static int de_bitcount(uint32_t u32) { /* de:38-47 */
+  uint32_t tmp = u32 - ((u32 >> 1) & 033333333333) - ((u32 >> 2) & 011111111111);
+  tmp = ((tmp + (tmp >> 3)) & 030707070707);
+  tmp = (tmp + (tmp >> 6));
+  tmp = (tmp + (tmp >> 12) + (tmp >> 24)) & 077;
+  return (int)tmp;
+}
+
+static void de_mean_fix(int32_t new_value, int factor, int32_t* mean_value) { /* de:672-684 */
+  int32_t diff = new_value - *mean_value;
+  if (diff < 0) {
+    diff = -((-diff) >> factor);
+  } else {
+    diff = (diff >> factor);
+  }
+  *mean_value += diff;
+}
+
+static uint32_t de_binary_spectrum(const float* spectrum, float* threshold, int32_t* initialized) { /* dw:96-124 */
+  const float kScale = 1 / 64.0;
+  uint32_t out = 0;
+  int i;
+  if (!(*initialized)) {
+    for (i = DE_BAND_FIRST; i <= DE_BAND_LAST; i++) {
+      if (spectrum[i] > 0.0f) {
+        threshold[i] = (spectrum[i] / 2);
+        *initialized = 1;
+      }
+    }
+  }
+  for (i = DE_BAND_FIRST; i <= DE_BAND_LAST; i++) {
+    threshold[i] += (spectrum[i] - threshold[i]) * kScale; /* MeanEstimatorFloat, dw:43-48 */
+    if (spectrum[i] > threshold[i]) out |= (1u << (i - DE_BAND_FIRST));
+  }
+  return out;
+}
+
+static void de_add_far(AspAecDelayState* d, const float* far_spectrum) { /* dw:231-255, de:356-369 */
+  const uint32_t b = de_binary_spectrum(far_spectrum, d->mean_far_spectrum, &d->far_spectrum_initialized);
+  memmove(&d->binary_far_history[1], &d->binary_far_history[0], (DE_HIST - 1) * sizeof(uint32_t));
+  d->binary_far_history[0] = b;
+  memmove(&d->far_bit_counts[1], &d->far_bit_counts[0], (DE_HIST - 1) * sizeof(int32_t));
+  d->far_bit_counts[0] = de_bitcount(b);
+}
+
+static void de_update_robust(AspAecDelayState* d, int candidate_delay, int32_t valley_depth_q14,
+                             int32_t valley_level_q14) { /* de:90-146 */
+  const float kQ14Scaling = 1.f / (1 << 14);
+  const float valley_depth = valley_depth_q14 * kQ14Scaling;
+  float decrease_in_last_set = valley_depth;
+  const int max_hits_for_slow_change = (candidate_delay < d->last_delay) ? 10 : 1000;
+  if (candidate_delay != d->last_candidate_delay) {
+    d->candidate_hits = 0;
+    d->last_candidate_delay = candidate_delay;
+  }
+  d->candidate_hits++;
+  d->histogram[candidate_delay] += valley_depth;
+  if (d->histogram[candidate_delay] > 3000.f) d->histogram[candidate_delay] = 3000.f;
+  if (d->candidate_hits < max_hits_for_slow_change)
+    decrease_in_last_set = (d->mean_bit_counts[d->compare_delay] - valley_level_q14) * kQ14Scaling;
+  for (int i = 0; i < DE_HIST; ++i) {
+    const int is_in_last_set = (i >= d->last_delay - 2) && (i <= d->last_delay + 1) && (i != candidate_delay);
+    const int is_in_candidate_set = (i >= candidate_delay - 2) && (i <= candidate_delay + 1);
+    d->histogram[i] -= decrease_in_last_set * is_in_last_set + valley_depth * (!is_in_last_set && !is_in_candidate_set);
+    if (d->histogram[i] < 0) d->histogram[i] = 0;
+  }
+}
+
+static int de_histogram_valid(const AspAecDelayState* d, int candidate_delay) { /* de:173-214 */
+  float fraction = 1.f;
+  float histogram_threshold = d->histogram[d->compare_delay];
+  const int delay_difference = candidate_delay - d->last_delay;
+  if (delay_difference > d->allowed_offset) {
+    fraction = 1.f - 0.05f * (delay_difference - d->allowed_offset);
+    fraction = (fraction > 0.5f ? fraction : 0.5f);
+  } else if (delay_difference < 0) {
+    fraction = 0.25f - 0.05f * delay_difference;
+    fraction = (fraction > 1.f ? 1.f : fraction);
+  }
+  histogram_threshold *= fraction;
+  histogram_threshold = (histogram_threshold > 1.5f ? histogram_threshold : 1.5f);
+  return (d->histogram[candidate_delay] >= histogram_threshold) && (d->candidate_hits > 10);
+}
+
+static int de_process(AspAecDelayState* d, const float* near_spectrum) { /* dw:446-469, de:513-644 */
+  uint32_t binary_near = de_binary_spectrum(near_spectrum, d->mean_near_spectrum, &d->near_spectrum_initialized);
+  int i, candidate_delay = -1, valid_candidate;
+  int32_t value_best_candidate = kMaxBitCountsQ9, value_worst_candidate = 0, valley_depth;
+  memmove(&d->binary_near_history[1], &d->binary_near_history[0], (DE_NEAR - 1) * sizeof(uint32_t));
+  d->binary_near_history[0] = binary_near;
+  binary_near = d->binary_near_history[d->lookahead];
+  for (i = 0; i < DE_HIST; i++) d->bit_counts[i] = (int32_t)de_bitcount(binary_near ^ d->binary_far_history[i]);
+  for (i = 0; i < DE_HIST; i++) {
+    const int32_t bit_count = (d->bit_counts[i] << 9);
+    if (d->far_bit_counts[i] > 0) {
+      int shifts = 13;                          /* kShiftsAtZero */
+      shifts -= (3 * d->far_bit_counts[i]) >> 4; /* kShiftsLinearSlope */
+      de_mean_fix(bit_count, shifts, &d->mean_bit_counts[i]);
+    }
+  }
+  for (i = 0; i < DE_HIST; i++) {
+    if (d->mean_bit_counts[i] < value_best_candidate) {
+      value_best_candidate = d->mean_bit_counts[i];
+      candidate_delay = i;
+    }
+    if (d->mean_bit_counts[i] > value_worst_candidate) value_worst_candidate = d->mean_bit_counts[i];
+  }
+  valley_depth = value_worst_candidate - value_best_candidate;
+  if ((d->minimum_probability > 8704) && (valley_depth > 2816)) { /* kProbabilityLowerLimit, kProbabilityMinSpread */
+    int32_t threshold = value_best_candidate + 1024;                /* kProbabilityOffset */
+    if (threshold < 8704) threshold = 8704;
+    if (d->minimum_probability > threshold) d->minimum_probability = threshold;
+  }
+  d->last_delay_probability++;
+  valid_candidate = ((valley_depth > 1024) && ((value_best_candidate < d->minimum_probability) ||
+                                               (value_best_candidate < d->last_delay_probability)));
+  { /* robust validation, de:610-618 and 236-258 */
+    int is_histogram_valid, is_robust;
+    de_update_robust(d, candidate_delay, valley_depth, value_best_candidate);
+    is_histogram_valid = de_histogram_valid(d, candidate_delay);
+    is_robust = (d->last_delay < 0) && (valid_candidate || is_histogram_valid);
+    is_robust |= valid_candidate && is_histogram_valid;
+    is_robust |= is_histogram_valid && (d->histogram[candidate_delay] > d->last_delay_histogram);
+    valid_candidate = is_robust;
+  }
+  if (valid_candidate) {
+    if (candidate_delay != d->last_delay) {
+      d->last_delay_histogram = (d->histogram[candidate_delay] > 250.f ? 250.f : d->histogram[candidate_delay]);
+      if (d->histogram[candidate_delay] < d->histogram[d->compare_delay])
+        d->histogram[d->compare_delay] = d->histogram[candidate_delay];
+    }
+    d->last_delay = candidate_delay;
+    if (value_best_candidate < d->last_delay_probability) d->last_delay_probability = value_best_candidate;
+    d->compare_delay = d->last_delay;
+  }
+  return d->last_delay;
+}
+
+static float de_quality(const AspAecDelayState* d) { return d->histogram[d->compare_delay] / 3000.f; } /* de:655-658 */
+
+static void de_soft_reset(AspAecDelayState* d, int delay_shift) { /* de:309-339, 500-511 */
+  const int abs_shift = abs(delay_shift);
+  const int shift_size = DE_HIST - abs_shift;
+  int dest_index = 0, src_index = 0, padding_index = 0;
+  d->lookahead -= delay_shift; /* WebRtc_SoftResetBinaryDelayEstimator */
+  if (d->lookahead < 0) d->lookahead = 0;
+  if (d->lookahead > DE_NEAR - 1) d->lookahead = DE_NEAR - 1;
+  if (delay_shift == 0) return; /* ...Farend */
+  if (delay_shift > 0) {
+    dest_index = abs_shift;
+  } else {
+    src_index = abs_shift;
+    padding_index = shift_size;
+  }
+  memmove(&d->binary_far_history[dest_index], &d->binary_far_history[src_index], sizeof(uint32_t) * shift_size);
+  memset(&d->binary_far_history[padding_index], 0, sizeof(uint32_t) * abs_shift);
+  memmove(&d->far_bit_counts[dest_index], &d->far_bit_counts[src_index], sizeof(int32_t) * shift_size);
+  memset(&d->far_bit_counts[padding_index], 0, sizeof(int32_t) * abs_shift);
+}
+
 static void init_core(AspAecOracle* o, int sampFreq) { /* WebRtcAec_InitAec, core:1460-1615 */
   AspAecState* s = &o->st;
   if (sampFreq == 8000) {
@@ -572,14 +771,21 @@ static void init_core(AspAecOracle* o, int sampFreq) { /* WebRtcAec_InitAec, cor
   o->blocks_processed = 0;
   o->extended_filter_enabled = 0; /* core:1522-1523 */
   o->num_partitions = NPART_NORMAL;
+  o->reported_delay_enabled = 1;  /* core:1517-1521 (not Android) */
+  o->de.allowed_offset = o->num_partitions / 2; /* core:1529 */
+  de_init(&o->de);
 }
 
 /* WebRtcAec_enable_delay_correction / _delay_correction_enabled, core:1876-1885 (reached through
- * WebRtcAec_aec_core(handle)).  The delay estimator's allowed offset is outside the restated path. */
+ * WebRtcAec_aec_core(handle)). */
 void asp_aec_oracle_enable_delay_correction(AspAecOracle* o, int enable) {
   o->extended_filter_enabled = enable;
   o->num_partitions = enable ? NPART_MAX : NPART_NORMAL;
+  o->de.allowed_offset = o->num_partitions / 2; /* core:1880 */
 }
+/* WebRtcAec_enable_reported_delay / _reported_delay_enabled, core:1868-1874: 0 = the delay-agnostic mode */
+void asp_aec_oracle_enable_reported_delay(AspAecOracle* o, int enable) { o->reported_delay_enabled = enable; }
+int asp_aec_oracle_reported_delay_enabled(const AspAecOracle* o) { return o->reported_delay_enabled; }
 int asp_aec_oracle_delay_correction_enabled(const AspAecOracle* o) { return o->extended_filter_enabled; }
 
 int asp_aec_oracle_set_config(AspAecOracle* o, AecConfig config) { /* ec:410-438 */
@@ -605,14 +811,11 @@ int asp_aec_oracle_set_config(AspAecOracle* o, AecConfig config) { /* ec:410-438
     o->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
   }
-  if (config.skewMode || config.delay_logging) {
-    /* outside the covered configuration (header) */
-    o->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
-    return -1;
-  }
   o->nlp_mode = config.nlpMode; /* WebRtcAec_SetConfigCore, core:1844-1862 */
   o->metricsMode = config.metricsMode;
   if (o->metricsMode) init_metrics(&o->met);
+  o->delay_logging = config.delay_logging;
+  if (o->delay_logging) memset(o->de.delay_histogram, 0, sizeof o->de.delay_histogram);
   return 0;
 }
 
@@ -633,17 +836,24 @@ int asp_aec_oracle_init(AspAecOracle* o, int32_t sampFreq, int32_t scSampFreq) {
   }
   o->scSampFreq = scSampFreq;
   init_core(o, sampFreq);
+  memset(o->rs_buffer, 0, sizeof o->rs_buffer); /* WebRtcAec_InitResampler(resampler, scSampFreq), ec:221; rs:55-66 */
+  o->rs_position = 0.0;
+  o->rs_deviceSampleRateHz = scSampFreq;
+  memset(o->rs_skewData, 0, sizeof o->rs_skewData);
+  o->rs_skewDataIndex = 0;
+  o->rs_skewEstimate = 0.0;
   rp_init(&o->pre_pos, PRE_LEN);
   memset(o->pre, 0, sizeof o->pre);
   rp_move_read(&o->pre_pos, -PART_LEN); /* start overlap, ec:226 */
   o->initFlag = kInitCheck;
   o->splitSampFreq = sampFreq == 32000 ? 16000 : sampFreq; /* ec:231-235 */
   o->rate_factor = o->splitSampFreq / 8000;
+  o->sampFactor = (o->scSampFreq * 1.0f) / o->splitSampFreq; /* ec:238 */
   o->sum = 0;
   o->counter = 0;
   o->checkBuffSize = 1;
   o->firstVal = 0;
-  o->startup_phase = 1; /* reported_delay_enabled, core:1527-1531 */
+  o->startup_phase = o->reported_delay_enabled; /* ec:247 (1: InitAec has just set it) */
   o->bufSizeStart = 0;
   o->checkBufSizeCtr = 0;
   o->msInSndCardBuf = 0;
@@ -651,6 +861,10 @@ int asp_aec_oracle_init(AspAecOracle* o, int32_t sampFreq, int32_t scSampFreq) {
   o->timeForDelayChange = 0;
   o->knownDelay = 0;
   o->lastDelayDiff = 0;
+  o->skewFrCtr = 0; /* ec:256-259 */
+  o->resample = kAecFalse;
+  o->highSkewCtr = 0;
+  o->skew = 0;
   o->farend_started = 0;
   cfg.nlpMode = kAecNlpModerate;
   cfg.skewMode = kAecFalse;
@@ -1032,11 +1246,14 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
   asp_aec_oracle_rdft128(fft, 1);
   unpack_spectrum(fft, df);
 
+  float abs_far_spectrum[PART_LEN1], abs_near_spectrum[PART_LEN1];
   for (i = 0; i < PART_LEN1; i++) { /* core:1144-1156 */
     const float far_spectrum = (xf[0][i] * xf[0][i]) + (xf[1][i] * xf[1][i]);
     const float near_spectrum = df[0][i] * df[0][i] + df[1][i] * df[1][i];
     s->xPow[i] = gPow[0] * s->xPow[i] + gPow[1] * o->num_partitions * far_spectrum;
     s->dPow[i] = gPow[0] * s->dPow[i] + gPow[1] * near_spectrum;
+    abs_far_spectrum[i] = sqrtf(far_spectrum);
+    abs_near_spectrum[i] = sqrtf(near_spectrum);
   }
   if (s->noiseEstCtr > 50) { /* core:1159-1168 */
     for (i = 0; i < PART_LEN1; i++) {
@@ -1056,6 +1273,13 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
       } else {
         s->dInitMinPow[i] = s->dMinPow[i];
       }
+    }
+  }
+  if (o->delay_logging) { /* block-wise delay estimation, core:1191-1203 */
+    de_add_far(&o->de, abs_far_spectrum);
+    {
+      const int delay_estimate = de_process(&o->de, abs_near_spectrum);
+      if (delay_estimate >= 0) o->de.delay_histogram[delay_estimate]++;
     }
   }
 
@@ -1162,6 +1386,33 @@ static void process_block(AspAecOracle* o) { /* core:1084-1287 */
 }
 
 /* ------------------------------------------------------------ frame plumbing */
+static int signal_based_delay_correction(AspAecOracle* o) { /* SignalBasedDelayCorrection, core:797-850 */
+  AspAecDelayState* d = &o->de;
+  int delay_correction = 0;
+  const int last_delay = d->last_delay;
+  if ((last_delay >= 0) && (last_delay != d->previous_delay) && (de_quality(d) > d->delay_quality_threshold)) {
+    const int delay = last_delay - d->lookahead;
+    if (delay <= 0 || delay > (o->num_partitions / 4)) {
+      const int available_read = rp_avail_read(&o->far_pos);
+      delay_correction = -(delay - d->shift_offset);
+      d->shift_offset--;
+      d->shift_offset = (d->shift_offset <= 1 ? 1 : d->shift_offset);
+      if (delay_correction > available_read - o->mult - 1) {
+        delay_correction = 0;
+      } else {
+        d->previous_delay = last_delay;
+        ++d->delay_correction_count;
+      }
+    }
+  }
+  if (d->delay_correction_count > 0) {
+    float delay_quality = de_quality(d);
+    delay_quality = (delay_quality > 0.07f ? 0.07f : delay_quality); /* kDelayQualityThresholdMax */
+    d->delay_quality_threshold = (delay_quality > d->delay_quality_threshold ? delay_quality : d->delay_quality_threshold);
+  }
+  return delay_correction;
+}
+
 static void process_frames(AspAecOracle* o, const float* nearend, const float* nearendH,
                            int num_samples, int knownDelay, float* out,
                            float* outH) { /* WebRtcAec_ProcessFrames, core:1647-1778 */
@@ -1173,10 +1424,16 @@ static void process_frames(AspAecOracle* o, const float* nearend, const float* n
     }
     ring_write(&o->near_pos, o->nearfr, 1, nearend + j, FRAME_LEN);
     if (o->system_delay < FRAME_LEN) far_move_read(o, -(o->mult + 1));
-    {
+    if (o->reported_delay_enabled) { /* 2 a), core:1703-1718 */
       const int move_elements = (o->core_knownDelay - knownDelay - 32) / PART_LEN;
       const int moved_elements = rp_move_read(&o->far_pos, move_elements);
       o->core_knownDelay -= moved_elements * PART_LEN;
+    } else { /* 2 b) signal based delay correction, core:1719-1732 */
+      const int move_elements = signal_based_delay_correction(o);
+      const int moved_elements = rp_move_read(&o->far_pos, move_elements);
+      de_soft_reset(&o->de, moved_elements);
+      /* the under-run guard of this branch, core:1747-1750 */
+      if (rp_avail_read(&o->far_pos) < (o->mult + 1)) far_move_read(o, -(o->mult + 1));
     }
     while (rp_avail_read(&o->near_pos) >= PART_LEN) process_block(o);
     o->system_delay -= FRAME_LEN;
@@ -1195,6 +1452,7 @@ static void est_buf_delay_normal(AspAecOracle* o) { /* EstBufDelayNormal, ec:816
   int current_delay = nSampSndCard - o->system_delay;
   int delay_difference;
   current_delay += FRAME_LEN * o->rate_factor;
+  if (o->skewMode == kAecTrue && o->resample == kAecTrue) current_delay -= RS_DELAY; /* ec:831-833 */
   if (current_delay < PART_LEN) current_delay += far_move_read(o, 1) * PART_LEN;
   o->filtDelay = o->filtDelay < 0 ? 0 : o->filtDelay;
   {
@@ -1229,7 +1487,7 @@ static void est_buf_delay_extended(AspAecOracle* o) { /* EstBufDelayExtended, ec
   int current_delay = reported_delay - o->system_delay;
   int delay_difference;
   current_delay += FRAME_LEN * o->rate_factor;
-  /* skewMode is off in the restated configuration (ec:885-887) */
+  if (o->skewMode == kAecTrue && o->resample == kAecTrue) current_delay -= RS_DELAY; /* ec:884-886 */
   if (current_delay < PART_LEN) current_delay += far_move_read(o, 2) * PART_LEN;
   if (o->filtDelay == -1) {
     const double v = 0.5 * current_delay; /* WEBRTC_SPL_MAX(0, 0.5 * current_delay) -> short */
@@ -1280,11 +1538,94 @@ static void process_extended(AspAecOracle* o, const float* nearend, const float*
     far_move_read(o, overhead_elements);
     o->startup_phase = 0;
   }
-  est_buf_delay_extended(o); /* reported_delay_enabled is 1 off Android, core:1517-1521 */
+  if (o->reported_delay_enabled) est_buf_delay_extended(o); /* ec:796-798 */
   {
     const int adjusted = o->knownDelay + delay_diff_offset;
     process_frames(o, nearend, nearendH, nrOfSamples, adjusted > 0 ? adjusted : 0, out, outH);
   }
+}
+
+enum { MAX_RESAMP_LEN = 5 * FRAME_LEN }; /* ec:92 */
+
+/* WebRtcAec_ResampleLinear, rs:74-123 */
+static void resample_linear(AspAecOracle* o, const float* inspeech, int size, float skew, float* outspeech,
+                            int* size_out) {
+  float* y;
+  float be, tnew;
+  int tn, mm;
+  memcpy(&o->rs_buffer[FRAME_LEN + RS_DELAY], inspeech, size * sizeof(inspeech[0]));
+  be = 1 + skew;
+  mm = 0;
+  y = &o->rs_buffer[FRAME_LEN];
+  tnew = be * mm + o->rs_position;
+  tn = (int)tnew;
+  while (tn < size) {
+    outspeech[mm] = y[tn] + (tnew - tn) * (y[tn + 1] - y[tn]);
+    mm++;
+    tnew = be * mm + o->rs_position;
+    tn = (int)tnew;
+  }
+  *size_out = mm;
+  o->rs_position += (*size_out) * be - size;
+  memmove(o->rs_buffer, &o->rs_buffer[size], (RS_BUF - size) * sizeof(o->rs_buffer[0]));
+}
+
+static int estimate_skew(const int* rawSkew, int size, int deviceSampleRateHz, float* skewEst) { /* rs:143-217 */
+  const int absLimitOuter = (int)(0.04f * deviceSampleRateHz);
+  const int absLimitInner = (int)(0.0025f * deviceSampleRateHz);
+  int i = 0, n = 0, upperLimit = 0, lowerLimit = 0;
+  float rawAvg = 0, err = 0, rawAbsDev = 0, cumSum = 0, x = 0, x2 = 0, y = 0, xy = 0, xAvg = 0, denom = 0, skew = 0;
+  *skewEst = 0;
+  for (i = 0; i < size; i++) {
+    if ((rawSkew[i] < absLimitOuter && rawSkew[i] > -absLimitOuter)) {
+      n++;
+      rawAvg += rawSkew[i];
+    }
+  }
+  if (n == 0) return -1;
+  rawAvg /= n;
+  for (i = 0; i < size; i++) {
+    if ((rawSkew[i] < absLimitOuter && rawSkew[i] > -absLimitOuter)) {
+      err = rawSkew[i] - rawAvg;
+      rawAbsDev += err >= 0 ? err : -err;
+    }
+  }
+  rawAbsDev /= n;
+  upperLimit = (int)(rawAvg + 5 * rawAbsDev + 1);
+  lowerLimit = (int)(rawAvg - 5 * rawAbsDev - 1);
+  n = 0;
+  for (i = 0; i < size; i++) {
+    if ((rawSkew[i] < absLimitInner && rawSkew[i] > -absLimitInner) ||
+        (rawSkew[i] < upperLimit && rawSkew[i] > lowerLimit)) {
+      n++;
+      cumSum += rawSkew[i];
+      x += n;
+      x2 += n * n;
+      y += cumSum;
+      xy += n * cumSum;
+    }
+  }
+  if (n == 0) return -1;
+  xAvg = x / n;
+  denom = x2 - xAvg * x;
+  if (denom != 0) skew = (xy - xAvg * y) / denom;
+  *skewEst = skew;
+  return 0;
+}
+
+static int get_skew(AspAecOracle* o, int rawSkew, float* skewEst) { /* WebRtcAec_GetSkew, rs:125-141 */
+  int err = 0;
+  if (o->rs_skewDataIndex < RS_EST) {
+    o->rs_skewData[o->rs_skewDataIndex] = rawSkew;
+    o->rs_skewDataIndex++;
+  } else if (o->rs_skewDataIndex == RS_EST) {
+    err = estimate_skew(o->rs_skewData, RS_EST, o->rs_deviceSampleRateHz, skewEst);
+    o->rs_skewEstimate = *skewEst;
+    o->rs_skewDataIndex++;
+  } else {
+    *skewEst = o->rs_skewEstimate;
+  }
+  return err;
 }
 
 int asp_aec_oracle_buffer_farend(AspAecOracle* o, const float* farend, int nrOfSamples) { /* ec:278-339 */
@@ -1300,9 +1641,17 @@ int asp_aec_oracle_buffer_farend(AspAecOracle* o, const float* farend, int nrOfS
     o->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
   }
-  o->farend_started = 1;
-  o->system_delay += nrOfSamples;
-  ring_write(&o->pre_pos, o->pre, 1, farend, nrOfSamples);
+  {
+    float new_farend[MAX_RESAMP_LEN];
+    int newNrOfSamples = nrOfSamples;
+    if (o->skewMode == kAecTrue && o->resample == kAecTrue) { /* ec:304-313 */
+      resample_linear(o, farend, nrOfSamples, o->skew, new_farend, &newNrOfSamples);
+      farend = new_farend;
+    }
+    o->farend_started = 1;
+    o->system_delay += newNrOfSamples;
+    ring_write(&o->pre_pos, o->pre, 1, farend, newNrOfSamples);
+  }
   while (rp_avail_read(&o->pre_pos) >= PART_LEN2) {
     float tmp[PART_LEN2];
     ring_read(&o->pre_pos, o->pre, 1, tmp, PART_LEN2);
@@ -1314,11 +1663,34 @@ int asp_aec_oracle_buffer_farend(AspAecOracle* o, const float* farend, int nrOfS
 
 static int process_normal(AspAecOracle* o, const float* nearend, const float* nearendH, float* out,
                           float* outH, int nrOfSamples,
-                          int16_t msInSndCardBuf) { /* ProcessNormal, ec:594-742 */
+                          int16_t msInSndCardBuf, int32_t skew) { /* ProcessNormal, ec:594-742 */
   const int nBlocks10ms = nrOfSamples / (FRAME_LEN * o->rate_factor);
+  int retVal = 0;
   msInSndCardBuf = msInSndCardBuf > kMaxTrustedDelayMs ? kMaxTrustedDelayMs : msInSndCardBuf;
   msInSndCardBuf += 10;
   o->msInSndCardBuf = msInSndCardBuf;
+  if (o->skewMode == kAecTrue) { /* ec:614-645 */
+    if (o->skewFrCtr < 25) {
+      o->skewFrCtr++;
+    } else {
+      if (get_skew(o, skew, &o->skew) == -1) {
+        o->skew = 0;
+        o->lastError = AEC_BAD_PARAMETER_WARNING;
+        retVal = -1;
+      }
+      o->skew /= o->sampFactor * nrOfSamples;
+      if (o->skew < 1.0e-3 && o->skew > -1.0e-3) {
+        o->resample = kAecFalse;
+      } else {
+        o->resample = kAecTrue;
+      }
+      if (o->skew < -0.5f) {
+        o->skew = -0.5f;
+      } else if (o->skew > 1.0f) {
+        o->skew = 1.0f;
+      }
+    }
+  }
   if (o->startup_phase) {
     if (nearend != out) memcpy(out, nearend, sizeof(float) * nrOfSamples);
     if (o->num_bands > 1 && nearendH != outH) memcpy(outH, nearendH, sizeof(float) * nrOfSamples);
@@ -1358,10 +1730,10 @@ static int process_normal(AspAecOracle* o, const float* nearend, const float* ne
       }
     }
   } else {
-    est_buf_delay_normal(o);
+    if (o->reported_delay_enabled) est_buf_delay_normal(o); /* ec:725-727 */
     process_frames(o, nearend, nearendH, nrOfSamples, o->knownDelay, out, outH);
   }
-  return 0;
+  return retVal;
 }
 
 int asp_aec_oracle_process(AspAecOracle* o, const float* nearend, float* out, int nrOfSamples,
@@ -1373,7 +1745,6 @@ int asp_aec_oracle_process_bands(AspAecOracle* o, const float* nearend, const fl
                                  float* out, float* outH, int nrOfSamples, int msInSndCardBuf,
                                  int32_t skew) { /* WebRtcAec_Process, ec:341-408 */
   int retVal = 0;
-  (void)skew;
   if (out == NULL) {
     o->lastError = AEC_NULL_POINTER_ERROR;
     return -1;
@@ -1400,12 +1771,66 @@ int asp_aec_oracle_process_bands(AspAecOracle* o, const float* nearend, const fl
   }
   if (o->extended_filter_enabled) /* ec:377-394 */
     process_extended(o, nearend, nearendH, out, outH, nrOfSamples, (int16_t)msInSndCardBuf);
-  else if (process_normal(o, nearend, nearendH, out, outH, nrOfSamples, (int16_t)msInSndCardBuf) != 0)
+  else if (process_normal(o, nearend, nearendH, out, outH, nrOfSamples, (int16_t)msInSndCardBuf, skew) != 0)
     retVal = -1;
   return retVal;
 }
 
 int asp_aec_oracle_echo_status(const AspAecOracle* o) { return o->st.echoState; }
+
+/* WebRtcAec_GetDelayMetrics, ec:550-571 + WebRtcAec_GetDelayMetricsCore, core:1780-1836 */
+int asp_aec_oracle_get_delay_metrics(AspAecOracle* o, int* median, int* std) {
+  int i, delay_values = 0, num_delay_values = 0, my_median = 0;
+  const int kMsPerBlock = PART_LEN / (o->mult * 8);
+  float l1_norm = 0;
+  if (median == NULL || std == NULL) {
+    o->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (o->initFlag != kInitCheck) {
+    o->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  if (o->delay_logging == 0) {
+    o->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
+    return -1;
+  }
+  for (i = 0; i < DE_HIST; i++) num_delay_values += o->de.delay_histogram[i];
+  if (num_delay_values == 0) {
+    *median = -1;
+    *std = -1;
+    return 0;
+  }
+  delay_values = num_delay_values >> 1;
+  for (i = 0; i < DE_HIST; i++) {
+    delay_values -= o->de.delay_histogram[i];
+    if (delay_values < 0) {
+      my_median = i;
+      break;
+    }
+  }
+  *median = (my_median - o->de.lookahead) * kMsPerBlock;
+  for (i = 0; i < DE_HIST; i++) l1_norm += (float)abs(i - my_median) * o->de.delay_histogram[i];
+  *std = (int)(l1_norm / (float)num_delay_values + 0.5f) * kMsPerBlock;
+  memset(o->de.delay_histogram, 0, sizeof o->de.delay_histogram);
+  return 0;
+}
+
+/* the delay estimator's state with the stream's far-buffer read side and system delay next to it */
+void asp_aec_oracle_export_delay(const AspAecOracle* o, AspAecDelayState* d) {
+  *d = o->de;
+  d->far_read = o->far_pos.read;
+  d->far_write = o->far_pos.write;
+  d->far_wrap = o->far_pos.wrap;
+  d->system_delay = o->system_delay;
+}
+/* the resampler's position and the skew the next BufferFarend call resamples with (rs:29-37, ec internal) */
+void asp_aec_oracle_export_skew(const AspAecOracle* o, float* position, float* skew, int* resample, int* index) {
+  *position = o->rs_position;
+  *skew = o->skew;
+  *resample = o->resample;
+  *index = o->rs_skewDataIndex;
+}
 void asp_aec_oracle_export_metrics(const AspAecOracle* o, AspAecMetricsState* m) { *m = o->met; }
 
 static void level_of(const AspAecStats* s, AecLevel* out) { /* ec:479-494 */

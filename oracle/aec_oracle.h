@@ -27,6 +27,11 @@ int asp_aec_oracle_set_config(AspAecOracle* o, AecConfig config);
 /* WebRtcAec_enable_delay_correction on the core (aec_core.c:1876-1885): the extended filter, 32 partitions */
 void asp_aec_oracle_enable_delay_correction(AspAecOracle* o, int enable);
 int asp_aec_oracle_delay_correction_enabled(const AspAecOracle* o);
+void asp_aec_oracle_enable_reported_delay(AspAecOracle* o, int enable);  /* core:1868-1870; 0 = delay-agnostic */
+int asp_aec_oracle_reported_delay_enabled(const AspAecOracle* o);
+int asp_aec_oracle_get_delay_metrics(AspAecOracle* o, int* median, int* std); /* ec:550-571, core:1780-1836 */
+void asp_aec_oracle_export_delay(const AspAecOracle* o, AspAecDelayState* d);
+void asp_aec_oracle_export_skew(const AspAecOracle* o, float* position, float* skew, int* resample, int* index);
 int asp_aec_oracle_buffer_farend(AspAecOracle* o, const float* farend, int nrOfSamples);
 int asp_aec_oracle_process(AspAecOracle* o, const float* nearend, float* out, int nrOfSamples,
                            int msInSndCardBuf, int32_t skew);

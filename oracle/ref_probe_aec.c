@@ -201,3 +201,82 @@ void ref_aec_export_dbufh(void* h, float* out128) {
   const Aec* a = (const Aec*)h;
   memcpy(out128, a->aec->dBufH[0], sizeof(float) * 128);
 }
+
+/* ---- delay logging, the delay-agnostic mode and skew compensation (field copies / plain calls) ---- */
+#include "webrtc/modules/audio_processing/utility/delay_estimator_internal.h"
+#include "webrtc/modules/audio_processing/utility/delay_estimator_wrapper.h"
+
+int ref_aec_set_config_full(void* h, int mode, int metrics, int skew_mode, int delay_logging) {
+  AecConfig c;
+  c.nlpMode = (int16_t)mode;
+  c.skewMode = (int16_t)skew_mode;
+  c.metricsMode = (int16_t)metrics;
+  c.delay_logging = (int16_t)delay_logging;
+  return WebRtcAec_set_config(h, c);
+}
+void ref_aec_enable_reported_delay(void* h, int enable) {
+  WebRtcAec_enable_reported_delay(WebRtcAec_aec_core(h), enable);
+}
+int ref_aec_reported_delay_enabled(void* h) { return WebRtcAec_reported_delay_enabled(WebRtcAec_aec_core(h)); }
+int ref_aec_get_delay_metrics(void* h, int* median, int* std) { return WebRtcAec_GetDelayMetrics(h, median, std); }
+int ref_aec_error_code(void* h) { return WebRtcAec_get_error_code(h); }
+
+/* one frame with a skew argument (WebRtcAec_Process's last parameter) */
+int ref_aec_frame_skew(void* h, const float* far, const float* near, float* out, int n, int16_t delay_ms,
+                       int32_t skew) {
+  float nbuf[160], obuf[160];
+  const float* np[1] = {nbuf};
+  float* op[1] = {obuf};
+  int rc;
+  memcpy(nbuf, near, sizeof(float) * n);
+  rc = WebRtcAec_BufferFarend(h, far, (int16_t)n);
+  rc |= WebRtcAec_Process(h, np, 1, op, (int16_t)n, delay_ms, skew);
+  memcpy(out, obuf, sizeof(float) * n);
+  return rc;
+}
+void ref_aec_export_skew(void* h, float* skew, int* resample, int* skewFrCtr) {
+  const Aec* a = (const Aec*)h;
+  *skew = a->skew;
+  *resample = a->resample;
+  *skewFrCtr = a->skewFrCtr;
+}
+
+/* far_read carries the readable count of far_buf (ring positions are private to ring_buffer.c);
+ * far_write / far_wrap are -1 */
+void ref_aec_export_delay(void* h, AspAecDelayState* d) {
+  const AecCore* k = ((const Aec*)h)->aec;
+  const DelayEstimatorFarend* fe = (const DelayEstimatorFarend*)k->delay_estimator_farend;
+  const DelayEstimator* ne = (const DelayEstimator*)k->delay_estimator;
+  const BinaryDelayEstimatorFarend* bf = fe->binary_farend;
+  const BinaryDelayEstimator* bn = ne->binary_handle;
+  int i;
+  memset(d, 0, sizeof *d);
+  for (i = 0; i < 65; ++i) d->mean_far_spectrum[i] = fe->mean_far_spectrum[i].float_;
+  d->far_spectrum_initialized = fe->far_spectrum_initialized;
+  memcpy(d->binary_far_history, bf->binary_far_history, sizeof d->binary_far_history);
+  for (i = 0; i < ASP_AEC_DELAY_HISTORY; ++i) d->far_bit_counts[i] = bf->far_bit_counts[i];
+  for (i = 0; i < 65; ++i) d->mean_near_spectrum[i] = ne->mean_near_spectrum[i].float_;
+  d->near_spectrum_initialized = ne->near_spectrum_initialized;
+  memcpy(d->binary_near_history, bn->binary_near_history, sizeof d->binary_near_history);
+  memcpy(d->mean_bit_counts, bn->mean_bit_counts, sizeof d->mean_bit_counts);
+  memcpy(d->bit_counts, bn->bit_counts, sizeof d->bit_counts);
+  memcpy(d->histogram, bn->histogram, sizeof d->histogram);
+  d->minimum_probability = bn->minimum_probability;
+  d->last_delay_probability = bn->last_delay_probability;
+  d->last_delay = bn->last_delay;
+  d->last_candidate_delay = bn->last_candidate_delay;
+  d->compare_delay = bn->compare_delay;
+  d->candidate_hits = bn->candidate_hits;
+  d->last_delay_histogram = bn->last_delay_histogram;
+  d->lookahead = bn->lookahead;
+  d->allowed_offset = bn->allowed_offset;
+  memcpy(d->delay_histogram, k->delay_histogram, sizeof d->delay_histogram);
+  d->previous_delay = k->previous_delay;
+  d->delay_correction_count = k->delay_correction_count;
+  d->shift_offset = k->shift_offset;
+  d->delay_quality_threshold = k->delay_quality_threshold;
+  d->far_read = (int32_t)WebRtc_available_read(k->far_buf);
+  d->far_write = -1;
+  d->far_wrap = -1;
+  d->system_delay = k->system_delay;
+}

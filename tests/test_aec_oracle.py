@@ -228,8 +228,9 @@ def test_oracle_error_behaviour():
     assert oracle_lib.OracleAec(44100).init_rc == -1
     assert oracle_lib.OracleAec(16000, sc_fs=0).init_rc == -1
     assert o.set_nlp(3) == -1 and o.error_code() == 12004
-    assert o.set_nlp(1, skew=1) == -1 and o.error_code() == 12001      # outside the built configuration
-    assert o.set_nlp(1, delay_logging=1) == -1 and o.error_code() == 12001
+    assert o.set_nlp(1, skew=2) == -1 and o.error_code() == 12004
+    assert o.set_nlp(1, delay_logging=2) == -1 and o.error_code() == 12004
+    assert o.set_nlp(1, skew=1, delay_logging=1) == 0
     assert o.set_nlp(1, metrics=2) == -1 and o.error_code() == 12004
     assert o.set_nlp(1, metrics=1) == 0
     assert o.set_nlp(2) == 0
@@ -369,3 +370,137 @@ def test_oracle_two_bands_equals_reference_live():
     # the high band is attenuated while the far end is loud and the near end silent of speech
     assert np.abs(rhs[170:240]).mean() < 0.9 * np.abs(nh[170:240]).mean()
     assert oracle_lib.OracleAec(48000).init_rc == -1
+
+
+def _delayed_near(S, F, lag_frames, stream=0):
+    """far / near of the synthetic generator with the near end (echo included) `lag_frames` x 10 ms late:
+    an echo path delay the 12-partition filter cannot span, which the delay estimator has to find."""
+    far, near = aec_frames(S, F + lag_frames)
+    far, near = far[:, stream], near[:, stream]
+    return far[lag_frames:].copy(), near[:F].copy()
+
+
+@needs_ref
+@pytest.mark.parametrize("fs,n,ext", [(16000, 160, 0), (16000, 80, 0), (8000, 80, 0), (16000, 160, 1)])
+def test_oracle_delay_logging_equals_reference_live(fs, n, ext):
+    """set_config(delay_logging = kAecTrue): the binary-spectrum delay estimator (utility/delay_estimator.c,
+    delay_estimator_wrapper.c float path, robust validation on) fed per block (aec_core.c:1191-1203), its whole
+    state, the logging histogram and WebRtcAec_GetDelayMetrics (echo_cancellation.c:550-571, aec_core.c:1780-1836)
+    equal to the reference frame by frame; the audio path is untouched by it."""
+    F = 520 * 160 // n
+    far, near = _delayed_near(2, 520, 6)
+    far, near = far.reshape(-1, n)[:F], near.reshape(-1, n)[:F]
+    ref, ora = oracle_lib.RefAec(fs), oracle_lib.OracleAec(fs)
+    assert ref.delay_metrics()[0] == -1 and ora.delay_metrics()[0] == -1        # logging disabled
+    assert ref.error_code() == 12001 and ora.error_code() == 12001
+    assert ref.set_config(1, delay_logging=1) == 0 and ora.set_nlp(1, delay_logging=1) == 0
+    if ext:
+        ref.enable_delay_correction(1)
+        ora.enable_delay_correction(1)
+    assert ref.delay_metrics() == ora.delay_metrics() == (0, -1, -1)            # no values yet
+    seen = set()
+    for f in range(F):
+        o_ref, rc_ref = ref.frame(far[f], near[f], 20)
+        o_ora, rc_ora = ora.frame(far[f], near[f], 20)
+        assert rc_ref == rc_ora and np.array_equal(_bits(o_ref), _bits(o_ora)), f
+        if f % 20 == 19 or f == F - 1:
+            assert ora.delay_state().diff(ref.delay_state()) == [], f
+        if f % (130 * 160 // n) == 129:
+            m_ref, m_ora = ref.delay_metrics(), ora.delay_metrics()
+            assert m_ref == m_ora, f
+            seen.add(m_ref)
+    ca, _ = _compare_states(ref, ora)
+    if ca.startup_phase == 0:   # (80-sample calls at 16 kHz never leave the reference's start-up phase: nBlocks10ms = 0)
+        assert any(m[1] >= 0 for m in seen), seen       # the estimator did find the echo path's delay
+
+
+@needs_ref
+@pytest.mark.parametrize("fs,n,lag,ext", [(16000, 160, 9, 0), (16000, 80, 9, 0), (8000, 80, 5, 0), (16000, 160, 14, 1),
+                                          (16000, 160, 0, 0)])
+def test_oracle_delay_agnostic_equals_reference_live(fs, n, lag, ext):
+    """WebRtcAec_enable_reported_delay(core, 0) with delay logging on -- the delay-agnostic mode:
+    SignalBasedDelayCorrection (aec_core.c:797-850) moves the far-end read pointer by the estimated delay instead
+    of the reported one (:1719-1732), the estimator is soft-reset by the move (delay_estimator.c:309-339, 500-511),
+    EstBufDelay is skipped (echo_cancellation.c:725-727, 796-798).  Outputs, float state, control integers and
+    the estimator's state equal to the reference frame by frame, through at least one correction."""
+    F = 700 * 160 // n
+    far, near = _delayed_near(2, 700, lag, stream=1)
+    far, near = far.reshape(-1, n)[:F], near.reshape(-1, n)[:F]
+    ref, ora = oracle_lib.RefAec(fs), oracle_lib.OracleAec(fs)
+    assert ref.set_config(1, delay_logging=1) == 0 and ora.set_nlp(1, delay_logging=1) == 0
+    ref.enable_reported_delay(0)
+    ora.enable_reported_delay(0)
+    if ext:
+        ref.enable_delay_correction(1)
+        ora.enable_delay_correction(1)
+    for f in range(F):
+        d = 700 if f in (300, 301) else 40
+        o_ref, rc_ref = ref.frame(far[f], near[f], d)
+        o_ora, rc_ora = ora.frame(far[f], near[f], d)
+        assert rc_ref == rc_ora, f
+        assert np.array_equal(_bits(o_ref), _bits(o_ora)), f
+        if f % 25 == 24 or f == F - 1:
+            assert ora.delay_state().diff(ref.delay_state()) == [], f
+            _compare_states(ref, ora)
+    d = ora.delay_state()
+    print("delay-agnostic fs=%d n=%d lag=%d: corrections %d, last_delay %d, lookahead %d"
+          % (fs, n, lag, d.delay_correction_count, d.last_delay, d.lookahead))
+    if lag and ora.export()[1].startup_phase == 0:
+        assert d.delay_correction_count >= 1
+
+
+@needs_ref
+@pytest.mark.parametrize("fs,n,sc_skew", [(16000, 160, 12), (16000, 80, -9), (8000, 80, 30)])
+def test_oracle_skew_mode_equals_reference_live(fs, n, sc_skew):
+    """set_config(skewMode = kAecTrue): the skew estimate from the reported per-call sample-count differences
+    (WebRtcAec_GetSkew / EstimateSkew, aec_resampler.c:125-217; echo_cancellation.c:614-645) and the linear
+    resampling of the far end (WebRtcAec_ResampleLinear, aec_resampler.c:74-123; echo_cancellation.c:304-313,
+    831-833): outputs, state and control plane equal to the reference frame by frame, across the estimate
+    (call 425) and the resampled frames after it."""
+    F = 560
+    far, near = aec_frames(2, F * 160 // n if n == 80 else F)
+    far = far.reshape(-1, 2, 160)[:, 0].reshape(-1, n)[:F]
+    near = near.reshape(-1, 2, 160)[:, 0].reshape(-1, n)[:F]
+    ref, ora = oracle_lib.RefAec(fs), oracle_lib.OracleAec(fs)
+    assert ref.set_config(1, skew=1) == 0 and ora.set_nlp(1, skew=1) == 0
+    rng = np.random.default_rng(3)
+    resampled = 0
+    for f in range(F):
+        sk = int(sc_skew + rng.integers(-2, 3))
+        if f % 97 == 0:
+            sk = 5000          # an outlier the estimator has to reject
+        o_ref, rc_ref = ref.frame_skew(far[f], near[f], 30, sk)
+        o_ora, rc_ora = ora.frame_skew(far[f], near[f], 30, sk)
+        assert rc_ref == rc_ora, f
+        assert np.array_equal(_bits(o_ref), _bits(o_ora)), f
+        s_ref, s_ora = ref.skew_state(), ora.skew_state()
+        assert np.float32(s_ref[0]).view(np.uint32) == np.float32(s_ora[0]).view(np.uint32) and s_ref[1] == s_ora[1], f
+        resampled += s_ref[1]
+        if f % 40 == 39 or f == F - 1:
+            _compare_states(ref, ora)
+    assert resampled > 50       # the far end was resampled for the rest of the run
+
+
+def test_oracle_optional_modes_reproduce_golden():
+    """tests/golden/aec_modes_golden.npz (written by the reference build): the delay-agnostic mode with its
+    GetDelayMetrics values, and the skew mode, from the restatement bit for bit."""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "aec_modes_golden.npz")))
+    far, near = g["agn_far_i16"].astype(np.float32), g["agn_near_i16"].astype(np.float32)
+    F, S = far.shape[:2]
+    at = list(g["agn_metrics_at"])
+    for s in range(S):
+        o = oracle_lib.OracleAec(16000)
+        assert o.set_nlp(1, delay_logging=1) == 0
+        o.enable_reported_delay(0)
+        for f in range(F):
+            out, rc = o.frame(far[f, s], near[f, s], 40)
+            assert rc == 0 and np.array_equal(_bits(out), _bits(g["agn_out_f32"][f, s])), (s, f)
+            if f in at:
+                assert tuple(g["agn_metrics"][at.index(f), s]) == o.delay_metrics(), (s, f)
+    far, near = g["skew_far_i16"].astype(np.float32), g["skew_near_i16"].astype(np.float32)
+    for s in range(S):
+        o = oracle_lib.OracleAec(16000)
+        assert o.set_nlp(1, skew=1) == 0
+        for f in range(F):
+            out, _ = o.frame_skew(far[f, s], near[f, s], 30, int(g["skew_arg"][f]))
+            assert np.array_equal(_bits(out), _bits(g["skew_out_f32"][f, s])), (s, f)
