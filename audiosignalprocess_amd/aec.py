@@ -22,6 +22,10 @@ def _lib():
             "AspAecBatch_set_config": [vp, AecConfig],
             "AspAecBatch_num_streams": [vp],
             "AspAecBatch_enable_delay_correction": [vp, ip],
+            "AspAecBatch_enable_reported_delay": [vp, ip],
+            "AspAecBatch_reported_delay_enabled": [vp],
+            "AspAecBatch_GetDelayMetrics": [vp, vp, vp],
+            "AspAecBatch_ExportDelayState": [vp, ip, vp],
             "AspAecBatch_delay_correction_enabled": [vp],
             "AspAecBatch_BufferFarend": [vp, vp, ip, ip],
             "AspAecBatch_Process": [vp, vp, vp, ip, ip, C.c_int32, ip],
@@ -77,6 +81,24 @@ class AecBatch:
 
     def delay_correction_enabled(self):
         return int(self.lib.AspAecBatch_delay_correction_enabled(self.h))
+
+    def enable_reported_delay(self, enable=1):
+        """WebRtcAec_enable_reported_delay for every stream; 0 = the delay-agnostic mode."""
+        _check(self.lib.AspAecBatch_enable_reported_delay(self.h, int(enable)), "AspAecBatch_enable_reported_delay")
+
+    def delay_metrics(self):
+        """(rc, median[S], std[S]) of WebRtcAec_GetDelayMetrics for every stream"""
+        med, std = np.full(self.S, -99, np.int32), np.full(self.S, -99, np.int32)
+        rc = self.lib.AspAecBatch_GetDelayMetrics(self.h, med.ctypes.data, std.ctypes.data)
+        if rc not in (0, -1):
+            raise AspError("AspAecBatch_GetDelayMetrics failed (%d)" % rc)
+        return rc, med, std
+
+    def delay_state(self, stream):
+        from ._abi import AspAecDelayState
+        d = AspAecDelayState()
+        _check(self.lib.AspAecBatch_ExportDelayState(self.h, stream, C.byref(d)), "AspAecBatch_ExportDelayState")
+        return d
 
     def error_code(self):
         return self.lib.AspAecBatch_get_error_code(self.h)

@@ -11,7 +11,7 @@ LIBDIR = os.path.join(PKG, "lib")
 # ASP_AMD_LIB: load another build of the library (same-box A / B runs against an earlier build)
 LIB = os.environ.get("ASP_AMD_LIB") or os.path.join(LIBDIR, "libasp_amd.so")
 SOURCES = ["ns_kernels.hip", "ns_kernels1.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_kernels8.hip", "bt_api.hip",
-           "aec_kernels.hip", "aec_api.hip", "qmf_kernels.hip", "qmf_api.hip", "sinc_kernels.hip", "sinc_api.hip"]
+           "aec_kernels.hip", "aec_delay_kernels.hip", "aec_api.hip", "qmf_kernels.hip", "qmf_api.hip", "sinc_kernels.hip", "sinc_api.hip"]
 C_SOURCES = ["wav_io.c"]  # host-only C (kept C, as in the reference)
 # -ffp-contract=off: parity with the reference depends on unfused mul/add.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,7 +29,10 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
                               const float* near_high, float* out_high, float* metrics,
                               hipStream_t s, unsigned long long* stamps = nullptr, int stream0 = 0,
-                              int stream_end = -1, int num_part = kNumPartNormal);
+                              int stream_end = -1, int num_part = kNumPartNormal, float* spectra = nullptr,
+                              const DelayBlock* dblocks = nullptr);
+hipError_t launch_aec_delay(DelayBlock* blocks, const float* spectra, int num_streams, const DelayOps& ops,
+                            hipStream_t s);
 hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
                               hipStream_t s);
 }  // namespace aspaec
@@ -204,6 +208,14 @@ struct AspAecBatch {
   float* state = nullptr;     // [S][AecRows(num_part).state_dwords]
   // WebRtcAec_enable_delay_correction (aec_core.c:1876-1881): the extended filter, 32 partitions instead of 12
   int extended = 0, num_part = kNumPartNormal;
+  // delay estimation (set_config delay_logging) and the delay-agnostic mode (WebRtcAec_enable_reported_delay 0):
+  // per-stream estimator blocks, the power spectra the process kernel leaves for them, and -- once the agnostic mode
+  // has taken over a stream's far-buffer read side (agn_synced) -- the BufferFarend calls the device has yet to replay
+  DelayBlock* dblocks = nullptr;  // [S]
+  float* spectra = nullptr;       // [S][kSpecBlocks][kSpecDwords]
+  int delay_logging = 0, reported_delay_enabled = 1;
+  bool agn_synced = false;
+  int nevents = 0, ev_samples[kMaxFarEvents] = {}, ev_parts[kMaxFarEvents] = {};
   float* far_ring = nullptr;  // [kFarSlots][S][kFarSlotDwords]
   AecTables* tables = nullptr;
   float *stage_far = nullptr, *stage_near = nullptr, *stage_out = nullptr;  // [S][160]
@@ -257,13 +269,13 @@ hipError_t batch_launch_process(AspAecBatch* b, const float* near_dev, float* ou
                                 float* metrics, unsigned long long* stamps) {
   if (!b->dual)
     return launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops, near_high,
-                              out_high, metrics, b->stream, stamps, 0, -1, b->num_part);
+                              out_high, metrics, b->stream, stamps, 0, -1, b->num_part, b->spectra, b->dblocks);
   const int half = ((b->S / 2 + 3) / 4) * 4;
   hipError_t e = launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
-                                    near_high, out_high, metrics, b->stream, stamps, 0, half, b->num_part);
+                                    near_high, out_high, metrics, b->stream, stamps, 0, half, b->num_part, b->spectra, b->dblocks);
   if (e == hipSuccess)
     e = launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops, near_high,
-                           out_high, metrics, b->side, nullptr, half, b->S, b->num_part);
+                           out_high, metrics, b->side, nullptr, half, b->S, b->num_part, b->spectra, b->dblocks);
   return e;
 }
 }  // namespace
@@ -274,6 +286,36 @@ int far_move_read(AspAecBatch* b, int elements) {  // WebRtcAec_MoveFarReadPtr, 
   const int moved = rp_move_read(&b->far_pos, elements);
   b->system_delay -= moved * kPartLen;
   return moved;
+}
+
+// WebRtc_InitDelayEstimatorFarend / WebRtc_InitDelayEstimator and the AecCore fields around them (aec_core.c:1502-1516,
+// delay_estimator_wrapper.c:175-191, 305-322, delay_estimator.c:303-307, 476-498) for every stream.  The lookahead
+// is not part of Init: a stream keeps what Create set or the agnostic mode's soft resets left (as the reference does).
+void init_delay_state(AspAecDelayState* d, int lookahead, int allowed_offset) {
+  memset(d, 0, sizeof *d);
+  d->lookahead = lookahead;
+  d->allowed_offset = allowed_offset;
+  for (int i = 0; i <= ASP_AEC_DELAY_HISTORY; ++i) d->mean_bit_counts[i] = (20 << 9);
+  d->minimum_probability = 32 << 9;
+  d->last_delay_probability = 32 << 9;
+  d->last_delay = -2;
+  d->last_candidate_delay = -2;
+  d->compare_delay = ASP_AEC_DELAY_HISTORY;
+  d->previous_delay = -2;
+  d->shift_offset = 5;  // kInitialShiftOffset, aec_core.c:102
+}
+int init_delay_device(AspAecBatch* b) {
+  std::vector<DelayBlock> all((size_t)b->S);
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  AEC_TRY(hipMemcpy(all.data(), b->dblocks, all.size() * sizeof(DelayBlock), hipMemcpyDeviceToHost));
+  for (auto& d : all) {
+    const int lookahead = d.s.lookahead;
+    memset(&d, 0, sizeof d);
+    init_delay_state(&d.s, lookahead, kNumPartNormal / 2);  // WebRtc_set_allowed_offset(num_partitions / 2), aec_core.c:1529
+  }
+  AEC_TRY(hipMemcpy(b->dblocks, all.data(), all.size() * sizeof(DelayBlock), hipMemcpyHostToDevice));
+  return 0;
 }
 
 // InitMetrics (aec_core.c:548-583) for every stream, ordered on the batch's stream.
@@ -472,6 +514,21 @@ int flush_pending_farend(AspAecBatch* b) {
   return 0;
 }
 
+// Delay-agnostic mode with more far-end calls waiting than a descriptor holds: replay them now (no sub-frame follows).
+int flush_far_events(AspAecBatch* b) {
+  DelayOps d;
+  memset(&d, 0, sizeof d);
+  d.control = 2;
+  d.mult = b->mult;
+  d.num_part = b->num_part;
+  d.nevents = b->nevents;
+  memcpy(d.ev_samples, b->ev_samples, sizeof d.ev_samples);
+  memcpy(d.ev_parts, b->ev_parts, sizeof d.ev_parts);
+  b->nevents = 0;
+  if (!b->sim) AEC_TRY(launch_aec_delay(b->dblocks, b->spectra, b->S, d, b->stream));
+  return 0;
+}
+
 // defer = true: when the call needs one launch descriptor (the normal case) its device work is
 // kept for the following Process launch instead of being launched on its own.
 int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer = false) {
@@ -485,13 +542,22 @@ int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer
   memset(&ops, 0, sizeof ops);
   ops.n = rp_write(&b->pre_pos, n, &ops.wpos);
   bool pending = true;
+  int parts_of_call = 0;
   while (rp_avail_read(&b->pre_pos) >= kPartLen2) {
     int rpos;
     rp_read(&b->pre_pos, kPartLen2, &rpos);
-    if (rp_avail_write(&b->far_pos) < 1) far_move_read(b, 1);  // aec_core.c:1622-1625
     int slot;
-    rp_write(&b->far_pos, 1, &slot);
-    if (slot >= kFarSlots) slot -= kFarSlots;
+    if (b->agn_synced) {
+      // the read side (and with it "is the buffer full", aec_core.c:1622-1625) is the stream's own and lives on
+      // the device; the write position stays common to the batch: every stream writes one partition here
+      slot = b->far_pos.write >= kFarSlots ? b->far_pos.write - kFarSlots : b->far_pos.write;
+      b->far_pos.write = slot + 1;
+    } else {
+      if (rp_avail_write(&b->far_pos) < 1) far_move_read(b, 1);  // aec_core.c:1622-1625
+      rp_write(&b->far_pos, 1, &slot);
+      if (slot >= kFarSlots) slot -= kFarSlots;
+    }
+    ++parts_of_call;
     ops.rpos[ops.nparts] = rpos;
     ops.slot[ops.nparts] = slot;
     ops.nparts++;
@@ -501,6 +567,15 @@ int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer
       memset(&ops, 0, sizeof ops);
       pending = false;
     }
+  }
+  if (b->agn_synced) {  // the device replays this call on every stream's own read side at its next control step
+    if (b->nevents == kMaxFarEvents) {
+      const int rc = flush_far_events(b);
+      if (rc != 0) return rc;
+    }
+    b->ev_samples[b->nevents] = n;
+    b->ev_parts[b->nevents] = parts_of_call;
+    b->nevents++;
   }
   if (pending || ops.nparts > 0) {
     if (defer && pending) {  // everything of this call fits one descriptor
@@ -552,6 +627,8 @@ void est_buf_delay_normal(AspAecBatch* b) {  // echo_cancellation.c:816-867
 int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n, int knownDelay) {
   ProcOps ops;
   memset(&ops, 0, sizeof ops);
+  const RingPos far_at_entry = b->far_pos;  // what the agnostic mode's first control step starts every stream from
+  const int system_delay_at_entry = b->system_delay;
   const int kNumPart = b->num_part;
   ops.mult = b->mult;
   ops.nlp_mode = b->nlp_mode;
@@ -562,7 +639,7 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
     SubFrame& sf = ops.sub[ops.nsub++];
     rp_write(&b->near_pos, kFrameLen, &sf.near_wpos);
     if (b->system_delay < kFrameLen) far_move_read(b, -(b->mult + 1));
-    {
+    if (b->reported_delay_enabled) {  // 2 a) aec_core.c:1703-1718 (2 b, the agnostic mode, runs per stream on the device)
       const int move_elements = (b->core_knownDelay - knownDelay - 32) / kPartLen;
       const int moved_elements = rp_move_read(&b->far_pos, move_elements);
       b->core_knownDelay -= moved_elements * kPartLen;
@@ -594,9 +671,69 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
     far_src = b->far_src;
     fops = b->far_ops;
   }
-  if (!b->sim)
-    AEC_TRY(batch_launch_process(b, near_dev, out_dev, n, ops, far_src, fops, b->cur_near_high, b->cur_out_high,
-                                 b->metricsMode ? b->metrics : nullptr, b->debug_stamps));
+  ops.spectra = b->delay_logging;
+  if (b->sim) return b->reported_delay_enabled ? 0 : aec_fail(ASP_ERR_STATE, "the delay-agnostic mode needs the device");
+  float* met = b->metricsMode ? b->metrics : nullptr;
+  if (b->reported_delay_enabled) {
+    AEC_TRY(batch_launch_process(b, near_dev, out_dev, n, ops, far_src, fops, b->cur_near_high, b->cur_out_high, met,
+                                 b->debug_stamps));
+    if (b->delay_logging) {  // the estimator takes the blocks of this call (aec_core.c:1191-1203)
+      DelayOps d;
+      memset(&d, 0, sizeof d);
+      for (int j = 0; j < ops.nsub; ++j) d.npending += ops.sub[j].nblocks;
+      d.logging = 1;
+      d.mult = b->mult;
+      d.num_part = b->num_part;
+      if (d.npending > 0) AEC_TRY(launch_aec_delay(b->dblocks, b->spectra, b->S, d, b->stream));
+    }
+    return 0;
+  }
+  // ---- delay-agnostic mode: per 80-sample sub-frame the per-stream control step (with the estimator's share of the
+  // previous sub-frame's blocks), then the blocks themselves with the far slots that step chose
+  ops.agnostic = 1;
+  int prev_blocks = 0;
+  for (int j = 0; j < ops.nsub; ++j) {
+    DelayOps d;
+    memset(&d, 0, sizeof d);
+    d.npending = b->delay_logging ? prev_blocks : 0;
+    d.logging = b->delay_logging;
+    d.control = 1;
+    d.mult = b->mult;
+    d.num_part = b->num_part;
+    d.nblocks = ops.sub[j].nblocks;
+    if (!b->agn_synced) {  // the first sub-frame after Init: every stream starts from the batch's values
+      d.sync = 1;
+      d.h_far_read = far_at_entry.read;
+      d.h_far_write = far_at_entry.write;
+      d.h_far_wrap = far_at_entry.wrap;
+      d.h_system_delay = system_delay_at_entry;
+      b->agn_synced = true;
+      b->nevents = 0;
+    } else if (j == 0) {
+      d.nevents = b->nevents;
+      memcpy(d.ev_samples, b->ev_samples, sizeof d.ev_samples);
+      memcpy(d.ev_parts, b->ev_parts, sizeof d.ev_parts);
+      b->nevents = 0;
+    }
+    AEC_TRY(launch_aec_delay(b->dblocks, b->spectra, b->S, d, b->stream));
+    ProcOps one = ops;
+    one.nsub = 1;
+    one.sub[0] = ops.sub[j];
+    const size_t off = (size_t)kFrameLen * j;
+    AEC_TRY(batch_launch_process(b, near_dev + off, out_dev + off, n, one, j == 0 ? far_src : nullptr, fops,
+                                 b->cur_near_high ? b->cur_near_high + off : nullptr,
+                                 b->cur_out_high ? b->cur_out_high + off : nullptr, met, j == 0 ? b->debug_stamps : nullptr));
+    prev_blocks = ops.sub[j].nblocks;
+  }
+  if (b->delay_logging && prev_blocks > 0) {  // the last sub-frame's blocks
+    DelayOps d;
+    memset(&d, 0, sizeof d);
+    d.npending = prev_blocks;
+    d.logging = 1;
+    d.mult = b->mult;
+    d.num_part = b->num_part;
+    AEC_TRY(launch_aec_delay(b->dblocks, b->spectra, b->S, d, b->stream));
+  }
   return 0;
 }
 
@@ -653,7 +790,7 @@ int process_normal_device(AspAecBatch* b, const float* near_dev, float* out_dev,
     }
     return 0;
   }
-  est_buf_delay_normal(b);
+  if (b->reported_delay_enabled) est_buf_delay_normal(b);  // echo_cancellation.c:725-727
   return process_frames_device(b, near_dev, out_dev, n, b->knownDelay);
 }
 
@@ -714,7 +851,7 @@ int process_extended_device(AspAecBatch* b, const float* near_dev, float* out_de
     far_move_read(b, overhead_elements);
     b->startup_phase = 0;
   }
-  est_buf_delay_extended(b);  // reported_delay_enabled is on off Android (aec_core.c:1517-1521)
+  if (b->reported_delay_enabled) est_buf_delay_extended(b);  // echo_cancellation.c:796-798
   const int adjusted = b->knownDelay + kDelayDiffOffsetSamples;
   return process_frames_device(b, near_dev, out_dev, n, adjusted > 0 ? adjusted : 0);
 }
@@ -778,6 +915,14 @@ int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device) {
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_near_h, (size_t)num_streams * 160 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out_h, (size_t)num_streams * 160 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->metrics, (size_t)num_streams * kMetDwords * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->dblocks, (size_t)num_streams * sizeof(DelayBlock));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->spectra, (size_t)num_streams * kSpecBlocks * kSpecDwords * sizeof(float));
+  if (e == hipSuccess) {  // WebRtc_set_lookahead at Create (aec_core.c:1374-1378); the Init functions leave it alone
+    std::vector<DelayBlock> all((size_t)num_streams);
+    memset(all.data(), 0, all.size() * sizeof(DelayBlock));
+    for (auto& d : all) d.s.lookahead = ASP_AEC_DELAY_LOOKAHEAD;
+    e = hipMemcpy(b->dblocks, all.data(), all.size() * sizeof(DelayBlock), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev1);
   if (e == hipSuccess) {
@@ -822,6 +967,8 @@ int AspAecBatch_Free(AspAecBatch* b) {
   if (b->stage_near_h) (void)hipFree(b->stage_near_h);
   if (b->stage_out_h) (void)hipFree(b->stage_out_h);
   if (b->metrics) (void)hipFree(b->metrics);
+  if (b->dblocks) (void)hipFree(b->dblocks);
+  if (b->spectra) (void)hipFree(b->spectra);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->side) {
@@ -862,7 +1009,7 @@ int AspAecBatch_set_config(AspAecBatch* b, AecConfig config) {  // echo_cancella
     b->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
   }
-  if (config.skewMode || config.delay_logging) {
+  if (config.skewMode) {
     b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;  // outside the built configuration (asp_aec.h)
     return -1;
   }
@@ -871,6 +1018,12 @@ int AspAecBatch_set_config(AspAecBatch* b, AecConfig config) {  // echo_cancella
   if (b->metricsMode && !b->sim) {
     const int err = init_metrics_device(b);
     if (err) return err;
+  }
+  b->delay_logging = config.delay_logging;
+  if (b->delay_logging && !b->sim) {  // memset(delay_histogram), aec_core.c:1858-1860
+    AEC_TRY(hipSetDevice(b->device));
+    AEC_TRY(hipMemset2DAsync(reinterpret_cast<char*>(b->dblocks) + offsetof(DelayBlock, s.delay_histogram), sizeof(DelayBlock), 0,
+                             sizeof(((AspAecDelayState*)nullptr)->delay_histogram), (size_t)b->S, b->stream));
   }
   return 0;
 }
@@ -933,7 +1086,13 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
     AEC_TRY(hipStreamSynchronize(b->stream));
     const int err = init_metrics_device(b);  // aec_core.c:1612-1613
     if (err) return err;
+    const int err2 = init_delay_device(b);   // aec_core.c:1502-1516
+    if (err2) return err2;
   }
+  b->delay_logging = 0;
+  b->reported_delay_enabled = 1;  // aec_core.c:1517-1521 (not Android)
+  b->agn_synced = false;
+  b->nevents = 0;
   b->num_part = kNumPartNormal;
   rp_init(&b->pre_pos, kPreLen);
   rp_move_read(&b->pre_pos, -kPartLen);  // start overlap, echo_cancellation.c:226
@@ -944,7 +1103,7 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
   b->counter = 0;
   b->checkBuffSize = 1;
   b->firstVal = 0;
-  b->startup_phase = 1;
+  b->startup_phase = 1;  // = reported_delay_enabled, which InitAec has just set (echo_cancellation.c:247)
   b->bufSizeStart = 0;
   b->checkBufSizeCtr = 0;
   b->msInSndCardBuf = 0;
@@ -1123,7 +1282,7 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
   // two chains when the batch is large enough to fill the chip twice over and past its start-up phase
   // (whose pass-through copies stay on the main stream); ASP_AEC_CHAINS=1 keeps one
   const char* ch = getenv("ASP_AEC_CHAINS");
-  const bool dual = b->S >= 2048 && !b->startup_phase && !(ch && atoi(ch) == 1);
+  const bool dual = b->S >= 2048 && !b->startup_phase && !(ch && atoi(ch) == 1) && !b->delay_logging && b->reported_delay_enabled;
   if (dual && !b->side) {
     AEC_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     AEC_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -1228,6 +1387,98 @@ int AspAecBatch_enable_delay_correction(AspAecBatch* b, int enable) {
     b->num_part = np;
   }
   b->extended = enable;  // the reference stores the argument as given
+  if (!b->sim) {  // WebRtc_set_allowed_offset(delay_estimator, num_partitions / 2), aec_core.c:1880
+    std::vector<int32_t> v((size_t)b->S, b->num_part / 2);
+    AEC_TRY(hipSetDevice(b->device));
+    AEC_TRY(hipStreamSynchronize(b->stream));
+    AEC_TRY(hipMemcpy2D(reinterpret_cast<char*>(b->dblocks) + offsetof(DelayBlock, s.allowed_offset), sizeof(DelayBlock), v.data(),
+                        sizeof(int32_t), sizeof(int32_t), (size_t)b->S, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// WebRtcAec_enable_reported_delay(WebRtcAec_aec_core(inst), enable) for every stream (aec_core.c:1868-1874).
+// enable = 0 is the delay-agnostic mode: EstBufDelay is skipped and WebRtcAec_ProcessFrames steers the far-end read
+// pointer by the delay estimator (which runs when delay logging is on) instead of the reported delay -- per stream,
+// on the device.  Once streams have moved apart, switching the reported delays back on needs a new Init.
+int AspAecBatch_enable_reported_delay(AspAecBatch* b, int enable) {
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  if (enable && !b->reported_delay_enabled && b->agn_synced)
+    return aec_fail(ASP_ERR_STATE, "enable_reported_delay: the streams' far buffers have moved apart; Init first");
+  b->reported_delay_enabled = enable ? 1 : 0;
+  return 0;
+}
+int AspAecBatch_reported_delay_enabled(const AspAecBatch* b) { return b ? b->reported_delay_enabled : 0; }
+
+// The delay estimator's state of one stream with the stream's far-buffer read side and system delay.
+int AspAecBatch_ExportDelayState(AspAecBatch* b, int stream, AspAecDelayState* out) {
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_ExportDelayState: control-only handle");
+  if (!b || !out || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ExportDelayState: bad argument");
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  AEC_TRY(hipMemcpy(out, &b->dblocks[stream].s, sizeof *out, hipMemcpyDeviceToHost));
+  if (!b->agn_synced) {  // lock-step: the batch's values
+    out->far_read = b->far_pos.read;
+    out->far_write = b->far_pos.write;
+    out->far_wrap = b->far_pos.wrap;
+    out->system_delay = b->system_delay;
+  }
+  return ASP_OK;
+}
+
+// WebRtcAec_GetDelayMetrics for every stream (echo_cancellation.c:550-571, aec_core.c:1780-1836): median and
+// spread (L1 norm around the median) of the block-wise delay estimates since the last call, in ms; the
+// histograms are cleared.  median / std [num_streams].
+int AspAecBatch_GetDelayMetrics(AspAecBatch* b, int* median, int* std) {
+  if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_GetDelayMetrics: control-only handle");
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  if (median == nullptr || std == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  if (b->initFlag != kInitCheck) {
+    b->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  if (b->delay_logging == 0) {
+    b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;  // logging disabled
+    return -1;
+  }
+  AEC_TRY(hipSetDevice(b->device));
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  constexpr int H = ASP_AEC_DELAY_HISTORY;
+  std::vector<int32_t> hist((size_t)b->S * H), look((size_t)b->S);
+  AEC_TRY(hipMemcpy2D(hist.data(), H * sizeof(int32_t), reinterpret_cast<char*>(b->dblocks) + offsetof(DelayBlock, s.delay_histogram),
+                      sizeof(DelayBlock), H * sizeof(int32_t), (size_t)b->S, hipMemcpyDeviceToHost));
+  AEC_TRY(hipMemcpy2D(look.data(), sizeof(int32_t), reinterpret_cast<char*>(b->dblocks) + offsetof(DelayBlock, s.lookahead),
+                      sizeof(DelayBlock), sizeof(int32_t), (size_t)b->S, hipMemcpyDeviceToHost));
+  const int kMsPerBlock = kPartLen / (b->mult * 8);
+  for (int s = 0; s < b->S; ++s) {
+    const int32_t* h = hist.data() + (size_t)s * H;
+    int num_delay_values = 0, my_median = 0;
+    for (int i = 0; i < H; i++) num_delay_values += h[i];
+    if (num_delay_values == 0) {
+      median[s] = -1;
+      std[s] = -1;
+      continue;
+    }
+    int delay_values = num_delay_values >> 1;
+    for (int i = 0; i < H; i++) {
+      delay_values -= h[i];
+      if (delay_values < 0) {
+        my_median = i;
+        break;
+      }
+    }
+    median[s] = (my_median - look[s]) * kMsPerBlock;
+    float l1_norm = 0;
+    for (int i = 0; i < H; i++) l1_norm += (float)abs(i - my_median) * h[i];
+    std[s] = (int)(l1_norm / (float)num_delay_values + 0.5f) * kMsPerBlock;
+  }
+  // (a stream without values keeps its -- empty -- histogram; the others are cleared: aec_core.c:1833)
+  AEC_TRY(hipMemset2DAsync(reinterpret_cast<char*>(b->dblocks) + offsetof(DelayBlock, s.delay_histogram), sizeof(DelayBlock), 0,
+                           H * sizeof(int32_t), (size_t)b->S, b->stream));
+  AEC_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
 
@@ -1478,16 +1729,7 @@ int WebRtcAec_GetMetrics(void* handle, AecMetrics* metrics) {  // echo_cancellat
 int WebRtcAec_GetDelayMetrics(void* handle, int* median, int* std) {  // echo_cancellation.c:550-571
   AspAecBatch* b = (AspAecBatch*)handle;
   if (b == nullptr) return -1;
-  if (median == nullptr || std == nullptr) {
-    b->lastError = AEC_NULL_POINTER_ERROR;
-    return -1;
-  }
-  if (b->initFlag != kInitCheck) {
-    b->lastError = AEC_UNINITIALIZED_ERROR;
-    return -1;
-  }
-  b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;  // delay logging is disabled
-  return -1;
+  return AspAecBatch_GetDelayMetrics(b, median, std) == 0 ? 0 : -1;
 }
 
 int32_t WebRtcAec_get_error_code(void* aecInst) {
@@ -1505,6 +1747,15 @@ void WebRtcAec_enable_delay_correction(struct AecCore* self, int enable) {
 
 int WebRtcAec_delay_correction_enabled(struct AecCore* self) {
   return AspAecBatch_delay_correction_enabled(reinterpret_cast<AspAecBatch*>(self));
+}
+
+// aec_core.h:121-126 / aec_core.c:1868-1874
+void WebRtcAec_enable_reported_delay(struct AecCore* self, int enable) {
+  (void)AspAecBatch_enable_reported_delay(reinterpret_cast<AspAecBatch*>(self), enable);
+}
+
+int WebRtcAec_reported_delay_enabled(struct AecCore* self) {
+  return AspAecBatch_reported_delay_enabled(reinterpret_cast<AspAecBatch*>(self));
 }
 
 }  // extern "C"

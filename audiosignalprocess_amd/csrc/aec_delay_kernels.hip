@@ -1,0 +1,467 @@
+// aec_delay_kernels.hip -- the AEC's delay estimation and the per-stream part of its control plane (gfx950).
+//
+// Replaces, per stream and bit for bit:
+//   * the block-wise delay estimation of ProcessBlock (aec_core.c:1191-1203): WebRtc_AddFarSpectrumFloat +
+//     WebRtc_DelayEstimatorProcessFloat = BinarySpectrumFloat (utility/delay_estimator_wrapper.c:43-48, 96-124),
+//     WebRtc_AddBinaryFarSpectrum, WebRtc_ProcessBinarySpectrum with the robust validation
+//     (utility/delay_estimator.c:38-146, 173-258, 356-369, 513-644), and the logging histogram;
+//   * in the delay-agnostic mode (WebRtcAec_enable_reported_delay(core, 0)) the far-buffer side of
+//     WebRtcAec_ProcessFrames for one 80-sample sub-frame (aec_core.c:1696-1751): the under-run stuffing,
+//     SignalBasedDelayCorrection (:797-850), the read-pointer move, the estimator's soft reset
+//     (delay_estimator.c:309-339, 500-511) and the far slots of the blocks to come -- and, replayed first, the
+//     read-side bookkeeping of the WebRtcAec_BufferFarend calls since the last step (aec_core.c:1618-1635:
+//     a full far buffer drops its oldest partition).
+//
+// One wave64 per stream, four per workgroup.  The process kernel leaves |X|^2 and |D|^2 of each block in a
+// scratch ([stream][block][2][kRow]); this kernel runs after it.  Lane q owns entries q and q + 64 of the
+// 125 / 126-entry histories, which sit in LDS while the wave works; every lane carries the estimator's scalars
+// (wave-uniform) and lane 0 writes them back.  Integer and float operations are the reference's, in its order.
+//
+// Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "aec_layout.h"
+
+using namespace aspaec;
+
+namespace {
+
+constexpr int kHist = ASP_AEC_DELAY_HISTORY;        // 125
+constexpr int kNearHist = ASP_AEC_DELAY_HISTORY + 1;  // max_lookahead = kHistorySizeBlocks (aec_core.c:1363-1366)
+constexpr int kBandFirst = 12, kBandLast = 43;        // delay_estimator_wrapper.c:20-23
+constexpr int kMaxBitCountsQ9 = 32 << 9;              // delay_estimator.h:17
+
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const int o = __shfl_xor(v, m, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const int o = __shfl_xor(v, m, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// ring_buffer.c position logic on the stream's far buffer (250 partitions)
+struct FarPos {
+  int read, write, wrap;
+};
+__device__ __forceinline__ int fp_avail_read(const FarPos& r) {  // ring_buffer.c:231-240
+  return r.wrap == 0 ? r.write - r.read : kFarSlots - r.read + r.write;
+}
+__device__ __forceinline__ int fp_move_read(FarPos& r, int n) {  // WebRtc_MoveReadPtr, ring_buffer.c:195-228
+  const int readable = fp_avail_read(r), free_elements = kFarSlots - readable;
+  int pos = r.read;
+  if (n > readable) n = readable;
+  if (n < -free_elements) n = -free_elements;
+  pos += n;
+  if (pos > kFarSlots) {
+    pos -= kFarSlots;
+    r.wrap = 0;
+  }
+  if (pos < 0) {
+    pos += kFarSlots;
+    r.wrap = 1;
+  }
+  r.read = pos;
+  return n;
+}
+__device__ __forceinline__ void fp_write_one(FarPos& r) {  // WebRtc_WriteBuffer of one element, ring_buffer.c:161-192
+  const int free_elements = kFarSlots - fp_avail_read(r);
+  const int write_elements = free_elements < 1 ? free_elements : 1;
+  int m = write_elements;
+  const int margin = kFarSlots - r.write;
+  if (write_elements > margin) {
+    r.write = 0;
+    m -= margin;
+    r.wrap = 1;
+  }
+  r.write += m;
+}
+
+// per-wave LDS: five 128-entry arrays
+constexpr int kLFarHist = 0, kLFarBits = 128, kLNearHist = 256, kLMean = 384, kLHistogram = 512, kLdsWave = 640;
+
+struct Scalars {  // the wave-uniform part of AspAecDelayState
+  int far_init, near_init;
+  int minimum_probability, last_delay_probability, last_delay, last_candidate_delay, compare_delay, candidate_hits;
+  float last_delay_histogram;
+  int lookahead, allowed_offset;
+  int previous_delay, delay_correction_count, shift_offset;
+  float delay_quality_threshold;
+};
+
+// BinarySpectrumFloat (delay_estimator_wrapper.c:96-124): lane = band; the threshold of band `lane` in `thr`
+__device__ __forceinline__ unsigned binary_spectrum(float spec, float& thr, int& initialized, int lane) {
+  const bool band = lane >= kBandFirst && lane <= kBandLast;
+  const float kScale = 1 / 64.0;
+  if (!initialized) {
+    const bool pos = band && spec > 0.0f;
+    if (pos) thr = spec / 2;
+    if (__ballot(pos) != 0) initialized = 1;
+  }
+  bool bit = false;
+  if (band) {
+    thr += (spec - thr) * kScale;  // MeanEstimatorFloat, :43-48
+    bit = spec > thr;
+  }
+  return (unsigned)((__ballot(bit) >> kBandFirst) & 0xffffffffull);
+}
+
+__device__ __forceinline__ void mean_fix(int new_value, int factor, int& mean_value) {  // delay_estimator.c:672-684
+  int diff = new_value - mean_value;
+  if (diff < 0) {
+    diff = -((-diff) >> factor);
+  } else {
+    diff = (diff >> factor);
+  }
+  mean_value += diff;
+}
+
+// one block: AddFarSpectrum + DelayEstimatorProcessFloat; returns last_delay
+__device__ __forceinline__ int estimator_block(AspAecDelayState* __restrict__ g, unsigned* __restrict__ wl,
+                                               Scalars& sc, float far_pow, float near_pow, float& thr_far,
+                                               float& thr_near, int lane) {
+  unsigned* far_hist = wl + kLFarHist;
+  int* far_bits = reinterpret_cast<int*>(wl + kLFarBits);
+  unsigned* near_hist = wl + kLNearHist;
+  int* mean_bc = reinterpret_cast<int*>(wl + kLMean);
+  float* histogram = reinterpret_cast<float*>(wl + kLHistogram);
+  const int i0 = lane, i1 = lane + 64;
+  const bool has1 = i1 < kHist;
+  // ---- far end (aec_core.c:1194-1195)
+  const unsigned bfar = binary_spectrum(sqrtf(far_pow), thr_far, sc.far_init, lane);
+  {
+    const unsigned h0 = i0 > 0 ? far_hist[i0 - 1] : bfar, h1 = far_hist[i1 - 1];
+    const int c0 = i0 > 0 ? far_bits[i0 - 1] : __popc(bfar), c1 = far_bits[i1 - 1];
+    wave_fence();
+    far_hist[i0] = h0;
+    far_bits[i0] = c0;
+    if (has1) {
+      far_hist[i1] = h1;
+      far_bits[i1] = c1;
+    }
+  }
+  // ---- near end (:1196-1197): shift the near history, pull out the delayed spectrum
+  unsigned bnear = binary_spectrum(sqrtf(near_pow), thr_near, sc.near_init, lane);
+  {
+    const unsigned n0 = i0 > 0 ? near_hist[i0 - 1] : bnear, n1 = near_hist[i1 - 1];
+    wave_fence();
+    near_hist[i0] = n0;
+    if (i1 < kNearHist) near_hist[i1] = n1;
+  }
+  wave_fence();
+  bnear = near_hist[sc.lookahead];
+  // bit counts and their smoothed version (delay_estimator.c:541-560)
+  int m0, m1 = kMaxBitCountsQ9;
+  {
+    const int bc0 = __popc(bnear ^ far_hist[i0]);
+    g->bit_counts[i0] = bc0;
+    m0 = mean_bc[i0];
+    const int fb0 = far_bits[i0];
+    if (fb0 > 0) mean_fix(bc0 << 9, 13 - ((3 * fb0) >> 4), m0);
+    mean_bc[i0] = m0;
+    if (has1) {
+      const int bc1 = __popc(bnear ^ far_hist[i1]);
+      g->bit_counts[i1] = bc1;
+      m1 = mean_bc[i1];
+      const int fb1 = far_bits[i1];
+      if (fb1 > 0) mean_fix(bc1 << 9, 13 - ((3 * fb1) >> 4), m1);
+      mean_bc[i1] = m1;
+    }
+  }
+  // best (first minimum below 32 in Q9) and worst candidates (:564-574): value * 128 + index orders by value, then index
+  int key = kMaxBitCountsQ9 * 128 + 127;
+  if (m0 < kMaxBitCountsQ9) key = m0 * 128 + i0;
+  if (has1 && m1 < kMaxBitCountsQ9 && m1 * 128 + i1 < key) key = m1 * 128 + i1;
+  key = wave_min_i(key);
+  int worst = m0 > 0 ? m0 : 0;
+  if (has1 && m1 > worst) worst = m1;
+  worst = wave_max_i(worst);
+  const int value_best_candidate = key >> 7;
+  const int candidate_delay = (key & 127) == 127 ? -1 : (key & 127);
+  const int valley_depth = worst - value_best_candidate;
+  if ((sc.minimum_probability > 8704) && (valley_depth > 2816)) {  // kProbabilityLowerLimit, kProbabilityMinSpread
+    int threshold = value_best_candidate + 1024;                     // kProbabilityOffset
+    if (threshold < 8704) threshold = 8704;
+    if (sc.minimum_probability > threshold) sc.minimum_probability = threshold;
+  }
+  sc.last_delay_probability++;
+  int valid_candidate = (valley_depth > 1024) && ((value_best_candidate < sc.minimum_probability) ||
+                                                  (value_best_candidate < sc.last_delay_probability));
+  wave_fence();
+  if (candidate_delay >= 0) {  // (-1 needs every smoothed count at 32: not reachable from the initial 20)
+    // ---- UpdateRobustValidationStatistics (:90-146)
+    const float kQ14Scaling = 1.f / (1 << 14);
+    const float valley = valley_depth * kQ14Scaling;
+    float decrease_in_last_set = valley;
+    const int max_hits_for_slow_change = (candidate_delay < sc.last_delay) ? 10 : 1000;
+    if (candidate_delay != sc.last_candidate_delay) {
+      sc.candidate_hits = 0;
+      sc.last_candidate_delay = candidate_delay;
+    }
+    sc.candidate_hits++;
+    if (sc.candidate_hits < max_hits_for_slow_change)
+      decrease_in_last_set = (mean_bc[sc.compare_delay] - value_best_candidate) * kQ14Scaling;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = t == 0 ? i0 : i1;
+      if (i < kHist) {
+        float h = histogram[i];
+        if (i == candidate_delay) {
+          h += valley;
+          if (h > 3000.f) h = 3000.f;
+        }
+        const int is_in_last_set = (i >= sc.last_delay - 2) && (i <= sc.last_delay + 1) && (i != candidate_delay);
+        const int is_in_candidate_set = (i >= candidate_delay - 2) && (i <= candidate_delay + 1);
+        h -= decrease_in_last_set * is_in_last_set + valley * (!is_in_last_set && !is_in_candidate_set);
+        if (h < 0) h = 0;
+        histogram[i] = h;
+      }
+    }
+    wave_fence();
+    // ---- HistogramBasedValidation (:173-214) and RobustValidation (:236-258)
+    float fraction = 1.f;
+    float histogram_threshold = histogram[sc.compare_delay];
+    const int delay_difference = candidate_delay - sc.last_delay;
+    if (delay_difference > sc.allowed_offset) {
+      fraction = 1.f - 0.05f * (delay_difference - sc.allowed_offset);
+      fraction = (fraction > 0.5f ? fraction : 0.5f);
+    } else if (delay_difference < 0) {
+      fraction = 0.25f - 0.05f * delay_difference;
+      fraction = (fraction > 1.f ? 1.f : fraction);
+    }
+    histogram_threshold *= fraction;
+    histogram_threshold = (histogram_threshold > 1.5f ? histogram_threshold : 1.5f);
+    const float h_cand = histogram[candidate_delay];
+    const int is_histogram_valid = (h_cand >= histogram_threshold) && (sc.candidate_hits > 10);
+    int is_robust = (sc.last_delay < 0) && (valid_candidate || is_histogram_valid);
+    is_robust |= valid_candidate && is_histogram_valid;
+    is_robust |= is_histogram_valid && (h_cand > sc.last_delay_histogram);
+    valid_candidate = is_robust;
+    if (valid_candidate) {  // :619-641
+      if (candidate_delay != sc.last_delay) {
+        sc.last_delay_histogram = (h_cand > 250.f ? 250.f : h_cand);
+        const float h_cmp = histogram[sc.compare_delay];
+        wave_fence();
+        if (h_cand < h_cmp && lane == 0) histogram[sc.compare_delay] = h_cand;
+        wave_fence();
+      }
+      sc.last_delay = candidate_delay;
+      if (value_best_candidate < sc.last_delay_probability) sc.last_delay_probability = value_best_candidate;
+      sc.compare_delay = sc.last_delay;
+    }
+  }
+  return sc.last_delay;
+}
+
+// WebRtc_SoftResetDelayEstimator + ...Farend (delay_estimator.c:500-511, 309-339) by `delay_shift` partitions
+__device__ __forceinline__ void soft_reset(unsigned* __restrict__ wl, Scalars& sc, int delay_shift, int lane) {
+  sc.lookahead -= delay_shift;
+  if (sc.lookahead < 0) sc.lookahead = 0;
+  if (sc.lookahead > kNearHist - 1) sc.lookahead = kNearHist - 1;
+  if (delay_shift == 0) return;
+  unsigned* far_hist = wl + kLFarHist;
+  unsigned* far_bits = wl + kLFarBits;
+  // entry i takes entry i - delay_shift (zero outside the history)
+  unsigned h[2], c[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = lane + 64 * t, src = i - delay_shift;
+    const bool ok = i < kHist && src >= 0 && src < kHist;
+    h[t] = ok ? far_hist[src] : 0u;
+    c[t] = ok ? far_bits[src] : 0u;
+  }
+  wave_fence();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = lane + 64 * t;
+    if (i < kHist) {
+      far_hist[i] = h[t];
+      far_bits[i] = c[t];
+    }
+  }
+  wave_fence();
+}
+
+__global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__ blocks, const float* __restrict__ spectra,
+                                                        int num_streams, DelayOps ops) {
+  __shared__ unsigned lds[4 * kLdsWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  unsigned* wl = lds + wave * kLdsWave;
+  DelayBlock* blk = blocks + stream;
+  AspAecDelayState* g = &blk->s;
+  // ---- the histories into LDS, the scalars into registers
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = lane + 64 * t;
+    wl[kLFarHist + i] = i < kHist ? g->binary_far_history[i] : 0u;
+    wl[kLFarBits + i] = i < kHist ? (unsigned)g->far_bit_counts[i] : 0u;
+    wl[kLNearHist + i] = i < kNearHist ? g->binary_near_history[i] : 0u;
+    wl[kLMean + i] = i < kHist + 1 ? (unsigned)g->mean_bit_counts[i] : 0u;
+    wl[kLHistogram + i] = i < kHist + 1 ? __float_as_uint(g->histogram[i]) : 0u;
+  }
+  Scalars sc;
+  sc.far_init = g->far_spectrum_initialized;
+  sc.near_init = g->near_spectrum_initialized;
+  sc.minimum_probability = g->minimum_probability;
+  sc.last_delay_probability = g->last_delay_probability;
+  sc.last_delay = g->last_delay;
+  sc.last_candidate_delay = g->last_candidate_delay;
+  sc.compare_delay = g->compare_delay;
+  sc.candidate_hits = g->candidate_hits;
+  sc.last_delay_histogram = g->last_delay_histogram;
+  sc.lookahead = g->lookahead;
+  sc.allowed_offset = g->allowed_offset;
+  sc.previous_delay = g->previous_delay;
+  sc.delay_correction_count = g->delay_correction_count;
+  sc.shift_offset = g->shift_offset;
+  sc.delay_quality_threshold = g->delay_quality_threshold;
+  float thr_far = lane < 65 ? g->mean_far_spectrum[lane] : 0.f;
+  float thr_near = lane < 65 ? g->mean_near_spectrum[lane] : 0.f;
+  wave_fence();
+
+  // ---- the blocks the process kernel left behind (aec_core.c:1191-1203)
+  const float* sp = spectra + (size_t)stream * kSpecBlocks * kSpecDwords;
+  for (int k = 0; k < ops.npending; ++k) {
+    const float far_pow = sp[k * kSpecDwords + lane], near_pow = sp[k * kSpecDwords + kRow + lane];
+    const int delay_estimate = estimator_block(g, wl, sc, far_pow, near_pow, thr_far, thr_near, lane);
+    if (ops.logging && delay_estimate >= 0 && lane == 0) g->delay_histogram[delay_estimate]++;
+    wave_fence();
+  }
+
+  // ---- agnostic mode: the stream's far buffer for the coming sub-frame
+  if (ops.control) {
+    FarPos fp;
+    int sd;
+    if (ops.sync) {
+      fp.read = ops.h_far_read;
+      fp.write = ops.h_far_write;
+      fp.wrap = ops.h_far_wrap;
+      sd = ops.h_system_delay;
+    } else {
+      fp.read = g->far_read;
+      fp.write = g->far_write;
+      fp.wrap = g->far_wrap;
+      sd = g->system_delay;
+    }
+    for (int e = 0; e < ops.nevents; ++e) {  // WebRtcAec_BufferFarend since the last step (echo_cancellation.c:316-336)
+      sd += ops.ev_samples[e];
+      for (int p = 0; p < ops.ev_parts[e]; ++p) {
+        if (kFarSlots - fp_avail_read(fp) < 1) sd -= fp_move_read(fp, 1) * kPartLen;  // aec_core.c:1622-1625
+        fp_write_one(fp);
+      }
+    }
+    int slot0 = 0, slot1 = 0;
+    if (ops.control == 1) {  // (2: only the replay above)
+    if (sd < kFrameLen) sd -= fp_move_read(fp, -(ops.mult + 1)) * kPartLen;  // 1) aec_core.c:1696-1700
+    {
+      // SignalBasedDelayCorrection (aec_core.c:797-850)
+      const float* histogram = reinterpret_cast<const float*>(wl + kLHistogram);
+      const float quality = histogram[sc.compare_delay] / 3000.f;  // WebRtc_binary_last_delay_quality, robust validation on
+      int delay_correction = 0;
+      const int last_delay = sc.last_delay;
+      if ((last_delay >= 0) && (last_delay != sc.previous_delay) && (quality > sc.delay_quality_threshold)) {
+        const int delay = last_delay - sc.lookahead;
+        if (delay <= 0 || delay > (ops.num_part / 4)) {
+          const int available_read = fp_avail_read(fp);
+          delay_correction = -(delay - sc.shift_offset);
+          sc.shift_offset--;
+          sc.shift_offset = (sc.shift_offset <= 1 ? 1 : sc.shift_offset);
+          if (delay_correction > available_read - ops.mult - 1) {
+            delay_correction = 0;
+          } else {
+            sc.previous_delay = last_delay;
+            ++sc.delay_correction_count;
+          }
+        }
+      }
+      if (sc.delay_correction_count > 0) {
+        float delay_quality = quality;
+        delay_quality = (delay_quality > 0.07f ? 0.07f : delay_quality);  // kDelayQualityThresholdMax
+        sc.delay_quality_threshold = (delay_quality > sc.delay_quality_threshold ? delay_quality : sc.delay_quality_threshold);
+      }
+      const int moved_elements = fp_move_read(fp, delay_correction);  // 2 b) aec_core.c:1719-1730
+      soft_reset(wl, sc, moved_elements, lane);
+      if (fp_avail_read(fp) < (ops.mult + 1)) sd -= fp_move_read(fp, -(ops.mult + 1)) * kPartLen;  // :1747-1750
+    }
+    for (int k = 0; k < ops.nblocks; ++k) {  // WebRtc_ReadBuffer(far_buf) of each block to come (aec_core.c:1140-1141)
+      const int s = fp.read >= kFarSlots ? fp.read - kFarSlots : fp.read;
+      if (k == 0) slot0 = s; else slot1 = s;
+      fp_move_read(fp, 1);
+    }
+    sd -= kFrameLen;  // 5) aec_core.c:1758
+    }
+    if (lane == 0) {
+      g->far_read = fp.read;
+      g->far_write = fp.write;
+      g->far_wrap = fp.wrap;
+      g->system_delay = sd;
+      blk->slot[0] = slot0;
+      blk->slot[1] = slot1;
+    }
+  }
+
+  // ---- back to HBM
+  wave_fence();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = lane + 64 * t;
+    if (i < kHist) {
+      g->binary_far_history[i] = wl[kLFarHist + i];
+      g->far_bit_counts[i] = (int)wl[kLFarBits + i];
+    }
+    if (i < kNearHist) g->binary_near_history[i] = wl[kLNearHist + i];
+    if (i < kHist + 1) {
+      g->mean_bit_counts[i] = (int)wl[kLMean + i];
+      g->histogram[i] = __uint_as_float(wl[kLHistogram + i]);
+    }
+  }
+  if (lane < 65) {
+    g->mean_far_spectrum[lane] = thr_far;
+    g->mean_near_spectrum[lane] = thr_near;
+  }
+  if (lane == 0) {
+    g->far_spectrum_initialized = sc.far_init;
+    g->near_spectrum_initialized = sc.near_init;
+    g->minimum_probability = sc.minimum_probability;
+    g->last_delay_probability = sc.last_delay_probability;
+    g->last_delay = sc.last_delay;
+    g->last_candidate_delay = sc.last_candidate_delay;
+    g->compare_delay = sc.compare_delay;
+    g->candidate_hits = sc.candidate_hits;
+    g->last_delay_histogram = sc.last_delay_histogram;
+    g->lookahead = sc.lookahead;
+    g->previous_delay = sc.previous_delay;
+    g->delay_correction_count = sc.delay_correction_count;
+    g->shift_offset = sc.shift_offset;
+    g->delay_quality_threshold = sc.delay_quality_threshold;
+  }
+}
+
+}  // namespace
+
+namespace aspaec {
+
+hipError_t launch_aec_delay(DelayBlock* blocks, const float* spectra, int num_streams, const DelayOps& ops,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(aec_delay_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, blocks, spectra, num_streams, ops);
+  return hipGetLastError();
+}
+
+}  // namespace aspaec

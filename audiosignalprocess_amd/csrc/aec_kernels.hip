@@ -653,7 +653,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
                                               int nlp_mode, float mu, float error_threshold,
                                               int lane, const double* __restrict__ exp2_global,
                                               int num_high, float* __restrict__ met,
-                                              unsigned long long* stamps) {
+                                              unsigned long long* stamps, float* __restrict__ spec_out) {
   // diagnostic phase stamps (never enabled by the product entry points)
 #define AEC_STAMP(k) \
   if (stamps != nullptr) stamps[k] = __builtin_amdgcn_s_memtime();
@@ -880,6 +880,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     const float near_spectrum = DFR[bin] * DFR[bin] + DFI[bin] * DFI[bin];
     const float xp = 0.9f * (t_ == 0 ? p_xpow : c64[R_XPOW]) + 0.1f * kNumPart * far_spectrum;
     const float dp = 0.9f * (t_ == 0 ? p_dpow : c64[R_DPOW]) + 0.1f * near_spectrum;
+    if (spec_out != nullptr) {  // delay estimation on: |X|^2 and |D|^2 of the block for aec_delay_kernel (aec_core.c:1154-1155, 1191-1203)
+      spec_out[bin] = far_spectrum;
+      spec_out[kRow + bin] = near_spectrum;
+    }
     ROW_ST(R_XPOW, xp);
     ROW_ST(R_DPOW, dp);
     XPW[bin] = xp;
@@ -1365,7 +1369,8 @@ __global__ __launch_bounds__(256, kMetrics ? 2 : NP == kNumPartNormal ? AEC_WAVE
                                                           const float* __restrict__ farend, FarOps fops,
                                                           const float* near_high, float* out_high,
                                                           float* metrics,
-                                                          unsigned long long* __restrict__ stamps) {
+                                                          unsigned long long* __restrict__ stamps,
+                                                          float* spectra, const DelayBlock* dblocks) {
   __shared__ SharedTables T;
   constexpr int kWaveLds = lds_wave(NP, kMetrics);
   __shared__ float lds[4 * kWaveLds];
@@ -1386,6 +1391,7 @@ __global__ __launch_bounds__(256, kMetrics ? 2 : NP == kNumPartNormal ? AEC_WAVE
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
+  int blk = 0;  // blocks of this launch so far
   for (int s = 0; s < ops.nsub; ++s) {
     const SubFrame& sf = ops.sub[s];
     // near samples of this sub-frame are read into registers first: `out` may alias `nearend`
@@ -1406,10 +1412,15 @@ __global__ __launch_bounds__(256, kMetrics ? 2 : NP == kNumPartNormal ? AEC_WAVE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     for (int k = 0; k < sf.nblocks; ++k) {
       const BlockOp& op = sf.blk[k];
-      const float* slot = far_ring + ((size_t)op.far_slot * num_streams + stream) * kFarSlotDwords;
+      // the far slot: the batch's (lock-step), or in the delay-agnostic mode the stream's own (aec_delay_kernel)
+      const int far_slot = ops.agnostic ? __builtin_amdgcn_readfirstlane(dblocks[stream].slot[blk & 1]) : op.far_slot;
+      const float* slot = far_ring + ((size_t)far_slot * num_streams + stream) * kFarSlotDwords;
+      float* spec_out = ops.spectra ? spectra + ((size_t)stream * kSpecBlocks + (blk & (kSpecBlocks - 1))) * kSpecDwords : nullptr;
+      ++blk;
       process_block<kMetrics, NP>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
                     ops.num_high, met,
-                    (stamps != nullptr && stream == 0 && s == 0 && k == 0) ? stamps : nullptr);  // wave-uniform; every lane stores the same scalar time
+                    (stamps != nullptr && stream == 0 && s == 0 && k == 0) ? stamps : nullptr,  // wave-uniform; every lane stores the same scalar time
+                    spec_out);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1479,14 +1490,14 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const ProcOps& ops, const float* farend, const FarOps& fops,
                               const float* near_high, float* out_high, float* metrics,
                               hipStream_t s, unsigned long long* stamps, int stream0, int stream_end,
-                              int num_part) {
+                              int num_part, float* spectra, const DelayBlock* dblocks) {
   if (stream_end < 0) stream_end = num_streams;
   if (num_part != kNumPartNormal && num_part != kNumPartMax) return hipErrorInvalidValue;
   const dim3 grid((stream_end - stream0 + 3) / 4);
 #define ASP_AEC_LAUNCH(MET, NP)                                                                              \
   hipLaunchKernelGGL((aec_process_kernel<MET, NP>), grid, dim3(256), 0, s, stream0, stream_end, state,        \
                      far_ring, T, nearend, out, num_streams, nrOfSamples, ops, farend, fops, near_high,      \
-                     out_high, metrics, stamps)
+                     out_high, metrics, stamps, spectra, dblocks)
   if (num_part == kNumPartNormal) {
     if (metrics != nullptr) ASP_AEC_LAUNCH(true, kNumPartNormal); else ASP_AEC_LAUNCH(false, kNumPartNormal);
   } else {

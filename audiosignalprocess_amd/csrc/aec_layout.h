@@ -21,6 +21,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "asp_aec.h"  // AspAecDelayState: the per-stream delay-estimator block is the canonical struct itself
+
 namespace aspaec {
 
 constexpr int kPartLen = 64, kPartLen1 = 65, kPartLen2 = 128, kFrameLen = 80;
@@ -122,7 +124,37 @@ struct ProcOps {
   int32_t nlp_mode;
   int32_t num_high;  // 0, or 1 at 32 kHz
   float mu, error_threshold;
+  int32_t spectra;   // 1: every block leaves its far / near power spectra in the scratch (delay estimation on)
+  int32_t agnostic;  // 1: the blocks' far slots come from the stream's DelayBlock (delay-agnostic mode)
   SubFrame sub[2];
+};
+
+// ---- delay estimation (set_config delay_logging) and the delay-agnostic mode (reported delays off) ----
+// Per stream one DelayBlock: the canonical estimator state, then what only the device needs.  In the agnostic
+// mode the stream's own far-buffer read side and system delay live in it (s.far_read .. s.system_delay): the
+// estimator moves them apart between the streams of a batch, so that part of the control plane runs per stream on
+// the device (aec_delay_kernels.hip) and hands the far-ring slots of the coming blocks to the process kernel.
+struct DelayBlock {
+  AspAecDelayState s;
+  int32_t slot[2];   // far-ring slots of the coming sub-frame's blocks (agnostic mode)
+  int32_t pad[3];
+};
+static_assert(sizeof(DelayBlock) % 16 == 0, "delay blocks stay 16-byte aligned");
+
+constexpr int kSpecBlocks = 4;             // power spectra of up to 4 blocks wait for the estimator
+constexpr int kSpecDwords = 2 * kRow;      // per block: |X|^2 then |D|^2, 65 bins each (aec_core.c:1148-1155)
+constexpr int kMaxFarEvents = 8;
+
+struct DelayOps {
+  int32_t npending;  // blocks of the preceding process launch whose power spectra wait in the scratch
+  int32_t logging;   // delay_logging_enabled: estimates go into delay_histogram (aec_core.c:1199-1202)
+  int32_t control;   // agnostic mode: run the stream's far-buffer control of the coming sub-frame (aec_core.c:1696-1751)
+  int32_t sync;      // first control step after Init: start from the batch-wide values below
+  int32_t h_far_read, h_far_write, h_far_wrap, h_system_delay;
+  int32_t mult, num_part;
+  int32_t nblocks;   // blocks of the coming sub-frame (0..2)
+  int32_t nevents;   // WebRtcAec_BufferFarend calls since the last control step: samples and partitions of each
+  int32_t ev_samples[kMaxFarEvents], ev_parts[kMaxFarEvents];
 };
 
 }  // namespace aspaec

@@ -74,8 +74,8 @@ int32_t WebRtcAec_Process(void* aecInst, const float* const* nearend, int num_ba
 int WebRtcAec_set_config(void* handle, AecConfig config);                       /* .h:175 */
 int WebRtcAec_get_echo_status(void* handle, int* status);                       /* .h:191 */
 /* GetMetrics: echo_cancellation.c:456-548 (the values stay at kOffsetLevel = -100 until
- * set_config enables metricsMode).  Delay logging is not built: GetDelayMetrics fails with
- * AEC_UNSUPPORTED_FUNCTION_ERROR exactly as the reference does with logging disabled. */
+ * set_config enables metricsMode).  GetDelayMetrics: echo_cancellation.c:550-571 (set_config with
+ * delay_logging = kAecTrue; AEC_UNSUPPORTED_FUNCTION_ERROR while logging is off). */
 int WebRtcAec_GetMetrics(void* handle, AecMetrics* metrics);                    /* .h:207 */
 int WebRtcAec_GetDelayMetrics(void* handle, int* median, int* std);             /* .h:224 */
 int32_t WebRtcAec_get_error_code(void* aecInst);                                /* .h:237 */
@@ -86,6 +86,9 @@ struct AecCore* WebRtcAec_aec_core(void* handle);                               
  * aec_core.c:1876-1885.  As in the reference, Init switches it off again. */
 void WebRtcAec_enable_delay_correction(struct AecCore* self, int enable);
 int WebRtcAec_delay_correction_enabled(struct AecCore* self);
+/* Reported delays off = the delay-agnostic mode (aec_core.h:121-126, aec_core.c:1868-1874). */
+void WebRtcAec_enable_reported_delay(struct AecCore* self, int enable);
+int WebRtcAec_reported_delay_enabled(struct AecCore* self);
 #endif /* reference header not included */
 
 #define ASP_AEC_PART_LEN 64    /* aec_core.h:21 */
@@ -236,6 +239,19 @@ int AspAecBatch_get_error_code(const AspAecBatch* b);
  * aec_core.c:1522-1523 does); the per-stream blocks are re-packed to the new filter length. */
 int AspAecBatch_enable_delay_correction(AspAecBatch* b, int enable);
 int AspAecBatch_delay_correction_enabled(const AspAecBatch* b);
+/* WebRtcAec_enable_reported_delay for every stream (aec_core.c:1868-1874).  enable = 0 is the delay-agnostic
+ * mode: EstBufDelay is skipped (echo_cancellation.c:725-727, 796-798) and WebRtcAec_ProcessFrames steers every
+ * stream's far-end read pointer by that stream's own delay estimate (SignalBasedDelayCorrection,
+ * aec_core.c:797-850, 1719-1751) -- the estimator runs when set_config switched delay_logging on.  From the first
+ * processed frame on the streams' far buffers move apart; that part of the control plane then runs per stream on the
+ * device, and switching reported delays back on needs a new Init. */
+int AspAecBatch_enable_reported_delay(AspAecBatch* b, int enable);
+int AspAecBatch_reported_delay_enabled(const AspAecBatch* b);
+/* WebRtcAec_GetDelayMetrics for every stream (echo_cancellation.c:550-571): median and spread, in ms, of the
+ * block-wise delay estimates since the last call (set_config with delay_logging = kAecTrue; -1 / -1 for a
+ * stream without estimates; AEC_UNSUPPORTED_FUNCTION_ERROR when logging is off).  median / std [num_streams]. */
+int AspAecBatch_GetDelayMetrics(AspAecBatch* b, int* median, int* std);
+int AspAecBatch_ExportDelayState(AspAecBatch* b, int stream, AspAecDelayState* out);
 int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out);
 int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in);
 int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* out);

@@ -250,6 +250,167 @@ def test_extended_filter_golden_and_layer1(aec):
     assert lib.WebRtcAec_Free(h) == 0
 
 
+def _lagged_frames(S, F, lags):
+    """far / near [F][S][160] of the generator with stream s's near end (echo included) lags[s] x 10 ms late"""
+    L = max(lags)
+    far, near = aec_frames(S, F + L)
+    far_o, near_o = np.empty((F, S, 160), np.float32), np.empty((F, S, 160), np.float32)
+    for s in range(S):
+        far_o[:, s] = far[lags[s]:lags[s] + F, s]
+        near_o[:, s] = near[:F, s]
+    return far_o, near_o
+
+
+@pytest.mark.parametrize("fs,ext", [(16000, 0), (8000, 0), (16000, 1)])
+def test_delay_logging_vs_oracle(aec, fs, ext):
+    """set_config(delay_logging = kAecTrue): the block-wise binary-spectrum delay estimator (aec_delay_kernel) against
+    the oracle (== reference build, tests/test_aec_oracle.py): the estimator's whole state bit for bit -- thresholds,
+    binary histories, smoothed bit counts, validation histogram, scalars -- the logging histogram and
+    WebRtcAec_GetDelayMetrics of every stream; the audio path is not touched by it."""
+    S, F = 6, 420
+    n = 160 if fs == 16000 else 80
+    far, near = _lagged_frames(S, F, [6, 0, 9, 3, 6, 12])
+    far, near = far[:, :, :n], near[:, :, :n]
+    g = aec.AecBatch(S, fs)
+    rc, _, _ = g.delay_metrics()
+    assert rc == -1 and g.error_code() == 12001          # logging disabled
+    assert g.set_config(1, delay_logging=1) == 0
+    oras = [OracleAec(fs) for _ in range(S)]
+    for o in oras:
+        assert o.set_nlp(1, delay_logging=1) == 0
+    if ext:
+        g.enable_delay_correction(1)
+        for o in oras:
+            o.enable_delay_correction(1)
+    seen = []
+    for f in range(F):
+        og, rc_g = g.frame(far[f], near[f], 20)
+        for s in range(S):
+            oo, rc_o = oras[s].frame(far[f, s], near[f, s], 20)
+            assert rc_g == rc_o and _rel_l2(og[s], oo) <= 1e-5, (f, s)
+        if f % 60 == 59 or f == F - 1:
+            for s in range(S):
+                assert g.delay_state(s).diff(oras[s].delay_state()) == [], (f, s)
+        if f % 140 == 139:
+            rc, med, std = g.delay_metrics()
+            assert rc == 0
+            for s in range(S):
+                assert (0, int(med[s]), int(std[s])) == oras[s].delay_metrics(), (f, s)
+            seen.append(med.copy())
+    assert any((m >= 0).any() for m in seen), seen
+
+
+@pytest.mark.parametrize("fs,n,ext", [(16000, 160, 0), (8000, 80, 0), (16000, 160, 1)])
+def test_delay_agnostic_mode_vs_oracle(aec, fs, n, ext):
+    """AspAecBatch_enable_reported_delay(b, 0) + delay logging: every stream's far-end read pointer follows its OWN
+    delay estimate (SignalBasedDelayCorrection, aec_core.c:797-850, 1719-1751), so the streams of one batch move apart
+    -- different echo-path delays per stream here.  Against one oracle per stream (== reference build): outputs
+    <= 1e-5 rel-L2, linear state bit-exact, and the per-stream estimator / far-buffer / system-delay state bit for
+    bit, through corrections in both directions and an under-run guard."""
+    S, F = 6, 520
+    lags = [9, 0, 14, 5, 9, 2]
+    far, near = _lagged_frames(S, F, lags)
+    far, near = far[:, :, :n], near[:, :, :n]
+    g = aec.AecBatch(S, fs)
+    assert g.set_config(1, delay_logging=1) == 0
+    g.enable_reported_delay(0)
+    oras = [OracleAec(fs) for _ in range(S)]
+    for o in oras:
+        assert o.set_nlp(1, delay_logging=1) == 0
+        o.enable_reported_delay(0)
+    if ext:
+        g.enable_delay_correction(1)
+        for o in oras:
+            o.enable_delay_correction(1)
+    out_g = np.empty((F, S, n), np.float32)
+    out_o = np.empty((F, S, n), np.float32)
+    for f in range(F):
+        d = 700 if f in (300, 301) else 40
+        out_g[f], rc_g = g.frame(far[f], near[f], d)
+        for s in range(S):
+            out_o[f, s], rc_o = oras[s].frame(far[f, s], near[f, s], d)
+            assert rc_g == rc_o, (f, s)
+        if f % 65 == 64 or f == F - 1:
+            for s in range(S):
+                assert g.delay_state(s).diff(oras[s].delay_state(), skip=()) == [], (f, s)
+                st_o, _ = oras[s].export()
+                rep = _state_report(g.export_state(s), st_o)
+                bad = [k for k in LINEAR_FIELDS if not rep[k][0]]
+                assert bad == [], (f, s, {k: rep[k] for k in bad})
+    corr = [g.delay_state(s).delay_correction_count for s in range(S)]
+    reads = {g.delay_state(s).far_read for s in range(S)}
+    print("delay-agnostic fs=%d n=%d ext=%d: corrections per stream %s, %d distinct far read positions, worst rel-L2 %.2e"
+          % (fs, n, ext, corr, len(reads), max(_rel_l2(out_g[:, s], out_o[:, s]) for s in range(S))))
+    for s in range(S):
+        assert _rel_l2(out_g[:, s], out_o[:, s]) <= 1e-5, s
+    assert max(corr) >= 1 and len(reads) > 1          # the streams did move apart
+    rc, med, std = g.delay_metrics()
+    assert rc == 0
+    for s in range(S):
+        assert (0, int(med[s]), int(std[s])) == oras[s].delay_metrics(), s
+
+
+def test_delay_agnostic_golden_and_layer1(aec):
+    """tests/golden/aec_modes_golden.npz (written by the reference build): the delay-agnostic mode through the batch
+    and through the per-stream WebRtcAec_enable_reported_delay / WebRtcAec_GetDelayMetrics symbols: outputs <= 1e-5
+    rel-L2 (bar 1e-4), the reference's own delay metrics reproduced."""
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "aec_modes_golden.npz")))
+    far, near = gold["agn_far_i16"].astype(np.float32), gold["agn_near_i16"].astype(np.float32)
+    F, S = far.shape[:2]
+    at = list(gold["agn_metrics_at"])
+    g = aec.AecBatch(S, 16000)
+    assert g.set_config(1, delay_logging=1) == 0
+    g.enable_reported_delay(0)
+    out = np.empty_like(near)
+    for f in range(F):
+        out[f], rc = g.frame(far[f], near[f], 40)
+        assert rc == 0
+        if f in at:
+            rc, med, std = g.delay_metrics()
+            for s in range(S):
+                assert tuple(gold["agn_metrics"][at.index(f), s]) == (rc, int(med[s]), int(std[s])), (f, s)
+    for s in range(S):
+        assert _rel_l2(out[:, s], gold["agn_out_f32"][:, s]) <= 1e-5, s
+    lib = g.lib
+    f32p = C.POINTER(C.c_float)
+    lib.WebRtcAec_Create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.WebRtcAec_Init.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.WebRtcAec_BufferFarend.argtypes = [C.c_void_p, f32p, C.c_int16]
+    lib.WebRtcAec_Process.argtypes = [C.c_void_p, C.POINTER(f32p), C.c_int, C.POINTER(f32p), C.c_int16, C.c_int16, C.c_int32]
+    lib.WebRtcAec_Free.argtypes = [C.c_void_p]
+    lib.WebRtcAec_aec_core.restype = C.c_void_p
+    lib.WebRtcAec_aec_core.argtypes = [C.c_void_p]
+    lib.WebRtcAec_enable_reported_delay.restype = None
+    lib.WebRtcAec_enable_reported_delay.argtypes = [C.c_void_p, C.c_int]
+    lib.WebRtcAec_reported_delay_enabled.argtypes = [C.c_void_p]
+    lib.WebRtcAec_GetDelayMetrics.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.WebRtcAec_set_config.argtypes = [C.c_void_p, aec.AecConfig]
+    lib.WebRtcAec_get_error_code.argtypes = [C.c_void_p]
+    h = C.c_void_p()
+    assert lib.WebRtcAec_Create(C.byref(h)) == 0 and lib.WebRtcAec_Init(h, 16000, 48000) == 0
+    med, std = C.c_int(), C.c_int()
+    assert lib.WebRtcAec_GetDelayMetrics(h, C.byref(med), C.byref(std)) == -1 and lib.WebRtcAec_get_error_code(h) == 12001
+    assert lib.WebRtcAec_set_config(h, aec.AecConfig(1, 0, 0, 1)) == 0
+    core = lib.WebRtcAec_aec_core(h)
+    assert lib.WebRtcAec_reported_delay_enabled(core) == 1
+    lib.WebRtcAec_enable_reported_delay(core, 0)
+    assert lib.WebRtcAec_reported_delay_enabled(core) == 0
+    F1 = at[0] + 1
+    got = np.empty((F1, 160), np.float32)
+    for f in range(F1):
+        fr, nr = np.ascontiguousarray(far[f, 1]), np.ascontiguousarray(near[f, 1])
+        assert lib.WebRtcAec_BufferFarend(h, fr.ctypes.data_as(f32p), 160) == 0
+        o = np.empty(160, np.float32)
+        pin = (f32p * 1)(nr.ctypes.data_as(f32p))
+        pout = (f32p * 1)(o.ctypes.data_as(f32p))
+        assert lib.WebRtcAec_Process(h, pin, 1, pout, 160, 40, 0) == 0
+        got[f] = o
+    assert _rel_l2(got, gold["agn_out_f32"][:F1, 1]) <= 1e-5
+    assert lib.WebRtcAec_GetDelayMetrics(h, C.byref(med), C.byref(std)) == 0
+    assert (0, med.value, std.value) == tuple(gold["agn_metrics"][0, 1])
+    assert lib.WebRtcAec_Free(h) == 0
+
+
 def test_golden_reference_outputs(aec, aec_golden):
     """The reference's own outputs (committed fixture): <= 1e-5 per-stream rel-L2 (bar 1e-4),
     start-up frames passed through untouched, echo cancelled by > 15 dB."""
