@@ -129,9 +129,9 @@ class AecBatch:
         ol, oh, rc2 = self.process_bands(near_low, near_high, delay_ms)
         return ol, oh, rc | rc2
 
-    def frame(self, far, near, delay_ms=0):
+    def frame(self, far, near, delay_ms=0, skew=0):
         rc = self.buffer_farend(far)
-        out, rc2 = self.process(near, delay_ms)
+        out, rc2 = self.process(near, delay_ms, skew)
         return out, rc | rc2
 
     def run(self, far, near, delay_ms=0):

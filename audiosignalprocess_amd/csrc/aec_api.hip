@@ -33,6 +33,8 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const DelayBlock* dblocks = nullptr);
 hipError_t launch_aec_delay(DelayBlock* blocks, const float* spectra, int num_streams, const DelayOps& ops,
                             hipStream_t s);
+hipError_t launch_aec_resample(float* rs_buffer, const float* farend, float* out, int num_streams, int size, int size_out,
+                               float be, float position, hipStream_t s);
 hipError_t launch_aec_rdft128(const float* src, float* dst, int isgn, int count, const AecTables* T,
                               hipStream_t s);
 }  // namespace aspaec
@@ -216,6 +218,16 @@ struct AspAecBatch {
   int delay_logging = 0, reported_delay_enabled = 1;
   bool agn_synced = false;
   int nevents = 0, ev_samples[kMaxFarEvents] = {}, ev_parts[kMaxFarEvents] = {};
+  // skew compensation (set_config skewMode; echo_cancellation.c:304-313, 614-645, aec_resampler.c): the skew estimate
+  // and the resampler's position are functions of the calls' skew arguments alone -- one copy for the batch, on the
+  // host; the resampler's sample buffer is per stream, on the device
+  int skewFrCtr = 0, resample = 0;
+  float skew = 0.f, sampFactor = 1.f;
+  float rs_position = 0.f;
+  int rs_skewData[kSkewEstimateFrames] = {}, rs_skewDataIndex = 0;
+  float rs_skewEstimate = 0.f;
+  float* rs_buffer = nullptr;  // [S][kResamplerBufferSize]
+  float* stage_rs = nullptr;   // [S][kResamplerBufferSize]: the resampled far frame of the call in flight
   float* far_ring = nullptr;  // [kFarSlots][S][kFarSlotDwords]
   AecTables* tables = nullptr;
   float *stage_far = nullptr, *stage_near = nullptr, *stage_out = nullptr;  // [S][160]
@@ -253,6 +265,52 @@ struct AspAecBatch {
   float* metrics = nullptr;
 };
 
+
+namespace {
+// EstimateSkew (aec_resampler.c:143-217): least-squares slope of the cumulated, outlier-cleaned skew reports
+int estimate_skew(const int* rawSkew, int size, int deviceSampleRateHz, float* skewEst) {
+  const int absLimitOuter = (int)(0.04f * deviceSampleRateHz);
+  const int absLimitInner = (int)(0.0025f * deviceSampleRateHz);
+  int n = 0;
+  float rawAvg = 0, err = 0, rawAbsDev = 0, cumSum = 0, x = 0, x2 = 0, y = 0, xy = 0, xAvg = 0, denom = 0, skew = 0;
+  *skewEst = 0;
+  for (int i = 0; i < size; i++) {
+    if ((rawSkew[i] < absLimitOuter && rawSkew[i] > -absLimitOuter)) {
+      n++;
+      rawAvg += rawSkew[i];
+    }
+  }
+  if (n == 0) return -1;
+  rawAvg /= n;
+  for (int i = 0; i < size; i++) {
+    if ((rawSkew[i] < absLimitOuter && rawSkew[i] > -absLimitOuter)) {
+      err = rawSkew[i] - rawAvg;
+      rawAbsDev += err >= 0 ? err : -err;
+    }
+  }
+  rawAbsDev /= n;
+  const int upperLimit = (int)(rawAvg + 5 * rawAbsDev + 1);
+  const int lowerLimit = (int)(rawAvg - 5 * rawAbsDev - 1);
+  n = 0;
+  for (int i = 0; i < size; i++) {
+    if ((rawSkew[i] < absLimitInner && rawSkew[i] > -absLimitInner) ||
+        (rawSkew[i] < upperLimit && rawSkew[i] > lowerLimit)) {
+      n++;
+      cumSum += rawSkew[i];
+      x += n;
+      x2 += n * n;
+      y += cumSum;
+      xy += n * cumSum;
+    }
+  }
+  if (n == 0) return -1;
+  xAvg = x / n;
+  denom = x2 - xAvg * x;
+  if (denom != 0) skew = (xy - xAvg * y) / denom;
+  *skewEst = skew;
+  return 0;
+}
+}  // namespace
 
 namespace {
 // every device launch of a batch goes through these two: one launch, or one per half on the two chains
@@ -536,6 +594,26 @@ int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer
     const int rc = flush_pending_farend(b);
     if (rc != 0) return rc;
   }
+  if (b->skewMode == kAecTrue && b->resample == kAecTrue) {
+    // WebRtcAec_ResampleLinear (aec_resampler.c:74-123): the sample positions follow from the skew and the
+    // resampler's position alone, so the output length and the new position are computed here, once; the device
+    // interpolates every stream's samples with the same float expressions
+    const float be = 1 + b->skew;
+    int mm = 0;
+    float tnew = be * mm + b->rs_position;
+    int tn = (int)tnew;
+    while (tn < n) {
+      mm++;
+      tnew = be * mm + b->rs_position;
+      tn = (int)tnew;
+    }
+    if (!b->sim) {
+      AEC_TRY(launch_aec_resample(b->rs_buffer, far_dev, b->stage_rs, b->S, n, mm, be, b->rs_position, b->stream));
+      far_dev = b->stage_rs;
+    }
+    b->rs_position += mm * be - n;
+    n = mm;
+  }
   b->farend_started = 1;
   b->system_delay += n;
   FarOps ops;
@@ -593,6 +671,7 @@ void est_buf_delay_normal(AspAecBatch* b) {  // echo_cancellation.c:816-867
   const int nSampSndCard = b->msInSndCardBuf * kSampMsNb * b->rate_factor;
   int current_delay = nSampSndCard - b->system_delay;
   current_delay += kFrameLen * b->rate_factor;
+  if (b->skewMode == kAecTrue && b->resample == kAecTrue) current_delay -= kResamplingDelay;  // echo_cancellation.c:831-833
   if (current_delay < kPartLen) current_delay += far_move_read(b, 1) * kPartLen;
   b->filtDelay = b->filtDelay < 0 ? 0 : b->filtDelay;
   {
@@ -739,11 +818,44 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
 
 // ProcessNormal (echo_cancellation.c:594-742) on device buffers.
 int process_normal_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n,
-                          int16_t msInSndCardBuf) {
+                          int16_t msInSndCardBuf, int32_t skew, int* rc_ref) {
   const int nBlocks10ms = n / (kFrameLen * b->rate_factor);
   msInSndCardBuf = msInSndCardBuf > kMaxTrustedDelayMs ? kMaxTrustedDelayMs : msInSndCardBuf;
   msInSndCardBuf += 10;
   b->msInSndCardBuf = msInSndCardBuf;
+  if (b->skewMode == kAecTrue) {  // echo_cancellation.c:614-645
+    if (b->skewFrCtr < 25) {
+      b->skewFrCtr++;
+    } else {
+      int err = 0;  // WebRtcAec_GetSkew, aec_resampler.c:125-141
+      if (b->rs_skewDataIndex < kSkewEstimateFrames) {
+        b->rs_skewData[b->rs_skewDataIndex] = skew;
+        b->rs_skewDataIndex++;
+      } else if (b->rs_skewDataIndex == kSkewEstimateFrames) {
+        err = estimate_skew(b->rs_skewData, kSkewEstimateFrames, b->scSampFreq, &b->skew);
+        b->rs_skewEstimate = b->skew;
+        b->rs_skewDataIndex++;
+      } else {
+        b->skew = b->rs_skewEstimate;
+      }
+      if (err == -1) {
+        b->skew = 0;
+        b->lastError = AEC_BAD_PARAMETER_WARNING;
+        *rc_ref = -1;
+      }
+      b->skew /= b->sampFactor * n;
+      if (b->skew < 1.0e-3 && b->skew > -1.0e-3) {
+        b->resample = kAecFalse;
+      } else {
+        b->resample = kAecTrue;
+      }
+      if (b->skew < -0.5f) {
+        b->skew = -0.5f;
+      } else if (b->skew > 1.0f) {
+        b->skew = 1.0f;
+      }
+    }
+  }
   if (b->startup_phase) {
     {
       const int rc = flush_pending_farend(b);
@@ -798,7 +910,7 @@ void est_buf_delay_extended(AspAecBatch* b) {  // EstBufDelayExtended, echo_canc
   const int reported_delay = b->msInSndCardBuf * kSampMsNb * b->rate_factor;
   int current_delay = reported_delay - b->system_delay;
   current_delay += kFrameLen * b->rate_factor;
-  // (skew compensation, :885-887: skewMode is refused by set_config)
+  if (b->skewMode == kAecTrue && b->resample == kAecTrue) current_delay -= kResamplingDelay;  // :884-886
   if (current_delay < kPartLen) current_delay += far_move_read(b, 2) * kPartLen;
   if (b->filtDelay == -1) {
     const double v = 0.5 * current_delay;
@@ -858,7 +970,7 @@ int process_extended_device(AspAecBatch* b, const float* near_dev, float* out_de
 
 // WebRtcAec_Process checks (echo_cancellation.c:341-375); *rc is the reference's return value.
 int process_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n, int msInSndCardBuf,
-                   int* rc) {
+                   int* rc, int32_t skew = 0) {
   *rc = 0;
   if (msInSndCardBuf < 0) {
     msInSndCardBuf = 0;
@@ -869,7 +981,7 @@ int process_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n,
     *rc = -1;
   }
   if (b->extended) return process_extended_device(b, near_dev, out_dev, n, (int16_t)msInSndCardBuf);  // :377-394
-  return process_normal_device(b, near_dev, out_dev, n, (int16_t)msInSndCardBuf);
+  return process_normal_device(b, near_dev, out_dev, n, (int16_t)msInSndCardBuf, skew, rc);
 }
 
 int check_running(AspAecBatch* b, const void* p, int n) {
@@ -915,6 +1027,8 @@ int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device) {
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_near_h, (size_t)num_streams * 160 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->stage_out_h, (size_t)num_streams * 160 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->metrics, (size_t)num_streams * kMetDwords * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->rs_buffer, (size_t)num_streams * kResamplerBufferSize * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->stage_rs, (size_t)num_streams * kResamplerBufferSize * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&b->dblocks, (size_t)num_streams * sizeof(DelayBlock));
   if (e == hipSuccess) e = hipMalloc((void**)&b->spectra, (size_t)num_streams * kSpecBlocks * kSpecDwords * sizeof(float));
   if (e == hipSuccess) {  // WebRtc_set_lookahead at Create (aec_core.c:1374-1378); the Init functions leave it alone
@@ -968,6 +1082,8 @@ int AspAecBatch_Free(AspAecBatch* b) {
   if (b->stage_out_h) (void)hipFree(b->stage_out_h);
   if (b->metrics) (void)hipFree(b->metrics);
   if (b->dblocks) (void)hipFree(b->dblocks);
+  if (b->rs_buffer) (void)hipFree(b->rs_buffer);
+  if (b->stage_rs) (void)hipFree(b->stage_rs);
   if (b->spectra) (void)hipFree(b->spectra);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -1007,10 +1123,6 @@ int AspAecBatch_set_config(AspAecBatch* b, AecConfig config) {  // echo_cancella
   }
   if (config.delay_logging != kAecFalse && config.delay_logging != kAecTrue) {
     b->lastError = AEC_BAD_PARAMETER_ERROR;
-    return -1;
-  }
-  if (config.skewMode) {
-    b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;  // outside the built configuration (asp_aec.h)
     return -1;
   }
   b->nlp_mode = config.nlpMode;  // WebRtcAec_SetConfigCore, aec_core.c:1844-1862
@@ -1089,6 +1201,15 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
     const int err2 = init_delay_device(b);   // aec_core.c:1502-1516
     if (err2) return err2;
   }
+  if (!b->sim)  // WebRtcAec_InitResampler (echo_cancellation.c:221, aec_resampler.c:55-66)
+    AEC_TRY(hipMemsetAsync(b->rs_buffer, 0, (size_t)b->S * kResamplerBufferSize * sizeof(float), b->stream));
+  b->rs_position = 0.f;
+  memset(b->rs_skewData, 0, sizeof b->rs_skewData);
+  b->rs_skewDataIndex = 0;
+  b->rs_skewEstimate = 0.f;
+  b->skewFrCtr = 0;  // echo_cancellation.c:256-259
+  b->resample = kAecFalse;
+  b->skew = 0.f;
   b->delay_logging = 0;
   b->reported_delay_enabled = 1;  // aec_core.c:1517-1521 (not Android)
   b->agn_synced = false;
@@ -1099,6 +1220,7 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
   b->initFlag = kInitCheck;
   b->splitSampFreq = sampFreq == 32000 ? 16000 : sampFreq;  // echo_cancellation.c:231-235
   b->rate_factor = b->splitSampFreq / 8000;
+  b->sampFactor = (b->scSampFreq * 1.0f) / b->splitSampFreq;  // echo_cancellation.c:237
   b->sum = 0;
   b->counter = 0;
   b->checkBuffSize = 1;
@@ -1141,33 +1263,31 @@ int AspAecBatch_BufferFarend(AspAecBatch* b, const float* farend, int nrOfSample
 }
 
 static int process_impl(AspAecBatch* b, const float* nearend, const float* near_high, float* out,
-                        float* out_high, int nrOfSamples, int msInSndCardBuf, int mem);
+                        float* out_high, int nrOfSamples, int msInSndCardBuf, int mem, int32_t skew);
 
 int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nrOfSamples,
                         int msInSndCardBuf, int32_t skew, int mem) {
-  (void)skew;
   if (b && b->num_high > 0) {
     b->lastError = AEC_BAD_PARAMETER_ERROR;  // a 32 kHz batch needs both bands (ProcessBands)
     return -1;
   }
-  return process_impl(b, nearend, nullptr, out, nullptr, nrOfSamples, msInSndCardBuf, mem);
+  return process_impl(b, nearend, nullptr, out, nullptr, nrOfSamples, msInSndCardBuf, mem, skew);
 }
 
 int AspAecBatch_ProcessBands(AspAecBatch* b, const float* near_low, const float* near_high,
                              float* out_low, float* out_high, int nrOfSamples, int msInSndCardBuf,
                              int32_t skew, int mem) {
-  (void)skew;
   if (b && (b->num_high < 1 || near_high == nullptr || out_high == nullptr)) {
     b->lastError = b->num_high < 1 ? AEC_BAD_PARAMETER_ERROR : AEC_NULL_POINTER_ERROR;
     return -1;
   }
-  return process_impl(b, near_low, near_high, out_low, out_high, nrOfSamples, msInSndCardBuf, mem);
+  return process_impl(b, near_low, near_high, out_low, out_high, nrOfSamples, msInSndCardBuf, mem, skew);
 }
 
 int AspAecBatch_num_bands(const AspAecBatch* b) { return b ? 1 + b->num_high : 0; }
 
 static int process_impl(AspAecBatch* b, const float* nearend, const float* near_high, float* out,
-                        float* out_high, int nrOfSamples, int msInSndCardBuf, int mem) {
+                        float* out_high, int nrOfSamples, int msInSndCardBuf, int mem, int32_t skew) {
   if (b && out == nullptr) {
     b->lastError = AEC_NULL_POINTER_ERROR;
     return -1;
@@ -1178,7 +1298,7 @@ static int process_impl(AspAecBatch* b, const float* nearend, const float* near_
     int rc_sim = 0;
     b->cur_near_high = near_high;
     b->cur_out_high = out_high;
-    const int err_sim = process_device(b, nearend, out, nrOfSamples, msInSndCardBuf, &rc_sim);
+    const int err_sim = process_device(b, nearend, out, nrOfSamples, msInSndCardBuf, &rc_sim, skew);
     return err_sim != 0 ? err_sim : rc_sim;
   }
   AEC_TRY(hipSetDevice(b->device));
@@ -1198,7 +1318,7 @@ static int process_impl(AspAecBatch* b, const float* nearend, const float* near_
     }
   }
   int rc = 0;
-  const int err = process_device(b, nd, od, nrOfSamples, msInSndCardBuf, &rc);
+  const int err = process_device(b, nd, od, nrOfSamples, msInSndCardBuf, &rc, skew);
   if (err != 0) return err;
   if (mem == ASP_MEM_HOST) {
     AEC_TRY(hipMemcpyAsync(out, od, bytes, hipMemcpyDeviceToHost, b->stream));
@@ -1282,7 +1402,7 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
   // two chains when the batch is large enough to fill the chip twice over and past its start-up phase
   // (whose pass-through copies stay on the main stream); ASP_AEC_CHAINS=1 keeps one
   const char* ch = getenv("ASP_AEC_CHAINS");
-  const bool dual = b->S >= 2048 && !b->startup_phase && !(ch && atoi(ch) == 1) && !b->delay_logging && b->reported_delay_enabled;
+  const bool dual = b->S >= 2048 && !b->startup_phase && !(ch && atoi(ch) == 1) && !b->delay_logging && b->reported_delay_enabled && !b->skewMode;
   if (dual && !b->side) {
     AEC_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     AEC_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));

@@ -454,9 +454,45 @@ __global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__
   }
 }
 
+// WebRtcAec_ResampleLinear for every stream (aec_resampler.c:74-123; echo_cancellation.c:304-313, skew compensation):
+// the new far frame goes behind the buffered one (one sample of look-ahead), output sample mm is the linear
+// interpolation at be * mm + position -- the same positions for every stream, computed per lane with the reference's
+// float expressions -- and the buffer moves up by `size`.  One wave per stream; the 320-sample buffer passes through LDS.
+__global__ __launch_bounds__(256) void aec_resample_kernel(float* __restrict__ rs_buffer, const float* __restrict__ farend,
+                                                           float* __restrict__ out, int num_streams, int size,
+                                                           int size_out, float be, float position) {
+  __shared__ float lds[4 * kResamplerBufferSize];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  float* buffer = lds + wave * kResamplerBufferSize;
+  float* g = rs_buffer + (size_t)stream * kResamplerBufferSize;
+  for (int i = lane; i < kResamplerBufferSize; i += 64) buffer[i] = g[i];
+  wave_fence();
+  for (int i = lane; i < size; i += 64) buffer[kFrameLen + kResamplingDelay + i] = farend[(size_t)stream * size + i];
+  wave_fence();
+  const float* y = buffer + kFrameLen;  // the current frame
+  for (int mm = lane; mm < size_out; mm += 64) {
+    const float tnew = be * mm + position;
+    const int tn = (int)tnew;
+    out[(size_t)stream * size_out + mm] = y[tn] + (tnew - tn) * (y[tn + 1] - y[tn]);
+  }
+  for (int i = lane; i < kResamplerBufferSize - size; i += 64) g[i] = buffer[i + size];  // memmove(buffer, &buffer[size], ...)
+  for (int i = kResamplerBufferSize - size + lane; i < kResamplerBufferSize; i += 64) g[i] = buffer[i];
+}
+
 }  // namespace
 
 namespace aspaec {
+
+hipError_t launch_aec_resample(float* rs_buffer, const float* farend, float* out, int num_streams, int size, int size_out,
+                               float be, float position, hipStream_t s) {
+  if (size < 0 || size > 2 * kFrameLen || size_out < 0 || size_out > kResamplerBufferSize) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(aec_resample_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, rs_buffer, farend, out, num_streams,
+                     size, size_out, be, position);
+  return hipGetLastError();
+}
 
 hipError_t launch_aec_delay(DelayBlock* blocks, const float* spectra, int num_streams, const DelayOps& ops,
                             hipStream_t s) {

@@ -141,6 +141,9 @@ struct DelayBlock {
 };
 static_assert(sizeof(DelayBlock) % 16 == 0, "delay blocks stay 16-byte aligned");
 
+// skew compensation (aec_resampler.h:16-21, aec_resampler.c:23-25)
+constexpr int kResamplingDelay = 1, kResamplerBufferSize = 4 * kFrameLen, kSkewEstimateFrames = 400;
+
 constexpr int kSpecBlocks = 4;             // power spectra of up to 4 blocks wait for the estimator
 constexpr int kSpecDwords = 2 * kRow;      // per block: |X|^2 then |D|^2, 65 bins each (aec_core.c:1148-1155)
 constexpr int kMaxFarEvents = 8;

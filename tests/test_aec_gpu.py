@@ -411,6 +411,62 @@ def test_delay_agnostic_golden_and_layer1(aec):
     assert lib.WebRtcAec_Free(h) == 0
 
 
+@pytest.mark.parametrize("fs,n,sc_skew", [(16000, 160, 12), (8000, 80, -9)])
+def test_skew_mode_vs_oracle(aec, fs, n, sc_skew):
+    """set_config(skewMode = kAecTrue): the skew estimate from the calls' skew arguments (host, once per batch) and
+    the linear resampling of every stream's far end on the device (aec_resample_kernel; aec_resampler.c:74-123,
+    echo_cancellation.c:304-313, 614-645, 831-833) against the oracle (== reference build): control plane equal,
+    linear state bit-exact, outputs <= 1e-5 rel-L2, across the estimate (call 425) and 130 resampled frames."""
+    S, F = 5, 560
+    far, near = aec_frames(S, F)
+    far, near = far[:, :, :n], near[:, :, :n]
+    g = aec.AecBatch(S, fs)
+    assert g.set_config(1, skew=1) == 0
+    oras = [OracleAec(fs) for _ in range(S)]
+    for o in oras:
+        assert o.set_nlp(1, skew=1) == 0
+    rng = np.random.default_rng(3)
+    out_g = np.empty((F, S, n), np.float32)
+    out_o = np.empty((F, S, n), np.float32)
+    resampled = 0
+    for f in range(F):
+        sk = 5000 if f % 97 == 0 else int(sc_skew + rng.integers(-2, 3))
+        out_g[f], rc_g = g.frame(far[f], near[f], 30, sk)
+        for s in range(S):
+            out_o[f, s], rc_o = oras[s].frame_skew(far[f, s], near[f, s], 30, sk)
+            assert rc_g == rc_o, (f, s)
+        resampled += oras[0].skew_state()[1]
+        if f % 70 == 69 or f == F - 1:
+            cg = g.control()
+            _, co = oras[0].export()
+            for name, _t in cg._fields_:
+                assert getattr(cg, name) == getattr(co, name), (f, name)
+            for s in range(S):
+                st_o, _ = oras[s].export()
+                rep = _state_report(g.export_state(s), st_o)
+                bad = [k for k in LINEAR_FIELDS if not rep[k][0]]
+                assert bad == [], (f, s, {k: rep[k] for k in bad})
+    assert resampled > 100
+    worst = max(_rel_l2(out_g[:, s], out_o[:, s]) for s in range(S))
+    print("AEC skew fs=%d: %d resampled frames, %.4f of output samples bit-equal to the oracle, worst rel-L2 %.2e"
+          % (fs, resampled, (_bits(out_g) == _bits(out_o)).mean(), worst))
+    assert worst <= 1e-5
+
+
+def test_skew_mode_golden(aec):
+    """The reference's own skew-mode outputs (tests/golden/aec_modes_golden.npz): <= 1e-5 per-stream rel-L2."""
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "aec_modes_golden.npz")))
+    far, near = gold["skew_far_i16"].astype(np.float32), gold["skew_near_i16"].astype(np.float32)
+    F, S = far.shape[:2]
+    g = aec.AecBatch(S, 16000)
+    assert g.set_config(1, skew=1) == 0
+    out = np.empty_like(near)
+    for f in range(F):
+        out[f], _ = g.frame(far[f], near[f], 30, int(gold["skew_arg"][f]))
+    for s in range(S):
+        assert _rel_l2(out[:, s], gold["skew_out_f32"][:, s]) <= 1e-5, s
+
+
 def test_golden_reference_outputs(aec, aec_golden):
     """The reference's own outputs (committed fixture): <= 1e-5 per-stream rel-L2 (bar 1e-4),
     start-up frames passed through untouched, echo cancelled by > 15 dB."""

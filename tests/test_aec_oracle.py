@@ -298,11 +298,15 @@ def test_host_control_plane_matches_oracle():
 
     lib = aec_mod._lib()
     lib.AspAecBatch_CreateControlOnly.argtypes = [C.POINTER(C.c_void_p), C.c_int]
-    for fs, n, ext in [(16000, 160, 0), (16000, 80, 0), (8000, 80, 0), (16000, 160, 1), (8000, 80, 1)]:
+    from audiosignalprocess_amd._abi import AecConfig
+    for fs, n, ext, skw in [(16000, 160, 0, 0), (16000, 80, 0, 0), (8000, 80, 0, 0), (16000, 160, 1, 0), (8000, 80, 1, 0),
+                            (16000, 160, 0, 17), (8000, 80, 0, -11)]:
         h = C.c_void_p()
         assert lib.AspAecBatch_CreateControlOnly(C.byref(h), 7) == 0
         assert lib.AspAecBatch_Init(h, fs, 48000) == 0
         ora = oracle_lib.OracleAec(fs)
+        if skw:     # skewMode: GetSkew / EstimateSkew and the resampler's sample counts (system_delay follows them)
+            assert lib.AspAecBatch_set_config(h, AecConfig(1, 1, 0, 0)) == 0 and ora.set_nlp(1, skew=1) == 0
         if ext:     # ProcessExtended / EstBufDelayExtended (echo_cancellation.c:744-814, 869-922)
             assert lib.AspAecBatch_enable_delay_correction(h, 1) == 0
             assert lib.AspAecBatch_delay_correction_enabled(h) == 1
@@ -319,15 +323,16 @@ def test_host_control_plane_matches_oracle():
                 d = 90
             if 600 <= f < 640:
                 d = 20
-            rc_o = ora.frame(z, z, d)[1]
+            sk = (skw + (f * 7) % 5 - 2) if f % 89 else 4000
+            rc_o = ora.frame_skew(z, z, d, sk)[1]
             rc_b = lib.AspAecBatch_BufferFarend(h, dummy.ctypes.data, n, 1)
-            rc_b |= lib.AspAecBatch_Process(h, dummy.ctypes.data, dummy.ctypes.data, n, d, 0, 1)
-            assert (rc_b != 0) == (rc_o != 0), (fs, n, ext, f)
+            rc_b |= lib.AspAecBatch_Process(h, dummy.ctypes.data, dummy.ctypes.data, n, d, sk, 1)
+            assert (rc_b != 0) == (rc_o != 0), (fs, n, ext, skw, f)
             cb = AspAecControl()
             assert lib.AspAecBatch_GetControl(h, C.byref(cb)) == 0
             _, co = ora.export()
             for name, _t in cb._fields_:
-                assert getattr(cb, name) == getattr(co, name), (fs, n, ext, f, name)
+                assert getattr(cb, name) == getattr(co, name), (fs, n, ext, skw, f, name)
         assert lib.AspAecBatch_get_error_code(h) == ora.error_code()
         # data-touching entry points refuse a control-only handle
         lib.AspAecBatch_Synchronize.argtypes = [C.c_void_p]
