@@ -11,10 +11,14 @@
  * the call sequence and the reported delays, so one host copy serves every stream of a
  * batch; the per-stream float state and the four ring buffers live in HBM.
  *
- * Built configuration = what test_aec_module.cpp:60-88 runs: 8 or 16 kHz (one band), plus 32 kHz
- * (two bands),
- * 12 partitions, reported-delay mode, no skew compensation, no delay logging; echo metrics
- * (ERL / ERLE / A_NLP) optional.  Anything else is refused with the reference's own error codes.
+ * (The delay-agnostic mode is the exception: there every stream steers its far-end read pointer by
+ * its own delay estimate, and that part of the control plane runs per stream on the device.)
+ *
+ * Built configuration = what test_aec_module.cpp:60-88 runs -- 8 or 16 kHz (one band), 12 partitions,
+ * reported-delay mode -- plus 32 kHz (two bands) and the reference's optional modes: echo metrics
+ * (ERL / ERLE / A_NLP), the extended filter (32 partitions), delay logging with GetDelayMetrics, the
+ * delay-agnostic mode (reported delays off) and skew compensation.  48 kHz is refused (the reference's
+ * own init breaks there) with the reference's error codes.
  */
 #ifndef ASP_AEC_H_
 #define ASP_AEC_H_
