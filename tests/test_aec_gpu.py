@@ -577,6 +577,44 @@ def test_scale_4096_streams_identical_inputs(aec):
     assert not np.array_equal(out[F - 1, 0], near1[F - 1, 0])
 
 
+def test_scale_4096_streams_optional_modes(aec):
+    """BASELINE config-4 scale with every optional mode on at once -- extended filter, echo metrics, delay logging,
+    the delay-agnostic mode (per-stream far-buffer control on the device) and skew compensation: 4096 streams of 4
+    distinct signals with 4 different echo-path delays; equal inputs give bit-equal outputs and equal per-stream
+    control state wherever the stream sits in the grid, streams with different delays end at different far-buffer
+    positions, and stream k equals an oracle fed the same calls (<= 1e-5 rel-L2, estimator state bit for bit)."""
+    S, F = 4096, 460      # past call 425: the skew estimate exists and the far end is resampled
+    far4, near4 = _lagged_frames(4, F, [9, 0, 14, 5])
+    idx = np.arange(S) % 4
+    g = aec.AecBatch(S)
+    assert g.set_config(1, skew=1, metrics=1, delay_logging=1) == 0
+    g.enable_reported_delay(0)
+    g.enable_delay_correction(1)
+    oras = [OracleAec(16000) for _ in range(4)]
+    for o in oras:
+        assert o.set_nlp(1, skew=1, metrics=1, delay_logging=1) == 0
+        o.enable_reported_delay(0)
+        o.enable_delay_correction(1)
+    out = np.empty((F, S, 160), np.float32)
+    out_o = np.empty((F, 4, 160), np.float32)
+    for f in range(F):
+        out[f], rc = g.frame(far4[f][idx], near4[f][idx], 40, 15 + f % 3)
+        for k in range(4):
+            out_o[f, k], rc_o = oras[k].frame_skew(far4[f, k], near4[f, k], 40, 15 + f % 3)
+            assert rc == rc_o, (f, k)
+    assert np.isfinite(out).all()
+    for k in range(4):
+        assert np.array_equal(_bits(out[:, k::4]), _bits(np.broadcast_to(out[:, k][:, None], out[:, k::4].shape))), k
+        assert _rel_l2(out[:, k], out_o[:, k]) <= 1e-5, k
+        for s in (k, 2048 + k, 4092 + k):
+            assert g.delay_state(s).diff(oras[k].delay_state(), skip=()) == [], s
+    assert len({g.delay_state(k).far_read for k in range(4)}) > 1
+    rc, med, std = g.delay_metrics()
+    assert rc == 0
+    for k in range(4):
+        assert (med[k::4] == med[k]).all() and (0, int(med[k]), int(std[k])) == oras[k].delay_metrics(), k
+
+
 def test_timed_steps_two_chains_equal_one_chain(aec, monkeypatch):
     """The K-step path (AspAecBatch_TimedSteps) runs large batches as two launch chains over the two halves
     of the batch: outputs and the filter state must equal the single-chain run bit for bit, and an odd half
