@@ -783,6 +783,44 @@ def test_two_bands_32khz_vs_oracle(aec):
     assert aec.AecBatch(2, 48000).init_rc == -1
 
 
+def test_two_bands_32khz_optional_modes_vs_oracle(aec):
+    """32 kHz with the extended filter, delay logging and the delay-agnostic mode together (each 160-sample call is two
+    per-sub-frame launches with both bands' buffers offset by 80 samples): both bands within 1e-5 rel-L2 of one
+    oracle per stream, linear state and the per-stream estimator / far-buffer state bit for bit."""
+    from tests.test_aec_oracle import _aec_band_frames
+
+    S, F = 4, 460
+    lags = [7, 0, 11, 4]
+    far1, nl1, nh1 = _aec_band_frames(F + max(lags))
+    far = np.stack([far1[l:l + F] for l in lags], axis=1)
+    nl = np.repeat(nl1[:F, None, :], S, axis=1)
+    nh = np.repeat(nh1[:F, None, :], S, axis=1)
+    g = aec.AecBatch(S, 32000)
+    assert g.set_config(1, delay_logging=1) == 0
+    g.enable_reported_delay(0)
+    g.enable_delay_correction(1)
+    oras = [OracleAec(32000) for _ in range(S)]
+    for o in oras:
+        assert o.set_nlp(1, delay_logging=1) == 0
+        o.enable_reported_delay(0)
+        o.enable_delay_correction(1)
+    gl, gh = np.empty_like(nl), np.empty_like(nh)
+    ol, oh = np.empty_like(nl), np.empty_like(nh)
+    for f in range(F):
+        gl[f], gh[f], rc_g = g.frame_bands(far[f], nl[f], nh[f], 30)
+        for s in range(S):
+            ol[f, s], oh[f, s], rc_o = oras[s].frame_bands(far[f, s], nl[f, s], nh[f, s], 30)
+            assert rc_g == rc_o, (f, s)
+    for s in range(S):
+        st_o, _ = oras[s].export()
+        rep = _state_report(g.export_state(s), st_o)
+        bad = [k for k in LINEAR_FIELDS + ["dBufH"] if not rep[k][0]]
+        assert bad == [], (s, {k: rep[k] for k in bad})
+        assert g.delay_state(s).diff(oras[s].delay_state(), skip=()) == [], s
+        assert _rel_l2(gl[:, s], ol[:, s]) <= 1e-5 and _rel_l2(gh[:, s], oh[:, s]) <= 1e-5, s
+    assert max(g.delay_state(s).delay_correction_count for s in range(S)) >= 1
+
+
 def _metrics_compare(ma, mb):
     """ma: HIP image, mb: oracle image (uint32[65], include/asp_aec.h: AspAecMetricsState).
     far / near / linear-out levels come from bit-exact spectra summed in the reference's order:

@@ -509,3 +509,26 @@ def test_oracle_optional_modes_reproduce_golden():
         for f in range(F):
             out, _ = o.frame_skew(far[f, s], near[f, s], 30, int(g["skew_arg"][f]))
             assert np.array_equal(_bits(out), _bits(g["skew_out_f32"][f, s])), (s, f)
+
+
+@needs_ref
+def test_oracle_two_bands_optional_modes_equal_reference_live():
+    """32 kHz (two bands) with the extended filter, delay logging and the delay-agnostic mode together: low and high
+    band, float state, control plane and the estimator's state equal to the reference frame by frame."""
+    F = 460
+    far, nl, nh = _aec_band_frames(F + 7)
+    far, nl, nh = far[7:], nl[:F], nh[:F]          # near end 70 ms late
+    ref, ora = oracle_lib.RefAec(32000), oracle_lib.OracleAec(32000)
+    assert ref.set_config(1, delay_logging=1) == 0 and ora.set_nlp(1, delay_logging=1) == 0
+    for o in (ref, ora):
+        o.enable_reported_delay(0)
+        o.enable_delay_correction(1)
+    for f in range(F):
+        rl, rh, rc_r = ref.frame_bands(far[f], nl[f], nh[f], 30)
+        ol, oh, rc_o = ora.frame_bands(far[f], nl[f], nh[f], 30)
+        assert rc_r == rc_o, f
+        assert np.array_equal(_bits(rl), _bits(ol)) and np.array_equal(_bits(rh), _bits(oh)), f
+        if f % 60 == 59 or f == F - 1:
+            _compare_states(ref, ora)
+            assert ora.delay_state().diff(ref.delay_state()) == [], f
+    assert ora.delay_state().delay_correction_count >= 1
