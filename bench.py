@@ -246,6 +246,11 @@ def bench_aec(args):
     ext = bool(getattr(args, "aec_extended", False))
     if ext:     # WebRtcAec_enable_delay_correction: the 32-partition extended filter
         g.enable_delay_correction(1)
+    dmode = getattr(args, "aec_delay", "off")
+    if dmode != "off":      # delay logging (one estimator launch per frame) / the delay-agnostic mode (per sub-frame)
+        assert g.set_config(1, delay_logging=1) == 0
+        if dmode == "agnostic":
+            g.enable_reported_delay(0)
     steps, warm = max(args.steps // 4, 10), max(args.warmup // 2, 80)   # warm-up passes the start-up phase
     g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, warm)
     torch.cuda.synchronize()
@@ -268,12 +273,13 @@ def bench_aec(args):
         "data": "synthetic",
         "config": {"workload": "WebRTC AEC (test_aec_module): 10 ms/16 kHz far+near frames, %d concurrent "
                                "streams on 1 MI355X, %d partitions, the far-end work fused into the process "
-                               "launch of each frame" % (S, 32 if ext else 12)},
+                               "launch of each frame%s" % (S, 32 if ext else 12, "" if dmode == "off" else
+                                                           "; delay estimation: " + dmode)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None if ext else AEC_TRAFFIC_BYTES_PER_FRAME * S,
                      "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE; 4-byte-per-lane accesses, a width MI355X_MICROARCH.md does not calibrate), per frame step of all streams; not measured in this run",
                      "kernel": "aec_process_kernel (the far-end work of the frame inside it)",
-                     "launch_chains": 2 if S >= 2048 else 1,
+                     "launch_chains": 2 if S >= 2048 and dmode == "off" else 1,
                      "algorithmic_bytes_per_step": algo * S, "avg_step_us": step_s * 1e6},
     }
     if not args.no_cpu_baseline:
@@ -442,6 +448,8 @@ def main():
                     help="fused-step kernel: 0 / 3 = one stream per wave, pair layout (ns_kernels1.hip, the default), "
                          "1 = one stream per wave, bins q / q + 64 (ns_kernels.hip)")
     ap.add_argument("--aec-extended", action="store_true", help="--workload aec: the 32-partition extended filter")
+    ap.add_argument("--aec-delay", default="off", choices=["off", "logging", "agnostic"],
+                    help="--workload aec: delay logging, or the delay-agnostic mode (per-stream far-buffer control)")
     ap.add_argument("--workload", default="ns", choices=["ns", "bt1024", "bt256", "aec", "split48"],
                     help="ns = the headline metric (default); bt* / aec / split48 = secondary lines")
     args = ap.parse_args()
