@@ -1535,6 +1535,10 @@ int AspAecBatch_ExportDelayState(AspAecBatch* b, int stream, AspAecDelayState* o
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_ExportDelayState: control-only handle");
   if (!b || !out || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ExportDelayState: bad argument");
   AEC_TRY(hipSetDevice(b->device));
+  if (b->agn_synced && b->nevents > 0) {  // far-end calls the streams' read sides have not seen yet
+    const int rc = flush_far_events(b);
+    if (rc != 0) return rc;
+  }
   AEC_TRY(hipStreamSynchronize(b->stream));
   AEC_TRY(hipMemcpy(out, &b->dblocks[stream].s, sizeof *out, hipMemcpyDeviceToHost));
   if (!b->agn_synced) {  // lock-step: the batch's values

@@ -350,6 +350,73 @@ def test_delay_agnostic_mode_vs_oracle(aec, fs, n, ext):
         assert (0, int(med[s]), int(std[s])) == oras[s].delay_metrics(), s
 
 
+def test_delay_agnostic_bursty_far_end_vs_oracle(aec):
+    """Delay-agnostic mode under an irregular call pattern: far-end frames arrive in bursts (several
+    WebRtcAec_BufferFarend calls between two WebRtcAec_Process calls -- more than one launch descriptor holds, so the
+    replay is flushed early -- and once 215 in a row, which overflows the 250-partition far buffer: every stream then
+    drops ITS oldest partitions, aec_core.c:1622-1625) and near-end frames catch up in bursts; both call sizes.  One
+    oracle per stream replays the same calls: return codes, outputs (<= 1e-5 rel-L2), linear state and the
+    per-stream estimator / far-buffer / system-delay state bit for bit."""
+    S = 5
+    lags = [9, 0, 14, 5, 2]
+    F = 620
+    far, near = _lagged_frames(S, F, lags)
+    g = aec.AecBatch(S, 16000)
+    assert g.set_config(1, delay_logging=1) == 0
+    g.enable_reported_delay(0)
+    oras = [OracleAec(16000) for _ in range(S)]
+    for o in oras:
+        assert o.set_nlp(1, delay_logging=1) == 0
+        o.enable_reported_delay(0)
+    # the schedule: ("F", frame) = BufferFarend, ("N", frame) = Process; far frames never run behind the near frames
+    sched, fi, ni = [], 0, 0
+    rng = np.random.default_rng(17)
+    flooded = False
+    while ni < 330:
+        burst = int(rng.choice([1, 1, 1, 2, 3, 11]))
+        if ni >= 260 and not flooded:
+            burst, flooded = 215, True
+        burst = min(burst, F - fi)
+        for _ in range(burst):
+            sched.append(("F", fi))
+            fi += 1
+        for _ in range(min(max(burst, 1), 12) if burst != 215 else 1):
+            if ni < fi and ni < 330:
+                sched.append(("N", ni))
+                ni += 1
+    outs_g, outs_o = [], [[] for _ in range(S)]
+    for k, (kind, f) in enumerate(sched):
+        half = (k % 7) == 3      # some calls as two 80-sample halves
+        parts = [(0, 80), (80, 160)] if half else [(0, 160)]
+        for lo, hi in parts:
+            if kind == "F":
+                rc_g = g.buffer_farend(far[f][:, lo:hi])
+                for s in range(S):
+                    rc_o = oras[s].lib.asp_aec_oracle_buffer_farend(oras[s].h, np.ascontiguousarray(far[f, s, lo:hi]), hi - lo)
+                    assert rc_g == rc_o, (k, s)
+            else:
+                og, rc_g = g.process(near[f][:, lo:hi], 40)
+                outs_g.append(og)
+                for s in range(S):
+                    nn = np.ascontiguousarray(near[f, s, lo:hi])
+                    oo = np.empty_like(nn)
+                    rc_o = oras[s].lib.asp_aec_oracle_process(oras[s].h, nn, oo, hi - lo, 40, 0)
+                    assert rc_g == rc_o, (k, s)
+                    outs_o[s].append(oo)
+        if k % 150 == 149 or k == len(sched) - 1:
+            for s in range(S):
+                assert g.delay_state(s).diff(oras[s].delay_state(), skip=()) == [], (k, s)
+                st_o, _ = oras[s].export()
+                rep = _state_report(g.export_state(s), st_o)
+                bad = [x for x in LINEAR_FIELDS if not rep[x][0]]
+                assert bad == [], (k, s, {x: rep[x] for x in bad})
+    for s in range(S):
+        a = np.concatenate([o[s] for o in outs_g])
+        b = np.concatenate(outs_o[s])
+        assert _rel_l2(a, b) <= 1e-5, s
+    assert len({g.delay_state(s).system_delay for s in range(S)}) > 1      # the overflow hit the streams differently
+
+
 def test_delay_agnostic_golden_and_layer1(aec):
     """tests/golden/aec_modes_golden.npz (written by the reference build): the delay-agnostic mode through the batch
     and through the per-stream WebRtcAec_enable_reported_delay / WebRtcAec_GetDelayMetrics symbols: outputs <= 1e-5
