@@ -120,9 +120,9 @@ def test_wide_segment_signals_bit_exact(bt):
     g.close()
 
 
-ANY_WINDOWS = [320, 480, 800, 960, 224, 136, 62, 1000, 1440, 1920, 2048]  # 20 / 30 / 50 / 60 ms at 16 kHz,
+ANY_WINDOWS = [320, 480, 800, 960, 224, 136, 62, 1000, 1440, 1920, 2048, 552]  # 20 / 30 / 50 / 60 ms at 16 kHz,
 # 10 / 20 / 30 / 40 ms at 48 kHz, lengths whose half has the prime factors 7, 17, 31 (generic butterfly) or is
-# odd / 4 5^3, and the longest window the LDS tiles hold
+# odd / 4 5^3, the longest window the LDS tiles hold, and the 552 points of the reference's unittest_real_fft.cpp:22
 
 
 @pytest.mark.parametrize("n", ANY_WINDOWS)

@@ -12,7 +12,8 @@ from tests.oracle_lib import OracleBt
 NEED_MORE, CAN_OUTPUT, ERR_PARAMS = 0x10, 0x20, 0x02
 
 
-@pytest.mark.parametrize("n", [256, 1024, 320, 480, 800, 960, 224, 136, 62, 1000, 1440, 1920, 2048])  # radix 4 / 2, then 3, 5, generic
+@pytest.mark.parametrize("n", [256, 1024, 320, 480, 800, 960, 224, 136, 62, 1000, 1440, 1920, 2048,
+                               552])  # radix 4 / 2, then 3, 5, generic; 552: the length of unittest_real_fft.cpp:22
 def test_kiss_fftr_matches_numpy_and_roundtrips(n):
     o = OracleBt(n)
     rng = np.random.default_rng(n)
