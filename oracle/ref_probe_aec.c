@@ -280,3 +280,16 @@ void ref_aec_export_delay(void* h, AspAecDelayState* d) {
   d->far_wrap = -1;
   d->system_delay = k->system_delay;
 }
+
+/* the two entry points called separately (the reference's system_delay_unittest.cc drives them so) */
+int ref_aec_buffer_farend(void* h, const float* far, int n) { return WebRtcAec_BufferFarend(h, far, (int16_t)n); }
+int ref_aec_process(void* h, const float* near, float* out, int n, int16_t delay_ms) {
+  float nbuf[160], obuf[160];
+  const float* np[1] = {nbuf};
+  float* op[1] = {obuf};
+  int rc;
+  memcpy(nbuf, near, sizeof(float) * n);
+  rc = WebRtcAec_Process(h, np, 1, op, (int16_t)n, delay_ms, 0);
+  memcpy(out, obuf, sizeof(float) * n);
+  return rc;
+}
