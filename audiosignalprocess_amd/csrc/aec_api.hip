@@ -1873,6 +1873,29 @@ int WebRtcAec_delay_correction_enabled(struct AecCore* self) {
   return AspAecBatch_delay_correction_enabled(reinterpret_cast<AspAecBatch*>(self));
 }
 
+// aec_core.h:110-114 / aec_core.c:1886-1894 (what echo_cancellation_unittest.cc:34-48 and the APM use): the buffered
+// far-end delay in samples.  In the delay-agnostic mode it is the stream's own (a handle is a batch of one stream).
+int WebRtcAec_system_delay(struct AecCore* self) {
+  AspAecBatch* b = reinterpret_cast<AspAecBatch*>(self);
+  if (!b) return 0;
+  if (b->agn_synced && !b->sim) {
+    AspAecDelayState d;
+    if (AspAecBatch_ExportDelayState(b, 0, &d) == ASP_OK) return d.system_delay;
+  }
+  return b->system_delay;
+}
+void WebRtcAec_SetSystemDelay(struct AecCore* self, int delay) {
+  AspAecBatch* b = reinterpret_cast<AspAecBatch*>(self);
+  if (!b || delay < 0) return;  // the reference asserts delay >= 0
+  b->system_delay = delay;
+  if (b->agn_synced && !b->sim) {
+    std::vector<int32_t> v((size_t)b->S, delay);
+    if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) return;
+    (void)hipMemcpy2D(reinterpret_cast<char*>(b->dblocks) + offsetof(DelayBlock, s.system_delay), sizeof(DelayBlock), v.data(),
+                      sizeof(int32_t), sizeof(int32_t), (size_t)b->S, hipMemcpyHostToDevice);
+  }
+}
+
 // aec_core.h:121-126 / aec_core.c:1868-1874
 void WebRtcAec_enable_reported_delay(struct AecCore* self, int enable) {
   (void)AspAecBatch_enable_reported_delay(reinterpret_cast<AspAecBatch*>(self), enable);

@@ -629,6 +629,29 @@ def test_layer1_reference_api(aec, aec_golden):
     assert _rel_l2(out, aec_golden["out_f32"][:F, 0]) <= 1e-5
 
 
+def test_layer1_handles_as_echo_cancellation_unittest(aec):
+    """The reference's EchoCancellationTest (aec/echo_cancellation_unittest.cc:26-50), restated on the exported symbols:
+    Create / Free reject NULL, the core handle is NULL for NULL, a system delay set through the core handle reads back."""
+    lib = aec._lib()
+    lib.WebRtcAec_Create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.WebRtcAec_Free.argtypes = [C.c_void_p]
+    lib.WebRtcAec_aec_core.restype = C.c_void_p
+    lib.WebRtcAec_aec_core.argtypes = [C.c_void_p]
+    lib.WebRtcAec_SetSystemDelay.restype = None
+    lib.WebRtcAec_SetSystemDelay.argtypes = [C.c_void_p, C.c_int]
+    lib.WebRtcAec_system_delay.argtypes = [C.c_void_p]
+    assert lib.WebRtcAec_Create(None) == -1
+    h = C.c_void_p()
+    assert lib.WebRtcAec_Create(C.byref(h)) == 0 and h.value
+    assert lib.WebRtcAec_Free(None) == -1
+    assert lib.WebRtcAec_aec_core(None) is None
+    core = lib.WebRtcAec_aec_core(h)
+    assert core
+    lib.WebRtcAec_SetSystemDelay(core, 111)
+    assert lib.WebRtcAec_system_delay(core) == 111
+    assert lib.WebRtcAec_Free(h) == 0
+
+
 def test_scale_4096_streams_identical_inputs(aec):
     """BASELINE config-4 scale: 4096 streams; streams fed the same data give the same output
     whatever their position in the grid, and all outputs are finite."""
