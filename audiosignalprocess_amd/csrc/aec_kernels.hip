@@ -37,7 +37,10 @@ namespace {
 
 // Per-bin loops: trip 0 puts bin q on lane q, trip 1 is bin 64 computed by every lane (uniform
 // values, identical stores), so both trips are straight-line code whose loads overlap.
-#define BINS_2TRIPS _Pragma("unroll") for (int t_ = 0, bin = lane; t_ < 2; ++t_, bin = 64)
+#ifndef AEC_TRIPS
+#define AEC_TRIPS 2  // (1: timing probe only -- bin 64 is then not computed and the results are wrong)
+#endif
+#define BINS_2TRIPS _Pragma("unroll") for (int t_ = 0, bin = lane; t_ < AEC_TRIPS; ++t_, bin = 64)
 
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Timing probe: what the second (bin 64) trip of the AEC's per-bin phases costs.  Builds aec_kernels.hip with
+# AEC_TRIPS=1 (bin 64 is then not computed: the results are WRONG, only the step time means something) next to the
+# normal build, same session.  Restores the normal build at the end.
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for FLAGS in "-DAEC_TRIPS=2" "-DAEC_TRIPS=1" "-DAEC_TRIPS=2"; do
+  export ASP_HIPCC_EXTRA="aec_kernels.hip:$FLAGS"
+  touch audiosignalprocess_amd/csrc/aec_kernels.hip
+  python -c "from audiosignalprocess_amd import build; build.build_library()" > gpurun_out/build.log 2>&1 || tail -5 gpurun_out/build.log
+  python3 - <<PY
+import numpy as np, torch
+from audiosignalprocess_amd.aec import AecBatch
+from audiosignalprocess_amd.synth import aec_frames
+S, ring = 4096, 40
+far1, near1 = aec_frames(64, ring)
+idx = np.arange(S) % 64
+d_far = torch.from_numpy(np.ascontiguousarray(far1[:, idx])).cuda()
+d_near = torch.from_numpy(np.ascontiguousarray(near1[:, idx])).cuda()
+d_out = torch.empty_like(d_near)
+g = AecBatch(S, 16000)
+g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, 125)
+for _ in range(2):
+    ms = g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, 250)
+    print("$FLAGS: step_us %.1f" % (1000 * ms / 250))
+PY
+done
