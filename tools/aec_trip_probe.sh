@@ -4,7 +4,7 @@
 # normal build, same session.  Restores the normal build at the end.
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for FLAGS in "-DAEC_TRIPS=2" "-DAEC_TRIPS=1" "-DAEC_TRIPS=2"; do
+for FLAGS in ${ABL_FLAGS:-"-DAEC_TRIPS=2" "-DAEC_TRIPS=1" "-DAEC_TRIPS=2"}; do
   export ASP_HIPCC_EXTRA="aec_kernels.hip:$FLAGS"
   touch audiosignalprocess_amd/csrc/aec_kernels.hip
   python -c "from audiosignalprocess_amd import build; build.build_library()" > gpurun_out/build.log 2>&1 || tail -5 gpurun_out/build.log
