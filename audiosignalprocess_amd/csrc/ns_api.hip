@@ -27,6 +27,10 @@ hipError_t launch_ns_frame(int mode, float* state, int32_t* hist, const NsTables
 hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTables* T,
                             const float* in, float* out, int num_streams, hipStream_t s,
                             unsigned long long* stamps = nullptr, int stamp_mode = 0);
+hipError_t launch_ns_frame1_flow(bool io16, float* state, int32_t* hist, const NsTables* T,
+                                 const float* in, float* out, int num_streams, hipStream_t s,
+                                 unsigned* seq, unsigned* abort_w, unsigned want, int steps, int slot0, int ring,
+                                 size_t per);
 hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_hb_live(const float* state, const NsTables* T, const float* in_low,
                              int32_t* live, int num_streams, int hist_off, hipStream_t s);
@@ -579,6 +583,14 @@ struct AspNsBatch {
   bool use_graph = false;  // plain launches measured 4-7 % faster per step than graph replay (round 2)
   unsigned long long* timeline = nullptr;  // diagnostic (AspNsBatch_DebugTimeline): [workgroup][4] real-time stamps
   double last_enqueue_us = 0.0;  // host time the last TimedSteps call spent enqueuing its launches
+  // Hand-off build of the multi-step entry points (ns_kernels1.hip, NsFlowArgs): up to kFlowMaxSteps
+  // consecutive frame steps of a K-step call per launch; a per-stream step counter in memory orders step
+  // k + 1 of a stream behind its step k.  -1 = default (on for the pair-layout kernel), 0 = off, 1 = on.
+  int flow = -1;
+  unsigned* flow_seq = nullptr;    // [S] completed hand-off steps per stream (== flow_count between calls)
+  unsigned* flow_abort = nullptr;  // 16 B: word 0 != 0 after a wait timed out
+  unsigned flow_count = 0;         // hand-off steps enqueued so far
+  bool flow_unchecked = false;     // hand-off launches enqueued since the abort word was last read
   // > 16 kHz: 1 or 2 high bands next to the low band (ns_core.c:1362-1414)
   uint32_t fs = 16000;
   int block = kBlockL;  // samples per frame and stream: 160, or 80 at 8 kHz (ns_core.c:89-98)
@@ -675,6 +687,8 @@ int AspNsBatch_Free(AspNsBatch* b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->state) (void)hipFree(b->state);
   if (b->hist) (void)hipFree(b->hist);
+  if (b->flow_seq) (void)hipFree(b->flow_seq);
+  if (b->flow_abort) (void)hipFree(b->flow_abort);
   if (b->stage_in) (void)hipFree(b->stage_in);
   if (b->stage_out) (void)hipFree(b->stage_out);
   if (b->hb_tail) (void)hipFree(b->hb_tail);
@@ -782,9 +796,64 @@ static int chain_parts(const AspNsBatch* b, int base[5]) {
   return parts;
 }
 
+static bool flow_default() {
+  const char* e = getenv("ASP_NS_FLOW");
+  return !(e && e[0] == '0');
+}
+
+// The hand-off build serves a K-step call of a batch in the fused representation on the pair-layout kernel.
+static bool flow_applies(const AspNsBatch* b, int steps) {
+  const bool on = b->flow < 0 ? flow_default() : b->flow != 0;
+  return on && steps >= 2 && b->paired && b->kernel != 1 && b->fs != 8000 && b->timeline == nullptr;
+}
+
+static int flow_resources(AspNsBatch* b) {
+  if (!b->flow_seq) {
+    HIP_TRY(hipMalloc((void**)&b->flow_seq, (size_t)b->S * sizeof(unsigned)));
+    HIP_TRY(hipMalloc((void**)&b->flow_abort, 16));
+    HIP_TRY(hipMemsetAsync(b->flow_seq, 0, (size_t)b->S * sizeof(unsigned), b->stream));
+    HIP_TRY(hipMemsetAsync(b->flow_abort, 0, 16, b->stream));
+    b->flow_count = 0;
+  }
+  return ASP_OK;
+}
+
+// K steps of the hand-off build on the batch's stream: launches of up to kFlowMaxSteps consecutive frame
+// steps each (grid y = step); launches follow each other in stream order.
+constexpr int kFlowMaxSteps = 64;
+static int flow_steps(AspNsBatch* b, const float* din, float* dout, int ring, int steps, bool io16) {
+  int rc = flow_resources(b);
+  if (rc) return rc;
+  const size_t per = (size_t)b->S * b->block / (io16 ? 2 : 1);
+  for (int k = 0; k < steps; k += kFlowMaxSteps) {
+    const int m = steps - k < kFlowMaxSteps ? steps - k : kFlowMaxSteps;
+    HIP_TRY(launch_ns_frame1_flow(io16, b->state, b->hist, b->tables, din, dout, b->S, b->stream, b->flow_seq,
+                                  b->flow_abort, b->flow_count, m, k % ring, ring, per));
+    b->flow_count += (unsigned)m;
+  }
+  b->flow_unchecked = true;
+  return ASP_OK;
+}
+
+// After the batch's stream has been synchronised: did a hand-off wait time out?  (It cannot while the
+// launches of one batch run as enqueued; a timeout means steps were skipped, so the call fails loudly and
+// the counters are put back in step.)
+static int flow_check(AspNsBatch* b) {
+  if (!b->flow_unchecked) return ASP_OK;
+  b->flow_unchecked = false;
+  unsigned a = 0;
+  HIP_TRY(hipMemcpy(&a, b->flow_abort, sizeof a, hipMemcpyDeviceToHost));
+  if (a == 0) return ASP_OK;
+  std::vector<unsigned> seq((size_t)b->S, b->flow_count);
+  HIP_TRY(hipMemcpy(b->flow_seq, seq.data(), seq.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(b->flow_abort, 0, 16));
+  return fail(ASP_ERR_HIP, "NS hand-off wait timed out: frame steps were skipped, re-initialise the batch");
+}
+
 // `steps` fused frame steps on device buffers; step k reads/writes ring slot k % ring.
 static int fused_steps(AspNsBatch* b, const float* din, float* dout, int ring, int steps,
                        bool io16 = false) {
+  if (flow_applies(b, steps)) return flow_steps(b, din, dout, ring, steps, io16);
   // offsets below are in float units; int16 frames are half as wide
   const size_t per = (size_t)b->S * b->block / (io16 ? 2 : 1);
 
@@ -921,6 +990,7 @@ static int run_frames(AspNsBatch* b, int kmode, const float* in, float* out, int
       HIP_TRY(hipMemcpyAsync(out, b->stage_out, per * num_frames * 4, hipMemcpyDeviceToHost,
                              b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    return flow_check(b);
   }
   return ASP_OK;
 }
@@ -1083,6 +1153,7 @@ int AspNsBatch_AnalyzeProcessS16(AspNsBatch* b, const int16_t* in, int16_t* out,
   if (mem == ASP_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(out, b->stage_out, bytes, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    return flow_check(b);
   }
   return ASP_OK;
 }
@@ -1131,7 +1202,7 @@ int AspNsBatch_TimedSteps(AspNsBatch* b, const float* in, float* out, int frames
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
   HIP_TRY(hipEventSynchronize(b->ev1));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
-  return ASP_OK;
+  return flow_check(b);
 }
 
 int AspNsBatch_ExportState(AspNsBatch* b, int stream, AspNsState* out) {
@@ -1142,6 +1213,8 @@ int AspNsBatch_ExportState(AspNsBatch* b, int stream, AspNsState* out) {
   std::vector<float> blk(kStreamDwords);
   std::vector<int32_t> hh(kHistDwords);
   HIP_TRY(hipStreamSynchronize(b->stream));
+  rc = flow_check(b);
+  if (rc) return rc;
   HIP_TRY(hipMemcpy(blk.data(), b->state + (size_t)stream * kStreamDwords, kStreamDwords * 4,
                     hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(hh.data(), b->hist + (size_t)stream * kHistDwords, kHistDwords * 4,
@@ -1254,6 +1327,21 @@ int AspNsBatch_LastEnqueueUs(AspNsBatch* b, double* us) {
   return ASP_OK;
 }
 
+int AspNsBatch_SetFlow(AspNsBatch* b, int mode) {
+  if (!b || mode < -1 || mode > 1) return fail(ASP_ERR_PARAM, "SetFlow: -1 (default), 0 (off) or 1 (on)");
+  b->flow = mode;
+  return ASP_OK;
+}
+
+// Diagnostic (tests only): make the next hand-off launches wait for a step that never ran, so that the
+// bounded wait, the abort word and the error path can be exercised: the host's step counter moves one
+// ahead of the device's.
+int AspNsBatch_DebugFlowDesync(AspNsBatch* b) {
+  if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
+  b->flow_count++;
+  return ASP_OK;
+}
+
 int AspNsBatch_SetGraph(AspNsBatch* b, int on) {
   if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
   b->use_graph = (on & 1) != 0;
@@ -1283,7 +1371,7 @@ int AspNsBatch_Synchronize(AspNsBatch* b) {
   if (!b) return fail(ASP_ERR_PARAM, "null batch handle");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
-  return ASP_OK;
+  return flow_check(b);
 }
 
 // ---- streaming-copy ceiling of the box (bench.py prints it next to the 8 TB/s spec peak) ----

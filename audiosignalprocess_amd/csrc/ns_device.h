@@ -573,6 +573,22 @@ struct PriorModel {
   float p0, p1, p3, p4, p5, p6;
 };
 
+// FLOW (ns_kernels1.hip's hand-off build): the histogram is read and cleared with agent-scope (sc1)
+// accesses, like every other state access of that build.
+template <bool FLOW>
+__device__ __forceinline__ int hist_ld(const int32_t* p) {
+  typedef __attribute__((address_space(1))) int gi32;
+  if constexpr (FLOW) return __hip_atomic_load((const gi32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool FLOW>
+__device__ __forceinline__ void hist_st(int32_t* p, int v) {
+  typedef __attribute__((address_space(1))) int gi32;
+  if constexpr (FLOW) __hip_atomic_store((gi32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+template <bool FLOW = false>
 __device__ inline __attribute__((noinline)) PriorModel close_histogram_window(int32_t* __restrict__ hist, int lane,
                                                           int updateWindow, bool zero_after,
                                                           PriorModel pm) {
@@ -581,7 +597,7 @@ __device__ inline __attribute__((noinline)) PriorModel close_histogram_window(in
   int numHistLrt = 0;
   for (int r = 0; r < 16; ++r) {
     const int i = r * 64 + lane;
-    const int v = i < kHist ? hist[i] : 0;
+    const int v = i < kHist ? hist_ld<FLOW>(hist + i) : 0;
     unsigned long long m = __ballot(v != 0);
     while (m) {
       const int p = __ffsll((long long)m) - 1;
@@ -621,7 +637,7 @@ __device__ inline __attribute__((noinline)) PriorModel close_histogram_window(in
     wt2[k] = 0;
     for (int r = 0; r < 16; ++r) {
       const int i = r * 64 + lane;
-      const int v = i < kHist ? hh[i] : 0;
+      const int v = i < kHist ? hist_ld<FLOW>(hh + i) : 0;
       unsigned long long m = __ballot(v != 0);
       while (m) {
         const int p = __ffsll((long long)m) - 1;
@@ -673,7 +689,7 @@ __device__ inline __attribute__((noinline)) PriorModel close_histogram_window(in
   pm.p6 = ((float)useDiff) / featureSum;
   if (zero_after) {  // :510-516
     for (int k = 0; k < 3; ++k)
-      for (int r = 0; r < 16; ++r) hist[k * kHistStride + r * 64 + lane] = 0;
+      for (int r = 0; r < 16; ++r) hist_st<FLOW>(hist + k * kHistStride + r * 64 + lane, 0);
   }
   return pm;
 }

@@ -39,8 +39,115 @@ __device__ __forceinline__ unsigned long long ns_cu_tag() {
 
 constexpr int NS3 = 3;  // 2 owned bins + the tail bin 128
 
+// ---- the hand-off build (FLOW): consecutive frame steps overlap on the chip.
+// One launch carries M consecutive frame steps of the whole batch: blockIdx.y is the step, blockIdx.x the
+// group of four streams.  Workgroups are dispatched in linear order (x fastest), so every workgroup of
+// step j has been dispatched before the first one of step j + 1: the wave that takes stream s in step
+// j + 1 may therefore WAIT for the wave that has stream s in step j -- that wave is resident or done,
+// whatever else runs on the chip (the argument of a decoupled look-back scan).  What orders the two is a
+// word in memory: the wave that has finished stream s of step k stores seq[s] = k + 1 after draining its
+// stores; the wave that takes stream s in step k + 1 polls seq[s] before its first state load.  Every
+// state access of this build is an sc1 access (write-through stores, loads that bypass the CU's L1), the
+// form MI355X_MICROARCH.md's visibility section lists for hand-offs without an agent-scope fence per wave;
+// `in` / `out` frames and the constant tables are not handed off and stay plain.  The state still goes
+// through memory every step (SURVEY 8(d)'s frame-synchronous model: nothing of a stream stays on chip
+// between its steps); what disappears is the chip-wide phase lock of one launch per step (all waves load,
+// then all compute, then all store) and the idle time at every launch boundary.  The x extent of the grid
+// is a multiple of 8, so that (with workgroups dealt round-robin to the 8 XCDs) the two workgroups of a
+// stream's consecutive steps come from the same XCD's in-order share of the grid.  The wait is bounded
+// all the same: a wave that gives up sets the abort word, which every later wait sees, and the host
+// reports the failure (ns_api.hip, flow_check).
+struct NsFlowArgs {
+  unsigned* seq;      // [num_streams]: number of hand-off steps stream s has completed
+  unsigned* abort_w;  // != 0: a wait timed out (1 + stream)
+  unsigned want;      // blockIdx.y == 0 processes step `want` of every stream
+  int slot0;          // ring slot of that step; step j of the launch uses slot (slot0 + j) % ring
+  int ring;
+  unsigned per;       // floats between two ring slots of `in` / `out`
+};
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+constexpr int kSc1 = 16;  // cache-policy operand of the buffer intrinsics: sc1
 
-template <bool IO16>
+// One stream's state block: `uni` is a wave-uniform dword offset, `vec` the lane's dword offset.
+template <bool FLOW>
+struct StateAcc {
+  float* st;
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ explicit StateAcc(float* p) : st(p) {
+    if constexpr (FLOW) rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, aspns::kStreamDwords * 4, 0x00020000);
+  }
+  __device__ __forceinline__ float ld1(int uni, int vec) const {
+    if constexpr (FLOW) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vec * 4, uni * 4, kSc1));
+    else return st[uni + vec];
+  }
+  __device__ __forceinline__ float2 ld2(int uni, int vec) const {
+    if constexpr (FLOW) {
+      const f32x2v v = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(rs, vec * 4, uni * 4, kSc1));
+      return make_float2(v.x, v.y);
+    } else {
+      return *reinterpret_cast<const float2*>(st + uni + vec);
+    }
+  }
+  __device__ __forceinline__ float4 ld4(int uni, int vec) const {
+    if constexpr (FLOW) {
+      const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, vec * 4, uni * 4, kSc1));
+      return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+      return *reinterpret_cast<const float4*>(st + uni + vec);
+    }
+  }
+  __device__ __forceinline__ void st1(int uni, int vec, float v) const {
+    if constexpr (FLOW) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vec * 4, uni * 4, kSc1);
+    else st[uni + vec] = v;
+  }
+  __device__ __forceinline__ void st2(int uni, int vec, float a, float b) const {
+    if constexpr (FLOW) {
+      const f32x2v v = {a, b};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rs, vec * 4, uni * 4, kSc1);
+    } else {
+      *reinterpret_cast<float2*>(st + uni + vec) = make_float2(a, b);
+    }
+  }
+  __device__ __forceinline__ void st4(int uni, int vec, float4 x) const {
+    if constexpr (FLOW) {
+      const f32x4v v = {x.x, x.y, x.z, x.w};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), rs, vec * 4, uni * 4, kSc1);
+    } else {
+      *reinterpret_cast<float4*>(st + uni + vec) = x;
+    }
+  }
+};
+
+// Wait until stream `stream` has completed `want` hand-off steps.  Returns false when the wait was given
+// up (the abort word is set: by this wave after ~0.1 s of polling, or by another one before).
+__device__ __forceinline__ bool flow_wait(const NsFlowArgs& fa, unsigned want, int stream, int lane) {
+  const gu32* f = (const gu32*)(fa.seq + stream);
+  unsigned spins = 0;
+  for (;;) {
+    const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) == want) break;
+    ++spins;
+    if ((spins & 63u) == 0u) {
+      const unsigned a = __hip_atomic_load((const gu32*)fa.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__builtin_amdgcn_readfirstlane((int)a) != 0) return false;
+    }
+    if (spins > (1u << 17)) {
+      if (lane == 0) __hip_atomic_store((gu32*)fa.abort_w, 1u + (unsigned)stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  // no instruction: keeps the compiler from moving the state loads above the poll
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return true;
+}
+
+
+template <bool IO16, bool FLOW>
 __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ state,
                                                            int32_t* __restrict__ hist_all,
                                                            const NsTables* __restrict__ T,
@@ -48,7 +155,7 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
                                                            float* __restrict__ out,
                                                            int num_streams,
                                                            unsigned long long* __restrict__ stamps,
-                                                           int stamp_mode) {
+                                                           int stamp_mode, NsFlowArgs fa) {
 #ifdef NS1_BUDGET
   // instruction-budget build (tools/ns_valu_budget.py, never shipped): the phase marks become
   // assembly comments and the steady-state conditions are asserted, so that the straight-line
@@ -97,66 +204,79 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
   const int lane = tid & 63;
   const int diagbits = T->diag[lane];
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int stream_raw = blockIdx.x * 4 + wv;
-  const bool wave_live = stream_raw < num_streams;
-  const int stream = wave_live ? stream_raw : num_streams - 1;  // clamped for the loads
-  float* __restrict__ st = state + (size_t)stream * kStreamDwords;
-  float* __restrict__ vec = st + kOffVec;
-  int32_t* __restrict__ hist = hist_all + (size_t)stream * kHistDwords;
   float2* tile = lds[wv];
   const int lam = lane >> 1, h = lane & 1;
   const int g = lam >> 4, q = lam & 15;
   const int binA = q + 64 * g + 16 * h;  // slot 0; slot 1 = binA + 32; slot 2 = bin 128
   const uint32_t gmask = g ? 0x80000000u : 0u;
+  const int stream_raw = blockIdx.x * 4 + wv;
+  bool wave_live = stream_raw < num_streams;
+  const int stream = wave_live ? stream_raw : num_streams - 1;  // clamped for the loads
+  float* __restrict__ st = state + (size_t)stream * kStreamDwords;
+  int32_t* __restrict__ hist = hist_all + (size_t)stream * kHistDwords;
+  const StateAcc<FLOW> sa(st);
+  unsigned flow_want = 0;
+  if constexpr (FLOW) {  // this workgroup's step of the launch: its ring slot, its step number
+    const unsigned j = blockIdx.y;
+    const unsigned slot = ((unsigned)fa.slot0 + j) % (unsigned)fa.ring;
+    in += (size_t)slot * fa.per;
+    out += (size_t)slot * fa.per;
+    flow_want = fa.want + j;
+  }
 
   // ---- scalars: lane k holds scalar k (wave-uniform values, read with v_readlane)
-  float sv = st[kOffScalars + lane];
+  float sv;
 #define SC_I(k) __builtin_amdgcn_readlane(__float_as_int(sv), (k))
 #define SC_F(k) __int_as_float(SC_I(k))
 #define SC_SET_I(k, val) sv = writelane_bits<(k)>(sv, (int)(val))
 #define SC_SET_F(k, val) sv = setlane_vgpr<(k)>(sv, (val))
-
   // ---- sliding analysis buffer [96 carried | 160 new]: lane L owns samples 4L .. 4L+3
-  float* hbuf = st + kOffAnaHist;
   float4 s4;
-  if (!IO16) {
-    const float* src = lane < 24 ? hbuf + 4 * lane : in + (size_t)stream * kBlockL + 4 * (lane - 24);
-    s4 = *reinterpret_cast<const float4*>(src);
-  } else {
-    const int lh = lane < 24 ? lane : 23, li = lane < 24 ? 24 : lane;
-    const float4 ha = *reinterpret_cast<const float4*>(hbuf + 4 * lh);
-    const short* in16 = reinterpret_cast<const short*>(in) + (size_t)stream * kBlockL + 4 * (li - 24);
-    const short4 a = *reinterpret_cast<const short4*>(in16);
-    const bool hsel = lane < 24;
-    s4.x = hsel ? ha.x : (float)a.x;
-    s4.y = hsel ? ha.y : (float)a.y;
-    s4.z = hsel ? ha.z : (float)a.z;
-    s4.w = hsel ? ha.w : (float)a.w;
-  }
-
-#define LOADV(dst, f)                                                                          \
-  {                                                                                            \
-    const float2 v2_ = *reinterpret_cast<const float2*>(vec + (f)*kVecStride + 2 * lane);      \
-    dst[0] = v2_.x; dst[1] = v2_.y;                                                            \
-  }
-#define LOADT(dst, f) dst[2] = SC_F(S_TAIL0 + (f));
-#define LOAD3(dst, f) LOADV(dst, f) LOADT(dst, f)
-#define STORE3(f, srcv)                                                                        \
-  {                                                                                            \
-    *reinterpret_cast<float2*>(vec + (f)*kVecStride + 2 * lane) = make_float2(srcv[0], srcv[1]); \
-    SC_SET_F(S_TAIL0 + (f), srcv[2]);                                                          \
-  }
-
-  // state rows are requested in two groups, just ahead of their use (requesting all of them before
-  // the first wait measured slower: every wave of a launch starts at once, and a bigger
-  // start-of-kernel burst makes every wave wait longer)
-  float LQ[3][NS3], DEN[3][NS3], quant[NS3];
-  float smooth[NS3], noisePrev[NS3], magnPrevA[NS3], logLrt[NS3], avgPause[NS3];
   // syntBuf[0..95]: the lane's output samples 2E, 2E+1 that still carry overlap are those of
   // slot 0 when g == 0 (2q + 32h) and of slot 1 when g == 0 and h == 0 (2q + 64); every lane
   // loads (no branch), the overlap-add uses the owners' values only
-  const float2 carryA = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * q + 32 * h);
-  const float2 carryB = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * q + 64);
+  float2 carryA, carryB;
+  if constexpr (FLOW) {
+    // the frame's new samples do not depend on the hand-off: requested before the poll; the state follows it
+    float4 s4in = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!IO16) {
+      if (lane >= 24) s4in = *reinterpret_cast<const float4*>(in + (size_t)stream * kBlockL + 4 * (lane - 24));
+    } else {
+      const int li = lane < 24 ? 24 : lane;
+      const short* in16 = reinterpret_cast<const short*>(in) + (size_t)stream * kBlockL + 4 * (li - 24);
+      const short4 a = *reinterpret_cast<const short4*>(in16);
+      s4in = make_float4((float)a.x, (float)a.y, (float)a.z, (float)a.w);
+    }
+    if (wave_live) wave_live = flow_wait(fa, flow_want, stream, lane);
+    sv = sa.ld1(kOffScalars, lane);
+    const float4 ha = sa.ld4(kOffAnaHist, 4 * (lane < 24 ? lane : 23));
+    const bool hsel = lane < 24;
+    s4.x = hsel ? ha.x : s4in.x;
+    s4.y = hsel ? ha.y : s4in.y;
+    s4.z = hsel ? ha.z : s4in.z;
+    s4.w = hsel ? ha.w : s4in.w;
+    carryA = sa.ld2(kOffSynt, 2 * q + 32 * h);
+    carryB = sa.ld2(kOffSynt, 2 * q + 64);
+  } else {
+    sv = st[kOffScalars + lane];
+    float* hbuf = st + kOffAnaHist;
+    if (!IO16) {
+      const float* src = lane < 24 ? hbuf + 4 * lane : in + (size_t)stream * kBlockL + 4 * (lane - 24);
+      s4 = *reinterpret_cast<const float4*>(src);
+    } else {
+      const int lh = lane < 24 ? lane : 23, li = lane < 24 ? 24 : lane;
+      const float4 ha = *reinterpret_cast<const float4*>(hbuf + 4 * lh);
+      const short* in16 = reinterpret_cast<const short*>(in) + (size_t)stream * kBlockL + 4 * (li - 24);
+      const short4 a = *reinterpret_cast<const short4*>(in16);
+      const bool hsel = lane < 24;
+      s4.x = hsel ? ha.x : (float)a.x;
+      s4.y = hsel ? ha.y : (float)a.y;
+      s4.z = hsel ? ha.z : (float)a.z;
+      s4.w = hsel ? ha.w : (float)a.w;
+    }
+    carryA = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * q + 32 * h);
+    carryB = *reinterpret_cast<const float2*>(st + kOffSynt + 2 * q + 64);
+  }
 
   // ---- table staging (the loads above are in flight behind it)
   reinterpret_cast<float4*>(tabs)[tid] = tab_v;
@@ -167,6 +287,36 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
   if (!wave_live) return;
   const float* tws = tabs;
   const float* spls = tabs + 3 * 64 * 4;
+  const PairFftLane fl = pair_fft_lane(lane, diagbits);
+
+#define LOADV(dst, f)                                                                          \
+  {                                                                                            \
+    const float2 v2_ = sa.ld2(kOffVec + (f)*kVecStride, 2 * lane);                             \
+    dst[0] = v2_.x; dst[1] = v2_.y;                                                            \
+  }
+#define LOADT(dst, f) dst[2] = SC_F(S_TAIL0 + (f));
+#define LOAD3(dst, f) LOADV(dst, f) LOADT(dst, f)
+#define STORE3(f, srcv)                                                                        \
+  {                                                                                            \
+    sa.st2(kOffVec + (f)*kVecStride, 2 * lane, srcv[0], srcv[1]);                              \
+    SC_SET_F(S_TAIL0 + (f), srcv[2]);                                                          \
+  }
+  // the step is done for this stream: the hand-off build publishes it, every store of this wave drained first
+#define NS_STREAM_DONE()                                                                       \
+  if constexpr (FLOW) {                                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+    if (lane == 0)                                                                             \
+      __hip_atomic_store((gu32*)(fa.seq + stream), flow_want + 1u, __ATOMIC_RELAXED,           \
+                         __HIP_MEMORY_SCOPE_AGENT);                                            \
+  }                                                                                            \
+  return;
+
+  // state rows are requested in two groups, just ahead of their use (requesting all of them before
+  // the first wait measured slower: every wave of a launch starts at once, and a bigger
+  // start-of-kernel burst makes every wave wait longer)
+  float LQ[3][NS3], DEN[3][NS3], quant[NS3];
+  float smooth[NS3], noisePrev[NS3], magnPrevA[NS3], logLrt[NS3], avgPause[NS3];
+
 
   const float4 w4 = *reinterpret_cast<const float4*>(wins + 4 * lane);
   const float wx0 = w4.x * s4.x, wx1 = w4.y * s4.y, wx2 = w4.z * s4.z, wx3 = w4.w * s4.w;
@@ -178,22 +328,21 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
   const float energy1 = wave_sum_bcast(epart);
 
   // the carried 96 samples of the next frame are this frame's last 96
-  if (lane >= 40) *reinterpret_cast<float4*>(hbuf + 4 * (lane - 40)) = s4;
+  if (lane >= 40) sa.st4(kOffAnaHist, 4 * (lane - 40), s4);
 
   NS_STEADY(energy1 != 0.0f);
   if (energy1 == 0.0f) {
     // Analyze: nothing but the buffer slide (ns_core.c:1072-1082); Process: emit the synthesis
     // tail and clear it (ns_core.c:1239-1264)
-    float* sy = st + kOffSynt;
     float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * kBlockL)
                     : out + (size_t)stream * kBlockL;
     float2 o01 = make_float2(0.f, 0.f);
-    if (lane < 48) o01 = *reinterpret_cast<const float2*>(sy + 2 * lane);
+    if (lane < 48) o01 = sa.ld2(kOffSynt, 2 * lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     store2p<IO16>(y, 2 * lane, sat16p(o01.x), sat16p(o01.y));
     if (lane < 16) store2p<IO16>(y, 128 + 2 * lane, 0.f, 0.f);
-    if (lane < 48) *reinterpret_cast<float2*>(sy + 2 * lane) = make_float2(0.f, 0.f);
-    return;
+    if (lane < 48) sa.st2(kOffSynt, 2 * lane, 0.f, 0.f);
+    NS_STREAM_DONE()
   }
 
   // the tracker rows are requested once the frame's samples are in; they are used after the
@@ -208,7 +357,6 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
   // ---- forward FFT (ns_core.c:886-911)
   *reinterpret_cast<float4*>(&tile[2 * lane]) = make_float4(wx0, wx1, wx2, wx3);
   lds_sync1();
-  const PairFftLane fl = pair_fft_lane(lane, diagbits);
   f32x2 er, ei;  // the lane's two bins {slot 0, slot 1}: real parts, imaginary parts
   {
     f32x2 ea, eb;
@@ -477,10 +625,10 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
       const float bw = lane == 1 ? 0.05f : 0.1f, rbw = lane == 1 ? 1.0f / 0.05f : 1.0f / 0.1f;
       const float lim = lane == 1 ? kHist * 0.05f : kHist * 0.1f;
       if (lane < 3 && (fv < lim) && (fv >= 0.0f))
-        atomicAdd(&hist[lane * kHistStride + (int)div_by_uniform(fv, bw, rbw)], 1);
+        atomicAdd(&hist[lane * kHistStride + (int)div_by_uniform(fv, bw, rbw)], 1);  // agent scope (sc1)
     }
     if (mup3 == 0) {
-      pm = close_histogram_window(hist, lane, mup1, mup0 >= 1, pm);
+      pm = close_histogram_window<FLOW>(hist, lane, mup1, mup0 >= 1, pm);
       window_closed = true;
       mup3 = mup1;
       if (updateParsFlag == 1) {
@@ -694,7 +842,6 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
 
   // ---- synthesis window, overlap-add, emit 160, carry 96 (ns_core.c:1344-1359)
   {
-    float* sy = st + kOffSynt;
     float* y = IO16 ? reinterpret_cast<float*>(reinterpret_cast<short*>(out) + (size_t)stream * kBlockL)
                     : out + (size_t)stream * kBlockL;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -706,12 +853,12 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
     const float oA0 = cA0 + factor * (wA.x * td0), oA1 = cA1 + factor * (wA.y * td1);
     const float oB0 = cB0 + factor * (wB.x * td2), oB1 = cB1 + factor * (wB.y * td3s);
     if (nA >= 160) {
-      *reinterpret_cast<float2*>(sy + nA - 160) = make_float2(oA0, oA1);
+      sa.st2(kOffSynt, nA - 160, oA0, oA1);
     } else {
       store2p<IO16>(y, nA, sat16p(oA0), sat16p(oA1));
     }
     if (nB >= 160) {
-      *reinterpret_cast<float2*>(sy + nB - 160) = make_float2(oB0, oB1);
+      sa.st2(kOffSynt, nB - 160, oB0, oB1);
     } else {
       store2p<IO16>(y, nB, sat16p(oB0), sat16p(oB1));
     }
@@ -747,8 +894,10 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
   SC_SET_F(S_FD6, fd6);
   SC_SET_I(S_BLOCKIND, blockInd);
   SC_SET_F(S_PRIORSPEECHPROB, priorSpeechProb);
-  st[kOffScalars + lane] = sv;
+  sa.st1(kOffScalars, lane, sv);
   NS_STAMP(15)
+  NS_STREAM_DONE()
+#undef NS_STREAM_DONE
 #undef NS_STAMP
 #undef SC_I
 #undef SC_F
@@ -769,12 +918,32 @@ hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTabl
                             const float* in, float* out, int num_streams, hipStream_t s,
                             unsigned long long* stamps, int stamp_mode) {
   const dim3 grid((num_streams + 3) / 4), block(256);
+  const NsFlowArgs none = {nullptr, nullptr, 0u, 0, 1, 0u};
   if (io16)
-    hipLaunchKernelGGL(ns_frame1_kernel<true>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps, stamp_mode);
+    hipLaunchKernelGGL((ns_frame1_kernel<true, false>), grid, block, 0, s, state, hist, T, in, out,
+                       num_streams, stamps, stamp_mode, none);
   else
-    hipLaunchKernelGGL(ns_frame1_kernel<false>, grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, stamps, stamp_mode);
+    hipLaunchKernelGGL((ns_frame1_kernel<false, false>), grid, block, 0, s, state, hist, T, in, out,
+                       num_streams, stamps, stamp_mode, none);
+  return hipGetLastError();
+}
+
+// `steps` consecutive frame steps of the hand-off build in one launch: steps want .. want + steps - 1 of every
+// stream (seq[s] == want on entry, want + steps on exit); step j reads / writes ring slot (slot0 + j) % ring of
+// in / out (slots `per` floats apart).
+hipError_t launch_ns_frame1_flow(bool io16, float* state, int32_t* hist, const NsTables* T,
+                                 const float* in, float* out, int num_streams, hipStream_t s,
+                                 unsigned* seq, unsigned* abort_w, unsigned want, int steps, int slot0, int ring,
+                                 size_t per) {
+  const int gx = ((num_streams + 3) / 4 + 7) / 8 * 8;
+  const dim3 grid(gx, steps), block(256);
+  const NsFlowArgs fa = {seq, abort_w, want, slot0, ring, (unsigned)per};
+  if (io16)
+    hipLaunchKernelGGL((ns_frame1_kernel<true, true>), grid, block, 0, s, state, hist, T, in, out,
+                       num_streams, (unsigned long long*)nullptr, 0, fa);
+  else
+    hipLaunchKernelGGL((ns_frame1_kernel<false, true>), grid, block, 0, s, state, hist, T, in, out,
+                       num_streams, (unsigned long long*)nullptr, 0, fa);
   return hipGetLastError();
 }
 

@@ -58,6 +58,8 @@ def load_library():
         "AspNsBatch_prior_speech_probability": [vp, vp],
         "AspNsBatch_SetStream": [vp, vp],
         "AspNsBatch_SetSplit": [vp, ip],
+        "AspNsBatch_SetFlow": [vp, ip],
+        "AspNsBatch_DebugFlowDesync": [vp],
         "AspNsBatch_SetKernel": [vp, ip],
         "AspNsBatch_Synchronize": [vp],
         "AspNsBatch_TimedSteps": [vp, vp, vp, ip, ip, fp],
@@ -74,6 +76,8 @@ def load_library():
         "AspNs_device_count": [],
     }
     for name, args in sig.items():
+        if os.environ.get("ASP_AMD_LIB") and not hasattr(lib, name):
+            continue  # an earlier build of the library loaded for a same-box A / B run (build.py)
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
@@ -256,6 +260,10 @@ class NsBatch:
 
     def set_stream(self, hip_stream):
         _check(self.lib.AspNsBatch_SetStream(self.h, C.c_void_p(hip_stream)), "AspNsBatch_SetStream")
+
+    def set_flow(self, mode):
+        """Hand-off build of the multi-frame entry points: -1 default, 0 off, 1 on (include/asp_ns.h)."""
+        _check(self.lib.AspNsBatch_SetFlow(self.h, mode), "AspNsBatch_SetFlow")
 
     def set_split(self, parts):
         _check(self.lib.AspNsBatch_SetSplit(self.h, parts), "AspNsBatch_SetSplit")

@@ -180,6 +180,20 @@ int AspNsBatch_SetSplit(AspNsBatch* b, int parts);
  * (ns_kernels.hip, the kernel of the two-call Analyze / Process protocol).  Same arithmetic; the ~10
  * cross-bin sums per frame are associated differently, so outputs agree to reduction-order rounding. */
 int AspNsBatch_SetKernel(AspNsBatch* b, int kernel);
+/* Hand-off build of the multi-frame entry points (AnalyzeProcess / AnalyzeProcessS16 with num_frames >= 2,
+ * AnalyzeProcessReplay, TimedSteps) on the pair-layout kernel: up to 64 consecutive frame steps of a call go
+ * into ONE launch (grid y = step), and a per-stream step counter in device memory orders step k + 1 of a
+ * stream behind its own step k (every state access write-through / L1-bypassing), so consecutive steps overlap
+ * on the chip instead of meeting at a launch boundary.  Same arithmetic, same results bit for bit; every step
+ * still reads and writes the whole state through memory (nothing of a stream stays on chip between steps).
+ * mode: -1 = default (on; the environment variable ASP_NS_FLOW=0 turns the default off), 0 = off, 1 = on.
+ * A wait that times out (workgroups are dispatched in grid order, so it cannot) makes the next synchronising
+ * call fail with ASP_ERR_HIP. */
+int AspNsBatch_SetFlow(AspNsBatch* b, int mode);
+/* Test hook: puts the host's hand-off step counter one ahead of the device's, so that the next multi-frame
+ * call's waits time out (about 0.2 s), its steps are skipped and the call (or the next synchronising one)
+ * returns ASP_ERR_HIP; the counters are back in step afterwards and the batch needs AspNsBatch_Init. */
+int AspNsBatch_DebugFlowDesync(AspNsBatch* b);
 void* AspNsBatch_GetStream(AspNsBatch* b);
 int AspNsBatch_Synchronize(AspNsBatch* b);
 

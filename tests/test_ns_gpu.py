@@ -697,8 +697,9 @@ def test_8khz_golden_protocols_and_pcm(ns, golden8k):
 # The timed entry point of bench.py (AspNsBatch_TimedSteps: K steps over a device ring, launch chains)
 # against the oracle: same launches as AnalyzeProcess, but the ring wrap-around (step k uses slot
 # k % ring) and the split into chains only run here.
-@pytest.mark.parametrize("S,split", [(16, 2), (4096, 2), (4100, 3)])
-def test_timed_steps_ring_wraparound_bit_exact_vs_oracle(ns, S, split):
+@pytest.mark.parametrize("S,split,flow", [(16, 2, 0), (4096, 2, 0), (4100, 3, 0), (16, 1, 1), (4096, 1, 1), (4100, 1, 1),
+                                          (9001, 1, 1)])
+def test_timed_steps_ring_wraparound_bit_exact_vs_oracle(ns, S, split, flow):
     from audiosignalprocess_amd.ns import DeviceBuffer
 
     ring, steps = 7, 60          # ring < steps: every slot is reused eight times
@@ -710,6 +711,7 @@ def test_timed_steps_ring_wraparound_bit_exact_vs_oracle(ns, S, split):
     din.upload(x)
     g = ns.NsBatch(S, policy=1)          # fresh batch, default kernel: the run crosses blockInd 50
     g.set_split(split)
+    g.set_flow(flow)             # 0: launch chains; 1: the hand-off build (one launch per step, steps overlap)
     ms = g.timed_steps(din.ptr, dout.ptr, ring, steps)
     assert ms > 0
     got = dout.download(x.shape)
@@ -722,6 +724,66 @@ def test_timed_steps_ring_wraparound_bit_exact_vs_oracle(ns, S, split):
         assert np.array_equal(got[:, k], want[:, idx[k]]), k
     for k in (0, S // 2 - 1, S // 2, S - 1):
         assert state_diff(g.export_state(k), o.export_state(int(idx[k]))) == {}, k
+    g.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# The hand-off build (AspNsBatch_SetFlow; the default of every multi-frame entry point) against the plain
+# launches of the same kernel: outputs and full state bit for bit over 520 steps -- through both start-up
+# windows and the first close of the histogram window (frame 500) -- with a silent stream (the early exit
+# publishes too), stream counts that leave the last workgroup ragged, and batches of more streams than the
+# chip holds waves (a wave then walks 2-4 streams per step).  Two hand-off batches run at the same time
+# (their launches interleave on the chip), so every wait happens under uneven load.
+@pytest.mark.parametrize("S", [5, 4100, 8192, 12290])
+def test_handoff_build_equals_plain_launches(ns, S):
+    from audiosignalprocess_amd.ns import DeviceBuffer
+
+    ring, steps, D = 9, 520, 16
+    base = ns_frames(D, ring, stream0=40)
+    base[:, 3] = 0.0                      # a silent stream: zero-energy exit every frame
+    base[4:, 7] = 0.0                     # and one that falls silent part of the time
+    idx = (np.arange(S) * 7) % D
+    x = np.ascontiguousarray(base[:, idx])
+    din = DeviceBuffer(x.nbytes)
+    din.upload(x)
+    outs, batches = [], []
+    for flow in (0, 1, 1):
+        g = ns.NsBatch(S, policy=2)
+        g.set_flow(flow)
+        g.set_split(2 if flow == 0 else 1)
+        dout = DeviceBuffer(x.nbytes)
+        g.analyze_process_replay(din.ptr, dout.ptr, ring, steps)   # asynchronous: the batches overlap
+        outs.append(dout)
+        batches.append(g)
+    for g in batches:
+        g.synchronize()
+    y = [o.download(x.shape) for o in outs]
+    assert np.isfinite(y[0]).all() and np.abs(y[0]).max() > 0
+    for k in (1, 2):
+        assert np.array_equal(y[0].view(np.uint32), y[k].view(np.uint32)), k
+    spots = sorted(set([0, 1, 3, 4, S // 2, S - 2, S - 1] + list(range(0, S, max(1, S // 37)))))
+    for s_ in spots:
+        want = batches[0].export_state(s_)
+        for k in (1, 2):
+            assert state_diff(batches[k].export_state(s_), want) == {}, (s_, k)
+    for g in batches:
+        g.close()
+
+
+def test_handoff_wait_times_out_loudly(ns):
+    """A hand-off launch whose predecessor never ran must not hang: the bounded wait gives up, the grid
+    drains, the call reports ASP_ERR_HIP, and the batch works again after Init."""
+    S = 64
+    x = ns_frames(S, 6, stream0=3)
+    g = ns.NsBatch(S, policy=1)
+    g.set_flow(1)
+    want = g.analyze_process(x)
+    g.lib.AspNsBatch_DebugFlowDesync(g.h)
+    with pytest.raises(RuntimeError):
+        g.analyze_process(x)
+    g.init(16000)
+    g.set_policy(1)
+    assert np.array_equal(g.analyze_process(x), want)
     g.close()
 
 
