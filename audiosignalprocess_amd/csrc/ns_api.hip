@@ -30,7 +30,7 @@ hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTabl
 hipError_t launch_ns_frame1_flow(bool io16, float* state, int32_t* hist, const NsTables* T,
                                  const float* in, float* out, int num_streams, hipStream_t s,
                                  unsigned* seq, unsigned* abort_w, unsigned want, int steps, int slot0, int ring,
-                                 size_t per);
+                                 size_t per, unsigned long long* stamps = nullptr);
 hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_hb_live(const float* state, const NsTables* T, const float* in_low,
                              int32_t* live, int num_streams, int hist_off, hipStream_t s);
@@ -582,6 +582,7 @@ struct AspNsBatch {
   int g_kernel = 0;
   bool use_graph = false;  // plain launches measured 4-7 % faster per step than graph replay (round 2)
   unsigned long long* timeline = nullptr;  // diagnostic (AspNsBatch_DebugTimeline): [workgroup][4] real-time stamps
+  unsigned long long* flow_stamps = nullptr;  // diagnostic (AspNsBatch_DebugFlowStamps): 17 phase stamps of one wave
   double last_enqueue_us = 0.0;  // host time the last TimedSteps call spent enqueuing its launches
   // Hand-off build of the multi-step entry points (ns_kernels1.hip, NsFlowArgs): up to kFlowMaxSteps
   // consecutive frame steps of a K-step call per launch; a per-stream step counter in memory orders step
@@ -828,7 +829,7 @@ static int flow_steps(AspNsBatch* b, const float* din, float* dout, int ring, in
   for (int k = 0; k < steps; k += kFlowMaxSteps) {
     const int m = steps - k < kFlowMaxSteps ? steps - k : kFlowMaxSteps;
     HIP_TRY(launch_ns_frame1_flow(io16, b->state, b->hist, b->tables, din, dout, b->S, b->stream, b->flow_seq,
-                                  b->flow_abort, b->flow_count, m, k % ring, ring, per));
+                                  b->flow_abort, b->flow_count, m, k % ring, ring, per, b->flow_stamps));
     b->flow_count += (unsigned)m;
   }
   b->flow_unchecked = true;
@@ -1290,6 +1291,30 @@ int AspNsBatch_DebugStamps(AspNsBatch* b, const float* in_dev, float* out_dev,
   (void)hipFree(d);
   if (e != hipSuccess) return fail(ASP_ERR_HIP, "DebugStamps", e);
   return ASP_OK;
+}
+
+// Diagnostic: `steps` frame steps of the hand-off build in one launch, with the 17 phase stamps (shader clock)
+// of one wave in the middle of the launch (x = grid / 2, y = steps / 2: the steady state, neighbours in every
+// phase): kernel start, the 15 phase marks of the frame step, stores drained.
+int AspNsBatch_DebugFlowStamps(AspNsBatch* b, const float* in_dev, float* out_dev, int frames_in_ring, int steps,
+                               unsigned long long* stamps17) {
+  DeviceScope dev_scope_;
+  int rc = check(b);
+  if (rc) return rc;
+  if (!in_dev || !out_dev || !stamps17 || steps < 2 || steps > kFlowMaxSteps || !flow_applies(b, steps))
+    return fail(ASP_ERR_PARAM, "DebugFlowStamps: bad argument (hand-off build, 2..64 steps)");
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 17 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d, 0, 17 * sizeof(unsigned long long));
+  b->flow_stamps = d;
+  if (e == hipSuccess) rc = flow_steps(b, in_dev, out_dev, frames_in_ring, steps, false);
+  b->flow_stamps = nullptr;
+  if (e == hipSuccess && rc == ASP_OK) e = hipStreamSynchronize(b->stream);
+  if (e == hipSuccess && rc == ASP_OK) e = hipMemcpy(stamps17, d, 17 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(ASP_ERR_HIP, "DebugFlowStamps", e);
+  return flow_check(b);
 }
 
 // Diagnostic: `steps` fused steps through the product launch path (chains as set by SetSplit) with every

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
 #define NS_STEADY(x) __builtin_assume(x)
 #else
   // diagnostic stamps (never passed by the product entry points).  stamp_mode 0: the 16 phase stamps
-  // (shader clock) of workgroup 0's first wave.  stamp_mode 1 ("timeline"): every workgroup's first
+  // (shader clock) of workgroup 0's first wave (hand-off build: of the workgroup in the middle of the
+  // launch, x = grid / 2, y = steps / 2, plus a 17th once its stores have drained).  stamp_mode 1 ("timeline"): every workgroup's first
   // wave records the 100 MHz real-time counter at its start, after its first loads, before its last
   // stores and at its end (4 values per workgroup) -- the launch-level picture.
 #define NS_STAMP(k)                                                                          \
@@ -177,7 +178,8 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
       if ((k) == 0 || (k) == 1 || (k) == 14 || (k) == 15)                                    \
         stamps[blockIdx.x * 4 + ((k) == 0 ? 0 : (k) == 1 ? 1 : (k) == 14 ? 2 : 3)] =        \
             __builtin_amdgcn_s_memrealtime() | ((k) == 0 ? ns_cu_tag() << 48 : 0ull);       \
-    } else if (blockIdx.x == 0) {                                                            \
+    } else if (FLOW ? (blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2)           \
+                    : blockIdx.x == 0) {                                                     \
       stamps[k] = __builtin_amdgcn_s_memtime();                                              \
     }                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(256, 4) void ns_frame1_kernel(float* __restrict__ s
 #define NS_STREAM_DONE()                                                                       \
   if constexpr (FLOW) {                                                                        \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+    NS_STAMP(16)                                                                               \
     if (lane == 0)                                                                             \
       __hip_atomic_store((gu32*)(fa.seq + stream), flow_want + 1u, __ATOMIC_RELAXED,           \
                          __HIP_MEMORY_SCOPE_AGENT);                                            \
@@ -934,16 +937,16 @@ hipError_t launch_ns_frame1(bool io16, float* state, int32_t* hist, const NsTabl
 hipError_t launch_ns_frame1_flow(bool io16, float* state, int32_t* hist, const NsTables* T,
                                  const float* in, float* out, int num_streams, hipStream_t s,
                                  unsigned* seq, unsigned* abort_w, unsigned want, int steps, int slot0, int ring,
-                                 size_t per) {
+                                 size_t per, unsigned long long* stamps) {
   const int gx = ((num_streams + 3) / 4 + 7) / 8 * 8;
   const dim3 grid(gx, steps), block(256);
   const NsFlowArgs fa = {seq, abort_w, want, slot0, ring, (unsigned)per};
   if (io16)
     hipLaunchKernelGGL((ns_frame1_kernel<true, true>), grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, (unsigned long long*)nullptr, 0, fa);
+                       num_streams, stamps, 0, fa);
   else
     hipLaunchKernelGGL((ns_frame1_kernel<false, true>), grid, block, 0, s, state, hist, T, in, out,
-                       num_streams, (unsigned long long*)nullptr, 0, fa);
+                       num_streams, stamps, 0, fa);
   return hipGetLastError();
 }
 

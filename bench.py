@@ -342,6 +342,16 @@ def _secondary(args, workload, cpu_baseline=True):
         return {"workload": workload, "error": str(e)[:300]}
 
 
+FLOW_MAX_STEPS = 64  # kFlowMaxSteps of ns_api.hip: frame steps per launch of the hand-off build
+
+
+def flow_active(args):
+    """Does the K-step timed region run the hand-off build?  (ns_api.hip, flow_applies)"""
+    if args.flow == "off" or (args.flow == "auto" and os.environ.get("ASP_NS_FLOW", "1")[:1] == "0"):
+        return False
+    return args.steps >= 2 and (args.kernel or 3) == 3 and not args.graph
+
+
 def ns_measure(args, S, rank, world, local_rank, dist):
     """Prime + warm up + time the fused NS frame step of S streams on this rank.  Returns the
     per-region hipEvent and wall times (seconds, length R) of `args.steps` steps each."""
@@ -362,6 +372,7 @@ def ns_measure(args, S, rank, world, local_rank, dist):
     ns.set_graph(args.graph)
     if args.split > 1:
         ns.set_split(args.split)
+    ns.set_flow({"auto": -1, "off": 0, "on": 1}[args.flow])
 
     def barrier():
         torch.cuda.synchronize()
@@ -443,7 +454,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) plain kernel launches")
     ap.add_argument("--secondary-steps", type=int, default=1000)
     ap.add_argument("--secondary-warmup", type=int, default=250)
-    ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4)")
+    ap.add_argument("--split", type=int, default=2, help="sub-launches per fused step (1..4) of the plain build (--flow off)")
+    ap.add_argument("--flow", default="auto", choices=["auto", "off", "on"],
+                    help="hand-off build of the K-step region (include/asp_ns.h, AspNsBatch_SetFlow): up to 64 frame steps per "
+                         "launch, a per-stream step counter in memory orders a stream's consecutive steps; auto = the library's "
+                         "default (on; ASP_NS_FLOW=0 turns it off)")
     ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 3],
                     help="fused-step kernel: 0 / 3 = one stream per wave, pair layout (ns_kernels1.hip, the default), "
                          "1 = one stream per wave, bins q / q + 64 (ns_kernels.hip)")
@@ -495,7 +510,10 @@ def main():
         step_s = float(np.median(ev)) / K            # THE clock of this line: hipEvents over the K-step region
         frames_per_region = S * world * args.steps
         achieved = ALGO_BYTES_PER_FRAME * S / step_s / 1e9
-        kernel = {1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false>"}[args.kernel or 3]
+        flow = flow_active(args)
+        steps_per_launch = min(max(args.steps, 1), FLOW_MAX_STEPS) if flow else 1
+        conc = 1 if flow else args.split
+        kernel = {1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false, true>" if flow else "ns_frame1_kernel<false, false>"}[args.kernel or 3]
         line = {
             "metric": "audio frames/sec (10 ms @16 kHz) Wiener NS",
             "value": frames_per_region / (step_s * K),
@@ -512,13 +530,16 @@ def main():
             "config": {
                 "workload": "WebRTC NS (test_ns_module): 10 ms/16 kHz frames, %d concurrent mono "
                             "streams per MI355X (%d in total on %d GPU%s), policy 1, Analyze+Process fused, "
-                            "frame-synchronous (1 launch per frame and sub-launch)"
-                            % (S, S * world, world, "" if world == 1 else "s"),
+                            "frame-synchronous (every step reads and writes the whole state through memory; %s)"
+                            % (S, S * world, world, "" if world == 1 else "s",
+                               "hand-off build: %d frame steps per launch, a stream's consecutive steps ordered by a "
+                               "step counter in memory" % steps_per_launch if flow else "1 launch per frame and sub-launch"),
                 "streams_per_gpu": S,
                 "total_streams": S * world,
                 "input_ring_frames": args.ring,
                 "primed_frames_in_setup": primed,
-                "sub_launches_per_step": args.split,
+                "sub_launches_per_step": conc,
+                "frame_steps_per_launch": steps_per_launch,
                 "launch": ("hipGraph replay (one linear graph per chain, kernel nodes only)" if args.graph else "plain launches"),
                 "parallelism": "stream-sharded x%d, no collectives" % world,
             },
@@ -542,18 +563,19 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (PMC_TRAFFIC_BYTES_PER_FRAME_PAIR if (args.kernel or 3) == 3 else PMC_TRAFFIC_BYTES_PER_FRAME) * S,
+                "traffic": (PMC_TRAFFIC_BYTES_PER_FRAME_PAIR if (args.kernel or 3) == 3 else PMC_TRAFFIC_BYTES_PER_FRAME) * S * steps_per_launch,
                 "traffic_source": "stored constant for the kernel named in this line: PMC passes kept under "
-                                  "profiles/r03_ns_traffic.txt (FETCH_SIZE / WRITE_SIZE in separate passes, reads "
-                                  "calibrated at 32768 streams; not measured in this run), per frame step of all streams",
+                                  "profiles/r04_ns_traffic.txt (FETCH_SIZE / WRITE_SIZE in separate passes, reads "
+                                  "calibrated at 32768 streams; not measured in this run), per launch",
                 "kernel": kernel,
                 # one frame step = `concurrent_launches` launches of this kernel side by side (one per HIP
                 # stream, S / concurrent_launches streams each); achieved = algorithmic bytes of the step /
                 # ms_per_step of this line
-                "concurrent_launches": args.split,
+                "concurrent_launches": conc,
+                "frame_steps_per_launch": steps_per_launch,
                 "algorithmic_bytes_per_step": ALGO_BYTES_PER_FRAME * S,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * S // max(args.split, 1),
-                "avg_launch_us": step_s * 1e6,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * S * steps_per_launch // max(conc, 1),
+                "avg_launch_us": step_s * 1e6 * steps_per_launch,
             },
         }
         if world == 1:
