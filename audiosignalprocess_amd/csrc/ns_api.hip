@@ -826,8 +826,13 @@ static int flow_steps(AspNsBatch* b, const float* din, float* dout, int ring, in
   int rc = flow_resources(b);
   if (rc) return rc;
   const size_t per = (size_t)b->S * b->block / (io16 ? 2 : 1);
-  for (int k = 0; k < steps; k += kFlowMaxSteps) {
-    const int m = steps - k < kFlowMaxSteps ? steps - k : kFlowMaxSteps;
+  int maxm = kFlowMaxSteps;
+  if (const char* e = getenv("ASP_NS_FLOW_MAX")) {  // tuning: frame steps per launch
+    const int v = atoi(e);
+    if (v >= 2 && v <= kFlowMaxSteps) maxm = v;
+  }
+  for (int k = 0; k < steps; k += maxm) {
+    const int m = steps - k < maxm ? steps - k : maxm;
     HIP_TRY(launch_ns_frame1_flow(io16, b->state, b->hist, b->tables, din, dout, b->S, b->stream, b->flow_seq,
                                   b->flow_abort, b->flow_count, m, k % ring, ring, per, b->flow_stamps));
     b->flow_count += (unsigned)m;

@@ -49,6 +49,10 @@ AEC_TRAFFIC_BYTES_PER_FRAME = (2 * 33.4001 + 32.9825) * 1024
 # reports exactly.  The one-stream kernel of the two-call protocol keeps its round-1 constant.
 PMC_TRAFFIC_BYTES_PER_FRAME = (4.832 * 1.638 + 9.158 / 1.09) * 1024      # ns_frame_kernel<true,true>
 PMC_TRAFFIC_BYTES_PER_FRAME_PAIR = 7808 * (3.8648 / 3.8233) + 7.21875 * 1024
+# the hand-off build ns_frame1_kernel<false, true> (profiles/r04_ns_traffic.txt): FETCH_SIZE 3.6010 KB per stream-frame at
+# 4096 streams against 3.8292 KB at 32768 streams, where every one of the kernel's 7 808 read bytes is HBM traffic;
+# WRITE_SIZE 7.2567 KB (7 392 B of state and samples, the step counter, partial lines)
+PMC_TRAFFIC_BYTES_PER_FRAME_FLOW = 7808 * (3.6010 / 3.8292) + 7.2567 * 1024
 NS_PRIME_FRAMES = 250  # untimed set-up frames + warm-up >= this (start-up phase of ns_core.c is 200)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -385,8 +389,9 @@ def ns_measure(args, S, rank, world, local_rank, dist):
     # the steady state of a long-running stream; the W warm-up steps then follow as asked
     primed = max(0, NS_PRIME_FRAMES - args.warmup)
     done = 0
+    chunk = min(ring, max(args.steps, 2))   # launches of the timed region's shape (hand-off build: K steps per launch)
     while done < primed:
-        n = min(ring, primed - done)
+        n = min(chunk, primed - done)
         ns.analyze_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
         done += n
     barrier()
@@ -563,7 +568,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (PMC_TRAFFIC_BYTES_PER_FRAME_PAIR if (args.kernel or 3) == 3 else PMC_TRAFFIC_BYTES_PER_FRAME) * S * steps_per_launch,
+                "traffic": (PMC_TRAFFIC_BYTES_PER_FRAME_FLOW if flow else PMC_TRAFFIC_BYTES_PER_FRAME_PAIR if (args.kernel or 3) == 3
+                            else PMC_TRAFFIC_BYTES_PER_FRAME) * S * steps_per_launch,
                 "traffic_source": "stored constant for the kernel named in this line: PMC passes kept under "
                                   "profiles/r04_ns_traffic.txt (FETCH_SIZE / WRITE_SIZE in separate passes, reads "
                                   "calibrated at 32768 streams; not measured in this run), per launch",
