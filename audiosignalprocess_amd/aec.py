@@ -1,6 +1,7 @@
 """Python mirror of the batched echo-canceller C-ABI (include/asp_aec.h) over ctypes.
 Plumbing only -- every call goes into libasp_amd.so; no CPU fallback."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -40,11 +41,14 @@ def _lib():
             "AspAecBatch_ImportState": [vp, ip, C.POINTER(AspAecState)],
             "AspAecBatch_GetControl": [vp, C.POINTER(AspAecControl)],
             "AspAecBatch_Synchronize": [vp],
+            "AspAecBatch_SetFlow": [vp, ip],
             "AspAecBatch_TimedSteps": [vp, vp, vp, vp, ip, ip, ip, C.POINTER(C.c_float)],
             "AspAec_rdft128_batch": [vp, vp, ip, ip, ip],
             "AspAec_host_table": [ip, vp, ip],
         }
         for name, args in sig.items():
+            if os.environ.get("ASP_AMD_LIB") and not hasattr(lib, name):
+                continue  # an earlier build of the library loaded for a same-box A / B run (build.py)
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = C.c_int
@@ -161,6 +165,10 @@ class AecBatch:
 
     def synchronize(self):
         _check(self.lib.AspAecBatch_Synchronize(self.h), "AspAecBatch_Synchronize")
+
+    def set_flow(self, mode):
+        """Hand-off build of run() / timed_steps(): -1 default, 0 off, 1 on (include/asp_aec.h)."""
+        _check(self.lib.AspAecBatch_SetFlow(self.h, mode), "AspAecBatch_SetFlow")
 
     def export_state(self, stream):
         st = AspAecState()

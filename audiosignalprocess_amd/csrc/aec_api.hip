@@ -31,6 +31,9 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               hipStream_t s, unsigned long long* stamps = nullptr, int stream0 = 0,
                               int stream_end = -1, int num_part = kNumPartNormal, float* spectra = nullptr,
                               const DelayBlock* dblocks = nullptr);
+hipError_t launch_aec_process_flow(float* state, float* far_ring, const AecTables* T, int num_streams, int nrOfSamples,
+                                   const AecFlowStep* descs, int steps, unsigned* seq, unsigned* abort_w, unsigned want,
+                                   int num_part, hipStream_t s);
 hipError_t launch_aec_delay(DelayBlock* blocks, const float* spectra, int num_streams, const DelayOps& ops,
                             hipStream_t s);
 hipError_t launch_aec_resample(float* rs_buffer, const float* farend, float* out, int num_streams, int size, int size_out,
@@ -238,6 +241,21 @@ struct AspAecBatch {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool dual = false;  // set only inside the K-step path
+  // Hand-off build of the multi-frame entry points (Run on device buffers, TimedSteps; aec_kernels.hip,
+  // AecFlowArgs): while flow_rec is set the Process launches are not issued one by one but recorded as
+  // descriptors; up to kAecFlowMaxSteps of them go into ONE launch (grid y = step), in which a per-stream step
+  // counter in memory orders a stream's consecutive steps.  -1 = default (on), 0 = off, 1 = on.
+  int flow = -1;
+  bool flow_rec = false;
+  int flow_n = 0, flow_nr = 0;               // descriptors recorded so far; samples per call of the recording
+  int flow_slot = 0;                         // ring of descriptor arrays: host (pinned) and device copies
+  AecFlowStep* flow_host = nullptr;          // [kAecFlowSlots][kAecFlowMaxSteps]
+  AecFlowStep* flow_dev = nullptr;
+  hipEvent_t flow_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // slot i's launch has consumed its descriptors
+  unsigned* flow_seq = nullptr;              // [S] completed hand-off steps per stream (== flow_count between calls)
+  unsigned* flow_abort = nullptr;            // 16 B: word 0 != 0 after a wait timed out
+  unsigned flow_count = 0;
+  bool flow_unchecked = false;
   // Aec (echo_cancellation_internal.h:17-65)
   int sampFreq = 0, scSampFreq = 0, splitSampFreq = 0, rate_factor = 0, initFlag = 0, lastError = 0;
   int farend_started = 0, skewMode = 0;
@@ -313,8 +331,87 @@ int estimate_skew(const int* rawSkew, int size, int deviceSampleRateHz, float* s
 }  // namespace
 
 namespace {
+constexpr int kAecFlowMaxSteps = 64, kAecFlowSlots = 4;
+
+bool aec_flow_default() {
+  const char* e = getenv("ASP_AEC_FLOW");
+  return !(e && e[0] == '0');
+}
+// The hand-off build serves the plain configuration: one band, reported delays, no delay logging, no skew
+// compensation, no metrics (the optional modes add launches of their own between the Process launches).
+bool aec_flow_applies(const AspAecBatch* b, int steps) {
+  const bool on = b->flow < 0 ? aec_flow_default() : b->flow != 0;
+  // default: the 12-partition filter only (measured, profiles/README.md round 4: 101.5 us against 103.8 us per
+  // 4096-stream frame with one launch per call; the extended filter's 32 partitions 190 us against 185.5 us)
+  if (b->flow < 0 && b->extended) return false;
+  return on && steps >= 2 && !b->sim && b->num_high == 0 && !b->metricsMode && !b->delay_logging &&
+         b->reported_delay_enabled && !b->skewMode && b->debug_stamps == nullptr;
+}
+int aec_flow_resources(AspAecBatch* b) {
+  if (b->flow_seq) return 0;
+  AEC_TRY(hipMalloc((void**)&b->flow_seq, (size_t)b->S * sizeof(unsigned)));
+  AEC_TRY(hipMalloc((void**)&b->flow_abort, 16));
+  AEC_TRY(hipMemsetAsync(b->flow_seq, 0, (size_t)b->S * sizeof(unsigned), b->stream));
+  AEC_TRY(hipMemsetAsync(b->flow_abort, 0, 16, b->stream));
+  AEC_TRY(hipHostMalloc((void**)&b->flow_host, sizeof(AecFlowStep) * kAecFlowSlots * kAecFlowMaxSteps, hipHostMallocDefault));
+  AEC_TRY(hipMalloc((void**)&b->flow_dev, sizeof(AecFlowStep) * kAecFlowSlots * kAecFlowMaxSteps));
+  for (int i = 0; i < kAecFlowSlots; ++i) AEC_TRY(hipEventCreateWithFlags(&b->flow_ev[i], hipEventDisableTiming));
+  b->flow_count = 0;
+  b->flow_slot = 0;
+  return 0;
+}
+// issue the recorded steps as one launch
+int aec_flow_flush(AspAecBatch* b) {
+  if (b->flow_n == 0) return 0;
+  const int slot = b->flow_slot;
+  AecFlowStep* h = b->flow_host + (size_t)slot * kAecFlowMaxSteps;
+  AecFlowStep* d = b->flow_dev + (size_t)slot * kAecFlowMaxSteps;
+  const int n = b->flow_n;
+  b->flow_n = 0;
+  AEC_TRY(hipMemcpyAsync(d, h, sizeof(AecFlowStep) * n, hipMemcpyHostToDevice, b->stream));
+  AEC_TRY(launch_aec_process_flow(b->state, b->far_ring, b->tables, b->S, b->flow_nr, d, n, b->flow_seq, b->flow_abort,
+                                  b->flow_count, b->num_part, b->stream));
+  AEC_TRY(hipEventRecord(b->flow_ev[slot], b->stream));
+  b->flow_count += (unsigned)n;
+  b->flow_unchecked = true;
+  b->flow_slot = (slot + 1) % kAecFlowSlots;
+  // the next slot's previous launch must have read its descriptors before they are overwritten
+  AEC_TRY(hipEventSynchronize(b->flow_ev[b->flow_slot]));
+  return 0;
+}
+int aec_flow_record(AspAecBatch* b, const float* near_dev, float* out_dev, int n, const ProcOps& ops, const float* far_src,
+                    const FarOps& fops) {
+  if (b->flow_n > 0 && b->flow_nr != n) {  // a launch carries calls of one length
+    const int rc = aec_flow_flush(b);
+    if (rc != 0) return rc;
+  }
+  b->flow_nr = n;
+  AecFlowStep& st = b->flow_host[(size_t)b->flow_slot * kAecFlowMaxSteps + b->flow_n++];
+  memset(&st, 0, sizeof st);
+  st.ops = ops;
+  st.fops = fops;
+  st.farend = far_src;
+  st.nearend = near_dev;
+  st.out = out_dev;
+  if (b->flow_n == kAecFlowMaxSteps) return aec_flow_flush(b);
+  return 0;
+}
+// after the batch's stream has been synchronised: did a hand-off wait time out?
+int aec_flow_check(AspAecBatch* b) {
+  if (!b->flow_unchecked) return 0;
+  b->flow_unchecked = false;
+  unsigned a = 0;
+  AEC_TRY(hipMemcpy(&a, b->flow_abort, sizeof a, hipMemcpyDeviceToHost));
+  if (a == 0) return 0;
+  std::vector<unsigned> seq((size_t)b->S, b->flow_count);
+  AEC_TRY(hipMemcpy(b->flow_seq, seq.data(), seq.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  AEC_TRY(hipMemset(b->flow_abort, 0, 16));
+  return aec_fail(ASP_ERR_HIP, "AEC hand-off wait timed out: frame steps were skipped, re-initialise the batch");
+}
+
 // every device launch of a batch goes through these two: one launch, or one per half on the two chains
 hipError_t batch_launch_farend(AspAecBatch* b, const float* far_dev, const FarOps& ops) {
+  if (b->flow_rec && aec_flow_flush(b) != 0) return hipErrorUnknown;  // a launch of its own: after the recorded steps
   if (!b->dual) return launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream, 0, -1, b->num_part);
   const int half = ((b->S / 2 + 3) / 4) * 4;
   hipError_t e = launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream, 0, half, b->num_part);
@@ -325,6 +422,7 @@ hipError_t batch_launch_farend(AspAecBatch* b, const float* far_dev, const FarOp
 hipError_t batch_launch_process(AspAecBatch* b, const float* near_dev, float* out_dev, int n, const ProcOps& ops,
                                 const float* far_src, const FarOps& fops, const float* near_high, float* out_high,
                                 float* metrics, unsigned long long* stamps) {
+  if (b->flow_rec) return aec_flow_record(b, near_dev, out_dev, n, ops, far_src, fops) == 0 ? hipSuccess : hipErrorUnknown;
   if (!b->dual)
     return launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops, near_high,
                               out_high, metrics, b->stream, stamps, 0, -1, b->num_part, b->spectra, b->dblocks);
@@ -858,7 +956,8 @@ int process_normal_device(AspAecBatch* b, const float* near_dev, float* out_dev,
   }
   if (b->startup_phase) {
     {
-      const int rc = flush_pending_farend(b);
+      int rc = flush_pending_farend(b);
+      if (rc == 0 && b->flow_rec) rc = aec_flow_flush(b);  // the pass-through copies below follow the recorded steps
       if (rc != 0) return rc;
     }
     if (near_dev != out_dev && !b->sim)
@@ -950,6 +1049,10 @@ int process_extended_device(AspAecBatch* b, const float* near_dev, float* out_de
   reported_delay_ms = reported_delay_ms >= kMaxTrustedDelayMs ? kFixedDelayMs : reported_delay_ms;
   b->msInSndCardBuf = reported_delay_ms;
   if (!b->farend_started) {  // pass the near end through until the far end starts (:768-776)
+    if (b->flow_rec) {
+      const int rc = aec_flow_flush(b);
+      if (rc != 0) return rc;
+    }
     if (near_dev != out_dev && !b->sim)
       AEC_TRY(hipMemcpyAsync(out_dev, near_dev, (size_t)b->S * n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
     if (b->num_high > 0 && b->cur_near_high != b->cur_out_high && !b->sim)
@@ -1085,6 +1188,12 @@ int AspAecBatch_Free(AspAecBatch* b) {
   if (b->rs_buffer) (void)hipFree(b->rs_buffer);
   if (b->stage_rs) (void)hipFree(b->stage_rs);
   if (b->spectra) (void)hipFree(b->spectra);
+  if (b->flow_seq) (void)hipFree(b->flow_seq);
+  if (b->flow_abort) (void)hipFree(b->flow_abort);
+  if (b->flow_dev) (void)hipFree(b->flow_dev);
+  if (b->flow_host) (void)hipHostFree(b->flow_host);
+  for (int i = 0; i < 4; ++i)
+    if (b->flow_ev[i]) (void)hipEventDestroy(b->flow_ev[i]);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->side) {
@@ -1361,11 +1470,17 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
         err = aec_fail(ASP_ERR_HIP, "Run: upload", e);
         break;
       }
+      if (aec_flow_applies(b, nf) && aec_flow_resources(b) == 0) b->flow_rec = true;
       for (int f = 0; f < nf && err == 0; ++f) {
         int rc = 0;
         err = buffer_farend_device(b, dfar + per * f, nrOfSamples, true);
         if (err == 0) err = process_device(b, dnear + per * f, dout + per * f, nrOfSamples, msInSndCardBuf, &rc);
         rc_all |= rc;
+      }
+      if (b->flow_rec) {
+        b->flow_rec = false;
+        if (err == 0) err = aec_flow_flush(b);
+        b->flow_n = 0;
       }
       if (err == 0) {
         e = hipMemcpyAsync(out + per * f0, dout, per * nf * sizeof(float), hipMemcpyDeviceToHost, b->stream);
@@ -1374,18 +1489,33 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
       }
     }
     (void)hipStreamSynchronize(b->stream);
+    if (err == 0) err = aec_flow_check(b);
     if (dfar) (void)hipFree(dfar);
     if (dnear) (void)hipFree(dnear);
     if (dout) (void)hipFree(dout);
     if (err != 0) return err;
     return rc_all;
   }
+  if (aec_flow_applies(b, num_frames)) {
+    const int rcf = aec_flow_resources(b);
+    if (rcf != 0) return rcf;
+    b->flow_rec = true;
+  }
   for (int f = 0; f < num_frames; ++f) {
     int rc = 0;
     int err = buffer_farend_device(b, farend + per * f, nrOfSamples, true);
     if (err == 0) err = process_device(b, nearend + per * f, out + per * f, nrOfSamples, msInSndCardBuf, &rc);
-    if (err != 0) return err;
+    if (err != 0) {
+      b->flow_rec = false;
+      b->flow_n = 0;
+      return err;
+    }
     rc_all |= rc;
+  }
+  if (b->flow_rec) {
+    b->flow_rec = false;
+    const int rcf = aec_flow_flush(b);
+    if (rcf != 0) return rcf;
   }
   return rc_all;
 }
@@ -1402,7 +1532,12 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
   // two chains when the batch is large enough to fill the chip twice over and past its start-up phase
   // (whose pass-through copies stay on the main stream); ASP_AEC_CHAINS=1 keeps one
   const char* ch = getenv("ASP_AEC_CHAINS");
-  const bool dual = b->S >= 2048 && !b->startup_phase && !(ch && atoi(ch) == 1) && !b->delay_logging && b->reported_delay_enabled && !b->skewMode;
+  const bool flow = aec_flow_applies(b, steps);
+  if (flow) {
+    const int rcf = aec_flow_resources(b);
+    if (rcf != 0) return rcf;
+  }
+  const bool dual = !flow && b->S >= 2048 && !b->startup_phase && !(ch && atoi(ch) == 1) && !b->delay_logging && b->reported_delay_enabled && !b->skewMode;
   if (dual && !b->side) {
     AEC_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     AEC_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -1415,11 +1550,17 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
     b->dual = true;
   }
   int err = 0;
+  b->flow_rec = flow;
   for (int k = 0; k < steps && err == 0; ++k) {
     const size_t off = per * (size_t)(k % frames_in_ring);
     int rc = 0;
     err = buffer_farend_device(b, farend + off, nrOfSamples, true);
     if (err == 0) err = process_device(b, nearend + off, out + off, nrOfSamples, 0, &rc);
+  }
+  if (flow) {
+    b->flow_rec = false;
+    if (err == 0) err = aec_flow_flush(b);
+    b->flow_n = 0;
   }
   if (dual) {
     b->dual = false;
@@ -1430,7 +1571,7 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
   AEC_TRY(hipEventRecord(b->ev1, b->stream));
   AEC_TRY(hipEventSynchronize(b->ev1));
   AEC_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
-  return ASP_OK;
+  return aec_flow_check(b);
 }
 
 int AspAecBatch_Synchronize(AspAecBatch* b) {
@@ -1438,6 +1579,12 @@ int AspAecBatch_Synchronize(AspAecBatch* b) {
   if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
   AEC_TRY(hipSetDevice(b->device));
   AEC_TRY(hipStreamSynchronize(b->stream));
+  return aec_flow_check(b);
+}
+
+int AspAecBatch_SetFlow(AspAecBatch* b, int mode) {
+  if (!b || mode < -1 || mode > 1) return aec_fail(ASP_ERR_PARAM, "SetFlow: -1 (default), 0 (off) or 1 (on)");
+  b->flow = mode;
   return ASP_OK;
 }
 

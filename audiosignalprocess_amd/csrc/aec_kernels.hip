@@ -386,12 +386,124 @@ __device__ __forceinline__ int ring_idx(int pos, int i, int count) {
   return p;
 }
 
+// The stream's state block through a buffer resource: one descriptor in SGPRs, the row offset as the
+// scalar offset, the lane's dword as the only vector offset.  (With flat global addressing the compiler
+// kept a 64-bit VGPR address per state row alive across the whole block: 100 registers.)
+// AUX: the cache-policy operand of every access through the descriptor: 0, or kSc1 in the hand-off build (below).
+constexpr int kSc1 = 16;
+template <int AUX>
+struct StateBufT {
+  __amdgpu_buffer_rsrc_t r;
+};
+using StateBuf = StateBufT<0>;
+template <int AUX = 0>
+__device__ __forceinline__ StateBufT<AUX> state_buf(const float* st, int dwords) {
+  StateBufT<AUX> b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st), 0, dwords * 4, 0x00020000);
+  return b;
+}
+// dword `uni + vec` of the block: uni wave-uniform, vec per lane
+template <int AUX>
+__device__ __forceinline__ float sld(const StateBufT<AUX>& b, int uni, int vec) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, vec * 4, uni * 4, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void sst(const StateBufT<AUX>& b, int uni, int vec, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, vec * 4, uni * 4, AUX);
+}
+
+// ---- the hand-off build (FLOW): consecutive frame steps overlap on the chip (the scheme of ns_kernels1.hip).
+// One launch carries M consecutive WebRtcAec_Process calls (each with the BufferFarend call before it) of the
+// whole batch: blockIdx.y is the step, its descriptor steps[blockIdx.y] sits in device memory.  Workgroups are
+// dispatched in linear order (x fastest), so the wave that takes stream s in step j + 1 may wait for the one
+// that has stream s in step j: it is resident or done.  The hand-off is a word in memory: seq[s] = k + 1 stored
+// by the wave that finished stream s of step k, its stores drained first; polled by the wave of step k + 1
+// before its first access to the stream's state or far-ring slots.  Every access to what a stream's steps hand
+// each other -- the state block and the far ring -- is an sc1 access (write-through stores, L1-bypassing loads;
+// MI355X_MICROARCH.md, visibility).  Frames in / out and the tables are plain.  The wait is bounded: a wave that
+// gives up sets the abort word, which every later wait sees (aec_api.hip reports it).
+struct AecFlowArgs {
+  const AecFlowStep* steps;  // [gridDim.y]
+  unsigned* seq;             // [num_streams]: hand-off steps stream s has completed
+  unsigned* abort_w;         // != 0: a wait timed out (1 + stream)
+  unsigned want;             // blockIdx.y == 0 is step `want` of every stream
+};
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ bool flow_wait(const AecFlowArgs& fa, unsigned want, int stream, int lane) {
+  const gu32* f = (const gu32*)(fa.seq + stream);
+  unsigned spins = 0;
+  for (;;) {
+    const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) == want) break;
+    ++spins;
+    if ((spins & 63u) == 0u) {
+      const unsigned a = __hip_atomic_load((const gu32*)fa.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__builtin_amdgcn_readfirstlane((int)a) != 0) return false;
+    }
+    if (spins > (1u << 17)) {
+      if (lane == 0) __hip_atomic_store((gu32*)fa.abort_w, 1u + (unsigned)stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the state loads below the poll
+  return true;
+}
+
+// The same into rows `re` / `im` (dword offsets) of a block behind a descriptor.
+template <int AUX>
+__device__ __forceinline__ void unpack_tile_buf(float* wl, int f, const StateBufT<AUX>& b, int re, int im, int lane) {
+  const float2 v = tile(wl, f)[lane];
+  if (lane == 0) {
+    sst(b, re, 0, v.x);
+    sst(b, im, 0, 0.f);
+    sst(b, re, 64, v.y);
+    sst(b, im, 64, 0.f);
+  } else {
+    sst(b, re, lane, v.x);
+    sst(b, im, lane, v.y);
+  }
+}
+
 // ------------------------------------------------------------------ far end
 // The far-end work of one WebRtcAec_BufferFarend call for this wave's stream.
+template <bool FLOW = false, class OPS = FarOps>
 __device__ __forceinline__ void farend_work(float* __restrict__ st, float* __restrict__ far_ring,
                                             float* __restrict__ wl, const SharedTables& T,
                                             const float* __restrict__ farend, int num_streams,
-                                            int stream, const FarOps& ops, int lane) {
+                                            int stream, const OPS& ops, int lane, int state_dwords = 0) {
+  if constexpr (FLOW) {
+    // the hand-off build: far_pre and the far-ring slots through descriptors, every access sc1
+    const StateBufT<kSc1> sb = state_buf<kSc1>(st, state_dwords);
+    for (int i = lane; i < ops.n; i += 64) sst(sb, kOffPre, ring_idx(ops.wpos, i, kPreLen), farend[(size_t)stream * ops.n + i]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int p = 0; p < ops.nparts; p += 2) {
+      const int np = ops.nparts - p < 2 ? ops.nparts - p : 2;  // wave-uniform
+      for (int q = 0; q < np; ++q) {
+        float* t0 = reinterpret_cast<float*>(tile(wl, 2 * q));
+        float* t1 = reinterpret_cast<float*>(tile(wl, 2 * q + 1));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = lane + 64 * h;
+          const float x = sld(sb, kOffPre, ring_idx(ops.rpos[p + q], i, kPreLen));
+          t0[i] = x;
+          t1[i] = x * (h == 0 ? T.hann[i] : T.hann[128 - i]);
+        }
+      }
+      wave_fence();
+      rdft_fwd_quad(wl, lane, T);
+      for (int q = 0; q < np; ++q) {
+        const StateBufT<kSc1> fb =
+            state_buf<kSc1>(far_ring + ((size_t)ops.slot[p + q] * num_streams + stream) * kFarSlotDwords, kFarSlotDwords);
+        unpack_tile_buf(wl, 2 * q, fb, 0, kRow, lane);
+        unpack_tile_buf(wl, 2 * q + 1, fb, 2 * kRow, 3 * kRow, lane);
+      }
+      wave_fence();
+    }
+    return;
+  }
   float* pre = st + kOffPre;
   for (int i = lane; i < ops.n; i += 64) pre[ring_idx(ops.wpos, i, kPreLen)] = farend[(size_t)stream * ops.n + i];
   // the partitions below read samples other lanes of this wave just wrote: order them (same CU,
@@ -629,30 +741,11 @@ __device__ __forceinline__ float set_lane(float row, int bits) {
   return __int_as_float(r);
 }
 
-// The stream's state block through a buffer resource: one descriptor in SGPRs, the row offset as the
-// scalar offset, the lane's dword as the only vector offset.  (With flat global addressing the compiler
-// kept a 64-bit VGPR address per state row alive across the whole block: 100 registers.)
-struct StateBuf {
-  __amdgpu_buffer_rsrc_t r;
-};
-__device__ __forceinline__ StateBuf state_buf(float* st, int dwords) {
-  StateBuf b;
-  b.r = __builtin_amdgcn_make_buffer_rsrc(st, 0, dwords * 4, 0x00020000);
-  return b;
-}
-// dword `uni + vec` of the block: uni wave-uniform, vec per lane
-__device__ __forceinline__ float sld(const StateBuf& b, int uni, int vec) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, vec * 4, uni * 4, 0));
-}
-__device__ __forceinline__ void sst(const StateBuf& b, int uni, int vec, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, vec * 4, uni * 4, 0);
-}
-
 // NP = 12 partitions, or 32: the extended filter (aec_core_internal.h:23-25, WebRtcAec_enable_delay_correction)
-template <bool kMetrics, int NP>
+template <bool kMetrics, int NP, bool FLOW = false, class BLOCKOP = BlockOp>
 __device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
                                               const float* __restrict__ far_slot,
-                                              const SharedTables& T, const BlockOp& op, int mult,
+                                              const SharedTables& T, const BLOCKOP& op, int mult,
                                               int nlp_mode, float mu, float error_threshold,
                                               int lane, const double* __restrict__ exp2_global,
                                               int num_high, float* __restrict__ met,
@@ -668,7 +761,8 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   constexpr bool kExtended = NP == kNumPartMax;
   constexpr int kC64Chunks = (R_COUNT + 63) / 64, kC64Lds = lds_c64_len(NP);
   static_assert(R_COUNT <= kC64Lds, "bin-64 column in LDS");
-  const StateBuf sb = state_buf(st, RW.state_dwords);
+  constexpr int kAux = FLOW ? kSc1 : 0;
+  const StateBufT<kAux> sb = state_buf<kAux>(st, RW.state_dwords);
   // the stream's 32 scalars: one row load, lane k holds scalar k (wave-uniform values read with v_readlane),
   // one row store at the end -- a scalar address apiece had cost an SGPR pair each across the block loop
   float scrow = sld(sb, kOffScalars, lane & 31);
@@ -719,10 +813,19 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #pragma unroll
   for (int k = 0; k < kC64Chunks; ++k) c64_in[k] = sld(sb, kOffC64 + 64 * k, lane);  // the column is padded to 256
   float fs_lane[4], fs_64[4];  // this block's far spectra (plain re/im, windowed re/im)
+  if constexpr (FLOW) {
+    const StateBufT<kSc1> fb = state_buf<kSc1>(far_slot, kFarSlotDwords);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    fs_lane[k] = far_slot[k * kRow + lane];
-    fs_64[k] = far_slot[k * kRow + 64];
+    for (int k = 0; k < 4; ++k) {
+      fs_lane[k] = sld(fb, k * kRow, lane);
+      fs_64[k] = sld(fb, k * kRow + 64, 0);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      fs_lane[k] = far_slot[k * kRow + lane];
+      fs_64[k] = far_slot[k * kRow + 64];
+    }
   }
   // ---- near block (aec_core.c:1114-1124) and the far spectra of this block (:1137, 888-891)
   const float ne = sld(sb, kOffNearFr, ring_idx(op.near_rpos, lane, kFrBufLen));
@@ -1357,8 +1460,83 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 #undef SC_SETF
 }
 
-// WebRtcAec_ProcessFrames for every stream (running phase): per 80-sample sub-frame append the
-// near samples, run the scheduled blocks, emit 80 output samples.
+// One WebRtcAec_Process call of one stream (running phase), after the far-end work that precedes it: per
+// 80-sample sub-frame append the near samples, run the scheduled blocks, emit 80 output samples.  OPS / FOPS:
+// the call's descriptors, in the kernel's arguments (plain build) or in device memory (hand-off build).
+template <bool kMetrics, int NP, bool FLOW, class OPS, class FOPS>
+__device__ __forceinline__ void process_call(float* __restrict__ st, float* far_ring, float* __restrict__ wl,
+                                             const SharedTables& T, const AecTables* __restrict__ G,
+                                             const float* __restrict__ nin, float* __restrict__ o, int num_streams,
+                                             int nrOfSamples, int stream, int lane, const OPS& ops,
+                                             const float* __restrict__ farend, const FOPS& fops,
+                                             const float* near_high, float* out_high, float* met,
+                                             unsigned long long* __restrict__ stamps, float* spectra,
+                                             const DelayBlock* dblocks) {
+  constexpr int kAux = FLOW ? kSc1 : 0;
+  constexpr int kDwords = AecRows(NP).state_dwords;
+  [[maybe_unused]] const StateBufT<kAux> sb = state_buf<kAux>(st, kDwords);
+  if (farend != nullptr) {
+    // the WebRtcAec_BufferFarend call that preceded this Process call, fused into the launch
+    farend_work<FLOW>(st, far_ring, wl, T, farend, num_streams, stream, fops, lane, kDwords);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  int blk = 0;  // blocks of this launch so far
+  for (int s = 0; s < ops.nsub; ++s) {
+    const auto& sf = ops.sub[s];
+    // near samples of this sub-frame are read into registers first: `out` may alias `nearend`
+    const float n0 = nin[80 * s + lane];
+    const float n1 = lane < 16 ? nin[80 * s + 64 + lane] : 0.f;
+    if constexpr (FLOW) {
+      sst(sb, kOffNearFr, ring_idx(sf.near_wpos, lane, kFrBufLen), n0);
+      if (lane < 16) sst(sb, kOffNearFr, ring_idx(sf.near_wpos, 64 + lane, kFrBufLen), n1);
+    } else {
+      st[kOffNearFr + ring_idx(sf.near_wpos, lane, kFrBufLen)] = n0;
+      if (lane < 16) st[kOffNearFr + ring_idx(sf.near_wpos, 64 + lane, kFrBufLen)] = n1;
+    }
+    if (!FLOW && ops.num_high > 0) {  // the high band's frame into its ring (aec_core.c:1691-1693)
+      const float* hin = near_high + (size_t)stream * nrOfSamples;
+      const float h0 = hin[80 * s + lane];
+      const float h1 = lane < 16 ? hin[80 * s + 64 + lane] : 0.f;
+      st[kOffNearFrH + ring_idx(sf.near_wpos, lane, kFrBufLen)] = h0;
+      if (lane < 16) st[kOffNearFrH + ring_idx(sf.near_wpos, 64 + lane, kFrBufLen)] = h1;
+    }
+    // ring traffic between lanes of this wave goes through L2: order it at workgroup scope (same CU and L1; agent scope would flush the XCD L2)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int k = 0; k < sf.nblocks; ++k) {
+      const auto& op = sf.blk[k];
+      // the far slot: the batch's (lock-step), or in the delay-agnostic mode the stream's own (aec_delay_kernel)
+      const int far_slot = (!FLOW && ops.agnostic) ? __builtin_amdgcn_readfirstlane(dblocks[stream].slot[blk & 1]) : op.far_slot;
+      const float* slot = far_ring + ((size_t)far_slot * num_streams + stream) * kFarSlotDwords;
+      float* spec_out = (!FLOW && ops.spectra) ? spectra + ((size_t)stream * kSpecBlocks + (blk & (kSpecBlocks - 1))) * kSpecDwords : nullptr;
+      ++blk;
+      process_block<kMetrics, NP, FLOW>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
+                    FLOW ? 0 : ops.num_high, met,
+                    (stamps != nullptr && stream == 0 && s == 0 && k == 0) ? stamps : nullptr,  // wave-uniform; every lane stores the same scalar time
+                    spec_out);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if constexpr (FLOW) {
+      o[80 * s + lane] = sld(sb, kOffOutFr, ring_idx(sf.out_rpos, lane, kFrBufLen));
+      if (lane < 16) o[80 * s + 64 + lane] = sld(sb, kOffOutFr, ring_idx(sf.out_rpos, 64 + lane, kFrBufLen));
+    } else {
+      o[80 * s + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, lane, kFrBufLen)];
+      if (lane < 16) o[80 * s + 64 + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, 64 + lane, kFrBufLen)];
+    }
+    if (!FLOW && ops.num_high > 0) {  // aec_core.c:1774-1776
+      float* ho = out_high + (size_t)stream * nrOfSamples;
+      ho[80 * s + lane] = st[kOffOutFrH + ring_idx(sf.out_rpos, lane, kFrBufLen)];
+      if (lane < 16) ho[80 * s + 64 + lane] = st[kOffOutFrH + ring_idx(sf.out_rpos, 64 + lane, kFrBufLen)];
+    }
+  }
+}
+
+// WebRtcAec_ProcessFrames for every stream (running phase).
 #ifndef AEC_WAVES
 #define AEC_WAVES 4  // waves per SIMD the register allocation aims at (4: every stream of a 4096-stream batch is resident at once)
 #endif
@@ -1387,55 +1565,38 @@ __global__ __launch_bounds__(256, kMetrics ? 2 : NP == kNumPartNormal ? AEC_WAVE
   const float* nin = nearend + (size_t)stream * nrOfSamples;
   float* o = out + (size_t)stream * nrOfSamples;
   float* met = kMetrics ? metrics + (size_t)stream * kMetDwords : nullptr;
-  if (farend != nullptr) {
-    // the WebRtcAec_BufferFarend call that preceded this Process call, fused into the launch
-    farend_work(st, far_ring, wl, T, farend, num_streams, stream, fops, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-  int blk = 0;  // blocks of this launch so far
-  for (int s = 0; s < ops.nsub; ++s) {
-    const SubFrame& sf = ops.sub[s];
-    // near samples of this sub-frame are read into registers first: `out` may alias `nearend`
-    const float n0 = nin[80 * s + lane];
-    const float n1 = lane < 16 ? nin[80 * s + 64 + lane] : 0.f;
-    st[kOffNearFr + ring_idx(sf.near_wpos, lane, kFrBufLen)] = n0;
-    if (lane < 16) st[kOffNearFr + ring_idx(sf.near_wpos, 64 + lane, kFrBufLen)] = n1;
-    if (ops.num_high > 0) {  // the high band's frame into its ring (aec_core.c:1691-1693)
-      const float* hin = near_high + (size_t)stream * nrOfSamples;
-      const float h0 = hin[80 * s + lane];
-      const float h1 = lane < 16 ? hin[80 * s + 64 + lane] : 0.f;
-      st[kOffNearFrH + ring_idx(sf.near_wpos, lane, kFrBufLen)] = h0;
-      if (lane < 16) st[kOffNearFrH + ring_idx(sf.near_wpos, 64 + lane, kFrBufLen)] = h1;
-    }
-    // ring traffic between lanes of this wave goes through L2: order it at workgroup scope (same CU and L1; agent scope would flush the XCD L2)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int k = 0; k < sf.nblocks; ++k) {
-      const BlockOp& op = sf.blk[k];
-      // the far slot: the batch's (lock-step), or in the delay-agnostic mode the stream's own (aec_delay_kernel)
-      const int far_slot = ops.agnostic ? __builtin_amdgcn_readfirstlane(dblocks[stream].slot[blk & 1]) : op.far_slot;
-      const float* slot = far_ring + ((size_t)far_slot * num_streams + stream) * kFarSlotDwords;
-      float* spec_out = ops.spectra ? spectra + ((size_t)stream * kSpecBlocks + (blk & (kSpecBlocks - 1))) * kSpecDwords : nullptr;
-      ++blk;
-      process_block<kMetrics, NP>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
-                    ops.num_high, met,
-                    (stamps != nullptr && stream == 0 && s == 0 && k == 0) ? stamps : nullptr,  // wave-uniform; every lane stores the same scalar time
-                    spec_out);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    o[80 * s + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, lane, kFrBufLen)];
-    if (lane < 16) o[80 * s + 64 + lane] = st[kOffOutFr + ring_idx(sf.out_rpos, 64 + lane, kFrBufLen)];
-    if (ops.num_high > 0) {  // aec_core.c:1774-1776
-      float* ho = out_high + (size_t)stream * nrOfSamples;
-      ho[80 * s + lane] = st[kOffOutFrH + ring_idx(sf.out_rpos, lane, kFrBufLen)];
-      if (lane < 16) ho[80 * s + 64 + lane] = st[kOffOutFrH + ring_idx(sf.out_rpos, 64 + lane, kFrBufLen)];
-    }
-  }
+  process_call<kMetrics, NP, false>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, ops, farend, fops,
+                                    near_high, out_high, met, stamps, spectra, dblocks);
+}
+
+// The hand-off build: grid (groups of four streams, frame steps); see AecFlowArgs.  One band, no metrics, no
+// delay estimation (aec_api.hip keeps the other configurations on the plain build).
+template <int NP>
+__global__ __launch_bounds__(256, NP == kNumPartNormal ? AEC_WAVES : 3) void aec_process_flow_kernel(
+    float* __restrict__ state, float* far_ring, const AecTables* __restrict__ G, int num_streams, int nrOfSamples,
+    AecFlowArgs fa) {
+  __shared__ SharedTables T;
+  constexpr int kWaveLds = lds_wave(NP, false);
+  __shared__ float lds[4 * kWaveLds];
+  stage_tables(T, G);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  // the step's descriptor: read-only for the whole launch, so it may come through the scalar cache
+  typedef const __attribute__((address_space(4))) AecFlowStep* StepPtr;
+  const StepPtr fs = (StepPtr)(fa.steps + blockIdx.y);
+  const unsigned want = fa.want + blockIdx.y;
+  float* wl = lds + wave * kWaveLds;
+  float* st = state + (size_t)stream * AecRows(NP).state_dwords;
+  const float* nin = fs->nearend + (size_t)stream * nrOfSamples;
+  float* o = fs->out + (size_t)stream * nrOfSamples;
+  if (!flow_wait(fa, want, stream, lane)) return;
+  process_call<false, NP, true>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, fs->ops,
+                                fs->farend, fs->fops, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  // publish: every store of this wave drained first
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store((gu32*)(fa.seq + stream), want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // aec_rdft_forward_128 / inverse_128 seam: four rows per wave.
@@ -1507,6 +1668,24 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
     if (metrics != nullptr) ASP_AEC_LAUNCH(true, kNumPartMax); else ASP_AEC_LAUNCH(false, kNumPartMax);
   }
 #undef ASP_AEC_LAUNCH
+  return hipGetLastError();
+}
+
+// `steps` consecutive frame steps of the hand-off build in one launch (grid y = step): steps want .. want + steps - 1
+// of every stream; `descs` [steps] in device memory.
+hipError_t launch_aec_process_flow(float* state, float* far_ring, const AecTables* T, int num_streams, int nrOfSamples,
+                                   const AecFlowStep* descs, int steps, unsigned* seq, unsigned* abort_w, unsigned want,
+                                   int num_part, hipStream_t s) {
+  if (num_part != kNumPartNormal && num_part != kNumPartMax) return hipErrorInvalidValue;
+  const int gx = ((num_streams + 3) / 4 + 7) / 8 * 8;  // a multiple of 8: a stream's consecutive steps on one XCD's in-order share
+  const dim3 grid(gx, steps);
+  const AecFlowArgs fa = {descs, seq, abort_w, want};
+  if (num_part == kNumPartNormal)
+    hipLaunchKernelGGL((aec_process_flow_kernel<kNumPartNormal>), grid, dim3(256), 0, s, state, far_ring, T, num_streams,
+                       nrOfSamples, fa);
+  else
+    hipLaunchKernelGGL((aec_process_flow_kernel<kNumPartMax>), grid, dim3(256), 0, s, state, far_ring, T, num_streams,
+                       nrOfSamples, fa);
   return hipGetLastError();
 }
 

@@ -129,6 +129,19 @@ struct ProcOps {
   SubFrame sub[2];
 };
 
+// One frame step of a hand-off launch (aec_kernels.hip, AecFlowArgs): the WebRtcAec_BufferFarend call that
+// preceded the WebRtcAec_Process call (when its device work fits one descriptor), the Process call, and the
+// frames they take and emit.  An array of these in device memory, one per grid row, written before the launch.
+struct AecFlowStep {
+  ProcOps ops;
+  FarOps fops;
+  int32_t pad;
+  const float* farend;   // nullptr: no far-end work in this step
+  const float* nearend;
+  float* out;
+};
+static_assert(sizeof(AecFlowStep) % 8 == 0, "steps stay 8-byte aligned in their array");
+
 // ---- delay estimation (set_config delay_logging) and the delay-agnostic mode (reported delays off) ----
 // Per stream one DelayBlock: the canonical estimator state, then what only the device needs.  In the agnostic
 // mode the stream's own far-buffer read side and system delay live in it (s.far_read .. s.system_delay): the

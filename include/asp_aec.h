@@ -263,6 +263,14 @@ int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out);
 int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in);
 int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* out);
 int AspAecBatch_Synchronize(AspAecBatch* b);
+/* Hand-off build of the multi-frame entry points (Run, TimedSteps) in the plain configuration (one band, reported
+ * delays, no delay logging / skew compensation / metrics): the Process launches of up to 64 consecutive frames go
+ * into ONE launch (grid y = frame step, its descriptors in device memory), and a per-stream step counter in device
+ * memory orders step k + 1 of a stream behind its own step k (every access to the stream's state and far-ring
+ * slots write-through / L1-bypassing), so consecutive steps overlap on the chip instead of meeting at a launch
+ * boundary.  Same arithmetic, same results bit for bit.  mode: -1 = default (on; ASP_AEC_FLOW=0 in the environment
+ * turns the default off), 0 = off, 1 = on.  A wait that times out makes the next synchronising call fail. */
+int AspAecBatch_SetFlow(AspAecBatch* b, int mode);
 /* `steps` frames of Run over a ring of `frames_in_ring` device frames, bracketed by
  * hipEvents on the launch stream; elapsed_ms of the whole region (bench.py). */
 int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nearend, float* out,

@@ -721,9 +721,10 @@ def test_timed_steps_two_chains_equal_one_chain(aec, monkeypatch):
     df.upload(far)
     dn.upload(near)
     outs, states = [], []
-    for chains in ("1", "2"):
+    for chains, flow in (("1", 0), ("2", 0), ("1", 1)):   # one chain, two chains, the hand-off build
         monkeypatch.setenv("ASP_AEC_CHAINS", chains)
         g = aec.AecBatch(S)
+        g.set_flow(flow)
         do = DeviceBuffer(near.nbytes)
         g.timed_steps(df.ptr, dn.ptr, do.ptr, 160, F, 100)   # through the start-up phase: one chain
         g.timed_steps(df.ptr + 100 * per, dn.ptr + 100 * per, do.ptr + 100 * per, 160, F - 100, F - 100)
@@ -731,9 +732,10 @@ def test_timed_steps_two_chains_equal_one_chain(aec, monkeypatch):
         outs.append(do.download(near.shape))
         states.append([np.ctypeslib.as_array(g.export_state(s).wfBuf).copy() for s in (0, 1023, 1027, 2049)])
         g.close()
-    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
-    for a, b in zip(*states):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for k in (1, 2):
+        assert np.array_equal(outs[0].view(np.uint32), outs[k].view(np.uint32)), k
+        for a, b in zip(states[0], states[k]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
     # and both equal the four distinct streams they replicate
     assert np.array_equal(outs[1][:, 4:8].view(np.uint32), outs[1][:, 2044:2048].view(np.uint32))
 
@@ -754,12 +756,14 @@ def test_timed_steps_equal_run_and_oracle(aec, monkeypatch):
     df.upload(far)
     dn.upload(near)
     gr = aec.AecBatch(S)
+    gr.set_flow(0)                      # the reference run: one launch per call
     out_run = gr.run(far, near)
     oras = [OracleAec() for _ in range(D)]
     out_o = np.stack([oras[s].run(far4[:, s], near4[:, s]) for s in range(D)], axis=1)
-    for chains in ("1", "2"):
-        monkeypatch.setenv("ASP_AEC_CHAINS", chains)
+    for chains, flow in (("1", 0), ("2", 0), ("1h", 1)):   # one chain, two chains, the hand-off build
+        monkeypatch.setenv("ASP_AEC_CHAINS", chains[0])
         g = aec.AecBatch(S)
+        g.set_flow(flow)
         do = DeviceBuffer(near.nbytes)
         g.timed_steps(df.ptr, dn.ptr, do.ptr, 160, F, 100)
         g.timed_steps(df.ptr + 100 * per, dn.ptr + 100 * per, do.ptr + 100 * per, 160, F - 100, F - 100)
@@ -776,6 +780,48 @@ def test_timed_steps_equal_run_and_oracle(aec, monkeypatch):
             assert _rel_l2(out_t[:, s], out_o[:, idx[s]]) <= 1e-5, (chains, s)
         g.close()
     gr.close()
+
+
+@pytest.mark.parametrize("S,ext", [(5, 0), (4100, 0), (9000, 0), (1030, 1)])
+def test_handoff_build_equals_plain_launches(aec, S, ext):
+    """The hand-off build (AspAecBatch_SetFlow; the default of Run / TimedSteps in the plain configuration) against
+    one launch per call: outputs and the whole state bit for bit over 300 frames (start-up, delay jumps are in
+    test_free_running_vs_oracle; here: many streams, ragged last workgroup, more streams than the chip holds
+    waves, the extended filter).  Two hand-off batches and the plain one run at the same time, so the waits
+    happen under uneven load."""
+    from audiosignalprocess_amd.ns import DeviceBuffer
+
+    F, D = 300, 8
+    far8, near8 = aec_frames(D, F)
+    idx = (np.arange(S) * 3) % D
+    far = np.ascontiguousarray(far8[:, idx])
+    near = np.ascontiguousarray(near8[:, idx])
+    df, dn = DeviceBuffer(far.nbytes), DeviceBuffer(near.nbytes)
+    df.upload(far)
+    dn.upload(near)
+    outs, batches = [], []
+    for flow in (0, 1, 1):
+        g = aec.AecBatch(S)
+        if ext:
+            g.enable_delay_correction(1)
+        g.set_flow(flow)
+        do = DeviceBuffer(near.nbytes)
+        g.run_device(df.ptr, dn.ptr, do.ptr, 160, F)   # asynchronous: the batches overlap on the chip
+        outs.append(do)
+        batches.append(g)
+    for g in batches:
+        g.synchronize()
+    y = [o.download(near.shape) for o in outs]
+    assert np.isfinite(y[0][-50:]).all() and np.abs(y[0]).max() > 0
+    for k in (1, 2):
+        assert np.array_equal(_bits(y[0]), _bits(y[k])), k
+    for s_ in sorted(set([0, 1, 3, 4, S // 2, S - 2, S - 1] + list(range(0, S, max(1, S // 23))))):
+        want = batches[0].export_state(s_)
+        for k in (1, 2):
+            rep = _state_report(batches[k].export_state(s_), want)
+            assert all(v[0] for v in rep.values()), (s_, k, {f: v for f, v in rep.items() if not v[0]})
+    for g in batches:
+        g.close()
 
 
 def test_wav_driver_end_to_end(aec, aec_golden, tmp_path):
