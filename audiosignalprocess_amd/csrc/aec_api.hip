@@ -6,6 +6,8 @@
 // ProcOps); all sample and spectrum data stays in HBM.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include "device_scope.h"
+
 #include <math.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -1109,6 +1111,7 @@ int check_running(AspAecBatch* b, const void* p, int n) {
 extern "C" {
 
 int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device) {
+  AspDeviceScope dev_scope_;
   if (!out || num_streams <= 0) return aec_fail(ASP_ERR_PARAM, "AspAecBatch_Create: bad argument");
   *out = nullptr;
   int count = 0;
@@ -1159,6 +1162,7 @@ int AspAecBatch_Create(AspAecBatch** out, int num_streams, int device) {
 // Process / set_config / GetControl behave as on a real batch, so the host logic can be checked
 // against the oracle on a machine without a GPU.  Every data-touching entry point refuses it.
 int AspAecBatch_CreateControlOnly(AspAecBatch** out, int num_streams) {
+  AspDeviceScope dev_scope_;
   if (!out || num_streams <= 0) return aec_fail(ASP_ERR_PARAM, "AspAecBatch_CreateControlOnly: bad argument");
   AspAecBatch* b = new AspAecBatch();
   b->S = num_streams;
@@ -1168,6 +1172,7 @@ int AspAecBatch_CreateControlOnly(AspAecBatch** out, int num_streams) {
 }
 
 int AspAecBatch_Free(AspAecBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return -1;
   if (b->sim) {
     delete b;
@@ -1295,10 +1300,10 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
       AEC_TRY(hipMalloc((void**)&b->state, state_bytes(b)));
     }
     const int kStateDwords = state_dwords(b);
-    static AspAecState s0;  // ~50 KB
-    init_canonical(&s0);
+    std::vector<AspAecState> s0(1);  // ~50 KB, per call: two batches may be initialised from two host threads at once
+    init_canonical(s0.data());
     std::vector<float> blk(kStateDwords);
-    pack_stream(b, &s0, blk.data());
+    pack_stream(b, s0.data(), blk.data());
     std::vector<float> all((size_t)b->S * kStateDwords);
     for (int s = 0; s < b->S; ++s) memcpy(all.data() + (size_t)s * kStateDwords, blk.data(), kStateDwords * sizeof(float));
     AEC_TRY(hipMemcpy(b->state, all.data(), state_bytes(b), hipMemcpyHostToDevice));
@@ -1356,6 +1361,7 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
 }
 
 int AspAecBatch_BufferFarend(AspAecBatch* b, const float* farend, int nrOfSamples, int mem) {
+  AspDeviceScope dev_scope_;
   const int chk = check_running(b, farend, nrOfSamples);
   if (chk != 0) return chk;
   if (b->sim) return buffer_farend_device(b, farend, nrOfSamples);
@@ -1376,6 +1382,7 @@ static int process_impl(AspAecBatch* b, const float* nearend, const float* near_
 
 int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nrOfSamples,
                         int msInSndCardBuf, int32_t skew, int mem) {
+  AspDeviceScope dev_scope_;
   if (b && b->num_high > 0) {
     b->lastError = AEC_BAD_PARAMETER_ERROR;  // a 32 kHz batch needs both bands (ProcessBands)
     return -1;
@@ -1386,6 +1393,7 @@ int AspAecBatch_Process(AspAecBatch* b, const float* nearend, float* out, int nr
 int AspAecBatch_ProcessBands(AspAecBatch* b, const float* near_low, const float* near_high,
                              float* out_low, float* out_high, int nrOfSamples, int msInSndCardBuf,
                              int32_t skew, int mem) {
+  AspDeviceScope dev_scope_;
   if (b && (b->num_high < 1 || near_high == nullptr || out_high == nullptr)) {
     b->lastError = b->num_high < 1 ? AEC_BAD_PARAMETER_ERROR : AEC_NULL_POINTER_ERROR;
     return -1;
@@ -1440,6 +1448,7 @@ static int process_impl(AspAecBatch* b, const float* nearend, const float* near_
 
 int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, float* out,
                     int nrOfSamples, int num_frames, int msInSndCardBuf, int mem) {
+  AspDeviceScope dev_scope_;
   if (b && b->num_high > 0) return aec_fail(ASP_ERR_STATE, "AspAecBatch_Run: single-band batches only (use ProcessBands)");
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_Run: control-only handle");
   if (b && out == nullptr) {
@@ -1450,6 +1459,8 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
   if (chk == 0) chk = check_running(b, nearend, nrOfSamples);
   if (chk != 0) return chk;
   if (num_frames < 0) return aec_fail(ASP_ERR_PARAM, "Run: num_frames < 0");
+  if (b->skewMode == kAecTrue)  // the skew estimate is a function of the calls' skew arguments: Process / ProcessBands carry one
+    return aec_fail(ASP_ERR_STATE, "Run: no skew argument; with skew compensation on, feed the frames through BufferFarend / Process");
   AEC_TRY(hipSetDevice(b->device));
   const size_t per = (size_t)b->S * nrOfSamples;
   int rc_all = 0;
@@ -1522,11 +1533,14 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
 
 int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nearend, float* out,
                            int nrOfSamples, int frames_in_ring, int steps, float* elapsed_ms) {
+  AspDeviceScope dev_scope_;
   if (b && b->num_high > 0) return aec_fail(ASP_ERR_STATE, "AspAecBatch_TimedSteps: single-band batches only (use ProcessBands)");
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_TimedSteps: control-only handle");
   if (!b || !farend || !nearend || !out || frames_in_ring <= 0 || steps < 0 || !elapsed_ms)
     return aec_fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
   if (check_running(b, farend, nrOfSamples) != 0) return -1;
+  if (b->skewMode == kAecTrue)
+    return aec_fail(ASP_ERR_STATE, "TimedSteps: no skew argument; with skew compensation on, feed the frames through BufferFarend / Process");
   AEC_TRY(hipSetDevice(b->device));
   const size_t per = (size_t)b->S * nrOfSamples;
   // two chains when the batch is large enough to fill the chip twice over and past its start-up phase
@@ -1575,6 +1589,7 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
 }
 
 int AspAecBatch_Synchronize(AspAecBatch* b) {
+  AspDeviceScope dev_scope_;
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_Synchronize: control-only handle");
   if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
   AEC_TRY(hipSetDevice(b->device));
@@ -1583,12 +1598,14 @@ int AspAecBatch_Synchronize(AspAecBatch* b) {
 }
 
 int AspAecBatch_SetFlow(AspAecBatch* b, int mode) {
+  AspDeviceScope dev_scope_;
   if (!b || mode < -1 || mode > 1) return aec_fail(ASP_ERR_PARAM, "SetFlow: -1 (default), 0 (off) or 1 (on)");
   b->flow = mode;
   return ASP_OK;
 }
 
 int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out) {
+  AspDeviceScope dev_scope_;
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_ExportState: control-only handle");
   if (!b || !out || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ExportState: bad argument");
   AEC_TRY(hipSetDevice(b->device));
@@ -1601,6 +1618,7 @@ int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out) {
 }
 
 int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in) {
+  AspDeviceScope dev_scope_;
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_ImportState: control-only handle");
   if (!b || !in || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ImportState: bad argument");
   AEC_TRY(hipSetDevice(b->device));
@@ -1622,10 +1640,17 @@ int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in) {
 // reference's do, except that the far-spectrum and filter partitions 12..31 are dropped when the filter is
 // shortened (the reference leaves them in place, stale, for a later re-enable).
 int AspAecBatch_enable_delay_correction(AspAecBatch* b, int enable) {
+  AspDeviceScope dev_scope_;
   if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
   const int np = enable ? kNumPartMax : kNumPartNormal;
   if (np != b->num_part) {
-    if (b->xf_pos >= np) return aec_fail(ASP_ERR_STATE, "enable_delay_correction: xfBufBlockPos beyond the shorter filter");
+    if (b->xf_pos >= np) {
+      // the reference keeps running with the large block position (aec_core.c:1876-1881 stores the flag only); the
+      // 12-partition state block has no rows 12..31, so the switch is refused until the position is below 12
+      // (include/asp_aec.h); the error code tells a caller of the void drop-in wrapper
+      b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
+      return aec_fail(ASP_ERR_STATE, "enable_delay_correction(0): xfBufBlockPos is beyond the 12-partition filter; feed frames until it is below 12");
+    }
     if (b->far_pending) {
       const int rc = flush_pending_farend(b);
       if (rc != 0) return rc;
@@ -1669,9 +1694,13 @@ int AspAecBatch_enable_delay_correction(AspAecBatch* b, int enable) {
 // pointer by the delay estimator (which runs when delay logging is on) instead of the reported delay -- per stream,
 // on the device.  Once streams have moved apart, switching the reported delays back on needs a new Init.
 int AspAecBatch_enable_reported_delay(AspAecBatch* b, int enable) {
+  AspDeviceScope dev_scope_;
   if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
   if (enable && !b->reported_delay_enabled && b->agn_synced)
     return aec_fail(ASP_ERR_STATE, "enable_reported_delay: the streams' far buffers have moved apart; Init first");
+  // the delay-agnostic mode steers every stream's far buffer on the device: a control-only handle refuses it here,
+  // not in the middle of a later Process call with its ring positions already advanced
+  if (!enable && b->sim) return aec_fail(ASP_ERR_STATE, "enable_reported_delay(0): the delay-agnostic mode needs the device");
   b->reported_delay_enabled = enable ? 1 : 0;
   return 0;
 }
@@ -1679,6 +1708,7 @@ int AspAecBatch_reported_delay_enabled(const AspAecBatch* b) { return b ? b->rep
 
 // The delay estimator's state of one stream with the stream's far-buffer read side and system delay.
 int AspAecBatch_ExportDelayState(AspAecBatch* b, int stream, AspAecDelayState* out) {
+  AspDeviceScope dev_scope_;
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_ExportDelayState: control-only handle");
   if (!b || !out || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ExportDelayState: bad argument");
   AEC_TRY(hipSetDevice(b->device));
@@ -1701,6 +1731,7 @@ int AspAecBatch_ExportDelayState(AspAecBatch* b, int stream, AspAecDelayState* o
 // spread (L1 norm around the median) of the block-wise delay estimates since the last call, in ms; the
 // histograms are cleared.  median / std [num_streams].
 int AspAecBatch_GetDelayMetrics(AspAecBatch* b, int* median, int* std) {
+  AspDeviceScope dev_scope_;
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_GetDelayMetrics: control-only handle");
   if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
   if (median == nullptr || std == nullptr) {
@@ -1756,6 +1787,7 @@ int AspAecBatch_GetDelayMetrics(AspAecBatch* b, int* median, int* std) {
 int AspAecBatch_delay_correction_enabled(const AspAecBatch* b) { return b ? b->extended : 0; }
 
 int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* c) {
+  AspDeviceScope dev_scope_;
   if (!b || !c) return aec_fail(ASP_ERR_PARAM, "GetControl: bad argument");
   c->startup_phase = b->startup_phase;
   c->checkBuffSize = b->checkBuffSize;
@@ -1787,6 +1819,7 @@ int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* c) {
 }
 
 int AspAecBatch_get_echo_status(AspAecBatch* b, int* status) {
+  AspDeviceScope dev_scope_;
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_get_echo_status: control-only handle");
   if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
   if (status == nullptr) {
@@ -1854,6 +1887,7 @@ int AspAecBatch_GetMetrics(AspAecBatch* b, AecMetrics* out) {  // WebRtcAec_GetM
 }
 
 int AspAecBatch_ExportMetricsState(AspAecBatch* b, int stream, AspAecMetricsState* out) {
+  AspDeviceScope dev_scope_;
   if (b && b->sim) return aec_fail(ASP_ERR_STATE, "AspAecBatch_ExportMetricsState: control-only handle");
   if (!b || !out || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "ExportMetricsState: bad argument");
   AEC_TRY(hipSetDevice(b->device));
@@ -1866,6 +1900,7 @@ int AspAecBatch_ExportMetricsState(AspAecBatch* b, int stream, AspAecMetricsStat
 // ticks) of stream 0's first block.
 int AspAecBatch_DebugStamps(AspAecBatch* b, const float* far_dev, const float* near_dev, float* out_dev,
                             unsigned long long* stamps16) {
+  AspDeviceScope dev_scope_;
   if (!b || !far_dev || !near_dev || !out_dev || !stamps16) return aec_fail(ASP_ERR_PARAM, "DebugStamps: bad argument");
   AEC_TRY(hipSetDevice(b->device));
   unsigned long long* d = nullptr;
@@ -1886,6 +1921,7 @@ int AspAecBatch_DebugStamps(AspAecBatch* b, const float* far_dev, const float* n
 }
 
 int AspAec_rdft128_batch(const float* src, float* dst, int isgn, int count, int device) {
+  AspDeviceScope dev_scope_;
   if (!src || !dst || count <= 0) return aec_fail(ASP_ERR_PARAM, "rdft128_batch: bad argument");
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -1912,6 +1948,7 @@ int AspAec_rdft128_batch(const float* src, float* dst, int isgn, int count, int 
 }
 
 int AspAec_host_table(int which, float* out, int capacity) {
+  AspDeviceScope dev_scope_;
   AecTables T;
   build_tables(&T);
   const float* src = nullptr;
@@ -1944,21 +1981,25 @@ int32_t WebRtcAec_Create(void** aecInst) {  // echo_cancellation.c:121-168
 }
 
 int32_t WebRtcAec_Free(void* aecInst) {
+  AspDeviceScope dev_scope_;
   if (aecInst == nullptr) return -1;
   return AspAecBatch_Free((AspAecBatch*)aecInst);
 }
 
 int32_t WebRtcAec_Init(void* aecInst, int32_t sampFreq, int32_t scSampFreq) {
+  AspDeviceScope dev_scope_;
   return AspAecBatch_Init((AspAecBatch*)aecInst, sampFreq, scSampFreq) == 0 ? 0 : -1;
 }
 
 int32_t WebRtcAec_BufferFarend(void* aecInst, const float* farend, int16_t nrOfSamples) {
+  AspDeviceScope dev_scope_;
   return AspAecBatch_BufferFarend((AspAecBatch*)aecInst, farend, nrOfSamples, ASP_MEM_HOST) == 0 ? 0 : -1;
 }
 
 int32_t WebRtcAec_Process(void* aecInst, const float* const* nearend, int num_bands,
                           float* const* out, int16_t nrOfSamples, int16_t msInSndCardBuf,
                           int32_t skew) {
+  AspDeviceScope dev_scope_;
   AspAecBatch* b = (AspAecBatch*)aecInst;
   if (b == nullptr) return -1;
   if (out == nullptr || nearend == nullptr) {
@@ -1976,10 +2017,12 @@ int32_t WebRtcAec_Process(void* aecInst, const float* const* nearend, int num_ba
 }
 
 int WebRtcAec_set_config(void* handle, AecConfig config) {
+  AspDeviceScope dev_scope_;
   return AspAecBatch_set_config((AspAecBatch*)handle, config) == 0 ? 0 : -1;
 }
 
 int WebRtcAec_get_echo_status(void* handle, int* status) {
+  AspDeviceScope dev_scope_;
   return AspAecBatch_get_echo_status((AspAecBatch*)handle, status) == 0 ? 0 : -1;
 }
 
@@ -2004,25 +2047,30 @@ int WebRtcAec_GetDelayMetrics(void* handle, int* median, int* std) {  // echo_ca
 }
 
 int32_t WebRtcAec_get_error_code(void* aecInst) {
+  AspDeviceScope dev_scope_;
   return AspAecBatch_get_error_code((AspAecBatch*)aecInst);
 }
 
 struct AecCore* WebRtcAec_aec_core(void* handle) {
+  AspDeviceScope dev_scope_;
   return reinterpret_cast<struct AecCore*>(handle);
 }
 
 // aec_core.h:129-133 / aec_core.c:1876-1885: `self` is the token WebRtcAec_aec_core returned
 void WebRtcAec_enable_delay_correction(struct AecCore* self, int enable) {
+  AspDeviceScope dev_scope_;
   (void)AspAecBatch_enable_delay_correction(reinterpret_cast<AspAecBatch*>(self), enable);
 }
 
 int WebRtcAec_delay_correction_enabled(struct AecCore* self) {
+  AspDeviceScope dev_scope_;
   return AspAecBatch_delay_correction_enabled(reinterpret_cast<AspAecBatch*>(self));
 }
 
 // aec_core.h:110-114 / aec_core.c:1886-1894 (what echo_cancellation_unittest.cc:34-48 and the APM use): the buffered
 // far-end delay in samples.  In the delay-agnostic mode it is the stream's own (a handle is a batch of one stream).
 int WebRtcAec_system_delay(struct AecCore* self) {
+  AspDeviceScope dev_scope_;
   AspAecBatch* b = reinterpret_cast<AspAecBatch*>(self);
   if (!b) return 0;
   if (b->agn_synced && !b->sim) {
@@ -2032,6 +2080,7 @@ int WebRtcAec_system_delay(struct AecCore* self) {
   return b->system_delay;
 }
 void WebRtcAec_SetSystemDelay(struct AecCore* self, int delay) {
+  AspDeviceScope dev_scope_;
   AspAecBatch* b = reinterpret_cast<AspAecBatch*>(self);
   if (!b || delay < 0) return;  // the reference asserts delay >= 0
   b->system_delay = delay;
@@ -2045,10 +2094,12 @@ void WebRtcAec_SetSystemDelay(struct AecCore* self, int delay) {
 
 // aec_core.h:121-126 / aec_core.c:1868-1874
 void WebRtcAec_enable_reported_delay(struct AecCore* self, int enable) {
+  AspDeviceScope dev_scope_;
   (void)AspAecBatch_enable_reported_delay(reinterpret_cast<AspAecBatch*>(self), enable);
 }
 
 int WebRtcAec_reported_delay_enabled(struct AecCore* self) {
+  AspDeviceScope dev_scope_;
   return AspAecBatch_reported_delay_enabled(reinterpret_cast<AspAecBatch*>(self));
 }
 

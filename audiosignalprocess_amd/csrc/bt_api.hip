@@ -3,6 +3,8 @@
 // implemented as a batch of one with host-side hop buffering.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include "device_scope.h"
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -247,6 +249,7 @@ struct AspBtBatch {
 extern "C" {
 
 int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int device) {
+  AspDeviceScope dev_scope_;
   if (!out || num_streams <= 0) return bt_fail(ASP_ERR_PARAM, "AspBtBatch_Create: bad argument");
   *out = nullptr;
   const bool any = win_size != 256 && win_size != 1024;
@@ -285,6 +288,7 @@ int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int devic
 }
 
 int AspBtBatch_Free(AspBtBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return ASP_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
@@ -306,6 +310,7 @@ int AspBtBatch_Free(AspBtBatch* b) {
 }
 
 int AspBtBatch_Reset(AspBtBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return bt_fail(ASP_ERR_PARAM, "null batch handle");
   BT_TRY(hipSetDevice(b->device));
   BT_TRY(hipMemsetAsync(b->state, 0, (size_t)b->S * b->state_floats * 4, b->stream));
@@ -356,15 +361,18 @@ static int bt_run(AspBtBatch* b, const float* in, float* out, int frames, int th
 }
 
 int AspBtBatch_Denoise(AspBtBatch* b, const float* in, float* out, int mem) {
+  AspDeviceScope dev_scope_;
   return bt_run(b, in, out, 8, 1, mem);
 }
 
 int AspBtBatch_Flush(AspBtBatch* b, const float* in, int hops, float* out, int mem) {
+  AspDeviceScope dev_scope_;
   if (hops < 0 || hops > 7) return bt_fail(ASP_ERR_PARAM, "Flush: hops must be 0..7");
   return bt_run(b, in, out, hops, 0, mem);
 }
 
 int AspBtBatch_Synchronize(AspBtBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return bt_fail(ASP_ERR_PARAM, "null batch handle");
   BT_TRY(hipSetDevice(b->device));
   BT_TRY(hipStreamSynchronize(b->stream));
@@ -373,6 +381,7 @@ int AspBtBatch_Synchronize(AspBtBatch* b) {
 
 int AspBtBatch_TimedSteps(AspBtBatch* b, const float* in, float* out, int blocks_in_ring,
                           int steps, float* elapsed_ms) {
+  AspDeviceScope dev_scope_;
   if (!b || !in || !out || blocks_in_ring <= 0 || steps < 0 || !elapsed_ms)
     return bt_fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
   BT_TRY(hipSetDevice(b->device));
@@ -427,6 +436,7 @@ int AspBtBatch_DebugStamps(AspBtBatch* b, const float* in_dev, float* out_dev,
 }
 
 int AspBtBatch_ExportState(AspBtBatch* b, int stream, AspBtState* out) {
+  AspDeviceScope dev_scope_;
   if (!b || !out || stream < 0 || stream >= b->S) return bt_fail(ASP_ERR_PARAM, "ExportState: bad argument");
   BT_TRY(hipSetDevice(b->device));
   BT_TRY(hipStreamSynchronize(b->stream));
@@ -440,6 +450,7 @@ int AspBtBatch_ExportState(AspBtBatch* b, int stream, AspBtState* out) {
 }
 
 int AspBtBatch_ImportState(AspBtBatch* b, int stream, const AspBtState* in) {
+  AspDeviceScope dev_scope_;
   if (!b || !in || stream < 0 || stream >= b->S) return bt_fail(ASP_ERR_PARAM, "ImportState: bad argument");
   if (in->win_size != b->win) return bt_fail(ASP_ERR_PARAM, "ImportState: win_size mismatch");
   BT_TRY(hipSetDevice(b->device));
@@ -479,9 +490,11 @@ static int bt_fft_seam(const float* src, float* dst, int n, int count, int inver
 }
 
 int AspBt_kiss_fftr_batch(const float* timedata, float* freqdata, int n, int count, int device) {
+  AspDeviceScope dev_scope_;
   return bt_fft_seam(timedata, freqdata, n, count, 0, device);
 }
 int AspBt_kiss_fftri_batch(const float* freqdata, float* timedata, int n, int count, int device) {
+  AspDeviceScope dev_scope_;
   return bt_fft_seam(freqdata, timedata, n, count, 1, device);
 }
 
@@ -507,6 +520,7 @@ static float bt_s16_to_float(int16_t v) {  // .c:267-271
 }
 
 MarsBlockThreshold_t* blockThreshold_init(int32_t time_win, int32_t fs, int32_t* err) {
+  AspDeviceScope dev_scope_;
   int32_t dummy;
   if (!err) err = &dummy;
   if (time_win <= 0 || fs <= 0) {
@@ -538,6 +552,7 @@ MarsBlockThreshold_t* blockThreshold_init(int32_t time_win, int32_t fs, int32_t*
 }
 
 int32_t blockThreshold_reset(MarsBlockThreshold_t* h) {
+  AspDeviceScope dev_scope_;
   if (!h) return MARS_ERROR_PARAMS;
   h->have_nblk_time = 0;
   memset(h->outbuf, 0, sizeof(float) * (size_t)h->macro_size);
@@ -545,17 +560,24 @@ int32_t blockThreshold_reset(MarsBlockThreshold_t* h) {
 }
 
 int32_t blockThreshold_denoise_float(MarsBlockThreshold_t* h, float* in, int32_t in_len) {
+  AspDeviceScope dev_scope_;
   if (!h || (in_len != h->half_win_size) || (!in)) return MARS_ERROR_PARAMS;
   memcpy(h->pending + (size_t)h->have_nblk_time * h->half_win_size, in,
          sizeof(float) * (size_t)h->half_win_size);
   h->have_nblk_time++;
   if (h->have_nblk_time != 8) return MARS_NEED_MORE_SAMPLES;
-  if (AspBtBatch_Denoise(h->batch, h->pending, h->outbuf, ASP_MEM_HOST) != ASP_OK) abort();
+  // a failed launch is reported with the reference's own code (audioDenoiseBlockTreshold.h:9); the eight hops stay
+  // pending, so the call can be repeated
+  if (AspBtBatch_Denoise(h->batch, h->pending, h->outbuf, ASP_MEM_HOST) != ASP_OK) {
+    h->have_nblk_time = 7;
+    return MARS_ERROR_MEMORY;
+  }
   h->have_nblk_time = 0;
   return MARS_CAN_OUTPUT;
 }
 
 int32_t blockThreshold_denoise_int16(MarsBlockThreshold_t* h, int16_t* in, int32_t in_len) {
+  AspDeviceScope dev_scope_;
   if (!h || (in_len != h->half_win_size) || (!in)) return MARS_ERROR_PARAMS;
   std::vector<float> tmp((size_t)in_len);
   for (int32_t i = 0; i < in_len; i++) tmp[i] = bt_s16_to_float(in[i]);
@@ -563,18 +585,21 @@ int32_t blockThreshold_denoise_int16(MarsBlockThreshold_t* h, int16_t* in, int32
 }
 
 int32_t blockThreshold_output_float(MarsBlockThreshold_t* h, float* out, int32_t out_len) {
+  AspDeviceScope dev_scope_;
   if (out_len < h->macro_size) return 0;
   memcpy(out, h->outbuf, sizeof(float) * (size_t)h->macro_size);
   return h->macro_size;
 }
 
 int32_t blockThreshold_output_int16(MarsBlockThreshold_t* h, int16_t* out, int32_t out_len) {
+  AspDeviceScope dev_scope_;
   if (out_len < h->macro_size) return 0;
   for (int32_t i = 0; i < h->macro_size; i++) out[i] = bt_float_to_s16(h->outbuf[i]);
   return h->macro_size;
 }
 
 int32_t blockThreshold_flush_float(MarsBlockThreshold_t* h, float* out, int32_t out_len) {
+  AspDeviceScope dev_scope_;
   const int32_t out_size = h->have_nblk_time * h->half_win_size;
   if (out_len < out_size) return -1;
   // with no pending hop the reference still shifts the overlap tail out of outbuf and clears it
@@ -586,6 +611,7 @@ int32_t blockThreshold_flush_float(MarsBlockThreshold_t* h, float* out, int32_t 
 }
 
 int32_t blockThreshold_flush_int16(MarsBlockThreshold_t* h, int16_t* out, int32_t out_len) {
+  AspDeviceScope dev_scope_;
   const int32_t out_size = h->have_nblk_time * h->half_win_size;
   if (out_len < out_size) return -1;
   std::vector<float> tmp((size_t)out_size + 1);
@@ -596,6 +622,7 @@ int32_t blockThreshold_flush_int16(MarsBlockThreshold_t* h, int16_t* out, int32_
 }
 
 void blockThreshold_free(MarsBlockThreshold_t* h) {
+  AspDeviceScope dev_scope_;
   if (!h) return;
   AspBtBatch_Free(h->batch);
   free(h->pending);

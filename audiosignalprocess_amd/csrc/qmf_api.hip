@@ -3,6 +3,8 @@
 // caller-owned states.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include "device_scope.h"
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -51,6 +53,7 @@ struct AspQmfBatch {
 extern "C" {
 
 int AspQmfBatch_Create(AspQmfBatch** out, int num_channels, int device) {
+  AspDeviceScope dev_scope_;
   if (!out || num_channels <= 0) return qmf_fail(ASP_ERR_PARAM, "AspQmfBatch_Create: bad argument");
   *out = nullptr;
   int count = 0;
@@ -77,6 +80,7 @@ int AspQmfBatch_Create(AspQmfBatch** out, int num_channels, int device) {
 }
 
 int AspQmfBatch_Free(AspQmfBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return -1;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
@@ -92,6 +96,7 @@ int AspQmfBatch_Free(AspQmfBatch* b) {
 int AspQmfBatch_num_channels(const AspQmfBatch* b) { return b ? b->C : 0; }
 
 int AspQmfBatch_Reset(AspQmfBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return qmf_fail(ASP_ERR_PARAM, "null batch handle");
   QMF_TRY(hipSetDevice(b->device));
   QMF_TRY(hipMemsetAsync(b->state, 0, (size_t)b->C * 24 * sizeof(int32_t), b->stream));
@@ -100,6 +105,7 @@ int AspQmfBatch_Reset(AspQmfBatch* b) {
 
 int AspQmfBatch_Analysis(AspQmfBatch* b, const int16_t* in, int band_length, int16_t* low,
                          int16_t* high, int mem) {
+  AspDeviceScope dev_scope_;
   if (!b || !in || !low || !high || band_length <= 0 || band_length > ASP_QMF_MAX_BAND)
     return qmf_fail(ASP_ERR_PARAM, "AspQmfBatch_Analysis: bad argument");
   QMF_TRY(hipSetDevice(b->device));
@@ -125,6 +131,7 @@ int AspQmfBatch_Analysis(AspQmfBatch* b, const int16_t* in, int band_length, int
 
 int AspQmfBatch_Synthesis(AspQmfBatch* b, const int16_t* low, const int16_t* high,
                           int band_length, int16_t* out, int mem) {
+  AspDeviceScope dev_scope_;
   if (!b || !out || !low || !high || band_length <= 0 || band_length > ASP_QMF_MAX_BAND)
     return qmf_fail(ASP_ERR_PARAM, "AspQmfBatch_Synthesis: bad argument");
   QMF_TRY(hipSetDevice(b->device));
@@ -149,6 +156,7 @@ int AspQmfBatch_Synthesis(AspQmfBatch* b, const int16_t* low, const int16_t* hig
 }
 
 int AspQmfBatch_ExportState(AspQmfBatch* b, int channel, AspQmfState* out) {
+  AspDeviceScope dev_scope_;
   if (!b || !out || channel < 0 || channel >= b->C) return qmf_fail(ASP_ERR_PARAM, "ExportState: bad argument");
   QMF_TRY(hipSetDevice(b->device));
   QMF_TRY(hipStreamSynchronize(b->stream));
@@ -157,6 +165,7 @@ int AspQmfBatch_ExportState(AspQmfBatch* b, int channel, AspQmfState* out) {
 }
 
 int AspQmfBatch_ImportState(AspQmfBatch* b, int channel, const AspQmfState* in) {
+  AspDeviceScope dev_scope_;
   if (!b || !in || channel < 0 || channel >= b->C) return qmf_fail(ASP_ERR_PARAM, "ImportState: bad argument");
   QMF_TRY(hipSetDevice(b->device));
   QMF_TRY(hipStreamSynchronize(b->stream));
@@ -165,6 +174,7 @@ int AspQmfBatch_ImportState(AspQmfBatch* b, int channel, const AspQmfState* in) 
 }
 
 int AspQmfBatch_Synchronize(AspQmfBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return qmf_fail(ASP_ERR_PARAM, "null batch handle");
   QMF_TRY(hipSetDevice(b->device));
   QMF_TRY(hipStreamSynchronize(b->stream));
@@ -185,6 +195,7 @@ static AspQmfBatch* one_channel() {
 
 void WebRtcSpl_AnalysisQMF(const int16_t* in_data, int in_data_length, int16_t* low_band,
                            int16_t* high_band, int32_t* filter_state1, int32_t* filter_state2) {
+  AspDeviceScope dev_scope_;
   AspQmfBatch* b = one_channel();
   AspQmfState st;
   memset(&st, 0, sizeof st);
@@ -200,6 +211,7 @@ void WebRtcSpl_AnalysisQMF(const int16_t* in_data, int in_data_length, int16_t* 
 
 void WebRtcSpl_SynthesisQMF(const int16_t* low_band, const int16_t* high_band, int band_length,
                             int16_t* out_data, int32_t* filter_state1, int32_t* filter_state2) {
+  AspDeviceScope dev_scope_;
   AspQmfBatch* b = one_channel();
   AspQmfState st;
   memset(&st, 0, sizeof st);
@@ -228,6 +240,7 @@ struct AspSplitBatch {
 extern "C" {
 
 int AspSplitBatch_Create(AspSplitBatch** out, int num_channels, int num_bands, int device) {
+  AspDeviceScope dev_scope_;
   if (!out || num_channels <= 0 || (num_bands != 2 && num_bands != 3))
     return qmf_fail(ASP_ERR_PARAM, "AspSplitBatch_Create: bad argument");
   *out = nullptr;
@@ -268,6 +281,7 @@ int AspSplitBatch_Create(AspSplitBatch** out, int num_channels, int num_bands, i
 }
 
 int AspSplitBatch_Free(AspSplitBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return -1;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
@@ -286,6 +300,7 @@ int AspSplitBatch_Free(AspSplitBatch* b) {
 }
 
 int AspSplitBatch_Analysis(AspSplitBatch* b, const int16_t* in, int16_t* bands, int mem) {
+  AspDeviceScope dev_scope_;
   if (!b || !in || !bands) return qmf_fail(ASP_ERR_PARAM, "AspSplitBatch_Analysis: bad argument");
   QMF_TRY(hipSetDevice(b->device));
   const size_t c = (size_t)b->C, total = c * 160 * b->nb * sizeof(int16_t);
@@ -318,6 +333,7 @@ int AspSplitBatch_Analysis(AspSplitBatch* b, const int16_t* in, int16_t* bands, 
 }
 
 int AspSplitBatch_Synthesis(AspSplitBatch* b, const int16_t* bands, int16_t* out, int mem) {
+  AspDeviceScope dev_scope_;
   if (!b || !out || !bands) return qmf_fail(ASP_ERR_PARAM, "AspSplitBatch_Synthesis: bad argument");
   QMF_TRY(hipSetDevice(b->device));
   const size_t c = (size_t)b->C, total = c * 160 * b->nb * sizeof(int16_t);

@@ -3,6 +3,8 @@
 // (doubles, exactly the reference's recurrence), and the batch handle.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include "device_scope.h"
+
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -154,6 +156,7 @@ extern "C" {
 
 int AspSincBatch_Create(AspSincBatch** out, int num_channels, int source_frames,
                         int destination_frames, int device) {
+  AspDeviceScope dev_scope_;
   if (!out || num_channels <= 0 || source_frames <= kKernelSize || destination_frames <= 0)
     return sinc_fail(ASP_ERR_PARAM, "AspSincBatch_Create: bad argument");
   *out = nullptr;
@@ -198,6 +201,7 @@ int AspSincBatch_Create(AspSincBatch** out, int num_channels, int source_frames,
 }
 
 int AspSincBatch_Free(AspSincBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return -1;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
@@ -215,6 +219,7 @@ int AspSincBatch_Free(AspSincBatch* b) {
 }
 
 int AspSincBatch_SetStream(AspSincBatch* b, void* hip_stream) {
+  AspDeviceScope dev_scope_;
   if (!b) return sinc_fail(ASP_ERR_PARAM, "null batch handle");
   SINC_TRY(hipSetDevice(b->device));
   SINC_TRY(hipStreamSynchronize(b->stream));
@@ -225,6 +230,7 @@ int AspSincBatch_SetStream(AspSincBatch* b, void* hip_stream) {
 int AspSincBatch_num_channels(const AspSincBatch* b) { return b ? b->C : 0; }
 
 int AspSincBatch_Resample(AspSincBatch* b, const int16_t* in, int16_t* out, int mem) {
+  AspDeviceScope dev_scope_;
   if (!b || !in || !out) return sinc_fail(ASP_ERR_PARAM, "AspSincBatch_Resample: bad argument");
   SINC_TRY(hipSetDevice(b->device));
   // PushSincResampler::Resample (push_sinc_resampler.cc:47-60): a priming pass on the first call
@@ -269,6 +275,7 @@ int AspSincBatch_Resample(AspSincBatch* b, const int16_t* in, int16_t* out, int 
 }
 
 int AspSincBatch_Synchronize(AspSincBatch* b) {
+  AspDeviceScope dev_scope_;
   if (!b) return sinc_fail(ASP_ERR_PARAM, "null batch handle");
   SINC_TRY(hipSetDevice(b->device));
   SINC_TRY(hipStreamSynchronize(b->stream));
@@ -276,6 +283,7 @@ int AspSincBatch_Synchronize(AspSincBatch* b) {
 }
 
 int AspSincBatch_kernel_table(const AspSincBatch* b, float* out, int capacity) {
+  AspDeviceScope dev_scope_;
   if (!b || !out || capacity < (int)b->kernel_host.size()) return sinc_fail(ASP_ERR_PARAM, "kernel_table: bad argument");
   memcpy(out, b->kernel_host.data(), b->kernel_host.size() * sizeof(float));
   return (int)b->kernel_host.size();

@@ -107,6 +107,17 @@ def cpu_baseline(seconds_budget=20.0):
     for _ in range(reps_t):
         eng.run(x, threads=threads)
     dt = time.perf_counter() - t0
+    # SURVEY 8(d) asks for both: the same code on ONE thread (a bounded sample of its own: 16 streams x 500 frames,
+    # about 0.1 core-seconds past its own warm-up)
+    s1, timed1 = 16, 500
+    x1 = np.ascontiguousarray(x[:, :s1])
+    eng1 = oracle_lib.RefNs(s1, policy=1) if kind == "reference" else oracle_lib.OracleNs(s1, policy=1)
+    for _ in range(reps_w):
+        eng1.run(x1, threads=1)
+    t1 = time.perf_counter()
+    for _ in range(timed1 // 50):
+        eng1.run(x1, threads=1)
+    dt1 = time.perf_counter() - t1
     return {
         "value": streams * timed / dt,
         "unit": "frames/s",
@@ -114,6 +125,8 @@ def cpu_baseline(seconds_budget=20.0):
         "kind": kind,
         "sample": "%d streams x %d frames after %d warm-up frames, %d pthreads over streams, "
                   "gcc -O2 -ffp-contract=off" % (streams, timed, warm, threads),
+        "single_thread": {"value": s1 * timed1 / dt1, "unit": "frames/s", "cores": 1,
+                          "sample": "%d streams x %d frames after %d warm-up frames, one thread" % (s1, timed1, warm)},
     }
 
 

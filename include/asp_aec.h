@@ -243,7 +243,14 @@ int AspAecBatch_get_error_code(const AspAecBatch* b);
  * kExtendedMu / kExtendedErrorThreshold, the extended smoothing coefficients and overdrive floors, no filter
  * reset on divergence) and the ProcessExtended / EstBufDelayExtended delay handling of
  * echo_cancellation.c:744-814, 869-922 (trusted-delay build).  Call it after Init (Init switches it off, as
- * aec_core.c:1522-1523 does); the per-stream blocks are re-packed to the new filter length. */
+ * aec_core.c:1522-1523 does); the per-stream blocks are re-packed to the new filter length.
+ * Restriction: switching it OFF mid-stream is refused (ASP_ERR_STATE, lastError = AEC_UNSUPPORTED_FUNCTION_ERROR,
+ * the handle stays in the extended mode) while xfBufBlockPos is 12 or more -- 20 of its 32 positions.  The
+ * reference accepts the call there and keeps walking partitions 12..31 of its fixed 32-partition arrays with
+ * the 12-partition wrap rule (aec_core.c:1203-1207, 147-169) until the position falls below 12; the 12-partition
+ * state block of this library has no such rows.  Feed frames until AspAecBatch_GetControl(...).xfBufBlockPos < 12
+ * and call again (a block decrements it by one; the void drop-in wrapper WebRtcAec_enable_delay_correction
+ * leaves the code in WebRtcAec_get_error_code). */
 int AspAecBatch_enable_delay_correction(AspAecBatch* b, int enable);
 int AspAecBatch_delay_correction_enabled(const AspAecBatch* b);
 /* WebRtcAec_enable_reported_delay for every stream (aec_core.c:1868-1874).  enable = 0 is the delay-agnostic

@@ -49,6 +49,21 @@ def check_free_running(rel, what="", known_flips=()):
         assert r <= (CHAOS_CAP if s in known_flips else 1e-4), (what, s, r, rel)
 
 
+def parity_note(line):
+    """A measured parity figure of the GPU suite: printed, and appended to the report file the
+    evidence scripts copy to profiles/ (gpurun_out/parity_report.txt under the repository root; `pytest -q`
+    swallows the print).  ASP_PARITY_REPORT names another file."""
+    print(line)
+    path = os.environ.get("ASP_PARITY_REPORT") or os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
 def free_running_report(y, ref, what=""):
     """Per-stream relative L2 of [F][S][160] outputs against the reference-equal truth `ref`, printed
     as SURVEY 8(c)(3) asks: median, 95th percentile, max with its stream, and the first frame whose own
@@ -61,8 +76,8 @@ def free_running_report(y, ref, what=""):
     over = np.nonzero((frame_rel > 1e-4).any(axis=1))[0]
     first = int(over[0]) if over.size else -1
     share = float((frame_rel > 1e-4).mean())
-    print("%s: per-stream rel-L2 median %.3g  p95 %.3g  max %.3g (stream %d); first frame beyond 1e-4: %d; "
-          "frames beyond 1e-4: %.4f %%" % (what, np.median(rel), np.percentile(rel, 95), rel.max(), worst, first, 100 * share))
+    parity_note("%s: per-stream rel-L2 median %.3g  p95 %.3g  max %.3g (stream %d); first frame beyond 1e-4: %d; "
+                "frames beyond 1e-4: %.4f %%" % (what, np.median(rel), np.percentile(rel, 95), rel.max(), worst, first, 100 * share))
     return rel, worst, first
 
 

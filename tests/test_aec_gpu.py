@@ -18,6 +18,8 @@ from audiosignalprocess_amd.synth import aec_frames
 from tests import oracle_lib
 from tests.oracle_lib import OracleAec
 
+from tests.conftest import parity_note
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -115,7 +117,7 @@ def test_free_running_vs_oracle(aec, fs, n, nlp):
         assert rep["outBuf"][1] <= 1e-5 and rep["overDrive"][1] <= 1e-6 and rep["overDriveSm"][1] <= 1e-6
         assert _rel_l2(out_g[:, s], out_o[:, s]) <= 1e-5, s
     frac_exact = (_bits(out_g) == _bits(out_o)).mean()
-    print("AEC fs=%d n=%d: %.4f of output samples bit-equal to the oracle, worst rel-L2 %.2e"
+    parity_note("AEC fs=%d n=%d: %.4f of output samples bit-equal to the oracle, worst rel-L2 %.2e"
           % (fs, n, frac_exact, max(_rel_l2(out_g[:, s], out_o[:, s]) for s in range(S))))
     assert frac_exact > 0.9
 
@@ -173,7 +175,7 @@ def test_extended_filter_vs_oracle(aec, fs, n, nlp):
     compare(F)
     worst = max(_rel_l2(out_g[:, s], out_o[:, s]) for s in range(S))
     frac_exact = (_bits(out_g) == _bits(out_o)).mean()
-    print("AEC extended fs=%d n=%d: %.4f of output samples bit-equal to the oracle, worst rel-L2 %.2e" % (fs, n, frac_exact, worst))
+    parity_note("AEC extended fs=%d n=%d: %.4f of output samples bit-equal to the oracle, worst rel-L2 %.2e" % (fs, n, frac_exact, worst))
     assert worst <= 1e-5 and frac_exact > 0.9
     assert np.abs(aec_state_arrays(g.export_state(0))["wfBuf"].reshape(2, 32 * 65)[:, 12 * 65:]).max() > 0   # the long filter is live
     # off again, mid-stream (legal where xfBufBlockPos lies inside the short filter, as in the reference): the
@@ -339,7 +341,7 @@ def test_delay_agnostic_mode_vs_oracle(aec, fs, n, ext):
                 assert bad == [], (f, s, {k: rep[k] for k in bad})
     corr = [g.delay_state(s).delay_correction_count for s in range(S)]
     reads = {g.delay_state(s).far_read for s in range(S)}
-    print("delay-agnostic fs=%d n=%d ext=%d: corrections per stream %s, %d distinct far read positions, worst rel-L2 %.2e"
+    parity_note("delay-agnostic fs=%d n=%d ext=%d: corrections per stream %s, %d distinct far read positions, worst rel-L2 %.2e"
           % (fs, n, ext, corr, len(reads), max(_rel_l2(out_g[:, s], out_o[:, s]) for s in range(S))))
     for s in range(S):
         assert _rel_l2(out_g[:, s], out_o[:, s]) <= 1e-5, s
@@ -515,7 +517,7 @@ def test_skew_mode_vs_oracle(aec, fs, n, sc_skew):
                 assert bad == [], (f, s, {k: rep[k] for k in bad})
     assert resampled > 100
     worst = max(_rel_l2(out_g[:, s], out_o[:, s]) for s in range(S))
-    print("AEC skew fs=%d: %d resampled frames, %.4f of output samples bit-equal to the oracle, worst rel-L2 %.2e"
+    parity_note("AEC skew fs=%d: %d resampled frames, %.4f of output samples bit-equal to the oracle, worst rel-L2 %.2e"
           % (fs, resampled, (_bits(out_g) == _bits(out_o)).mean(), worst))
     assert worst <= 1e-5
 
@@ -910,7 +912,7 @@ def test_two_bands_32khz_vs_oracle(aec):
         bad = [k for k in LINEAR_FIELDS + ["dBufH"] if not rep[k][0]]
         assert bad == [], (s, {k: rep[k] for k in bad})
         assert _rel_l2(gl[:, s], ol[:, s]) <= 1e-5 and _rel_l2(gh[:, s], oh[:, s]) <= 1e-5, s
-    print("AEC 32 kHz: low %.4f / high %.4f of output samples bit-equal to the oracle"
+    parity_note("AEC 32 kHz: low %.4f / high %.4f of output samples bit-equal to the oracle"
           % ((_bits(gl) == _bits(ol)).mean(), (_bits(gh) == _bits(oh)).mean()))
     assert np.abs(gh[170:240]).mean() < 0.9 * np.abs(nh[170:240]).mean()
     # a 32 kHz batch refuses the one-band entry point, 48 kHz is refused at Init

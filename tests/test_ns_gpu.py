@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 from audiosignalprocess_amd.synth import ns_frames
-from tests.conftest import (CHAOS_CAP, check_free_running, free_running_report, rel_l2_per_stream, state_diff,
+from tests.conftest import (parity_note, CHAOS_CAP, check_free_running, free_running_report, rel_l2_per_stream, state_diff,
                             state_from_bytes)
 from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE64P, OracleNs
 
@@ -987,6 +987,6 @@ def test_apm_ns_48khz_float_vs_reference_libapm(ns, tmp_path):
     gi = np.rint(got.astype(np.float64) * np.where(got > 0, 32767.0, 32768.0)).astype(np.int32)
     wi = np.rint(want.astype(np.float64) * np.where(want > 0, 32767.0, 32768.0)).astype(np.int32)
     d = np.abs(gi - wi)
-    print("APM_NS 48 kHz stereo float: %.4f of samples identical, max |diff| %d LSB" % ((d == 0).mean(), d.max()))
+    parity_note("APM_NS 48 kHz stereo float: %.4f of samples identical, max |diff| %d LSB" % ((d == 0).mean(), d.max()))
     assert d.max() <= 2 and (d == 0).mean() >= 0.99
     assert rel_l2_per_stream(got.reshape(-1, 1, 960), want.reshape(-1, 1, 960)).max() <= 1e-4

@@ -1,14 +1,13 @@
 #!/bin/bash
 # Timing probe: what the second (bin 64) trip of the AEC's per-bin phases costs.  Builds aec_kernels.hip with
-# AEC_TRIPS=1 (bin 64 is then not computed: the results are WRONG, only the step time means something) next to the
-# normal build, same session.  Restores the normal build at the end.
+# AEC_TRIPS=1 (bin 64 is then not computed: the results are WRONG, only the step time means something) into a
+# library of its OWN under tools/probe/bin (tools/build_variant.sh) and loads it through ASP_AMD_LIB: the in-tree
+# library every test and bench run loads is never replaced, whatever happens to this script.
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for FLAGS in ${ABL_FLAGS:-"-DAEC_TRIPS=2" "-DAEC_TRIPS=1" "-DAEC_TRIPS=2"}; do
-  export ASP_HIPCC_EXTRA="aec_kernels.hip:$FLAGS"
-  touch audiosignalprocess_amd/csrc/aec_kernels.hip
-  python -c "from audiosignalprocess_amd import build; build.build_library()" > gpurun_out/build.log 2>&1 || tail -5 gpurun_out/build.log
-  python3 - <<PY
+bash tools/build_variant.sh trips1 aec_kernels.hip -DAEC_TRIPS=1 > gpurun_out/build_trips1.log 2>&1 || { tail -5 gpurun_out/build_trips1.log; exit 1; }
+for L in "" tools/probe/bin/libasp_trips1.so ""; do
+  ASP_AMD_LIB="${L:+$PWD/$L}" python3 - <<PY
 import numpy as np, torch
 from audiosignalprocess_amd.aec import AecBatch
 from audiosignalprocess_amd.synth import aec_frames
@@ -22,6 +21,6 @@ g = AecBatch(S, 16000)
 g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, 125)
 for _ in range(2):
     ms = g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, 250)
-    print("$FLAGS: step_us %.1f" % (1000 * ms / 250))
+    print("${L:-in-tree (AEC_TRIPS=2)}: step_us %.1f" % (1000 * ms / 250))
 PY
 done
