@@ -130,6 +130,46 @@ def cpu_baseline(seconds_budget=20.0):
     }
 
 
+def init_ranks(args):
+    """(rank, world, local_rank, dist) of this process; with more than one rank (or under torch.distributed.run)
+    the RCCL process group is initialised: it serves the timing barrier and the MAX over ranks only."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1 or "RANK" in os.environ:
+        # launched by torch.distributed.run: the same code shape at every N (a one-rank launch rehearses
+        # the RCCL initialisation, the barrier and the MAX over ranks of the N-rank run)
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return rank, world, local_rank, dist
+
+
+def rank_barrier(dist):
+    import torch
+
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def finish_ranks(dist):
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_bt(args):
     """Secondary line (BASELINE config 3 / 1): BlockThresholding macroblocks per second, 1 GPU."""
     import torch
@@ -137,34 +177,43 @@ def bench_bt(args):
     from audiosignalprocess_amd.bt import BtBatch
     from audiosignalprocess_amd.synth import bt_samples
 
+    from audiosignalprocess_amd.shard import max_over_ranks, shard_streams
+
+    rank, world, local_rank, dist = init_ranks(args)
     n = 1024 if args.workload == "bt1024" else 256
-    S = args.streams_per_gpu
+    # every rank owns a disjoint contiguous shard of stream-channels on its own GPU (no data-path collective)
+    stream0, S = shard_streams(rank, world, args.streams_per_gpu)
     ring = 4
-    g = BtBatch(S, n)
-    x = bt_samples(S, ring * g.macro).reshape(S, ring, g.macro).transpose(1, 0, 2)
+    g = BtBatch(S, n, device=local_rank)
+    x = bt_samples(S, ring * g.macro, stream0=stream0).reshape(S, ring, g.macro).transpose(1, 0, 2)
     d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     d_out = torch.empty_like(d_in)
     steps, warm = max(args.steps // 10, 10), max(args.warmup // 10, 4)
     g.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, warm)
-    torch.cuda.synchronize()
+    rank_barrier(dist)
     t0 = time.perf_counter()
     ev_ms = g.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, steps)
-    torch.cuda.synchronize()
+    rank_barrier(dist)
     wall = time.perf_counter() - t0
+    ev_ms, wall = max_over_ranks(dist, [ev_ms, wall], device="cuda")   # the slowest rank's region
+    if rank != 0:
+        return finish_ranks(dist)
     algo = 40 * (n // 2) * 2 * 1  # 10 B per sample: in + out + both tails read and written
     algo = 10 * g.macro
     launch_s = ev_ms / 1e3 / steps             # one clock (hipEvents on the launch stream) for every number of the line
     achieved = algo * S / launch_s / 1e9
     line = {
-        "metric": "BlockThresholding macroblocks/sec (secondary)", "value": S / launch_s,
-        "unit": "macroblocks/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "metric": "BlockThresholding macroblocks/sec (secondary)", "value": S * world / launch_s,
+        "unit": "macroblocks/s", "n_gpus": world, "steps": steps, "warmup": warm,
         "ms_per_step": 1e3 * launch_s, "wall_ms_per_step": 1e3 * wall / steps,
         "parity": "unpinned (the reference's kiss_fft does not compile: _kiss_fft_guts.h is absent; DESIGN.md section 2)",
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Denoise/BlockThresholding: %d-pt STFT, Stein block threshold, %d "
-                               "stream-channels on 1 MI355X, one 8-hop macroblock per stream-channel and step" % (n, S),
-                   "samples_per_s": S * g.macro / launch_s},
+                               "stream-channels per MI355X (%d on %d GPU%s), one 8-hop macroblock per stream-channel and step"
+                               % (n, S, S * world, world, "" if world == 1 else "s"),
+                   "samples_per_s": S * world * g.macro / launch_s,
+                   "parallelism": "stream-sharded x%d, no collectives" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": BT_TRAFFIC_BYTES_PER_MACROBLOCK * S if n == 1024 else None,
                      "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), per step of all stream-channels; not measured in this run",
@@ -172,7 +221,7 @@ def bench_bt(args):
                      "launch_chains": 2 if S >= 2048 else 1,
                      "algorithmic_bytes_per_step": algo * S, "avg_step_us": launch_s * 1e6},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         # the CPU restatement (oracle/bt_oracle.c; the reference itself is unbuildable here, DESIGN.md
         # section 2), one stream-channel per thread; ctypes releases the GIL inside the C calls
         from concurrent.futures import ThreadPoolExecutor
@@ -197,6 +246,7 @@ def bench_bt(args):
                                 "sample": "%d stream-channels x %d macroblocks through oracle/bt_oracle.c, "
                                           "one thread each" % (cores, blocks)}
     print(json.dumps(line), flush=True)
+    finish_ranks(dist)
 
 
 def bench_split(args):
@@ -244,6 +294,11 @@ def bench_split(args):
     print(json.dumps(line), flush=True)
 
 
+def aec_flow_active(ext, dmode, steps):
+    """Does AspAecBatch_TimedSteps run the hand-off build?  (aec_api.hip, aec_flow_applies)"""
+    return os.environ.get("ASP_AEC_FLOW", "1")[:1] != "0" and not ext and dmode == "off" and steps >= 2
+
+
 def bench_aec(args):
     """Secondary line (BASELINE config 4): 10 ms / 16 kHz frames per second through the echo
     canceller (WebRtcAec_BufferFarend + WebRtcAec_Process per frame), 1 GPU."""
@@ -252,14 +307,19 @@ def bench_aec(args):
     from audiosignalprocess_amd.aec import AecBatch
     from audiosignalprocess_amd.synth import aec_frames
 
-    S = args.streams_per_gpu
+    from audiosignalprocess_amd.shard import max_over_ranks, shard_streams
+
+    rank, world, local_rank, dist = init_ranks(args)
+    # every rank owns a disjoint contiguous shard of streams on its own GPU (no data-path collective; the host
+    # control plane is per batch and simply replicated per rank)
+    stream0, S = shard_streams(rank, world, args.streams_per_gpu)
     ring = 40
-    far1, near1 = aec_frames(64, ring)                      # 64 distinct streams, tiled over S
+    far1, near1 = aec_frames(64, ring, stream0=(stream0 % 64))   # 64 distinct streams, tiled over the shard
     idx = np.arange(S) % 64
     d_far = torch.from_numpy(np.ascontiguousarray(far1[:, idx])).cuda()
     d_near = torch.from_numpy(np.ascontiguousarray(near1[:, idx])).cuda()
     d_out = torch.empty_like(d_near)
-    g = AecBatch(S, 16000)
+    g = AecBatch(S, 16000, device=local_rank)
     ext = bool(getattr(args, "aec_extended", False))
     if ext:     # WebRtcAec_enable_delay_correction: the 32-partition extended filter
         g.enable_delay_correction(1)
@@ -270,36 +330,44 @@ def bench_aec(args):
             g.enable_reported_delay(0)
     steps, warm = max(args.steps // 4, 10), max(args.warmup // 2, 80)   # warm-up passes the start-up phase
     g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, warm)
-    torch.cuda.synchronize()
+    rank_barrier(dist)
     assert g.control().startup_phase == 0
     t0 = time.perf_counter()
     ev_ms = g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, steps)
-    torch.cuda.synchronize()
+    rank_barrier(dist)
     wall = time.perf_counter() - t0
     assert bool(torch.isfinite(d_out).all())
+    ev_ms, wall = max_over_ranks(dist, [ev_ms, wall], device="cuda")   # the slowest rank's region
+    if rank != 0:
+        return finish_ranks(dist)
+    flow = aec_flow_active(ext, dmode, steps)
     # 2.5 blocks x 28 560 B per 10 ms frame; the same accounting with 32 partitions:
     # read X, W 2 x 32 x 130 + 1 229 floats, write W 32 x 130 + 1 231 floats = 59 760 B per block
     algo = 149400 if ext else 71400
     step_s = ev_ms / 1e3 / steps
     achieved = algo * S / step_s / 1e9
     line = {
-        "metric": "AEC 10 ms frames/sec (secondary)", "value": S / step_s, "unit": "frames/s",
-        "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * step_s,
+        "metric": "AEC 10 ms frames/sec (secondary)", "value": S * world / step_s, "unit": "frames/s",
+        "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * step_s,
         "wall_ms_per_step": 1e3 * wall / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "WebRTC AEC (test_aec_module): 10 ms/16 kHz far+near frames, %d concurrent "
-                               "streams on 1 MI355X, %d partitions, the far-end work fused into the process "
-                               "launch of each frame%s" % (S, 32 if ext else 12, "" if dmode == "off" else
-                                                           "; delay estimation: " + dmode)},
+                               "streams per MI355X (%d on %d GPU%s), %d partitions, the far-end work fused into the "
+                               "process launch of each frame%s%s"
+                               % (S, S * world, world, "" if world == 1 else "s", 32 if ext else 12,
+                                  "" if dmode == "off" else "; delay estimation: " + dmode,
+                                  "; hand-off build: %d frame steps per launch" % min(steps, 64) if flow else ""),
+                   "parallelism": "stream-sharded x%d, no collectives" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None if ext else AEC_TRAFFIC_BYTES_PER_FRAME * S,
                      "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE; 4-byte-per-lane accesses, a width MI355X_MICROARCH.md does not calibrate), per frame step of all streams; not measured in this run",
-                     "kernel": "aec_process_kernel (the far-end work of the frame inside it)",
-                     "launch_chains": 2 if S >= 2048 and dmode == "off" else 1,
+                     "kernel": ("aec_process_flow_kernel" if flow else "aec_process_kernel") + " (the far-end work of the frame inside it)",
+                     "launch_chains": 1 if flow else 2 if S >= 2048 and dmode == "off" else 1,
+                     "frame_steps_per_launch": min(steps, 64) if flow else 1,
                      "algorithmic_bytes_per_step": algo * S, "avg_step_us": step_s * 1e6},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         from tests import oracle_lib
         cores = host_cores()
         if oracle_lib.have_aec_ref():
@@ -333,6 +401,7 @@ def bench_aec(args):
                                     "sample": "%d streams x %d frames through oracle/aec_oracle.c (bit-exact "
                                               "restatement of the reference), %d pthreads" % (Sc, Fc, cores)}
     print(json.dumps(line), flush=True)
+    finish_ranks(dist)
 
 
 def copy_ceiling_gbs(device=0):
@@ -353,7 +422,10 @@ def _secondary(args, workload, cpu_baseline=True):
     if args.no_cpu_baseline or not cpu_baseline:
         cmd.append("--no-cpu-baseline")
     try:
-        out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()
+        # a plain single-process child, also when this process was started by torch.distributed.run
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE")}
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600, env=env).stdout.strip().splitlines()
         return json.loads(out[-1])
     except Exception as e:  # noqa: BLE001  (a failed secondary must not take the headline down)
         return {"workload": workload, "error": str(e)[:300]}
@@ -495,26 +567,8 @@ def main():
     if args.workload != "ns":
         return bench_bt(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher" % args.gpus)
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-
+    rank, world, local_rank, dist = init_ranks(args)
     import torch
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:
-        # launched by torch.distributed.run: the same code shape at every N (a one-rank launch rehearses
-        # the RCCL initialisation, the barrier and the MAX over ranks of the N-rank run)
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from audiosignalprocess_amd.shard import max_over_ranks
 

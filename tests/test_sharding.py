@@ -87,6 +87,27 @@ def test_bench_under_torchrun_one_rank():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workload,unit", [("aec", "frames/s"), ("bt1024", "macroblocks/s")])
+def test_secondary_bench_under_torchrun_one_rank(workload, unit):
+    """`bench.py --workload aec|bt1024 --gpus N` has the headline's shape (shard, barrier, MAX over ranks): rehearsed
+    with one rank under torch.distributed.run."""
+    import json
+    import subprocess
+    import sys
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--workload", workload, "--gpus", "1", "--steps", "40", "--warmup", "160", "--streams-per-gpu", "512",
+           "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["unit"] == unit
+    assert line["value"] > 0 and "x1" in line["config"]["parallelism"]
+
+
+@pytest.mark.gpu
 def test_two_shards_on_two_devices_vs_oracle():
     from audiosignalprocess_amd.ns import NsBatch, device_count
     from audiosignalprocess_amd.synth import ns_frames
@@ -105,3 +126,43 @@ def test_two_shards_on_two_devices_vs_oracle():
     assert np.array_equal(np.concatenate(ys, axis=1), full)
     for b in batches:
         b.close()
+
+
+@pytest.mark.gpu
+def test_two_shards_on_two_devices_aec_and_bt_vs_oracle():
+    """The `device >= 1` path of AecBatch and BtBatch (their own tables, streams and state on the second GPU), and the
+    caller's current device left alone by every entry point: two shards on two devices in one process against the
+    oracles.  Skipped on a one-GPU box."""
+    import torch
+
+    from audiosignalprocess_amd.aec import AecBatch
+    from audiosignalprocess_amd.bt import BtBatch
+    from audiosignalprocess_amd.ns import device_count
+    from audiosignalprocess_amd.synth import aec_frames, bt_samples
+    from tests.oracle_lib import OracleAec, OracleBt
+
+    if device_count() < 2:
+        pytest.skip("one HIP device on this box (the 8-GPU curve is the driver's to measure)")
+    torch.cuda.set_device(0)
+    per, F = 3, 130
+    outs = []
+    for rank in (0, 1):
+        s0, n = shard_streams(rank, 2, per)
+        far, near = aec_frames(n, F, stream0=s0)
+        g = AecBatch(n, device=rank)
+        outs.append((g.run(far, near), far, near))
+        g.close()
+        assert torch.cuda.current_device() == 0      # AspDeviceScope: the caller's device is put back
+    for out, far, near in outs:
+        for s in range(per):
+            want = OracleAec().run(far[:, s], near[:, s])
+            num = np.sqrt(((out[:, s] - want).astype(np.float64) ** 2).sum())
+            assert num <= 1e-5 * np.sqrt((want.astype(np.float64) ** 2).sum())
+    for rank in (0, 1):
+        s0, n = shard_streams(rank, 2, per)
+        bt = BtBatch(n, 1024, device=rank)
+        x = bt_samples(n, 3 * bt.macro, stream0=s0)
+        y = bt.run(x)
+        for ch in range(n):
+            assert np.array_equal(y[ch].view(np.uint32), OracleBt(1024).run(x[ch]).view(np.uint32))
+        assert torch.cuda.current_device() == 0
