@@ -19,6 +19,7 @@ def _lib():
             "AspBtBatch_Create": [C.POINTER(vp), ip, ip, ip],
             "AspBtBatch_Free": [vp],
             "AspBtBatch_Reset": [vp],
+            "AspBtBatch_ResetStream": [vp, C.c_int],
             "AspBtBatch_num_streams": [vp],
             "AspBtBatch_macro_size": [vp],
             "AspBtBatch_Denoise": [vp, vp, vp, ip],
@@ -89,6 +90,10 @@ class BtBatch:
 
     def reset(self):
         _check(self.lib.AspBtBatch_Reset(self.h), "AspBtBatch_Reset")
+
+    def reset_stream(self, stream):
+        """blockThreshold_reset of one stream-channel of the running batch."""
+        _check(self.lib.AspBtBatch_ResetStream(self.h, stream), "AspBtBatch_ResetStream")
 
     def synchronize(self):
         _check(self.lib.AspBtBatch_Synchronize(self.h), "AspBtBatch_Synchronize")

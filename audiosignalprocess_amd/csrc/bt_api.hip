@@ -175,20 +175,28 @@ int bt_build_any(int win, BtAnyTables* A, void** dev_block) {
     }
     perm[n] = (uint16_t)pos;
   }
+  // device block: the struct itself (256 B aligned head), then the tables
+  const size_t head = (sizeof(BtAnyTables) + 255) / 256 * 256;
   unsigned char* dev = nullptr;
-  BT_TRY(hipMalloc((void**)&dev, bytes));
-  hipError_t e = hipMemcpy(dev, host.data(), bytes, hipMemcpyHostToDevice);
+  BT_TRY(hipMalloc((void**)&dev, head + bytes));
+  hipError_t e = hipMemcpy(dev + head, host.data(), bytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     (void)hipFree(dev);
     return bt_fail(ASP_ERR_HIP, "uploading the window's tables", e);
   }
-  float* df = reinterpret_cast<float*>(dev);
+  float* df = reinterpret_cast<float*>(dev + head);
   A->hann = df;
   A->tw_f = df + win;
   A->tw_i = A->tw_f + 2 * nc;
   A->sup_f = A->tw_i + 2 * nc;
   A->sup_i = A->sup_f + 2 * (nc / 2);
   A->perm = reinterpret_cast<const uint16_t*>(A->sup_i + 2 * (nc / 2));
+  A->self = reinterpret_cast<const BtAnyTables*>(dev);
+  e = hipMemcpy(dev, A, sizeof(BtAnyTables), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(dev);
+    return bt_fail(ASP_ERR_HIP, "uploading the window's plan", e);
+  }
   *dev_block = dev;
   return ASP_OK;
 }
@@ -314,6 +322,17 @@ int AspBtBatch_Reset(AspBtBatch* b) {
   if (!b) return bt_fail(ASP_ERR_PARAM, "null batch handle");
   BT_TRY(hipSetDevice(b->device));
   BT_TRY(hipMemsetAsync(b->state, 0, (size_t)b->S * b->state_floats * 4, b->stream));
+  return ASP_OK;
+}
+
+// blockThreshold_reset of ONE stream-channel of a running batch (audioDenoiseBlockTreshold.c:692-707 per handle):
+// its input tail and overlap-add tail are cleared, the others untouched.
+int AspBtBatch_ResetStream(AspBtBatch* b, int stream) {
+  AspDeviceScope dev_scope_;
+  if (!b) return bt_fail(ASP_ERR_PARAM, "null batch handle");
+  if (stream < 0 || stream >= b->S) return bt_fail(ASP_ERR_PARAM, "ResetStream: stream out of range");
+  BT_TRY(hipSetDevice(b->device));
+  BT_TRY(hipMemsetAsync(b->state + (size_t)stream * b->state_floats, 0, (size_t)b->state_floats * 4, b->stream));
   return ASP_OK;
 }
 

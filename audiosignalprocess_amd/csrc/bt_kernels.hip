@@ -586,8 +586,9 @@ __device__ __forceinline__ void any_stages(cpx* work, const cpx* __restrict__ tw
 // SQW: columns of the squared-real table (32 for windows of up to 1024 samples: at most 31 macro-columns; else 64)
 template <int THREADS, int SQW, bool GENERIC>
 __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
-    float* __restrict__ state, BtAnyTables A, const float* __restrict__ in, float* __restrict__ out, int frames,
+    float* __restrict__ state, const BtAnyTables* __restrict__ Ap, const float* __restrict__ in, float* __restrict__ out, int frames,
     int threshold, int in_stride, int out_stride, unsigned long long* __restrict__ stamps) {
+  const BtAnyTables& A = *Ap;  // the plan stays in memory (scalar loads where it is read)
   // diagnostic phase stamps (never enabled by the product entry points): workgroup 0, thread 0
 #define BTA_STAMP(k) \
   if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
@@ -822,7 +823,8 @@ __global__ __launch_bounds__(THREADS) void bt_macroblock_any_kernel(
 
 // kiss_fftr / kiss_fftri seam for any even length: one workgroup per row
 __global__ __launch_bounds__(kAnyThreads) void bt_fftr_any_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                                   int inverse, BtAnyTables A) {
+                                                                   int inverse, const BtAnyTables* __restrict__ Ap) {
+  const BtAnyTables& A = *Ap;
   const int NC = A.nc, N = A.n, tid = threadIdx.x;
   extern __shared__ __align__(16) unsigned char smem[];
   cpx* work = reinterpret_cast<cpx*>(smem);  // [NC]
@@ -1033,10 +1035,10 @@ hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const fl
 #define BT_ANY_LAUNCH(TH, SQ)                                                                                  \
   do {                                                                                                         \
     if (generic)                                                                                               \
-      hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ, true>), dim3(num_streams), dim3(TH), lds, s, state, A, in, \
+      hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ, true>), dim3(num_streams), dim3(TH), lds, s, state, A.self, in, \
                          out, frames, threshold, in_stride, out_stride, stamps);                               \
     else                                                                                                       \
-      hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ, false>), dim3(num_streams), dim3(TH), lds, s, state, A, in, \
+      hipLaunchKernelGGL((bt_macroblock_any_kernel<TH, SQ, false>), dim3(num_streams), dim3(TH), lds, s, state, A.self, in, \
                          out, frames, threshold, in_stride, out_stride, stamps);                               \
   } while (0)
   if (threads == 512 && sqw == 64)
@@ -1055,7 +1057,7 @@ hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const fl
 
 hipError_t launch_bt_fftr_any(const BtAnyTables& A, const float* src, float* dst, int count, int inverse, hipStream_t s) {
   hipLaunchKernelGGL(bt_fftr_any_kernel, dim3(count), dim3(kAnyThreads), (size_t)(2 * A.nc + 1) * sizeof(cpx), s, src, dst,
-                     inverse, A);
+                     inverse, A.self);
   return hipGetLastError();
 }
 

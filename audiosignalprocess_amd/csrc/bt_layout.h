@@ -62,6 +62,10 @@ struct BtAnyTables {
   const float* sup_f;    // [nc / 2] complex
   const float* sup_i;
   const uint16_t* perm;  // [nc]
+  // the device copy of this struct (at the head of the device block the pointers above point into): the
+  // kernels take it by address -- passed by value the whole struct was copied into SGPRs at kernel entry and
+  // spilled from there (273 spilled SGPRs)
+  const BtAnyTables* self;
 };
 
 // ---------------------------------------------------------------- register layouts of the FFT stages of bt_kernels8.hip

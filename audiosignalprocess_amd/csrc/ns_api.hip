@@ -760,6 +760,47 @@ int AspNsBatch_Init(AspNsBatch* b, uint32_t fs) {
   return ASP_OK;
 }
 
+static int flow_check(AspNsBatch* b);
+
+// WebRtcNs_Init of ONE stream of a running batch (noise_suppression.c:35-39 per handle): its state block and
+// histograms go back to InitCore's values at the batch's sample rate (policy 0, as InitCore ends,
+// ns_core.c:207); the other streams are untouched.  Ordered on the batch's stream like every other call.
+int AspNsBatch_InitStream(AspNsBatch* b, int stream) {
+  DeviceScope dev_scope_;
+  int rc = check(b);
+  if (rc) return rc;
+  if (stream < 0 || stream >= b->S) return fail(ASP_ERR_PARAM, "InitStream: stream out of range");
+  std::vector<AspNsState> s0(1);
+  init_state(s0.data(), b->fs);
+  std::vector<float> blk(kStreamDwords);
+  std::vector<int32_t> hh(kHistDwords);
+  pack_stream(s0.data(), blk.data(), hh.data());  // every row, hot and cold: valid in the fused and the two-call representation
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  rc = flow_check(b);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(b->state + (size_t)stream * kStreamDwords, blk.data(), kStreamDwords * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->hist + (size_t)stream * kHistDwords, hh.data(), kHistDwords * 4, hipMemcpyHostToDevice));
+  if (b->num_high > 0)  // ns_core.c:110-112: the high bands' delay lines
+    HIP_TRY(hipMemset(b->hb_tail + (size_t)stream * 2 * kCarry, 0, (size_t)2 * kCarry * sizeof(float)));
+  return ASP_OK;
+}
+
+static const float kPolicyOver[4] = {1.f, 1.f, 1.1f, 1.25f};    // ns_core.c:1020-1039
+static const float kPolicyBound[4] = {0.5f, 0.25f, 0.125f, 0.09f};
+static const int kPolicyMap[4] = {0, 1, 1, 1};
+
+// WebRtcNs_set_policy of ONE stream (noise_suppression.c:41-44 per handle).
+int AspNsBatch_set_policy_stream(AspNsBatch* b, int stream, int mode) {
+  DeviceScope dev_scope_;
+  int rc = check(b);
+  if (rc) return rc;
+  if (stream < 0 || stream >= b->S) return fail(ASP_ERR_PARAM, "set_policy_stream: stream out of range");
+  if (mode < 0 || mode > 3) return fail(ASP_ERR_PARAM, "set_policy: mode must be 0..3");
+  HIP_TRY(launch_ns_set_policy(b->state + (size_t)stream * kStreamDwords, 1, mode, kPolicyOver[mode], kPolicyBound[mode],
+                               kPolicyMap[mode], b->stream));
+  return ASP_OK;
+}
+
 int AspNsBatch_set_policy(AspNsBatch* b, int mode) {
   DeviceScope dev_scope_;
   int rc = check(b);

@@ -43,6 +43,8 @@ def load_library():
         "AspNsBatch_Free": [vp],
         "AspNsBatch_Init": [vp, C.c_uint32],
         "AspNsBatch_set_policy": [vp, ip],
+        "AspNsBatch_InitStream": [vp, ip],
+        "AspNsBatch_set_policy_stream": [vp, ip, ip],
         "AspNsBatch_num_streams": [vp],
         "AspNsBatch_Analyze": [vp, vp, ip],
         "AspNsBatch_Process": [vp, vp, vp, ip],
@@ -165,6 +167,13 @@ class NsBatch:
 
     def set_policy(self, mode):
         _check(self.lib.AspNsBatch_set_policy(self.h, mode), "AspNsBatch_set_policy")
+
+    def init_stream(self, stream):
+        """WebRtcNs_Init of one stream of the running batch (policy back to 0)."""
+        _check(self.lib.AspNsBatch_InitStream(self.h, stream), "AspNsBatch_InitStream")
+
+    def set_policy_stream(self, stream, mode):
+        _check(self.lib.AspNsBatch_set_policy_stream(self.h, stream, mode), "AspNsBatch_set_policy_stream")
 
     # -- host-array convenience (copies in/out, synchronous)
     def analyze(self, frames):

@@ -66,6 +66,8 @@ typedef struct AspBtState {
 int AspBtBatch_Create(AspBtBatch** out, int num_streams, int win_size, int device);
 int AspBtBatch_Free(AspBtBatch* b);
 int AspBtBatch_Reset(AspBtBatch* b);
+/* blockThreshold_reset of ONE stream-channel of a running batch: its two tails are cleared, the others untouched. */
+int AspBtBatch_ResetStream(AspBtBatch* b, int stream);
 int AspBtBatch_num_streams(const AspBtBatch* b);
 int AspBtBatch_macro_size(const AspBtBatch* b); /* 8 * win_size / 2 samples per call */
 /* One macroblock per stream: in/out [num_streams][macro_size] float in [-1, 1]

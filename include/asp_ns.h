@@ -129,6 +129,12 @@ int AspNsBatch_Free(AspNsBatch* b);
 int AspNsBatch_Init(AspNsBatch* b, uint32_t fs);
 /* WebRtcNs_set_policy for every stream (ns_core.c:1013-1041). */
 int AspNsBatch_set_policy(AspNsBatch* b, int mode);
+/* Per-stream control of a running batch, as the reference's per-handle calls give it (noise_suppression.c:35-44):
+ * InitStream = WebRtcNs_Init of ONE stream at the batch's sample rate (state and histograms back to InitCore's values,
+ * policy 0 as InitCore leaves it), set_policy_stream = WebRtcNs_set_policy of ONE stream.  The other streams are
+ * untouched; the calls are ordered on the batch's stream with the frame steps around them. */
+int AspNsBatch_InitStream(AspNsBatch* b, int stream);
+int AspNsBatch_set_policy_stream(AspNsBatch* b, int stream, int mode);
 int AspNsBatch_num_streams(const AspNsBatch* b);
 
 /* frames: [num_streams][160] float ([num_streams][80] at 8 kHz, here and below).  Asynchronous on the batch's HIP stream

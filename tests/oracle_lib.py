@@ -100,6 +100,10 @@ class OracleNs:
             assert self.lib.asp_ns_oracle_init(C.byref(self.states[i]), fs) == 0
             assert self.lib.asp_ns_oracle_set_policy(C.byref(self.states[i]), policy) == 0
 
+    def set_policy(self, policy, stream=None):
+        for i in (range(self.S) if stream is None else [stream]):
+            assert self.lib.asp_ns_oracle_set_policy(C.byref(self.states[i]), policy) == 0
+
     def run(self, frames, threads=1):
         """frames [F][S][160] float32 ([F][S][80] at 8 kHz) -> output of the same shape."""
         frames = np.ascontiguousarray(frames, dtype=np.float32)

@@ -192,6 +192,26 @@ def test_state_roundtrip_and_reset(bt):
         h.close()
 
 
+@pytest.mark.parametrize("n", [256, 320, 1024])
+def test_reset_one_stream_of_a_running_batch(bt, n):
+    """blockThreshold_reset is per handle in the reference (audioDenoiseBlockTreshold.c:692-707): one stream-channel
+    of a running batch reset between two macroblocks continues as a fresh oracle, the others as theirs."""
+    S = 6
+    g = bt.BtBatch(S, n)
+    x = bt_samples(S, 4 * g.macro)
+    y1 = g.run(x[:, :2 * g.macro])
+    g.reset_stream(4)
+    y2 = g.run(x[:, 2 * g.macro:])
+    for s in range(S):
+        o = OracleBt(n)
+        w1 = o.run(x[s, :2 * g.macro])
+        if s == 4:
+            o = OracleBt(n)
+        w2 = o.run(x[s, 2 * g.macro:])
+        assert np.array_equal(y1[s].view(np.uint32), w1.view(np.uint32)), s
+        assert np.array_equal(y2[s].view(np.uint32), w2.view(np.uint32)), s
+
+
 def test_flush_partial_macroblock(bt):
     for n in (256, 1024, 320, 480):
         g = bt.BtBatch(2, n)

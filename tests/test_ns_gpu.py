@@ -770,6 +770,47 @@ def test_handoff_build_equals_plain_launches(ns, S):
         g.close()
 
 
+def test_per_stream_init_and_policy_vs_one_oracle_per_stream(ns):
+    """The reference takes Init and set_policy per handle (noise_suppression.c:35-44).  A batch whose streams run
+    four different policies, one of them re-initialised in the middle of the run and given another policy a few
+    frames later: every stream bit-equal (outputs and state) to its OWN oracle driven the same way."""
+    S, F = 8, 260
+    x = ns_frames(S, F, stream0=9)
+    g = ns.NsBatch(S)                      # policy 0 after Init
+    pol = [0, 1, 2, 3, 1, 2, 3, 0]
+    for s_, m in enumerate(pol):
+        g.set_policy_stream(s_, m)
+    cuts = [0, 70, 77, 180, F]            # re-init stream 5 at frame 70, policy 3 at 77, re-init stream 0 at 180
+    y = np.empty_like(x)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a == 70:
+            g.init_stream(5)
+        if a == 77:
+            g.set_policy_stream(5, 3)
+        if a == 180:
+            g.init_stream(0)
+        y[a:b] = g.analyze_process(x[a:b])
+    for s_ in range(S):
+        o = OracleNs(1, policy=pol[s_], reduce_mode=REDUCE_TREE64P)
+        xs = np.ascontiguousarray(x[:, s_:s_ + 1])
+        if s_ == 5:
+            want = o.run(xs[:70])
+            o = OracleNs(1, policy=0, reduce_mode=REDUCE_TREE64P)
+            w2 = o.run(xs[70:77])
+            o.set_policy(3)
+            w3 = o.run(xs[77:])
+            want = np.concatenate([want, w2, w3], axis=0)
+        elif s_ == 0:
+            w1 = o.run(xs[:180])
+            o = OracleNs(1, policy=0, reduce_mode=REDUCE_TREE64P)
+            want = np.concatenate([w1, o.run(xs[180:])], axis=0)
+        else:
+            want = o.run(xs)
+        assert np.array_equal(y[:, s_], want[:, 0]), s_
+        assert state_diff(g.export_state(s_), o.export_state(0)) == {}, s_
+    g.close()
+
+
 def test_handoff_wait_times_out_loudly(ns):
     """A hand-off launch whose predecessor never ran must not hang: the bounded wait gives up, the grid
     drains, the call reports ASP_ERR_HIP, and the batch works again after Init."""
