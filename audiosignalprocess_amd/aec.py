@@ -42,6 +42,9 @@ def _lib():
             "AspAecBatch_GetControl": [vp, C.POINTER(AspAecControl)],
             "AspAecBatch_Synchronize": [vp],
             "AspAecBatch_SetFlow": [vp, ip],
+            "AspAecBatch_ProcessV": [vp, vp, vp, ip, vp, vp, vp, ip],
+            "AspAecBatch_InitStream": [vp, ip],
+            "AspAecBatch_GetControlStream": [vp, ip, C.POINTER(AspAecControl)],
             "AspAecBatch_TimedSteps": [vp, vp, vp, vp, ip, ip, ip, C.POINTER(C.c_float)],
             "AspAec_rdft128_batch": [vp, vp, ip, ip, ip],
             "AspAec_host_table": [ip, vp, ip],
@@ -132,6 +135,28 @@ class AecBatch:
         rc = self.buffer_farend(far)
         ol, oh, rc2 = self.process_bands(near_low, near_high, delay_ms)
         return ol, oh, rc | rc2
+
+    def process_v(self, near, delays_ms):
+        """near [S][n], delays_ms [S] (each stream's own reported delay) -> (out [S][n], status [S] int32)."""
+        near = np.ascontiguousarray(near, np.float32)
+        ms = np.ascontiguousarray(delays_ms, np.int16)
+        assert ms.shape == (self.S,)
+        out = np.empty_like(near)
+        status = np.zeros(self.S, np.int32)
+        rc = self.lib.AspAecBatch_ProcessV(self.h, near.ctypes.data, out.ctypes.data, near.shape[-1], ms.ctypes.data,
+                                           None, status.ctypes.data, MEM_HOST)
+        if rc not in (0, -1):
+            raise AspError("AspAecBatch_ProcessV failed (%d)" % rc)
+        return out, status
+
+    def init_stream(self, stream):
+        """WebRtcAec_Init of one stream of the running batch."""
+        _check(self.lib.AspAecBatch_InitStream(self.h, stream), "AspAecBatch_InitStream")
+
+    def control_stream(self, stream):
+        c = AspAecControl()
+        _check(self.lib.AspAecBatch_GetControlStream(self.h, stream, C.byref(c)), "AspAecBatch_GetControlStream")
+        return c
 
     def frame(self, far, near, delay_ms=0, skew=0):
         rc = self.buffer_farend(far)

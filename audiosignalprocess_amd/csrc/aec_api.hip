@@ -36,6 +36,10 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
 hipError_t launch_aec_process_flow(float* state, float* far_ring, const AecTables* T, int num_streams, int nrOfSamples,
                                    const AecFlowStep* descs, int steps, unsigned* seq, unsigned* abort_w, unsigned want,
                                    int num_part, hipStream_t s);
+hipError_t launch_aec_farend_v(float* state, float* far_ring, const AecTables* T, const float* farend, int num_streams,
+                               const FarOps* vfar, int nrOfSamples, int num_part, hipStream_t s);
+hipError_t launch_aec_process_v(float* state, float* far_ring, const AecTables* T, const float* nearend, float* out,
+                                int num_streams, int nrOfSamples, const AecStreamStep* vdesc, int num_part, hipStream_t s);
 hipError_t launch_aec_delay(DelayBlock* blocks, const float* spectra, int num_streams, const DelayOps& ops,
                             hipStream_t s);
 hipError_t launch_aec_resample(float* rs_buffer, const float* farend, float* out, int num_streams, int size, int size_out,
@@ -208,18 +212,14 @@ const int kSampMsNb = 8;             // :58
 
 }  // namespace
 
-struct AspAecBatch {
-  int S = 0, device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  float* state = nullptr;     // [S][AecRows(num_part).state_dwords]
+// The control plane of ONE stream -- every integer the reference keeps per handle (Aec, echo_cancellation_internal.h:
+// 17-65; the integer part of AecCore, aec_core_internal.h:52-164; ring positions, ring_buffer.c:26-33) -- as plain
+// data.  A batch fed in lock-step has one of these (its base); once a caller drives streams apart (per-stream
+// reported delays, a stream re-initialised: AspAecBatch_ProcessV / _InitStream) it has one per stream (`per`), and
+// the control functions below run once per stream on a copy swapped into the base.
+struct AecCtl {
   // WebRtcAec_enable_delay_correction (aec_core.c:1876-1881): the extended filter, 32 partitions instead of 12
   int extended = 0, num_part = kNumPartNormal;
-  // delay estimation (set_config delay_logging) and the delay-agnostic mode (WebRtcAec_enable_reported_delay 0):
-  // per-stream estimator blocks, the power spectra the process kernel leaves for them, and -- once the agnostic mode
-  // has taken over a stream's far-buffer read side (agn_synced) -- the BufferFarend calls the device has yet to replay
-  DelayBlock* dblocks = nullptr;  // [S]
-  float* spectra = nullptr;       // [S][kSpecBlocks][kSpecDwords]
   int delay_logging = 0, reported_delay_enabled = 1;
   bool agn_synced = false;
   int nevents = 0, ev_samples[kMaxFarEvents] = {}, ev_parts[kMaxFarEvents] = {};
@@ -229,8 +229,38 @@ struct AspAecBatch {
   int skewFrCtr = 0, resample = 0;
   float skew = 0.f, sampFactor = 1.f;
   float rs_position = 0.f;
-  int rs_skewData[kSkewEstimateFrames] = {}, rs_skewDataIndex = 0;
+  int rs_skewDataIndex = 0;
   float rs_skewEstimate = 0.f;
+  // Aec (echo_cancellation_internal.h:17-65)
+  int sampFreq = 0, scSampFreq = 0, splitSampFreq = 0, rate_factor = 0, initFlag = 0, lastError = 0;
+  int farend_started = 0, skewMode = 0;
+  int bufSizeStart = 0, knownDelay = 0, timeForDelayChange = 0, startup_phase = 0, checkBuffSize = 0, sum = 0;
+  int16_t counter = 0, firstVal = 0, checkBufSizeCtr = 0, msInSndCardBuf = 0, filtDelay = 0, lastDelayDiff = 0;
+  // integer part of AecCore (aec_core_internal.h:52-164)
+  int system_delay = 0, core_knownDelay = 0, mult = 0, nlp_mode = 1;
+  float normal_mu = 0.f, normal_error_threshold = 0.f;
+  int xf_pos = 0, xfw_head = 0, blocks_processed = 0;
+  RingPos pre_pos{}, far_pos{}, near_pos{}, out_pos{};
+  // a BufferFarend whose device work is deferred into the next Process launch (Run / TimedSteps)
+  bool far_pending = false;
+  FarOps far_ops{};
+  const float* far_src = nullptr;
+  // 32 kHz: one high band (aec_core.c:1032-1067)
+  int num_high = 0;
+  int metricsMode = 0;
+};
+
+struct AspAecBatch : AecCtl {
+  int S = 0, device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  float* state = nullptr;     // [S][AecRows(num_part).state_dwords]
+  // delay estimation (set_config delay_logging) and the delay-agnostic mode (WebRtcAec_enable_reported_delay 0):
+  // per-stream estimator blocks, the power spectra the process kernel leaves for them, and -- once the agnostic mode
+  // has taken over a stream's far-buffer read side (agn_synced) -- the BufferFarend calls the device has yet to replay
+  DelayBlock* dblocks = nullptr;  // [S]
+  float* spectra = nullptr;       // [S][kSpecBlocks][kSpecDwords]
+  int rs_skewData[kSkewEstimateFrames] = {};
   float* rs_buffer = nullptr;  // [S][kResamplerBufferSize]
   float* stage_rs = nullptr;   // [S][kResamplerBufferSize]: the resampled far frame of the call in flight
   float* far_ring = nullptr;  // [kFarSlots][S][kFarSlotDwords]
@@ -258,30 +288,24 @@ struct AspAecBatch {
   unsigned* flow_abort = nullptr;            // 16 B: word 0 != 0 after a wait timed out
   unsigned flow_count = 0;
   bool flow_unchecked = false;
-  // Aec (echo_cancellation_internal.h:17-65)
-  int sampFreq = 0, scSampFreq = 0, splitSampFreq = 0, rate_factor = 0, initFlag = 0, lastError = 0;
-  int farend_started = 0, skewMode = 0;
-  int bufSizeStart = 0, knownDelay = 0, timeForDelayChange = 0, startup_phase = 0, checkBuffSize = 0, sum = 0;
-  int16_t counter = 0, firstVal = 0, checkBufSizeCtr = 0, msInSndCardBuf = 0, filtDelay = 0, lastDelayDiff = 0;
-  // integer part of AecCore (aec_core_internal.h:52-164)
-  int system_delay = 0, core_knownDelay = 0, mult = 0, nlp_mode = 1;
-  float normal_mu = 0.f, normal_error_threshold = 0.f;
-  int xf_pos = 0, xfw_head = 0, blocks_processed = 0;
-  RingPos pre_pos{}, far_pos{}, near_pos{}, out_pos{};
+  // Per-stream control (AspAecBatch_ProcessV / _InitStream): one control plane per stream on the host, the launch
+  // descriptors of a call recorded per stream and read by the kernels from device memory
+  std::vector<AecCtl> per;                   // empty while the batch runs in lock-step
+  bool vrec = false;                         // a per-stream control step is recording (vstream)
+  int vstream = 0;
+  AecStreamStep* vproc_host = nullptr;       // [S], pinned: this call's Process descriptor of every stream
+  AecStreamStep* vproc_dev = nullptr;
+  FarOps* vfar_host = nullptr;               // [S], pinned: this call's far-end work of every stream
+  FarOps* vfar_dev = nullptr;
+  int vfar_recorded = 0;
+  hipEvent_t vev = nullptr;                  // the last per-stream launch has read its descriptors
   unsigned long long* debug_stamps = nullptr;  // diagnostic only (AspAecBatch_DebugStamps)
-  // a BufferFarend whose device work is deferred into the next Process launch (Run / TimedSteps)
-  bool far_pending = false;
-  FarOps far_ops{};
-  const float* far_src = nullptr;
   // control-plane-only handle (AspAecBatch_CreateControlOnly): no device, nothing is launched
   bool sim = false;
-  // 32 kHz: one high band (aec_core.c:1032-1067)
-  int num_high = 0;
   float *stage_near_h = nullptr, *stage_out_h = nullptr;  // [S][160]
   const float* cur_near_high = nullptr;  // device pointers of the Process call in flight
   float* cur_out_high = nullptr;
   // echo metrics (aec_core.c:548-770): [S][kMetDwords], updated by the kernel when metricsMode is on
-  int metricsMode = 0;
   float* metrics = nullptr;
 };
 
@@ -346,6 +370,7 @@ bool aec_flow_applies(const AspAecBatch* b, int steps) {
   // default: the 12-partition filter only (measured, profiles/README.md round 4: 101.5 us against 103.8 us per
   // 4096-stream frame with one launch per call; the extended filter's 32 partitions 190 us against 185.5 us)
   if (b->flow < 0 && b->extended) return false;
+  if (!b->per.empty()) return false;  // per-stream control: one far-end and one Process launch per call
   return on && steps >= 2 && !b->sim && b->num_high == 0 && !b->metricsMode && !b->delay_logging &&
          b->reported_delay_enabled && !b->skewMode && b->debug_stamps == nullptr;
 }
@@ -413,6 +438,11 @@ int aec_flow_check(AspAecBatch* b) {
 
 // every device launch of a batch goes through these two: one launch, or one per half on the two chains
 hipError_t batch_launch_farend(AspAecBatch* b, const float* far_dev, const FarOps& ops) {
+  if (b->vrec) {  // per-stream control: this stream's far-end work of the call (one descriptor: nothing is deferred)
+    if (b->vfar_recorded++ != 0) return hipErrorUnknown;
+    b->vfar_host[b->vstream] = ops;
+    return hipSuccess;
+  }
   if (b->flow_rec && aec_flow_flush(b) != 0) return hipErrorUnknown;  // a launch of its own: after the recorded steps
   if (!b->dual) return launch_aec_farend(b->state, b->far_ring, b->tables, far_dev, b->S, ops, b->stream, 0, -1, b->num_part);
   const int half = ((b->S / 2 + 3) / 4) * 4;
@@ -424,6 +454,12 @@ hipError_t batch_launch_farend(AspAecBatch* b, const float* far_dev, const FarOp
 hipError_t batch_launch_process(AspAecBatch* b, const float* near_dev, float* out_dev, int n, const ProcOps& ops,
                                 const float* far_src, const FarOps& fops, const float* near_high, float* out_high,
                                 float* metrics, unsigned long long* stamps) {
+  if (b->vrec) {  // per-stream control: this stream's Process descriptor
+    if (far_src != nullptr) return hipErrorUnknown;
+    b->vproc_host[b->vstream].mode = 1;
+    b->vproc_host[b->vstream].ops = ops;
+    return hipSuccess;
+  }
   if (b->flow_rec) return aec_flow_record(b, near_dev, out_dev, n, ops, far_src, fops) == 0 ? hipSuccess : hipErrorUnknown;
   if (!b->dual)
     return launch_aec_process(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops, near_high,
@@ -962,11 +998,15 @@ int process_normal_device(AspAecBatch* b, const float* near_dev, float* out_dev,
       if (rc == 0 && b->flow_rec) rc = aec_flow_flush(b);  // the pass-through copies below follow the recorded steps
       if (rc != 0) return rc;
     }
-    if (near_dev != out_dev && !b->sim)
-      AEC_TRY(hipMemcpyAsync(out_dev, near_dev, (size_t)b->S * n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
-    if (b->num_high > 0 && b->cur_near_high != b->cur_out_high && !b->sim)
-      AEC_TRY(hipMemcpyAsync(b->cur_out_high, b->cur_near_high, (size_t)b->S * n * sizeof(float),
-                             hipMemcpyDeviceToDevice, b->stream));
+    if (b->vrec) {
+      b->vproc_host[b->vstream].mode = 0;  // this stream passes its near end through (the kernel copies it)
+    } else {
+      if (near_dev != out_dev && !b->sim)
+        AEC_TRY(hipMemcpyAsync(out_dev, near_dev, (size_t)b->S * n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+      if (b->num_high > 0 && b->cur_near_high != b->cur_out_high && !b->sim)
+        AEC_TRY(hipMemcpyAsync(b->cur_out_high, b->cur_near_high, (size_t)b->S * n * sizeof(float),
+                               hipMemcpyDeviceToDevice, b->stream));
+    }
     if (b->checkBuffSize) {
       b->checkBufSizeCtr++;
       if (b->counter == 0) {
@@ -1055,6 +1095,10 @@ int process_extended_device(AspAecBatch* b, const float* near_dev, float* out_de
       const int rc = aec_flow_flush(b);
       if (rc != 0) return rc;
     }
+    if (b->vrec) {
+      b->vproc_host[b->vstream].mode = 0;
+      return 0;
+    }
     if (near_dev != out_dev && !b->sim)
       AEC_TRY(hipMemcpyAsync(out_dev, near_dev, (size_t)b->S * n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
     if (b->num_high > 0 && b->cur_near_high != b->cur_out_high && !b->sim)
@@ -1104,6 +1148,120 @@ int check_running(AspAecBatch* b, const void* p, int n) {
     return -1;
   }
   return 0;
+}
+
+// ------------------------------------------------------------------ per-stream control
+// The reference takes the reported delay, Init and the call pattern per handle (echo_cancellation.c:341-347, 196-276).
+// Once a caller uses AspAecBatch_ProcessV / _InitStream the batch keeps one AecCtl per stream (`per`); every call
+// then runs the control functions above once per stream -- on that stream's copy, swapped into the handle's base --
+// with the launches they would issue recorded as that stream's descriptor; one far-end launch and one Process launch
+// per call read the descriptors from device memory (aec_farend_v_kernel, aec_process_v_kernel).
+bool vmode(const AspAecBatch* b) { return !b->per.empty(); }
+void ctl_load(AspAecBatch* b, int s) { static_cast<AecCtl&>(*b) = b->per[(size_t)s]; }
+void ctl_store(AspAecBatch* b, int s) { b->per[(size_t)s] = static_cast<const AecCtl&>(*b); }
+
+// one stream's control plane in the handle's base for the length of a scope (ExportState / ImportState / GetControlStream)
+struct StreamCtlScope {
+  AspAecBatch* b;
+  int s;
+  AecCtl saved;
+  StreamCtlScope(AspAecBatch* b_, int s_) : b(b_), s(s_) {
+    if (vmode(b)) {
+      saved = static_cast<const AecCtl&>(*b);
+      ctl_load(b, s);
+    }
+  }
+  ~StreamCtlScope() {
+    if (vmode(b)) {
+      ctl_store(b, s);
+      static_cast<AecCtl&>(*b) = saved;
+    }
+  }
+};
+
+int enter_vmode(AspAecBatch* b) {
+  if (vmode(b)) return 0;
+  if (b->sim) return aec_fail(ASP_ERR_STATE, "per-stream control: control-only handle");
+  if (b->num_high > 0 || b->delay_logging || !b->reported_delay_enabled || b->skewMode == kAecTrue || b->metricsMode)
+    return aec_fail(ASP_ERR_STATE, "per-stream control covers the one-band configuration with reported delays "
+                                   "(no delay logging / delay-agnostic mode / skew compensation / metrics)");
+  {
+    const int rc = flush_pending_farend(b);
+    if (rc != 0) return rc;
+  }
+  if (!b->vproc_host) {
+    AEC_TRY(hipHostMalloc((void**)&b->vproc_host, sizeof(AecStreamStep) * (size_t)b->S, hipHostMallocDefault));
+    AEC_TRY(hipMalloc((void**)&b->vproc_dev, sizeof(AecStreamStep) * (size_t)b->S));
+    AEC_TRY(hipHostMalloc((void**)&b->vfar_host, sizeof(FarOps) * (size_t)b->S, hipHostMallocDefault));
+    AEC_TRY(hipMalloc((void**)&b->vfar_dev, sizeof(FarOps) * (size_t)b->S));
+    AEC_TRY(hipEventCreateWithFlags(&b->vev, hipEventDisableTiming));
+  }
+  b->per.assign((size_t)b->S, static_cast<const AecCtl&>(*b));
+  return 0;
+}
+
+// WebRtcAec_BufferFarend of every stream, each on its own control plane
+int buffer_farend_v(AspAecBatch* b, const float* far_dev, int n) {
+  AEC_TRY(hipEventSynchronize(b->vev));  // the previous launches have read their descriptors
+  int err = 0;
+  for (int s = 0; s < b->S && err == 0; ++s) {
+    ctl_load(b, s);
+    memset(&b->vfar_host[s], 0, sizeof(FarOps));
+    b->vrec = true;
+    b->vstream = s;
+    b->vfar_recorded = 0;
+    err = buffer_farend_device(b, far_dev, n, false);
+    b->vrec = false;
+    ctl_store(b, s);
+  }
+  ctl_load(b, 0);
+  if (err != 0) return err;
+  AEC_TRY(hipMemcpyAsync(b->vfar_dev, b->vfar_host, sizeof(FarOps) * (size_t)b->S, hipMemcpyHostToDevice, b->stream));
+  AEC_TRY(launch_aec_farend_v(b->state, b->far_ring, b->tables, far_dev, b->S, b->vfar_dev, n, b->num_part, b->stream));
+  AEC_TRY(hipEventRecord(b->vev, b->stream));
+  return 0;
+}
+
+// WebRtcAec_Process of every stream with its own reported delay; status[s] (may be null) receives the reference's
+// return value of stream s (0, or -1 with lastError set: a delay outside 0 .. 500 ms still processes)
+int process_v(AspAecBatch* b, const float* near_dev, float* out_dev, int n, const int16_t* ms, int ms_stride,
+              int32_t* status, int* any_rc) {
+  AEC_TRY(hipEventSynchronize(b->vev));
+  int err = 0;
+  *any_rc = 0;
+  for (int s = 0; s < b->S && err == 0; ++s) {
+    ctl_load(b, s);
+    b->vproc_host[s].mode = 0;
+    b->vrec = true;
+    b->vstream = s;
+    int rc = 0;
+    err = process_device(b, near_dev, out_dev, n, ms[(size_t)s * ms_stride], &rc, 0);
+    b->vrec = false;
+    ctl_store(b, s);
+    if (status) status[s] = rc;
+    *any_rc |= rc;
+  }
+  ctl_load(b, 0);
+  if (err != 0) return err;
+  AEC_TRY(hipMemcpyAsync(b->vproc_dev, b->vproc_host, sizeof(AecStreamStep) * (size_t)b->S, hipMemcpyHostToDevice, b->stream));
+  AEC_TRY(launch_aec_process_v(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, b->vproc_dev, b->num_part,
+                               b->stream));
+  AEC_TRY(hipEventRecord(b->vev, b->stream));
+  return 0;
+}
+
+// BufferFarend + Process of one frame on device buffers (Run / TimedSteps): the batch's one control plane with the
+// far-end work deferred into the Process launch, or every stream's own
+int frame_device(AspAecBatch* b, const float* far_dev, const float* near_dev, float* out_dev, int n, int msInSndCardBuf, int* rc) {
+  if (vmode(b)) {
+    int err = buffer_farend_v(b, far_dev, n);
+    if (err != 0) return err;
+    const int16_t ms16 = (int16_t)(msInSndCardBuf < -32768 ? -32768 : msInSndCardBuf > 32767 ? 32767 : msInSndCardBuf);
+    return process_v(b, near_dev, out_dev, n, &ms16, 0, nullptr, rc);
+  }
+  const int err = buffer_farend_device(b, far_dev, n, true);
+  if (err != 0) return err;
+  return process_device(b, near_dev, out_dev, n, msInSndCardBuf, rc);
 }
 
 }  // namespace
@@ -1193,6 +1351,11 @@ int AspAecBatch_Free(AspAecBatch* b) {
   if (b->rs_buffer) (void)hipFree(b->rs_buffer);
   if (b->stage_rs) (void)hipFree(b->stage_rs);
   if (b->spectra) (void)hipFree(b->spectra);
+  if (b->vproc_host) (void)hipHostFree(b->vproc_host);
+  if (b->vproc_dev) (void)hipFree(b->vproc_dev);
+  if (b->vfar_host) (void)hipHostFree(b->vfar_host);
+  if (b->vfar_dev) (void)hipFree(b->vfar_dev);
+  if (b->vev) (void)hipEventDestroy(b->vev);
   if (b->flow_seq) (void)hipFree(b->flow_seq);
   if (b->flow_abort) (void)hipFree(b->flow_abort);
   if (b->flow_dev) (void)hipFree(b->flow_dev);
@@ -1239,6 +1402,11 @@ int AspAecBatch_set_config(AspAecBatch* b, AecConfig config) {  // echo_cancella
     b->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
   }
+  if (!b->per.empty()) {  // per-stream control: the suppression level of every stream; the optional modes are not covered
+    if (config.skewMode == kAecTrue || config.metricsMode == kAecTrue || config.delay_logging == kAecTrue)
+      return aec_fail(ASP_ERR_STATE, "set_config: per-stream control covers nlpMode only; Init the batch to switch modes");
+    for (auto& c : b->per) c.nlp_mode = config.nlpMode;
+  }
   b->nlp_mode = config.nlpMode;  // WebRtcAec_SetConfigCore, aec_core.c:1844-1862
   b->metricsMode = config.metricsMode;
   if (b->metricsMode && !b->sim) {
@@ -1254,23 +1422,11 @@ int AspAecBatch_set_config(AspAecBatch* b, AecConfig config) {  // echo_cancella
   return 0;
 }
 
-int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  // echo_cancellation.c:196-276
-  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
-  if (sampFreq != 8000 && sampFreq != 16000 && sampFreq != 32000 && sampFreq != 48000) {
-    b->lastError = AEC_BAD_PARAMETER_ERROR;
-    return -1;
-  }
-  if (sampFreq > 32000) {  // 48 kHz: the reference's own mult breaks there (aec_core.c:1541-1543)
-    b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
-    return -1;
-  }
+// The control plane as WebRtcAec_Init leaves it (echo_cancellation.c:196-276; WebRtcAec_InitAec, aec_core.c:1460-1615;
+// the default configuration of :261-270): host integers only.
+static void init_control(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {
   b->sampFreq = sampFreq;
-  if (scSampFreq < 1 || scSampFreq > 96000) {
-    b->lastError = AEC_BAD_PARAMETER_ERROR;
-    return -1;
-  }
   b->scSampFreq = scSampFreq;
-  // WebRtcAec_InitAec, aec_core.c:1460-1615
   if (sampFreq == 8000) {
     b->normal_mu = 0.6f;
     b->normal_error_threshold = 2e-6f;
@@ -1282,7 +1438,6 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
   rp_init(&b->out_pos, kFrBufLen);
   rp_init(&b->far_pos, kFarSlots);
   b->system_delay = 0;
-  b->nlp_mode = 1;
   b->num_high = sampFreq == 32000 ? 1 : 0;             // aec_core.c:1466-1473
   b->mult = sampFreq == 32000 ? 2 : sampFreq / 8000;    // aec_core.c:1541-1545
   b->core_knownDelay = 0;
@@ -1290,45 +1445,16 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
   b->xfw_head = 0;
   b->blocks_processed = 0;
   b->extended = 0;  // aec_core.c:1522-1523
-  if (!b->sim) {
-    AEC_TRY(hipSetDevice(b->device));
-    AEC_TRY(hipStreamSynchronize(b->stream));
-    if (b->num_part != kNumPartNormal) {  // back to the 12-partition blocks
-      b->num_part = kNumPartNormal;
-      AEC_TRY(hipFree(b->state));
-      b->state = nullptr;
-      AEC_TRY(hipMalloc((void**)&b->state, state_bytes(b)));
-    }
-    const int kStateDwords = state_dwords(b);
-    std::vector<AspAecState> s0(1);  // ~50 KB, per call: two batches may be initialised from two host threads at once
-    init_canonical(s0.data());
-    std::vector<float> blk(kStateDwords);
-    pack_stream(b, s0.data(), blk.data());
-    std::vector<float> all((size_t)b->S * kStateDwords);
-    for (int s = 0; s < b->S; ++s) memcpy(all.data() + (size_t)s * kStateDwords, blk.data(), kStateDwords * sizeof(float));
-    AEC_TRY(hipMemcpy(b->state, all.data(), state_bytes(b), hipMemcpyHostToDevice));
-    // on the batch's own (non-blocking) stream: a null-stream memset is not ordered with its kernels
-    AEC_TRY(hipMemsetAsync(b->far_ring, 0, far_bytes(b), b->stream));  // WebRtc_InitBuffer zeroes the rings
-    AEC_TRY(hipStreamSynchronize(b->stream));
-    const int err = init_metrics_device(b);  // aec_core.c:1612-1613
-    if (err) return err;
-    const int err2 = init_delay_device(b);   // aec_core.c:1502-1516
-    if (err2) return err2;
-  }
-  if (!b->sim)  // WebRtcAec_InitResampler (echo_cancellation.c:221, aec_resampler.c:55-66)
-    AEC_TRY(hipMemsetAsync(b->rs_buffer, 0, (size_t)b->S * kResamplerBufferSize * sizeof(float), b->stream));
+  b->num_part = kNumPartNormal;
   b->rs_position = 0.f;
-  memset(b->rs_skewData, 0, sizeof b->rs_skewData);
   b->rs_skewDataIndex = 0;
   b->rs_skewEstimate = 0.f;
   b->skewFrCtr = 0;  // echo_cancellation.c:256-259
   b->resample = kAecFalse;
   b->skew = 0.f;
-  b->delay_logging = 0;
   b->reported_delay_enabled = 1;  // aec_core.c:1517-1521 (not Android)
   b->agn_synced = false;
   b->nevents = 0;
-  b->num_part = kNumPartNormal;
   rp_init(&b->pre_pos, kPreLen);
   rp_move_read(&b->pre_pos, -kPartLen);  // start overlap, echo_cancellation.c:226
   b->initFlag = kInitCheck;
@@ -1348,14 +1474,59 @@ int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  //
   b->knownDelay = 0;
   b->lastDelayDiff = 0;
   b->farend_started = 0;
-  AecConfig cfg;
-  cfg.nlpMode = kAecNlpModerate;
-  cfg.skewMode = kAecFalse;
-  cfg.metricsMode = kAecFalse;
-  cfg.delay_logging = kAecFalse;
-  if (AspAecBatch_set_config(b, cfg) == -1) {
-    b->lastError = AEC_UNSPECIFIED_ERROR;
+  b->far_pending = false;
+  // the default configuration (echo_cancellation.c:261-270 through WebRtcAec_set_config)
+  b->nlp_mode = kAecNlpModerate;
+  b->skewMode = kAecFalse;
+  b->metricsMode = kAecFalse;
+  b->delay_logging = kAecFalse;
+}
+
+int AspAecBatch_Init(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq) {  // echo_cancellation.c:196-276
+  AspDeviceScope dev_scope_;
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  if (sampFreq != 8000 && sampFreq != 16000 && sampFreq != 32000 && sampFreq != 48000) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
     return -1;
+  }
+  if (sampFreq > 32000) {  // 48 kHz: the reference's own mult breaks there (aec_core.c:1541-1543)
+    b->lastError = AEC_UNSUPPORTED_FUNCTION_ERROR;
+    return -1;
+  }
+  b->sampFreq = sampFreq;
+  if (scSampFreq < 1 || scSampFreq > 96000) {
+    b->lastError = AEC_BAD_PARAMETER_ERROR;
+    return -1;
+  }
+  b->per.clear();  // back to one control plane for the batch
+  const int old_num_part = b->num_part;
+  init_control(b, sampFreq, scSampFreq);
+  memset(b->rs_skewData, 0, sizeof b->rs_skewData);
+  if (!b->sim) {
+    AEC_TRY(hipSetDevice(b->device));
+    AEC_TRY(hipStreamSynchronize(b->stream));
+    if (old_num_part != kNumPartNormal) {  // back to the 12-partition blocks
+      AEC_TRY(hipFree(b->state));
+      b->state = nullptr;
+      AEC_TRY(hipMalloc((void**)&b->state, state_bytes(b)));
+    }
+    const int kStateDwords = state_dwords(b);
+    std::vector<AspAecState> s0(1);  // ~50 KB, per call: two batches may be initialised from two host threads at once
+    init_canonical(s0.data());
+    std::vector<float> blk(kStateDwords);
+    pack_stream(b, s0.data(), blk.data());
+    std::vector<float> all((size_t)b->S * kStateDwords);
+    for (int s = 0; s < b->S; ++s) memcpy(all.data() + (size_t)s * kStateDwords, blk.data(), kStateDwords * sizeof(float));
+    AEC_TRY(hipMemcpy(b->state, all.data(), state_bytes(b), hipMemcpyHostToDevice));
+    // on the batch's own (non-blocking) stream: a null-stream memset is not ordered with its kernels
+    AEC_TRY(hipMemsetAsync(b->far_ring, 0, far_bytes(b), b->stream));  // WebRtc_InitBuffer zeroes the rings
+    AEC_TRY(hipStreamSynchronize(b->stream));
+    const int err = init_metrics_device(b);  // aec_core.c:1612-1613
+    if (err) return err;
+    const int err2 = init_delay_device(b);   // aec_core.c:1502-1516
+    if (err2) return err2;
+    // WebRtcAec_InitResampler (echo_cancellation.c:221, aec_resampler.c:55-66)
+    AEC_TRY(hipMemsetAsync(b->rs_buffer, 0, (size_t)b->S * kResamplerBufferSize * sizeof(float), b->stream));
   }
   return 0;
 }
@@ -1371,7 +1542,7 @@ int AspAecBatch_BufferFarend(AspAecBatch* b, const float* farend, int nrOfSample
     AEC_TRY(hipMemcpyAsync(b->stage_far, farend, (size_t)b->S * nrOfSamples * sizeof(float), hipMemcpyHostToDevice, b->stream));
     dev = b->stage_far;
   }
-  const int rc = buffer_farend_device(b, dev, nrOfSamples);
+  const int rc = vmode(b) ? buffer_farend_v(b, dev, nrOfSamples) : buffer_farend_device(b, dev, nrOfSamples);
   if (rc != 0) return rc;
   if (mem == ASP_MEM_HOST) AEC_TRY(hipStreamSynchronize(b->stream));
   return 0;
@@ -1402,6 +1573,93 @@ int AspAecBatch_ProcessBands(AspAecBatch* b, const float* near_low, const float*
 }
 
 int AspAecBatch_num_bands(const AspAecBatch* b) { return b ? 1 + b->num_high : 0; }
+
+// WebRtcAec_Process of every stream with the stream's OWN reported delay (echo_cancellation.c:341-347 takes it per
+// handle): msInSndCardBuf[num_streams]; skew[num_streams] may be null (skew compensation is not covered by the
+// per-stream control); status[num_streams] (may be null) receives each stream's reference return value.
+int AspAecBatch_ProcessV(AspAecBatch* b, const float* nearend, float* out, int nrOfSamples, const int16_t* msInSndCardBuf,
+                         const int32_t* skew, int32_t* status, int mem) {
+  AspDeviceScope dev_scope_;
+  (void)skew;
+  if (b && out == nullptr) {
+    b->lastError = AEC_NULL_POINTER_ERROR;
+    return -1;
+  }
+  const int chk = check_running(b, nearend, nrOfSamples);
+  if (chk != 0) return chk;
+  if (!msInSndCardBuf) return aec_fail(ASP_ERR_PARAM, "ProcessV: null delay array");
+  if (mem != ASP_MEM_HOST && mem != ASP_MEM_DEVICE) return aec_fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  AEC_TRY(hipSetDevice(b->device));
+  {
+    const int rc = enter_vmode(b);
+    if (rc != 0) return rc;
+  }
+  const size_t bytes = (size_t)b->S * nrOfSamples * sizeof(float);
+  const float* nd = nearend;
+  float* od = out;
+  if (mem == ASP_MEM_HOST) {
+    AEC_TRY(hipMemcpyAsync(b->stage_near, nearend, bytes, hipMemcpyHostToDevice, b->stream));
+    nd = b->stage_near;
+    od = b->stage_out;
+  }
+  int rc = 0;
+  const int err = process_v(b, nd, od, nrOfSamples, msInSndCardBuf, 1, status, &rc);
+  if (err != 0) return err;
+  if (mem == ASP_MEM_HOST) {
+    AEC_TRY(hipMemcpyAsync(out, od, bytes, hipMemcpyDeviceToHost, b->stream));
+    AEC_TRY(hipStreamSynchronize(b->stream));
+  }
+  return rc;
+}
+
+static void init_control(AspAecBatch* b, int32_t sampFreq, int32_t scSampFreq);
+
+// WebRtcAec_Init of ONE stream of a running batch (echo_cancellation.c:196-276 per handle): its control plane, its
+// state block and its far-ring slots go back to their initial values at the batch's sample rates; the other streams
+// are untouched.  The filter length (AspAecBatch_enable_delay_correction) stays the batch's.
+int AspAecBatch_InitStream(AspAecBatch* b, int stream) {
+  AspDeviceScope dev_scope_;
+  if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
+  if (b->initFlag != kInitCheck) {
+    b->lastError = AEC_UNINITIALIZED_ERROR;
+    return -1;
+  }
+  if (stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "InitStream: stream out of range");
+  AEC_TRY(hipSetDevice(b->device));
+  {
+    const int rc = enter_vmode(b);
+    if (rc != 0) return rc;
+  }
+  AEC_TRY(hipStreamSynchronize(b->stream));
+  {
+    StreamCtlScope sc(b, stream);
+    const int ext = b->extended, np = b->num_part, nlp = b->nlp_mode;
+    const int fs = b->sampFreq, sc_fs = b->scSampFreq;
+    init_control(b, fs, sc_fs);
+    b->extended = ext;  // the state blocks of a batch have one length
+    b->num_part = np;
+    b->nlp_mode = nlp;  // (set_config is batch-wide here; Init's own default is the moderate mode the batch started with)
+    const int kStateDwords = state_dwords(b);
+    std::vector<AspAecState> s0(1);
+    init_canonical(s0.data());
+    std::vector<float> blk(kStateDwords);
+    pack_stream(b, s0.data(), blk.data());
+    AEC_TRY(hipMemcpy(b->state + (size_t)stream * kStateDwords, blk.data(), (size_t)kStateDwords * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // WebRtc_InitBuffer zeroes the far rings: the stream's slice of every slot
+  AEC_TRY(hipMemset2D(b->far_ring + (size_t)stream * kFarSlotDwords, (size_t)b->S * kFarSlotDwords * sizeof(float), 0,
+                      (size_t)kFarSlotDwords * sizeof(float), (size_t)kFarSlots));
+  return 0;
+}
+
+static void fill_control(const AspAecBatch* b, AspAecControl* c);
+
+int AspAecBatch_GetControlStream(AspAecBatch* b, int stream, AspAecControl* c) {
+  if (!b || !c || stream < 0 || stream >= b->S) return aec_fail(ASP_ERR_PARAM, "GetControlStream: bad argument");
+  StreamCtlScope sc(b, stream);
+  fill_control(b, c);
+  return ASP_OK;
+}
 
 static int process_impl(AspAecBatch* b, const float* nearend, const float* near_high, float* out,
                         float* out_high, int nrOfSamples, int msInSndCardBuf, int mem, int32_t skew) {
@@ -1435,7 +1693,13 @@ static int process_impl(AspAecBatch* b, const float* nearend, const float* near_
     }
   }
   int rc = 0;
-  const int err = process_device(b, nd, od, nrOfSamples, msInSndCardBuf, &rc, skew);
+  int err;
+  if (vmode(b)) {  // the batch's streams have their own control planes: the same delay for every one of them
+    const int16_t ms16 = (int16_t)(msInSndCardBuf < -32768 ? -32768 : msInSndCardBuf > 32767 ? 32767 : msInSndCardBuf);
+    err = process_v(b, nd, od, nrOfSamples, &ms16, 0, nullptr, &rc);
+  } else {
+    err = process_device(b, nd, od, nrOfSamples, msInSndCardBuf, &rc, skew);
+  }
   if (err != 0) return err;
   if (mem == ASP_MEM_HOST) {
     AEC_TRY(hipMemcpyAsync(out, od, bytes, hipMemcpyDeviceToHost, b->stream));
@@ -1484,8 +1748,7 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
       if (aec_flow_applies(b, nf) && aec_flow_resources(b) == 0) b->flow_rec = true;
       for (int f = 0; f < nf && err == 0; ++f) {
         int rc = 0;
-        err = buffer_farend_device(b, dfar + per * f, nrOfSamples, true);
-        if (err == 0) err = process_device(b, dnear + per * f, dout + per * f, nrOfSamples, msInSndCardBuf, &rc);
+        err = frame_device(b, dfar + per * f, dnear + per * f, dout + per * f, nrOfSamples, msInSndCardBuf, &rc);
         rc_all |= rc;
       }
       if (b->flow_rec) {
@@ -1514,8 +1777,7 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
   }
   for (int f = 0; f < num_frames; ++f) {
     int rc = 0;
-    int err = buffer_farend_device(b, farend + per * f, nrOfSamples, true);
-    if (err == 0) err = process_device(b, nearend + per * f, out + per * f, nrOfSamples, msInSndCardBuf, &rc);
+    const int err = frame_device(b, farend + per * f, nearend + per * f, out + per * f, nrOfSamples, msInSndCardBuf, &rc);
     if (err != 0) {
       b->flow_rec = false;
       b->flow_n = 0;
@@ -1551,7 +1813,7 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
     const int rcf = aec_flow_resources(b);
     if (rcf != 0) return rcf;
   }
-  const bool dual = !flow && b->S >= 2048 && !b->startup_phase && !(ch && atoi(ch) == 1) && !b->delay_logging && b->reported_delay_enabled && !b->skewMode;
+  const bool dual = !flow && b->per.empty() && b->S >= 2048 && !b->startup_phase && !(ch && atoi(ch) == 1) && !b->delay_logging && b->reported_delay_enabled && !b->skewMode;
   if (dual && !b->side) {
     AEC_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     AEC_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -1568,8 +1830,7 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
   for (int k = 0; k < steps && err == 0; ++k) {
     const size_t off = per * (size_t)(k % frames_in_ring);
     int rc = 0;
-    err = buffer_farend_device(b, farend + off, nrOfSamples, true);
-    if (err == 0) err = process_device(b, nearend + off, out + off, nrOfSamples, 0, &rc);
+    err = frame_device(b, farend + off, nearend + off, out + off, nrOfSamples, 0, &rc);
   }
   if (flow) {
     b->flow_rec = false;
@@ -1613,6 +1874,7 @@ int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out) {
   const int kStateDwords = state_dwords(b);
   std::vector<float> blk(kStateDwords);
   AEC_TRY(hipMemcpy(blk.data(), b->state + (size_t)stream * kStateDwords, kStateDwords * sizeof(float), hipMemcpyDeviceToHost));
+  StreamCtlScope sc(b, stream);  // the partition positions of the block are the stream's own
   unpack_stream(b, blk.data(), out);
   return ASP_OK;
 }
@@ -1626,6 +1888,7 @@ int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in) {
   const int kStateDwords = state_dwords(b);
   std::vector<float> blk(kStateDwords), cur(kStateDwords);
   AEC_TRY(hipMemcpy(cur.data(), b->state + (size_t)stream * kStateDwords, kStateDwords * sizeof(float), hipMemcpyDeviceToHost));
+  StreamCtlScope sc(b, stream);
   pack_stream(b, in, blk.data());
   // the time-domain rings are not part of AspAecState: keep the stream's own
   keep_rings(blk.data(), cur.data());
@@ -1643,6 +1906,8 @@ int AspAecBatch_enable_delay_correction(AspAecBatch* b, int enable) {
   AspDeviceScope dev_scope_;
   if (!b) return aec_fail(ASP_ERR_PARAM, "null batch handle");
   const int np = enable ? kNumPartMax : kNumPartNormal;
+  if (!b->per.empty() && np != b->num_part)
+    return aec_fail(ASP_ERR_STATE, "enable_delay_correction: the streams have their own control planes; Init the batch first");
   if (np != b->num_part) {
     if (b->xf_pos >= np) {
       // the reference keeps running with the large block position (aec_core.c:1876-1881 stores the flag only); the
@@ -1701,6 +1966,8 @@ int AspAecBatch_enable_reported_delay(AspAecBatch* b, int enable) {
   // the delay-agnostic mode steers every stream's far buffer on the device: a control-only handle refuses it here,
   // not in the middle of a later Process call with its ring positions already advanced
   if (!enable && b->sim) return aec_fail(ASP_ERR_STATE, "enable_reported_delay(0): the delay-agnostic mode needs the device");
+  if (!enable && !b->per.empty())
+    return aec_fail(ASP_ERR_STATE, "enable_reported_delay(0): per-stream control covers the reported-delay mode; Init the batch first");
   b->reported_delay_enabled = enable ? 1 : 0;
   return 0;
 }
@@ -1787,8 +2054,12 @@ int AspAecBatch_GetDelayMetrics(AspAecBatch* b, int* median, int* std) {
 int AspAecBatch_delay_correction_enabled(const AspAecBatch* b) { return b ? b->extended : 0; }
 
 int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* c) {
-  AspDeviceScope dev_scope_;
   if (!b || !c) return aec_fail(ASP_ERR_PARAM, "GetControl: bad argument");
+  fill_control(b, c);  // (with per-stream control: stream 0's)
+  return ASP_OK;
+}
+
+static void fill_control(const AspAecBatch* b, AspAecControl* c) {
   c->startup_phase = b->startup_phase;
   c->checkBuffSize = b->checkBuffSize;
   c->bufSizeStart = b->bufSizeStart;
@@ -1815,7 +2086,6 @@ int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* c) {
   c->out_write = b->out_pos.write;
   c->out_wrap = b->out_pos.wrap;
   c->blocks_processed = b->blocks_processed;
-  return ASP_OK;
 }
 
 int AspAecBatch_get_echo_status(AspAecBatch* b, int* status) {

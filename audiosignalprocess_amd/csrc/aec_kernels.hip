@@ -1599,6 +1599,57 @@ __global__ __launch_bounds__(256, NP == kNumPartNormal ? AEC_WAVES : 3) void aec
   if (lane == 0) __hip_atomic_store((gu32*)(fa.seq + stream), want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- per-stream control (AspAecBatch_ProcessV / _InitStream): every stream has its own descriptors, read from
+// device memory by the wave that owns the stream (wave-uniform: through the scalar cache)
+__global__ __launch_bounds__(256) void aec_farend_v_kernel(float* __restrict__ state, float* __restrict__ far_ring,
+                                                           const AecTables* __restrict__ G,
+                                                           const float* __restrict__ farend, int num_streams,
+                                                           const FarOps* __restrict__ vfar, int nrOfSamples, int state_dwords) {
+  __shared__ SharedTables T;
+  __shared__ float lds[4 * kLdsWave];
+  stage_tables(T, G);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  typedef const __attribute__((address_space(4))) FarOps* OpsPtr;
+  const OpsPtr ops = (OpsPtr)(vfar + stream);
+  float* wl = lds + wave * kLdsWave;
+  float* st = state + (size_t)stream * state_dwords;
+  // the caller's frame holds nrOfSamples per stream; a stream's own `n` is that or 0 (nothing to append)
+  farend_work(st, far_ring, wl, T, farend + (size_t)stream * (nrOfSamples - ops->n), num_streams, stream, *ops, lane);
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, NP == kNumPartNormal ? AEC_WAVES : 3) void aec_process_v_kernel(
+    float* __restrict__ state, float* far_ring, const AecTables* __restrict__ G, const float* __restrict__ nearend,
+    float* __restrict__ out, int num_streams, int nrOfSamples, const AecStreamStep* __restrict__ vdesc) {
+  __shared__ SharedTables T;
+  constexpr int kWaveLds = lds_wave(NP, false);
+  __shared__ float lds[4 * kWaveLds];
+  stage_tables(T, G);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  typedef const __attribute__((address_space(4))) AecStreamStep* StepPtr;
+  const StepPtr d = (StepPtr)(vdesc + stream);
+  float* wl = lds + wave * kWaveLds;
+  float* st = state + (size_t)stream * AecRows(NP).state_dwords;
+  const float* nin = nearend + (size_t)stream * nrOfSamples;
+  float* o = out + (size_t)stream * nrOfSamples;
+  if (d->mode == 0) {  // start-up: the near end passes through (echo_cancellation.c:660-664, 768-776)
+    for (int i = lane; i < nrOfSamples; i += 64) {
+      const float v = nin[i];
+      o[i] = v;
+    }
+    return;
+  }
+  const FarOps none = {};
+  process_call<false, NP, false>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, d->ops, nullptr, none,
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
 // aec_rdft_forward_128 / inverse_128 seam: four rows per wave.
 __global__ __launch_bounds__(256) void aec_rdft128_kernel(const float* __restrict__ src,
                                                           float* __restrict__ dst, int isgn,
@@ -1686,6 +1737,26 @@ hipError_t launch_aec_process_flow(float* state, float* far_ring, const AecTable
   else
     hipLaunchKernelGGL((aec_process_flow_kernel<kNumPartMax>), grid, dim3(256), 0, s, state, far_ring, T, num_streams,
                        nrOfSamples, fa);
+  return hipGetLastError();
+}
+
+// per-stream control: one far-end / Process descriptor per stream, in device memory
+hipError_t launch_aec_farend_v(float* state, float* far_ring, const AecTables* T, const float* farend, int num_streams,
+                               const FarOps* vfar, int nrOfSamples, int num_part, hipStream_t s) {
+  hipLaunchKernelGGL(aec_farend_v_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, state, far_ring, T, farend, num_streams,
+                     vfar, nrOfSamples, AecRows(num_part).state_dwords);
+  return hipGetLastError();
+}
+hipError_t launch_aec_process_v(float* state, float* far_ring, const AecTables* T, const float* nearend, float* out,
+                                int num_streams, int nrOfSamples, const AecStreamStep* vdesc, int num_part, hipStream_t s) {
+  if (num_part != kNumPartNormal && num_part != kNumPartMax) return hipErrorInvalidValue;
+  const dim3 grid((num_streams + 3) / 4);
+  if (num_part == kNumPartNormal)
+    hipLaunchKernelGGL((aec_process_v_kernel<kNumPartNormal>), grid, dim3(256), 0, s, state, far_ring, T, nearend, out, num_streams,
+                       nrOfSamples, vdesc);
+  else
+    hipLaunchKernelGGL((aec_process_v_kernel<kNumPartMax>), grid, dim3(256), 0, s, state, far_ring, T, nearend, out, num_streams,
+                       nrOfSamples, vdesc);
   return hipGetLastError();
 }
 

@@ -142,6 +142,14 @@ struct AecFlowStep {
 };
 static_assert(sizeof(AecFlowStep) % 8 == 0, "steps stay 8-byte aligned in their array");
 
+// Per-stream control (AspAecBatch_ProcessV): what one stream does in this WebRtcAec_Process call.
+struct AecStreamStep {
+  int32_t mode;   // 0: pass the near end through (start-up phase, echo_cancellation.c:660-664 / 768-776); 1: `ops`
+  int32_t pad;
+  ProcOps ops;
+};
+static_assert(sizeof(AecStreamStep) % 8 == 0, "steps stay 8-byte aligned in their array");
+
 // ---- delay estimation (set_config delay_logging) and the delay-agnostic mode (reported delays off) ----
 // Per stream one DelayBlock: the canonical estimator state, then what only the device needs.  In the agnostic
 // mode the stream's own far-buffer read side and system delay live in it (s.far_read .. s.system_delay): the

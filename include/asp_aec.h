@@ -229,6 +229,26 @@ int AspAecBatch_ProcessBands(AspAecBatch* b, const float* near_low, const float*
                              int32_t skew, int mem);
 int AspAecBatch_num_bands(const AspAecBatch* b);
 
+/* ---- per-stream control.  The reference takes the reported delay, Init and the call pattern per handle
+ * (WebRtcAec_Process(aecInst, ..., msInSndCardBuf, skew), echo_cancellation.c:341-347; WebRtcAec_Init, :196-276).  A
+ * batch starts in lock-step: one control plane (ring positions, start-up phase, EstBufDelay's filter, knownDelay) for
+ * all its streams, the far-end work fused into the Process launch.  The first AspAecBatch_ProcessV or
+ * AspAecBatch_InitStream call gives EVERY stream its own control plane (kept on the host, run once per stream and
+ * call; the kernels read one descriptor per stream from device memory), and the uniform-argument entry points
+ * (BufferFarend, Process, Run, TimedSteps) keep working on top of it.  AspAecBatch_Init returns to lock-step.
+ * Covered: one band (8 / 16 kHz), the normal and the extended filter, reported delays.  Not covered (ASP_ERR_STATE):
+ * 32 kHz, delay logging, the delay-agnostic mode, skew compensation, metrics.
+ *   ProcessV     msInSndCardBuf[num_streams]: each stream's reported delay; skew may be null (ignored);
+ *                status[num_streams] (may be null): each stream's reference return value (0, or -1 for a delay
+ *                outside 0 .. 500 ms, which still processes, echo_cancellation.c:367-375); returns -1 if any is.
+ *   InitStream   WebRtcAec_Init of ONE stream at the batch's sample rates: its control plane, state block and
+ *                far-ring slots back to their initial values (start-up phase included); the others untouched.
+ *   GetControlStream   AspAecBatch_GetControl of one stream. */
+int AspAecBatch_ProcessV(AspAecBatch* b, const float* nearend, float* out, int nrOfSamples,
+                         const int16_t* msInSndCardBuf, const int32_t* skew, int32_t* status, int mem);
+int AspAecBatch_InitStream(AspAecBatch* b, int stream);
+int AspAecBatch_GetControlStream(AspAecBatch* b, int stream, AspAecControl* out);
+
 /* num_frames x (BufferFarend + Process) on [num_frames][num_streams][n] buffers: the loop of
  * test_aec_module.cpp:75-88 in one call (amortises launches; device or host memory). */
 int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, float* out,

@@ -784,6 +784,75 @@ def test_timed_steps_equal_run_and_oracle(aec, monkeypatch):
     gr.close()
 
 
+@pytest.mark.parametrize("ext", [0, 1])
+def test_per_stream_delays_and_reinit_vs_one_oracle_per_stream(aec, ext):
+    """The reference takes the reported delay and Init per handle (echo_cancellation.c:341-347, 196-276).
+    AspAecBatch_ProcessV / _InitStream: twelve streams with different reported delays -- so their start-up phases end
+    at different frames and their far buffers, ring positions and partition positions move apart -- a delay jump, an
+    out-of-range delay (returns -1, still processes) and a negative one on three of them, one stream re-initialised
+    in the middle of the run, and the uniform-argument calls used on top of it: every stream against its OWN oracle
+    driven the same way, with the bars of test_free_running_vs_oracle (control plane equal, linear state bit-exact,
+    outputs within 1e-5)."""
+    S, F = 12, 460
+    far, near = aec_frames(S, F)
+    g = aec.AecBatch(S, 16000)
+    oras = [OracleAec(16000) for _ in range(S)]
+    if ext:
+        g.enable_delay_correction(1)
+        for o in oras:
+            o.enable_delay_correction(1)
+    base = [0, 0, 20, 40, 60, 100, 5, 0, 250, 30, 80, 10]
+
+    def delay(s, f):
+        d = base[s]
+        if s == 1 and f >= 130:
+            d = 90
+        if s == 4 and 200 <= f < 210:
+            d = 700
+        if s == 7 and f == 250:
+            d = -5
+        return d
+
+    out_g = np.empty((F, S, 160), np.float32)
+    out_o = np.empty((F, S, 160), np.float32)
+    born = [0] * S
+    for f in range(F):
+        if f == 170:
+            g.init_stream(5)
+            oras[5] = OracleAec(16000)
+            if ext:
+                oras[5].enable_delay_correction(1)
+            born[5] = f
+        uniform = 300 <= f < 320          # the uniform-argument entry points on top of the per-stream control
+        assert g.buffer_farend(far[f]) == 0
+        if uniform:
+            out_g[f], rc_g = g.process(near[f], 35)
+        else:
+            out_g[f], status = g.process_v(near[f], [delay(s, f) for s in range(S)])
+        for s in range(S):
+            out_o[f, s], rc_o = oras[s].frame(far[f, s], near[f, s], 35 if uniform else delay(s, f))
+            if not uniform:
+                assert status[s] == rc_o, (f, s)
+        if f % 50 == 49:
+            for s in range(S):
+                cg = g.control_stream(s)
+                _, co = oras[s].export()
+                for name, _t in cg._fields_:
+                    assert getattr(cg, name) == getattr(co, name), (f, s, name)
+    assert len({g.control_stream(s).far_read for s in range(S)}) > 3      # the streams did move apart
+    assert len({g.control_stream(s).blocks_processed for s in range(S)}) > 1
+    for s in range(S):
+        st_o, _ = oras[s].export()
+        rep = _state_report(g.export_state(s), st_o)
+        bad = [k for k in LINEAR_FIELDS if not rep[k][0]]
+        assert bad == [], (s, {k: rep[k] for k in bad})
+        assert _rel_l2(out_g[born[s]:, s], out_o[born[s]:, s]) <= 1e-5, s
+    parity_note("AEC per-stream control ext=%d: %d streams, %d distinct far read positions, worst rel-L2 %.2e"
+                % (ext, S, len({g.control_stream(s).far_read for s in range(S)}),
+                   max(_rel_l2(out_g[born[s]:, s], out_o[born[s]:, s]) for s in range(S))))
+    g.close()
+
+
 @pytest.mark.parametrize("S,ext", [(5, 0), (4100, 0), (9000, 0), (1030, 1)])
 def test_handoff_build_equals_plain_launches(aec, S, ext):
     """The hand-off build (AspAecBatch_SetFlow; the default of Run / TimedSteps in the plain configuration) against
