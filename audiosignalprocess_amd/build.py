@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 # ASP_AMD_LIB: load another build of the library (same-box A / B runs against an earlier build)
 LIB = os.environ.get("ASP_AMD_LIB") or os.path.join(LIBDIR, "libasp_amd.so")
-SOURCES = ["ns_kernels.hip", "ns_kernels1.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_kernels8.hip", "bt_api.hip",
+SOURCES = ["ns_kernels.hip", "ns_kernels1.hip", "ns_kernels2.hip", "ns_kernels_hb.hip", "ns_api.hip", "bt_kernels.hip", "bt_kernels8.hip", "bt_api.hip",
            "aec_kernels.hip", "aec_delay_kernels.hip", "aec_api.hip", "qmf_kernels.hip", "qmf_api.hip", "sinc_kernels.hip", "sinc_api.hip"]
 C_SOURCES = ["wav_io.c"]  # host-only C (kept C, as in the reference)
 # -ffp-contract=off: parity with the reference depends on unfused mul/add.
@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 # with dependent scalar loads before the first vector load can issue (-0.5 us per NS step, measured);
 # the object carries a prologue for firmware without the feature
 _PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=8"]
-EXTRA = {"ns_kernels.hip": list(_PRELOAD), "ns_kernels1.hip": list(_PRELOAD),
+EXTRA = {"ns_kernels.hip": list(_PRELOAD), "ns_kernels1.hip": list(_PRELOAD), "ns_kernels2.hip": list(_PRELOAD),
          # the echo canceller's block is long straight-line code at 4 waves per SIMD: the compiler's ILP-first
          # scheduling measured 92.7-93.8 us per step against 95.5 us in one session (max-ilp: 97-99 us)
          "aec_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}

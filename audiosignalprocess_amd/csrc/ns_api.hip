@@ -31,6 +31,13 @@ hipError_t launch_ns_frame1_flow(bool io16, float* state, int32_t* hist, const N
                                  const float* in, float* out, int num_streams, hipStream_t s,
                                  unsigned* seq, unsigned* abort_w, unsigned want, int steps, int slot0, int ring,
                                  size_t per, unsigned long long* stamps = nullptr);
+hipError_t launch_ns_frame2(bool io16, float* state, int32_t* hist, const NsTables* T,
+                            const float* in, float* out, int num_streams, hipStream_t s,
+                            unsigned long long* stamps = nullptr);
+hipError_t launch_ns_frame2_flow(bool io16, float* state, int32_t* hist, const NsTables* T,
+                                 const float* in, float* out, int num_streams, hipStream_t s,
+                                 unsigned* seq, unsigned* abort_w, unsigned want, int steps, int slot0, int ring,
+                                 size_t per, unsigned long long* stamps = nullptr);
 hipError_t launch_ns_unpair(float* state, int num_streams, hipStream_t s);
 hipError_t launch_ns_hb_live(const float* state, const NsTables* T, const float* in_low,
                              int32_t* live, int num_streams, int hist_off, hipStream_t s);
@@ -309,6 +316,34 @@ void build_tables(NsTables* T) {
     T->logtab[i][0] = invc;
     T->logtab[i][1] = c == 1.0L ? 0.0 : (double)(-logl((long double)invc));
   }
+  // full-butterfly twiddles of the two-streams-per-wave kernel (ns_kernels2.hip): block index B of pass 0/1/2 is
+  // lane, lane >> 2, lane >> 4 (same twiddle cases as above, fft4g.c:1008-1102 / 1114-1229)
+  for (int pass = 0; pass < 3; ++pass)
+    for (int lane = 0; lane < 32; ++lane) {
+      const int B = pass == 0 ? lane : (pass == 1 ? lane >> 2 : lane >> 4);
+      float* e = T->tw2[pass][lane];
+      e[0] = 1.f; e[1] = 0.f; e[2] = 1.f; e[3] = 0.f; e[4] = 1.f; e[5] = 0.f; e[6] = 0.f; e[7] = 0.f;
+      if (B == 1) {
+        e[0] = w[2];
+        e[2] = 0.f;
+        e[3] = 1.f;
+        e[6] = 1.f;
+      } else if (B >= 2) {
+        const int u = B >> 1;
+        const float wk2r = w[2 * u], wk2i = w[2 * u + 1];
+        if ((B & 1) == 0) {
+          const float w1r = w[4 * u], w1i = w[4 * u + 1];
+          e[0] = w1r; e[1] = w1i; e[2] = wk2r; e[3] = wk2i;
+          e[4] = w1r - 2 * wk2i * w1i;
+          e[5] = 2 * wk2i * w1r - w1i;
+        } else {
+          const float w1r = w[4 * u + 2], w1i = w[4 * u + 3];
+          e[0] = w1r; e[1] = w1i; e[2] = -wk2i; e[3] = wk2r;
+          e[4] = w1r - 2 * wk2r * w1i;
+          e[5] = 2 * wk2r * w1r - w1i;
+        }
+      }
+    }
   for (int lane = 0; lane < 32; ++lane)
     for (int t = 0; t < 4; ++t) {
       const int g = lane >> 4, pq = (lane & 15) + 16 * t;  // element E = pq + 64 g
@@ -825,6 +860,8 @@ static hipError_t fused_launch(AspNsBatch* b, bool io16, const float* din, float
   float* out = dout + (size_t)s0 * sper;
   if (b->kernel == 1 || b->fs == 8000)  // the pair-layout kernel is built for the 129-bin geometry only
     return launch_ns_frame(io16 ? 3 : 2, state, hist, b->tables, in, out, n, st, b->fs == 8000);
+  if (b->kernel == 2)  // two streams per wave (ns_kernels2.hip); an odd count leaves the last wave's high half idle
+    return launch_ns_frame2(io16, state, hist, b->tables, in, out, n, st);
   // timeline diagnostic: this sub-launch's first workgroup's slot, stamp mode 1
   unsigned long long* tl = b->timeline ? b->timeline + (size_t)(s0 / 4) * 4 : nullptr;
   return launch_ns_frame1(io16, state, hist, b->tables, in, out, n, st, tl, tl ? 1 : 0);
@@ -846,6 +883,8 @@ static bool flow_default() {
 // The hand-off build serves a K-step call of a batch in the fused representation on the pair-layout kernel.
 static bool flow_applies(const AspNsBatch* b, int steps) {
   const bool on = b->flow < 0 ? flow_default() : b->flow != 0;
+  // (the two-streams-per-wave kernel addresses the whole state array through one 32-bit buffer offset)
+  if (b->kernel == 2 && (size_t)b->S * kStreamDwords * 4 >= ((size_t)1 << 32)) return false;
   return on && steps >= 2 && b->paired && b->kernel != 1 && b->fs != 8000 && b->timeline == nullptr;
 }
 
@@ -874,8 +913,12 @@ static int flow_steps(AspNsBatch* b, const float* din, float* dout, int ring, in
   }
   for (int k = 0; k < steps; k += maxm) {
     const int m = steps - k < maxm ? steps - k : maxm;
-    HIP_TRY(launch_ns_frame1_flow(io16, b->state, b->hist, b->tables, din, dout, b->S, b->stream, b->flow_seq,
-                                  b->flow_abort, b->flow_count, m, k % ring, ring, per, b->flow_stamps));
+    if (b->kernel == 2)
+      HIP_TRY(launch_ns_frame2_flow(io16, b->state, b->hist, b->tables, din, dout, b->S, b->stream, b->flow_seq,
+                                    b->flow_abort, b->flow_count, m, k % ring, ring, per, b->flow_stamps));
+    else
+      HIP_TRY(launch_ns_frame1_flow(io16, b->state, b->hist, b->tables, din, dout, b->S, b->stream, b->flow_seq,
+                                    b->flow_abort, b->flow_count, m, k % ring, ring, per, b->flow_stamps));
     b->flow_count += (unsigned)m;
   }
   b->flow_unchecked = true;
@@ -1420,8 +1463,8 @@ int AspNsBatch_SetGraph(AspNsBatch* b, int on) {
 }
 
 int AspNsBatch_SetKernel(AspNsBatch* b, int kernel) {
-  if (!b || (kernel != 0 && kernel != 1 && kernel != 3))
-    return fail(ASP_ERR_PARAM, "SetKernel: 0 (default), 1 (one stream per wave, bins q / q + 64) or 3 (one stream per wave, pair layout)");
+  if (!b || kernel < 0 || kernel > 3)
+    return fail(ASP_ERR_PARAM, "SetKernel: 0 (default), 1 (one stream per wave, bins q / q + 64), 2 (two streams per wave) or 3 (one stream per wave, pair layout)");
   b->kernel = kernel;
   return ASP_OK;
 }

@@ -242,6 +242,70 @@ __device__ __forceinline__ void fdiv3(const float (&n)[3], const float (&d)[3], 
   q[0] = a.x; q[1] = a.y;
   q[2] = fdiv(n[2], d[2]);
 }
+// ---- the two-streams-per-wave kernel (ns_kernels2.hip): four owned bins + bin 128 per lane
+__device__ __forceinline__ void fdiv5(const float (&n)[5], const float (&d)[5], float (&q)[5]) {
+  const f32x2 a = fdiv2(f32x2{n[0], n[1]}, f32x2{d[0], d[1]});
+  const f32x2 b = fdiv2(f32x2{n[2], n[3]}, f32x2{d[2], d[3]});
+  q[0] = a.x; q[1] = a.y; q[2] = b.x; q[3] = b.y;
+  q[4] = fdiv(n[4], d[4]);
+}
+// Five bins of a lane (four owned + bin 128) as two packed pairs and a scalar: +, -, * and fma on
+// an F5 compile to v_pk_* for the pairs.  Every operation is the IEEE single operation of its
+// scalar spelling (no contraction), so results are bit-identical to the per-bin loops.
+struct B5 {
+  bool v[5];
+};
+struct F5 {
+  f32x2 a, b;
+  float t;
+  __device__ __forceinline__ F5() {}
+  __device__ __forceinline__ F5(f32x2 a_, f32x2 b_, float t_) : a(a_), b(b_), t(t_) {}
+  __device__ __forceinline__ explicit F5(float c) : a(f32x2{c, c}), b(f32x2{c, c}), t(c) {}
+  __device__ __forceinline__ explicit F5(const float (&x)[5]) : a(f32x2{x[0], x[1]}), b(f32x2{x[2], x[3]}), t(x[4]) {}
+  __device__ __forceinline__ void store(float (&x)[5]) const {
+    x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = t;
+  }
+  __device__ __forceinline__ float get(int k) const { return k == 0 ? a.x : k == 1 ? a.y : k == 2 ? b.x : k == 3 ? b.y : t; }
+};
+__device__ __forceinline__ F5 operator+(const F5& x, const F5& y) { return F5(x.a + y.a, x.b + y.b, x.t + y.t); }
+__device__ __forceinline__ F5 operator-(const F5& x, const F5& y) { return F5(x.a - y.a, x.b - y.b, x.t - y.t); }
+__device__ __forceinline__ F5 operator*(const F5& x, const F5& y) { return F5(x.a * y.a, x.b * y.b, x.t * y.t); }
+__device__ __forceinline__ F5 operator*(float c, const F5& y) { return F5(c) * y; }
+__device__ __forceinline__ F5 operator*(const F5& x, float c) { return x * F5(c); }
+__device__ __forceinline__ F5 operator+(const F5& x, float c) { return x + F5(c); }
+__device__ __forceinline__ F5 operator-(const F5& x, float c) { return x - F5(c); }
+__device__ __forceinline__ F5 operator-(float c, const F5& y) { return F5(c) - y; }
+__device__ __forceinline__ F5 operator-(const F5& x) { return F5(-x.a, -x.b, -x.t); }
+__device__ __forceinline__ F5 fma5(const F5& x, const F5& y, const F5& z) {
+  return F5(__builtin_elementwise_fma(x.a, y.a, z.a), __builtin_elementwise_fma(x.b, y.b, z.b),
+            __builtin_fmaf(x.t, y.t, z.t));
+}
+__device__ __forceinline__ F5 abs5(const F5& x) {
+  return F5(f32x2{fabsf(x.a.x), fabsf(x.a.y)}, f32x2{fabsf(x.b.x), fabsf(x.b.y)}, fabsf(x.t));
+}
+#define ASP_F5_CMP(name, op)                                                        \
+  __device__ __forceinline__ B5 name(const F5& x, const F5& y) {                    \
+    B5 r;                                                                           \
+    r.v[0] = x.a.x op y.a.x; r.v[1] = x.a.y op y.a.y; r.v[2] = x.b.x op y.b.x;      \
+    r.v[3] = x.b.y op y.b.y; r.v[4] = x.t op y.t;                                   \
+    return r;                                                                       \
+  }
+ASP_F5_CMP(gt5, >)
+ASP_F5_CMP(lt5, <)
+#undef ASP_F5_CMP
+__device__ __forceinline__ F5 sel5(const B5& c, const F5& x, const F5& y) {  // c ? x : y
+  return F5(f32x2{c.v[0] ? x.a.x : y.a.x, c.v[1] ? x.a.y : y.a.y},
+            f32x2{c.v[2] ? x.b.x : y.b.x, c.v[3] ? x.b.y : y.b.y}, c.v[4] ? x.t : y.t);
+}
+// div_by_uniform for five bins
+__device__ __forceinline__ F5 div_by_uniform5(const F5& a, float d, float rd) {
+  const F5 q0 = a * rd;
+  const F5 r = fma5(F5(-d), q0, a);
+  return fma5(r, F5(rd), q0);
+}
+__device__ __forceinline__ F5 fdiv5v(const F5& n, const F5& d) {
+  return F5(fdiv2(n.a, d.a), fdiv2(n.b, d.b), fdiv(n.t, d.t));
+}
 #define DIV129(a) div_by_uniform((a), 129.0f, 1.0f / 129.0f)
 
 // (float)log((double)x), the reference's idiom (ns_core.c:228,540,681,1096), for

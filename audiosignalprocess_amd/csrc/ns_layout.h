@@ -94,6 +94,9 @@ struct NsTables {
   float sum_log_i_square;
   float pad[2];
   double exp2_64[64];         // 2^(j/64), range-reduction table of the lean exp
+  // two-streams-per-wave kernel (ns_kernels2.hip): one full butterfly per lane and pass; that kernel stages
+  // tw2 and spl as ONE 4 KB block (256 threads x 16 B), so spl must follow tw2 directly
+  float tw2[3][32][8];        // (w1r, w1i, w2r, w2i, w3r, w3i, diag, 0)
   float spl[32][4][2];        // real-split (wkr, wki) of element (lam & 15) + 16 t + 64 (lam >> 4), lam = 0..31
   double logtab[128][2];      // {1/c, log c} of the table-driven log (ns_device.h: log_tab_f64)
   // 8 kHz geometry (ns_kernels.hip, G8): WebRtc_rdft(128) and kBlocks80w128
@@ -108,5 +111,7 @@ struct NsTables {
 };
 
 static_assert(__builtin_offsetof(NsTables, logtab) % 16 == 0, "logtab is read as double2");
+static_assert(__builtin_offsetof(NsTables, spl) == __builtin_offsetof(NsTables, tw2) + sizeof(float) * 3 * 32 * 8,
+              "ns_kernels2.hip stages tw2 and spl as one block");
 
 }  // namespace aspns

@@ -432,13 +432,14 @@ def _secondary(args, workload, cpu_baseline=True):
 
 
 FLOW_MAX_STEPS = 64  # kFlowMaxSteps of ns_api.hip: frame steps per launch of the hand-off build
+FLOW_KERNELS = (2, 3)   # kernels with a hand-off build
 
 
 def flow_active(args):
     """Does the K-step timed region run the hand-off build?  (ns_api.hip, flow_applies)"""
     if args.flow == "off" or (args.flow == "auto" and os.environ.get("ASP_NS_FLOW", "1")[:1] == "0"):
         return False
-    return args.steps >= 2 and (args.kernel or 3) == 3 and not args.graph
+    return args.steps >= 2 and (args.kernel or 3) in FLOW_KERNELS and not args.graph
 
 
 def ns_measure(args, S, rank, world, local_rank, dist):
@@ -549,7 +550,7 @@ def main():
                     help="hand-off build of the K-step region (include/asp_ns.h, AspNsBatch_SetFlow): up to 64 frame steps per "
                          "launch, a per-stream step counter in memory orders a stream's consecutive steps; auto = the library's "
                          "default (on; ASP_NS_FLOW=0 turns it off)")
-    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 3],
+    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2, 3],
                     help="fused-step kernel: 0 / 3 = one stream per wave, pair layout (ns_kernels1.hip, the default), "
                          "1 = one stream per wave, bins q / q + 64 (ns_kernels.hip)")
     ap.add_argument("--aec-extended", action="store_true", help="--workload aec: the 32-partition extended filter")
@@ -585,7 +586,8 @@ def main():
         flow = flow_active(args)
         steps_per_launch = min(max(args.steps, 1), FLOW_MAX_STEPS) if flow else 1
         conc = 1 if flow else args.split
-        kernel = {1: "ns_frame_kernel<true,true>", 3: "ns_frame1_kernel<false, true>" if flow else "ns_frame1_kernel<false, false>"}[args.kernel or 3]
+        kernel = {1: "ns_frame_kernel<true,true>", 2: "ns_frame2_kernel<false, true>" if flow else "ns_frame2_kernel<false, false>",
+                  3: "ns_frame1_kernel<false, true>" if flow else "ns_frame1_kernel<false, false>"}[args.kernel or 3]
         line = {
             "metric": "audio frames/sec (10 ms @16 kHz) Wiener NS",
             "value": frames_per_region / (step_s * K),

@@ -400,8 +400,20 @@ static float butterfly64(float* t) {
   return t[0];
 }
 
+/* The 32-lane association of the two-streams-per-wave kernel (ns_kernels2.hip): 32 partials,
+ * butterfly xor 1,2,4,8,16. */
+static float butterfly32(float* t) {
+  for (int m = 1; m <= 16; m <<= 1) {
+    float u[32];
+    for (int l = 0; l < 32; ++l) u[l] = t[l] + t[l ^ m];
+    memcpy(t, u, sizeof u);
+  }
+  return t[0];
+}
+
 /* Sum of x[0..BINS-1] (one value per bin).  TREE: lane l holds bins l and l+64,
- * lane 0 additionally bin 128.  TREE64P: see below.  With 65 bins (8 kHz) every device association is
+ * lane 0 additionally bin 128.  TREE32: lane l < 16 holds bins l, l+16, l+32, l+48, lane 16+l holds
+ * 64+l, 80+l, 96+l, 112+l (summed in that order); bin 128 is added to the butterfly's result.  TREE64P: see below.  With 65 bins (8 kHz) every device association is
  * the one of ns_kernels.hip's 8 kHz instantiation: lane l holds bin l, lane 0 additionally bin 64. */
 static float sum_bins(const float* x, int mode, int BINS) {
   if (BINS == 65 && mode != ASP_NS_REDUCE_SEQ) {
@@ -409,6 +421,14 @@ static float sum_bins(const float* x, int mode, int BINS) {
     for (int l = 0; l < 64; ++l) t[l] = x[l];
     t[0] = t[0] + x[64];
     return butterfly64(t);
+  }
+  if (mode == ASP_NS_REDUCE_TREE32) {
+    float t[32];
+    for (int l = 0; l < 32; ++l) {
+      const int b = (l & 15) + 64 * (l >> 4);
+      t[l] = ((x[b] + x[b + 16]) + x[b + 32]) + x[b + 48];
+    }
+    return butterfly32(t) + x[128];
   }
   if (mode == ASP_NS_REDUCE_TREE64P) {
     /* ns_kernels1.hip: lane l = 2 lam + h holds bins q + 64 g + 16 h and that + 32
@@ -446,6 +466,20 @@ static float energy256(const float* x, int mode, int by4, int ANAL) {
       t[l] = s;
     }
     return butterfly64(t);
+  }
+  if (mode == ASP_NS_REDUCE_TREE32) {
+    /* analysis side: lane l holds samples 8l..8l+7; synthesis side: lane l holds complex
+     * elements p = (l & 15) + 16 t + 64 (l >> 4), t = 0..3, i.e. samples 2p, 2p+1 */
+    float t[32];
+    for (int l = 0; l < 32; ++l) {
+      float s = 0.f;
+      for (int k = 0; k < 8; ++k) {
+        const int idx = by4 ? 8 * l + k : 2 * ((l & 15) + 16 * (k >> 1) + 64 * (l >> 4)) + (k & 1);
+        s = k == 0 ? x[idx] * x[idx] : s + x[idx] * x[idx];
+      }
+      t[l] = s;
+    }
+    return butterfly32(t);
   }
   if (mode == ASP_NS_REDUCE_TREE64P && !by4) {
     /* synthesis side of ns_kernels1.hip: lane l = 2 lam + h holds complex elements

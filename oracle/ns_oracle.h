@@ -29,7 +29,9 @@ extern "C" {
  *   TREE: the fixed wave64 butterfly order of the HIP kernels
  *         (slot-local sum, then xor 1,2,4,8,16,32), so the device path can be
  *         checked bit-for-bit against this restatement. */
-enum { ASP_NS_REDUCE_SEQ = 0, ASP_NS_REDUCE_TREE = 1, ASP_NS_REDUCE_TREE64P = 3 };
+enum { ASP_NS_REDUCE_SEQ = 0, ASP_NS_REDUCE_TREE = 1, ASP_NS_REDUCE_TREE32 = 2, ASP_NS_REDUCE_TREE64P = 3 };
+/*   TREE32: the association of the two-streams-per-wave kernel (ns_kernels2.hip: 32 lanes per stream, four
+ *         bins per lane summed in lane order, then xor 1,2,4,8,16, then bin 128). */
 /*   TREE64P: the association of the pair-layout kernel (ns_kernels1.hip): the two bins a lane owns,
  *         the wave64 butterfly over the 64 partials, then bin 128. */
 

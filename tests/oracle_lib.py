@@ -19,6 +19,7 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libns_ref.so")
 
 REDUCE_SEQ = 0
 REDUCE_TREE = 1
+REDUCE_TREE32 = 2
 REDUCE_TREE64P = 3   # ns_kernels1.hip: one stream per wave, pair layout
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")

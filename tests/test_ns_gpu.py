@@ -18,7 +18,7 @@ import pytest
 from audiosignalprocess_amd.synth import ns_frames
 from tests.conftest import (parity_note, CHAOS_CAP, check_free_running, free_running_report, rel_l2_per_stream, state_diff,
                             state_from_bytes)
-from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE64P, OracleNs
+from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P, OracleNs
 
 pytestmark = pytest.mark.gpu
 
@@ -516,9 +516,10 @@ def test_batched_wav_driver(ns, golden, tmp_path):
 
 # ---------------------------------------------------------------------------------------------
 # The one-stream-per-wave, two-bins-per-lane fused kernel: ns_kernels1.hip (kernel id 3, bin 128 on every
-# lane: ASP_NS_REDUCE_TREE64P): bit-exact against the oracle in the matching association, outputs and
-# every state array.
-PAIR_KERNELS = [(3, REDUCE_TREE64P)]
+# lane: ASP_NS_REDUCE_TREE64P), and the two-streams-per-wave kernel ns_kernels2.hip (kernel id 2, four bins per
+# lane of a half-wave: ASP_NS_REDUCE_TREE32): bit-exact against the oracle in the matching association,
+# outputs and every state array.
+PAIR_KERNELS = [(3, REDUCE_TREE64P), (2, REDUCE_TREE32)]
 
 @pytest.mark.parametrize("kid,mode", PAIR_KERNELS)
 def test_pair_kernel_free_running_bit_exact(ns, kid, mode):
@@ -548,7 +549,8 @@ def test_pair_kernel_edge_cases_policies_and_odd_count(ns, kid, mode):
         g = ns.NsBatch(S, policy=policy, kernel=kid)
         y = g.analyze_process(x)
         o = OracleNs(S, policy=policy, reduce_mode=mode)
-        assert np.array_equal(y, o.run(x)), policy
+        yo = o.run(x)
+        assert np.array_equal(y, yo), policy
         for s in range(S):
             assert state_diff(g.export_state(s), o.export_state(s)) == {}, (policy, s)
         g.close()
@@ -697,9 +699,9 @@ def test_8khz_golden_protocols_and_pcm(ns, golden8k):
 # The timed entry point of bench.py (AspNsBatch_TimedSteps: K steps over a device ring, launch chains)
 # against the oracle: same launches as AnalyzeProcess, but the ring wrap-around (step k uses slot
 # k % ring) and the split into chains only run here.
-@pytest.mark.parametrize("S,split,flow", [(16, 2, 0), (4096, 2, 0), (4100, 3, 0), (16, 1, 1), (4096, 1, 1), (4100, 1, 1),
-                                          (9001, 1, 1)])
-def test_timed_steps_ring_wraparound_bit_exact_vs_oracle(ns, S, split, flow):
+@pytest.mark.parametrize("S,split,flow,kid", [(16, 2, 0, 3), (4096, 2, 0, 3), (4100, 3, 0, 3), (16, 1, 1, 3), (4096, 1, 1, 3),
+                                              (4100, 1, 1, 3), (9001, 1, 1, 3), (16, 1, 1, 2), (4096, 1, 1, 2), (9001, 1, 1, 2)])
+def test_timed_steps_ring_wraparound_bit_exact_vs_oracle(ns, S, split, flow, kid):
     from audiosignalprocess_amd.ns import DeviceBuffer
 
     ring, steps = 7, 60          # ring < steps: every slot is reused eight times
@@ -709,13 +711,13 @@ def test_timed_steps_ring_wraparound_bit_exact_vs_oracle(ns, S, split, flow):
     x = np.ascontiguousarray(base[:, idx])
     din, dout = DeviceBuffer(x.nbytes), DeviceBuffer(x.nbytes)
     din.upload(x)
-    g = ns.NsBatch(S, policy=1)          # fresh batch, default kernel: the run crosses blockInd 50
+    g = ns.NsBatch(S, policy=1, kernel=kid)   # fresh batch: the run crosses blockInd 50
     g.set_split(split)
     g.set_flow(flow)             # 0: launch chains; 1: the hand-off build (one launch per step, steps overlap)
     ms = g.timed_steps(din.ptr, dout.ptr, ring, steps)
     assert ms > 0
     got = dout.download(x.shape)
-    o = OracleNs(D, policy=1, reduce_mode=REDUCE_TREE64P)
+    o = OracleNs(D, policy=1, reduce_mode=REDUCE_TREE64P if kid == 3 else REDUCE_TREE32)
     want = np.empty((ring, D, 160), np.float32)
     for k in range(steps):
         want[k % ring] = o.run(base[k % ring:k % ring + 1])[0]   # slot k % ring keeps the last step that used it
@@ -734,8 +736,8 @@ def test_timed_steps_ring_wraparound_bit_exact_vs_oracle(ns, S, split, flow):
 # publishes too), stream counts that leave the last workgroup ragged, and batches of more streams than the
 # chip holds waves (a wave then walks 2-4 streams per step).  Two hand-off batches run at the same time
 # (their launches interleave on the chip), so every wait happens under uneven load.
-@pytest.mark.parametrize("S", [5, 4100, 8192, 12290])
-def test_handoff_build_equals_plain_launches(ns, S):
+@pytest.mark.parametrize("S,kid", [(5, 3), (4100, 3), (8192, 3), (12290, 3), (5, 2), (4101, 2), (8192, 2), (12290, 2)])
+def test_handoff_build_equals_plain_launches(ns, S, kid):
     from audiosignalprocess_amd.ns import DeviceBuffer
 
     ring, steps, D = 9, 520, 16
@@ -748,7 +750,7 @@ def test_handoff_build_equals_plain_launches(ns, S):
     din.upload(x)
     outs, batches = [], []
     for flow in (0, 1, 1):
-        g = ns.NsBatch(S, policy=2)
+        g = ns.NsBatch(S, policy=2, kernel=kid)   # 3: one stream per wave (pair layout); 2: two streams per wave
         g.set_flow(flow)
         g.set_split(2 if flow == 0 else 1)
         dout = DeviceBuffer(x.nbytes)

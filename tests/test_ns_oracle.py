@@ -15,7 +15,7 @@ import pytest
 from audiosignalprocess_amd.synth import ns_frames
 from tests import oracle_lib
 from tests.conftest import check_free_running, rel_l2_per_stream, state_diff, state_from_bytes
-from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE64P, OracleNs
+from tests.oracle_lib import REDUCE_SEQ, REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P, OracleNs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 needs_ref = pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built here")
@@ -71,7 +71,7 @@ def test_golden_teacher_forced_single_step(golden):
         assert np.array_equal(y, golden["out_f32"][frames:frames + 1]), frames
 
 
-@pytest.mark.parametrize("mode", [REDUCE_TREE, REDUCE_TREE64P])
+@pytest.mark.parametrize("mode", [REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P])
 def test_tree_association_within_tolerance(golden, mode):
     """The device's fixed reduction orders stay within 1e-4 of the reference's sequential one
     (eight streams x 1100 frames of the reference's own outputs)."""
@@ -147,7 +147,7 @@ def test_free_running_vs_reference_bitwise(policy):
 
 
 @needs_ref
-@pytest.mark.parametrize("mode", [REDUCE_TREE, REDUCE_TREE64P])
+@pytest.mark.parametrize("mode", [REDUCE_TREE, REDUCE_TREE32, REDUCE_TREE64P])
 def test_device_associations_vs_live_reference_statistics(mode):
     """the three device reduction orders against the compiled reference,
     free running, 64 streams x 1500 frames: per-stream relative L2 median / 95th percentile / max
