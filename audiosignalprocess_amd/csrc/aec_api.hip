@@ -367,9 +367,6 @@ bool aec_flow_default() {
 // compensation, no metrics (the optional modes add launches of their own between the Process launches).
 bool aec_flow_applies(const AspAecBatch* b, int steps) {
   const bool on = b->flow < 0 ? aec_flow_default() : b->flow != 0;
-  // default: the 12-partition filter only (measured, profiles/README.md round 4: 101.5 us against 103.8 us per
-  // 4096-stream frame with one launch per call; the extended filter's 32 partitions 190 us against 185.5 us)
-  if (b->flow < 0 && b->extended) return false;
   if (!b->per.empty()) return false;  // per-stream control: one far-end and one Process launch per call
   return on && steps >= 2 && !b->sim && b->num_high == 0 && !b->metricsMode && !b->delay_logging &&
          b->reported_delay_enabled && !b->skewMode && b->debug_stamps == nullptr;
@@ -772,15 +769,15 @@ int buffer_farend_device(AspAecBatch* b, const float* far_dev, int n, bool defer
       if (slot >= kFarSlots) slot -= kFarSlots;
     }
     ++parts_of_call;
-    ops.rpos[ops.nparts] = rpos;
-    ops.slot[ops.nparts] = slot;
-    ops.nparts++;
-    rp_move_read(&b->pre_pos, -kPartLen);  // overlap, echo_cancellation.c:336
-    if (ops.nparts == 3) {
+    if (ops.nparts == 3) {  // a fourth partition in one call: the full descriptor goes out on its own
       if (!b->sim) AEC_TRY(batch_launch_farend(b, far_dev, ops));
       memset(&ops, 0, sizeof ops);
       pending = false;
     }
+    ops.rpos[ops.nparts] = rpos;
+    ops.slot[ops.nparts] = slot;
+    ops.nparts++;
+    rp_move_read(&b->pre_pos, -kPartLen);  // overlap, echo_cancellation.c:336
   }
   if (b->agn_synced) {  // the device replays this call on every stream's own read side at its next control step
     if (b->nevents == kMaxFarEvents) {

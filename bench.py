@@ -296,7 +296,7 @@ def bench_split(args):
 
 def aec_flow_active(ext, dmode, steps):
     """Does AspAecBatch_TimedSteps run the hand-off build?  (aec_api.hip, aec_flow_applies)"""
-    return os.environ.get("ASP_AEC_FLOW", "1")[:1] != "0" and not ext and dmode == "off" and steps >= 2
+    return os.environ.get("ASP_AEC_FLOW", "1")[:1] != "0" and dmode == "off" and steps >= 2
 
 
 def bench_aec(args):

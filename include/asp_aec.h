@@ -86,14 +86,14 @@ int32_t WebRtcAec_get_error_code(void* aecInst);                                
 /* The reference returns its internal AecCore; here it is an opaque token that is only
  * valid as an argument of the layer-1 functions of this library. */
 struct AecCore* WebRtcAec_aec_core(void* handle);                               /* .h:247 */
-/* The extended filter (32 partitions, ProcessExtended delay handling): aec_core.h:129-133,
+/* The extended filter (32 partitions, ProcessExtended delay handling): aec_core.h:106-113,
  * aec_core.c:1876-1885.  As in the reference, Init switches it off again. */
 void WebRtcAec_enable_delay_correction(struct AecCore* self, int enable);
 int WebRtcAec_delay_correction_enabled(struct AecCore* self);
-/* The buffered far-end delay in samples (aec_core.h:110-114, aec_core.c:1886-1894). */
+/* The buffered far-end delay in samples (aec_core.h:115-122, aec_core.c:1886-1894). */
 int WebRtcAec_system_delay(struct AecCore* self);
 void WebRtcAec_SetSystemDelay(struct AecCore* self, int delay);
-/* Reported delays off = the delay-agnostic mode (aec_core.h:121-126, aec_core.c:1868-1874). */
+/* Reported delays off = the delay-agnostic mode (aec_core.h:97-104, aec_core.c:1868-1874). */
 void WebRtcAec_enable_reported_delay(struct AecCore* self, int enable);
 int WebRtcAec_reported_delay_enabled(struct AecCore* self);
 #endif /* reference header not included */

@@ -8,7 +8,7 @@
  *     links against this library instead of the reference's C objects:
  *       WebRtcNs_Create / _Free / _Init / _set_policy / _Analyze / _Process /
  *       _prior_speech_probability
- *     (replaces webrtc/modules/audio_processing/ns/include/noise_suppression.h:16-122,
+ *     (replaces webrtc/modules/audio_processing/ns/include/noise_suppression.h:16-123,
  *      implemented in the reference by ns/noise_suppression.c:20-66 over ns/ns_core.c).
  *     Each handle is a batch of one stream on the GPU.
  *
@@ -40,16 +40,16 @@ extern "C" {
 
 typedef struct NsHandleT NsHandle; /* noise_suppression.h:16 */
 
-int WebRtcNs_Create(NsHandle** NS_inst);               /* noise_suppression.h:26  */
-int WebRtcNs_Free(NsHandle* NS_inst);                  /* noise_suppression.h:38  */
-int WebRtcNs_Init(NsHandle* NS_inst, uint32_t fs);     /* noise_suppression.h:54  */
-int WebRtcNs_set_policy(NsHandle* NS_inst, int mode);  /* noise_suppression.h:69  */
-void WebRtcNs_Analyze(NsHandle* NS_inst, const float* spframe); /* :84 */
-void WebRtcNs_Process(NsHandle* NS_inst,               /* noise_suppression.h:104 */
+int WebRtcNs_Create(NsHandle** NS_inst);               /* noise_suppression.h:35  */
+int WebRtcNs_Free(NsHandle* NS_inst);                  /* noise_suppression.h:48  */
+int WebRtcNs_Init(NsHandle* NS_inst, uint32_t fs);     /* noise_suppression.h:65  */
+int WebRtcNs_set_policy(NsHandle* NS_inst, int mode);  /* noise_suppression.h:80  */
+void WebRtcNs_Analyze(NsHandle* NS_inst, const float* spframe); /* :93 */
+void WebRtcNs_Process(NsHandle* NS_inst,               /* noise_suppression.h:108 */
                       const float* const* spframe,
                       int num_bands,
                       float* const* outframe);
-float WebRtcNs_prior_speech_probability(NsHandle* handle); /* :117 */
+float WebRtcNs_prior_speech_probability(NsHandle* handle); /* :123 */
 
 /* ---------------------------------------------------------------- layer 2 */
 
