@@ -20,6 +20,8 @@ def _lib():
             "AspBtBatch_Free": [vp],
             "AspBtBatch_Reset": [vp],
             "AspBtBatch_ResetStream": [vp, C.c_int],
+            "AspBtBatch_DenoiseBlocks": [vp, vp, vp, C.c_int, C.c_int],
+            "AspBtBatch_SetFlow": [vp, C.c_int],
             "AspBtBatch_num_streams": [vp],
             "AspBtBatch_macro_size": [vp],
             "AspBtBatch_Denoise": [vp, vp, vp, ip],
@@ -90,6 +92,19 @@ class BtBatch:
 
     def reset(self):
         _check(self.lib.AspBtBatch_Reset(self.h), "AspBtBatch_Reset")
+
+    def set_flow(self, mode):
+        """Hand-off build of denoise_blocks() / timed_steps(): -1 default, 0 off, 1 on (include/asp_bt.h)."""
+        _check(self.lib.AspBtBatch_SetFlow(self.h, mode), "AspBtBatch_SetFlow")
+
+    def denoise_blocks(self, x):
+        """x [K][S][macro] -> denoised, K consecutive macroblocks of every stream-channel in one call."""
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.ndim == 3 and x.shape[1:] == (self.S, self.macro)
+        y = np.empty_like(x)
+        _check(self.lib.AspBtBatch_DenoiseBlocks(self.h, x.ctypes.data, y.ctypes.data, x.shape[0], MEM_HOST),
+               "AspBtBatch_DenoiseBlocks")
+        return y
 
     def reset_stream(self, stream):
         """blockThreshold_reset of one stream-channel of the running batch."""

@@ -27,6 +27,9 @@ hipError_t launch_bt_macroblock(int n, float* state, const BtTables* T, const fl
                                 unsigned long long* stamps = nullptr);
 hipError_t launch_bt_fftr(int n, const float* src, float* dst, int count, int inverse,
                           const BtTables* T, hipStream_t s);
+hipError_t launch_bt_macroblock8_flow(bool q4, float* state, const BtTables* T, const float* in, float* out, int num_streams,
+                                      int stride, hipStream_t s, unsigned* seq, unsigned* abort_w, unsigned want, int steps,
+                                      int slot0, int ring, size_t per);
 hipError_t launch_bt_macroblock_any(const BtAnyTables& A, float* state, const float* in, float* out, int num_streams,
                                     int frames, int threshold, int in_stride, int out_stride, hipStream_t s,
                                     unsigned long long* stamps = nullptr);
@@ -252,7 +255,55 @@ struct AspBtBatch {
   // the two halves of a large batch run as two chains whose launch boundaries overlap
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Hand-off build of the multi-macroblock entry points (AspBtBatch_DenoiseBlocks, TimedSteps; bt_kernels8.hip,
+  // BtFlowArgs): up to 64 consecutive macroblocks of every stream-channel per launch, a per-stream counter in memory
+  // orders a stream-channel's overlap-add tails.  -1 = default (on for 256 / 1024-sample windows), 0 = off, 1 = on.
+  int flow = -1;
+  unsigned* flow_seq = nullptr;    // [S]
+  unsigned* flow_abort = nullptr;  // 16 B
+  unsigned flow_count = 0;
+  bool flow_unchecked = false;
 };
+
+namespace {
+bool bt_flow_applies(const AspBtBatch* b, int steps, const float* in, float* out) {
+  const char* e = getenv("ASP_BT_FLOW");
+  const bool on = b->flow < 0 ? !(e && e[0] == '0') : b->flow != 0;
+  // the tuned kernels' windows, 8-byte aligned frames (their 8-byte accesses), whole groups of four at 256 samples
+  return on && steps >= 2 && !b->any && (b->win == 1024 || (b->win == 256 && b->S % 4 == 0)) &&
+         ((uintptr_t)in & 7) == 0 && ((uintptr_t)out & 7) == 0;
+}
+int bt_flow_steps(AspBtBatch* b, const float* in, float* out, int ring, int steps) {
+  if (!b->flow_seq) {
+    BT_TRY(hipMalloc((void**)&b->flow_seq, (size_t)b->S * sizeof(unsigned)));
+    BT_TRY(hipMalloc((void**)&b->flow_abort, 16));
+    BT_TRY(hipMemsetAsync(b->flow_seq, 0, (size_t)b->S * sizeof(unsigned), b->stream));
+    BT_TRY(hipMemsetAsync(b->flow_abort, 0, 16, b->stream));
+    b->flow_count = 0;
+  }
+  const size_t per = (size_t)b->S * b->macro;
+  for (int k = 0; k < steps; k += 64) {
+    const int m = steps - k < 64 ? steps - k : 64;
+    BT_TRY(launch_bt_macroblock8_flow(b->win == 256, b->state, b->tables, in, out, b->S, b->macro, b->stream, b->flow_seq,
+                                      b->flow_abort, b->flow_count, m, k % ring, ring, per));
+    b->flow_count += (unsigned)m;
+  }
+  b->flow_unchecked = true;
+  return ASP_OK;
+}
+// after the batch's stream has been synchronised: did a hand-off wait time out?
+int bt_flow_check(AspBtBatch* b) {
+  if (!b->flow_unchecked) return ASP_OK;
+  b->flow_unchecked = false;
+  unsigned a = 0;
+  BT_TRY(hipMemcpy(&a, b->flow_abort, sizeof a, hipMemcpyDeviceToHost));
+  if (a == 0) return ASP_OK;
+  std::vector<unsigned> seq((size_t)b->S, b->flow_count);
+  BT_TRY(hipMemcpy(b->flow_seq, seq.data(), seq.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  BT_TRY(hipMemset(b->flow_abort, 0, 16));
+  return bt_fail(ASP_ERR_HIP, "BT hand-off wait timed out: overlap-add tails were skipped, reset the batch");
+}
+}  // namespace
 
 extern "C" {
 
@@ -302,6 +353,8 @@ int AspBtBatch_Free(AspBtBatch* b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->state) (void)hipFree(b->state);
   if (b->any_block) (void)hipFree(b->any_block);
+  if (b->flow_seq) (void)hipFree(b->flow_seq);
+  if (b->flow_abort) (void)hipFree(b->flow_abort);
   if (b->stage_in) (void)hipFree(b->stage_in);
   if (b->stage_out) (void)hipFree(b->stage_out);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -395,7 +448,58 @@ int AspBtBatch_Synchronize(AspBtBatch* b) {
   if (!b) return bt_fail(ASP_ERR_PARAM, "null batch handle");
   BT_TRY(hipSetDevice(b->device));
   BT_TRY(hipStreamSynchronize(b->stream));
+  return bt_flow_check(b);
+}
+
+int AspBtBatch_SetFlow(AspBtBatch* b, int mode) {
+  if (!b || mode < -1 || mode > 1) return bt_fail(ASP_ERR_PARAM, "SetFlow: -1 (default), 0 (off) or 1 (on)");
+  b->flow = mode;
   return ASP_OK;
+}
+
+// `nblocks` consecutive macroblocks of every stream-channel: in / out [nblocks][num_streams][macro] (the layout of
+// TimedSteps' ring).  The 256 / 1024-sample windows take the hand-off build (up to 64 macroblocks per launch), other
+// windows one launch per macroblock.  mem == ASP_MEM_HOST copies in and out around the launches and synchronises.
+int AspBtBatch_DenoiseBlocks(AspBtBatch* b, const float* in, float* out, int nblocks, int mem) {
+  AspDeviceScope dev_scope_;
+  if (!b || !in || !out || nblocks < 0) return bt_fail(ASP_ERR_PARAM, "DenoiseBlocks: bad argument");
+  if (mem != ASP_MEM_HOST && mem != ASP_MEM_DEVICE) return bt_fail(ASP_ERR_PARAM, "mem must be ASP_MEM_HOST or ASP_MEM_DEVICE");
+  if (nblocks == 0) return ASP_OK;
+  BT_TRY(hipSetDevice(b->device));
+  const size_t per = (size_t)b->S * b->macro;
+  const float* din = in;
+  float* dout = out;
+  float *tmp_in = nullptr, *tmp_out = nullptr;
+  if (mem == ASP_MEM_HOST) {
+    BT_TRY(hipMalloc((void**)&tmp_in, per * nblocks * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&tmp_out, per * nblocks * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp_in, in, per * nblocks * sizeof(float), hipMemcpyHostToDevice, b->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(tmp_in);
+      if (tmp_out) (void)hipFree(tmp_out);
+      return bt_fail(ASP_ERR_HIP, "DenoiseBlocks: staging", e);
+    }
+    din = tmp_in;
+    dout = tmp_out;
+  }
+  int rc = ASP_OK;
+  if (bt_flow_applies(b, nblocks, din, dout)) {
+    rc = bt_flow_steps(b, din, dout, nblocks, nblocks);
+  } else {
+    for (int k = 0; k < nblocks && rc == ASP_OK; ++k)
+      if (bt_launch(b, b->state, din + per * k, dout + per * k, b->S, 8, 1, b->macro, b->macro, b->stream) != hipSuccess)
+        rc = bt_fail(ASP_ERR_HIP, "DenoiseBlocks: launch");
+  }
+  if (mem == ASP_MEM_HOST) {
+    hipError_t e = hipSuccess;
+    if (rc == ASP_OK) e = hipMemcpyAsync(out, tmp_out, per * nblocks * sizeof(float), hipMemcpyDeviceToHost, b->stream);
+    const hipError_t e2 = hipStreamSynchronize(b->stream);
+    (void)hipFree(tmp_in);
+    (void)hipFree(tmp_out);
+    if (rc == ASP_OK && (e != hipSuccess || e2 != hipSuccess)) return bt_fail(ASP_ERR_HIP, "DenoiseBlocks: copy back", e != hipSuccess ? e : e2);
+    if (rc == ASP_OK) rc = bt_flow_check(b);
+  }
+  return rc;
 }
 
 int AspBtBatch_TimedSteps(AspBtBatch* b, const float* in, float* out, int blocks_in_ring,
@@ -405,6 +509,15 @@ int AspBtBatch_TimedSteps(AspBtBatch* b, const float* in, float* out, int blocks
     return bt_fail(ASP_ERR_PARAM, "TimedSteps: bad argument");
   BT_TRY(hipSetDevice(b->device));
   const size_t per = (size_t)b->S * b->macro;
+  if (bt_flow_applies(b, steps, in, out)) {
+    BT_TRY(hipEventRecord(b->ev0, b->stream));
+    const int rcf = bt_flow_steps(b, in, out, blocks_in_ring, steps);
+    if (rcf != ASP_OK) return rcf;
+    BT_TRY(hipEventRecord(b->ev1, b->stream));
+    BT_TRY(hipEventSynchronize(b->ev1));
+    BT_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+    return bt_flow_check(b);
+  }
   const char* ch = getenv("ASP_BT_CHAINS");
   const bool dual = b->S >= 2048 && !(ch && atoi(ch) == 1);
   if (dual && !b->side) {
@@ -459,6 +572,10 @@ int AspBtBatch_ExportState(AspBtBatch* b, int stream, AspBtState* out) {
   if (!b || !out || stream < 0 || stream >= b->S) return bt_fail(ASP_ERR_PARAM, "ExportState: bad argument");
   BT_TRY(hipSetDevice(b->device));
   BT_TRY(hipStreamSynchronize(b->stream));
+  {
+    const int rcf = bt_flow_check(b);
+    if (rcf != ASP_OK) return rcf;
+  }
   float blk[kAnyStateFloats];
   BT_TRY(hipMemcpy(blk, b->state + (size_t)stream * b->state_floats, sizeof(float) * b->state_floats, hipMemcpyDeviceToHost));
   memset(out, 0, sizeof *out);

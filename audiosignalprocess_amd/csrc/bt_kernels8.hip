@@ -545,10 +545,36 @@ __device__ __forceinline__ void scan_rows_full(const float (&pw)[8], int lastlan
 // Q4: four stream-channels of 256-sample windows per workgroup (workgroup g takes streams 4 g .. 4 g + 3): wave w =
 // frame w of all four, their samples interleaved on the way in so that the 512-point network computes four 128-point
 // transforms; 4 x 7 macro-columns + 4 x 16 edge lanes are the 512 threads of phase B2.
-template <bool Q4>
+// The hand-off build (FLOW): one launch carries M consecutive macroblocks of every stream-channel (blockIdx.y = the
+// step; its input / output is ring slot (slot0 + step) % ring).  What a stream-channel's consecutive macroblocks hand
+// each other is small: the input tail IS the last half window of the previous macroblock's input (read from there,
+// no hand-off; only the launch's first step reads the state's copy and only its last step writes it), and the
+// overlap-add tail, written by wave 7 at the very end of a macroblock and read by wave 0 of the next one just before
+// its own overlap-add -- ordered by a per-stream step counter in memory (sc1 stores drained, then the counter; wave 0
+// polls it, then sc1 loads), as in ns_kernels1.hip.  Workgroups are dispatched in grid order, so the macroblock
+// waited for has been dispatched a whole step earlier.  A wait that times out sets the abort word and the workgroup
+// carries on with a zero tail (the barriers that follow need every wave); bt_api.hip reports it.
+struct BtFlowArgs {
+  unsigned* seq;      // [num_streams]: macroblocks stream s has completed in hand-off launches
+  unsigned* abort_w;
+  unsigned want;      // blockIdx.y == 0 is macroblock `want` of every stream
+  int slot0, ring;
+  unsigned per;       // floats between two ring slots of in / out
+};
+typedef __attribute__((address_space(1))) unsigned bt_gu32;
+typedef __attribute__((address_space(1))) unsigned long long bt_gu64;
+__device__ __forceinline__ f32x2 ld2_sc1(const float* p) {
+  const unsigned long long v = __hip_atomic_load((const bt_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_bit_cast(f32x2, v);
+}
+__device__ __forceinline__ void st2_sc1(float* p, f32x2 v) {
+  __hip_atomic_store((bt_gu64*)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool Q4, bool FLOW>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, BT8_WAVES))) void bt_macroblock8_kernel(
     float* __restrict__ state, const BtTables* __restrict__ Tb, const float* __restrict__ in,
-    float* __restrict__ out, int in_stride, int out_stride, unsigned long long* __restrict__ stamps) {
+    float* __restrict__ out, int in_stride, int out_stride, unsigned long long* __restrict__ stamps, BtFlowArgs fa) {
   __shared__ __align__(256) cpx coef[8 * ROW];     // [frame][bin]; a wave's row is also its exchange buffer
   __shared__ __align__(16) float sq[128 * SQS];    // squared normalised real parts; later the OLA halves
   __shared__ float sure[NCOL * SUS + 15];          // [macro-column][segmentation], then a_const of the 15 segmentations
@@ -560,6 +586,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   // the stream whose samples this lane loads (Q4: input 4 n' + s of the interleaved array sits on lanes with lane & 3 = s)
   const int stream = Q4 ? 4 * blockIdx.x + (lane & 3) : blockIdx.x;
   float* st = state + (size_t)stream * kStateFloats;
+  const float* in_prev = in;  // hand-off build: the previous macroblock's input (steps after the launch's first)
+  unsigned flow_want = 0;
+  bool flow_first = true, flow_last = true;
+  if constexpr (FLOW) {
+    const unsigned j = blockIdx.y;
+    const unsigned slot = ((unsigned)fa.slot0 + j) % (unsigned)fa.ring;
+    const unsigned pslot = ((unsigned)fa.slot0 + j + (unsigned)fa.ring - 1u) % (unsigned)fa.ring;
+    in_prev = in + (size_t)pslot * fa.per;
+    in += (size_t)slot * fa.per;
+    out += (size_t)slot * fa.per;
+    flow_want = fa.want + j;
+    flow_first = j == 0;
+    flow_last = j + 1 == gridDim.y;
+  }
   const float* x = in + (size_t)stream * in_stride;
   float* y = out + (size_t)stream * out_stride;
   const BtSize& P = Q4 ? Tb->s256 : Tb->s1024;
@@ -581,7 +621,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int n = Q4 ? q4_input(lane, j) : lane + la_input(j);  // complex input index: samples 2n, 2n + 1 of the frame
-      const float* src = (wave == 0 && (j & 1) == 0) ? st + kOffInTail + 2 * n : x + HALFV * (wave - 1) + 2 * n;
+      // frame 0's first half window: the carried input tail -- the state's copy, or (hand-off build, not the
+      // launch's first step) the last half window of the previous macroblock's input, which is what that copy holds
+      const float* tail_src = (FLOW && !flow_first) ? in_prev + (size_t)stream * in_stride + 7 * HALFV + 2 * n
+                                                    : st + kOffInTail + 2 * n;
+      const float* src = (wave == 0 && (j & 1) == 0) ? tail_src : x + HALFV * (wave - 1) + 2 * n;
       s[j] = *reinterpret_cast<const f32x2*>(src);
       hw[j] = hann2[n];
     }
@@ -608,8 +652,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   BT8_WSTAMP(0)
   __syncthreads();
   BT8_STAMP(4)
-  // carry the last HALF input samples (wave 0 has read the old tail before the barrier)
-  if constexpr (Q4) {
+  // carry the last HALF input samples (wave 0 has read the old tail before the barrier); hand-off build: only the
+  // launch's last step (the steps in between read them from their predecessor's input)
+  if (!flow_last) {
+  } else if constexpr (Q4) {
     const size_t sq4 = (size_t)4 * blockIdx.x + (tid >> 7);
     state[sq4 * kStateFloats + kOffInTail + (tid & 127)] = in[sq4 * in_stride + 7 * HALFV + (tid & 127)];
   } else {
@@ -759,10 +805,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   const size_t g4 = (size_t)4 * blockIdx.x;
   f32x2 tail[4];
   if (wave == 0) {
+    if constexpr (FLOW) {
+      // the stream-channel's previous macroblock must have published its overlap-add tail (Q4: four stream-channels)
+      const bt_gu32* f = (const bt_gu32*)(fa.seq + (Q4 ? g4 + (lane & 3) : (size_t)blockIdx.x));
+      bool ok = true;
+      for (unsigned spins = 0;;) {
+        const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v == flow_want)) break;
+        ++spins;
+        if ((spins & 63u) == 0u &&
+            __builtin_amdgcn_readfirstlane((int)__hip_atomic_load((const bt_gu32*)fa.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
+          ok = false;
+          break;
+        }
+        if (spins > (1u << 17)) {
+          if (lane == 0) __hip_atomic_store((bt_gu32*)fa.abort_w, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tail[j] = f32x2{0.0f, 0.0f};
+        if (ok)
+          tail[j] = Q4 ? ld2_sc1(state + (g4 + j) * kStateFloats + kOffOutTail + 2 * lane)
+                       : ld2_sc1(st + kOffOutTail + 2 * (lane + 64 * j));
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       tail[j] = Q4 ? *reinterpret_cast<const f32x2*>(state + (g4 + j) * kStateFloats + kOffOutTail + 2 * lane)
                    : *reinterpret_cast<const f32x2*>(st + kOffOutTail + 2 * (lane + 64 * j));
+    }
   }
   cpx spi[8];  // the merge's super twiddles, requested ahead of the barrier
 #pragma unroll
@@ -807,8 +883,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
     }
     if (wave == 7) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<f32x2*>(state + (g4 + q) * kStateFloats + kOffOutTail + 2 * lane) = f32x2{0.0f, 0.0f} + v[2 * q + 1];
+      for (int q = 0; q < 4; ++q) {
+        float* dst = state + (g4 + q) * kStateFloats + kOffOutTail + 2 * lane;
+        if constexpr (FLOW) st2_sc1(dst, f32x2{0.0f, 0.0f} + v[2 * q + 1]);
+        else *reinterpret_cast<f32x2*>(dst) = f32x2{0.0f, 0.0f} + v[2 * q + 1];
+      }
+      if constexpr (FLOW) {  // publish the four stream-channels' macroblock: the tail stores drained first
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < 4) __hip_atomic_store((bt_gu32*)(fa.seq + g4 + lane), flow_want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   } else {
   // v[j] = samples 2p, 2p + 1 of the frame, p = lane + 64 j
@@ -835,7 +918,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BT8_WAVES, 
   if (wave == 7) {
 #pragma unroll
     for (int j = 4; j < 8; ++j) {
-      *reinterpret_cast<f32x2*>(st + kOffOutTail + 2 * (lane + 64 * (j - 4))) = f32x2{0.0f, 0.0f} + v[j];
+      float* dst = st + kOffOutTail + 2 * (lane + 64 * (j - 4));
+      if constexpr (FLOW) st2_sc1(dst, f32x2{0.0f, 0.0f} + v[j]);
+      else *reinterpret_cast<f32x2*>(dst) = f32x2{0.0f, 0.0f} + v[j];
+    }
+    if constexpr (FLOW) {  // publish the stream-channel's macroblock: the tail stores drained first
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store((bt_gu32*)(fa.seq + blockIdx.x), flow_want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   }
@@ -894,17 +983,33 @@ namespace aspbt {
 hipError_t launch_bt_macroblock8(float* state, const BtTables* T, const float* in, float* out,
                                  int num_streams, int in_stride, int out_stride, hipStream_t s,
                                  unsigned long long* stamps) {
-  hipLaunchKernelGGL(bt_macroblock8_kernel<false>, dim3(num_streams), dim3(512), 0, s, state, T, in, out,
-                     in_stride, out_stride, stamps);
+  const BtFlowArgs none = {nullptr, nullptr, 0u, 0, 1, 0u};
+  hipLaunchKernelGGL((bt_macroblock8_kernel<false, false>), dim3(num_streams), dim3(512), 0, s, state, T, in, out,
+                     in_stride, out_stride, stamps, none);
   return hipGetLastError();
 }
 
-// N = 256: `groups` workgroups of four consecutive stream-channels each (the caller runs what is left over
-// through bt_macroblock_kernel<256>)
 hipError_t launch_bt_macroblock8_q4(float* state, const BtTables* T, const float* in, float* out, int groups,
                                     int in_stride, int out_stride, hipStream_t s) {
-  hipLaunchKernelGGL(bt_macroblock8_kernel<true>, dim3(groups), dim3(512), 0, s, state, T, in, out, in_stride,
-                     out_stride, (unsigned long long*)nullptr);
+  const BtFlowArgs none = {nullptr, nullptr, 0u, 0, 1, 0u};
+  hipLaunchKernelGGL((bt_macroblock8_kernel<true, false>), dim3(groups), dim3(512), 0, s, state, T, in, out, in_stride,
+                     out_stride, (unsigned long long*)nullptr, none);
+  return hipGetLastError();
+}
+
+// The hand-off build: `steps` consecutive macroblocks of every stream-channel in one launch (grid y = step); step j
+// takes ring slot (slot0 + j) % ring of in / out (slots `per` floats apart, a stream-channel's macroblock `stride`
+// floats from the next one's).  q4: the 256-sample window's four-stream-channels-per-workgroup form (num_streams % 4 == 0).
+hipError_t launch_bt_macroblock8_flow(bool q4, float* state, const BtTables* T, const float* in, float* out, int num_streams,
+                                      int stride, hipStream_t s, unsigned* seq, unsigned* abort_w, unsigned want, int steps,
+                                      int slot0, int ring, size_t per) {
+  const BtFlowArgs fa = {seq, abort_w, want, slot0, ring, (unsigned)per};
+  if (q4)
+    hipLaunchKernelGGL((bt_macroblock8_kernel<true, true>), dim3(num_streams / 4, steps), dim3(512), 0, s, state, T, in, out,
+                       stride, stride, (unsigned long long*)nullptr, fa);
+  else
+    hipLaunchKernelGGL((bt_macroblock8_kernel<false, true>), dim3(num_streams, steps), dim3(512), 0, s, state, T, in, out,
+                       stride, stride, (unsigned long long*)nullptr, fa);
   return hipGetLastError();
 }
 

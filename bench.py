@@ -198,6 +198,7 @@ def bench_bt(args):
     ev_ms, wall = max_over_ranks(dist, [ev_ms, wall], device="cuda")   # the slowest rank's region
     if rank != 0:
         return finish_ranks(dist)
+    bt_flow = os.environ.get("ASP_BT_FLOW", "1")[:1] != "0" and (n == 1024 or S % 4 == 0) and steps >= 2   # bt_api.hip, bt_flow_applies
     algo = 40 * (n // 2) * 2 * 1  # 10 B per sample: in + out + both tails read and written
     algo = 10 * g.macro
     launch_s = ev_ms / 1e3 / steps             # one clock (hipEvents on the launch stream) for every number of the line
@@ -217,8 +218,9 @@ def bench_bt(args):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": BT_TRAFFIC_BYTES_PER_MACROBLOCK * S if n == 1024 else None,
                      "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), per step of all stream-channels; not measured in this run",
-                     "kernel": "bt_macroblock8_kernel<false>" if n == 1024 else "bt_macroblock8_kernel<true> (four stream-channels per workgroup)",
-                     "launch_chains": 2 if S >= 2048 else 1,
+                     "kernel": ("bt_macroblock8_kernel<false, %s>" if n == 1024 else "bt_macroblock8_kernel<true, %s> (four stream-channels per workgroup)") % ("true" if bt_flow else "false"),
+                     "launch_chains": 1 if bt_flow else 2 if S >= 2048 else 1,
+                     "macroblock_steps_per_launch": min(steps, 64) if bt_flow else 1,
                      "algorithmic_bytes_per_step": algo * S, "avg_step_us": launch_s * 1e6},
     }
     if not args.no_cpu_baseline and world == 1:

@@ -68,6 +68,14 @@ int AspBtBatch_Free(AspBtBatch* b);
 int AspBtBatch_Reset(AspBtBatch* b);
 /* blockThreshold_reset of ONE stream-channel of a running batch: its two tails are cleared, the others untouched. */
 int AspBtBatch_ResetStream(AspBtBatch* b, int stream);
+/* `nblocks` consecutive macroblocks (8 hops each) of every stream-channel in one call: in / out
+ * [nblocks][num_streams][macro_size] float32.  With 256- and 1024-sample windows the macroblocks of up to 64 steps
+ * go into ONE launch (the hand-off build: a stream-channel's input tail is read from the previous macroblock's
+ * input, its overlap-add tail is handed on through memory behind a per-stream counter); results are those of
+ * nblocks AspBtBatch_Denoise calls, bit for bit.  AspBtBatch_SetFlow: -1 default (on; ASP_BT_FLOW=0 in the
+ * environment turns the default off), 0 off (one launch per macroblock), 1 on. */
+int AspBtBatch_DenoiseBlocks(AspBtBatch* b, const float* in, float* out, int nblocks, int mem);
+int AspBtBatch_SetFlow(AspBtBatch* b, int mode);
 int AspBtBatch_num_streams(const AspBtBatch* b);
 int AspBtBatch_macro_size(const AspBtBatch* b); /* 8 * win_size / 2 samples per call */
 /* One macroblock per stream: in/out [num_streams][macro_size] float in [-1, 1]

@@ -212,6 +212,35 @@ def test_reset_one_stream_of_a_running_batch(bt, n):
         assert np.array_equal(y2[s].view(np.uint32), w2.view(np.uint32)), s
 
 
+@pytest.mark.parametrize("n,S", [(1024, 3), (1024, 1100), (256, 8), (256, 2052), (256, 7), (320, 5)])
+def test_handoff_build_equals_one_launch_per_macroblock(bt, n, S):
+    """AspBtBatch_DenoiseBlocks: K consecutive macroblocks per call -- at 256 / 1024 samples in ONE launch, a
+    stream-channel's tails handed from macroblock to macroblock through memory -- against K Denoise calls and the
+    oracle, bit for bit (outputs and the state left behind); two calls in a row (the tails cross the launch
+    boundary through the state), then a plain Denoise call on top.  (256, 7) and (320, 5) take the fallback: no
+    whole groups of four / a mixed-radix window.)"""
+    K = 7
+    D = min(S, 6)
+    xs = bt_samples(D, (2 * K + 1) * 4 * n)
+    idx = (np.arange(S) * 7) % D
+    macro = 4 * n
+    x = np.ascontiguousarray(xs[idx].reshape(S, 2 * K + 1, macro).transpose(1, 0, 2))   # [2K + 1][S][macro]
+    outs = []
+    for flow in (0, 1):
+        g = bt.BtBatch(S, n)
+        g.set_flow(flow)
+        y = np.concatenate([g.denoise_blocks(x[:K]), g.denoise_blocks(x[K:2 * K]), g.denoise(x[2 * K])[None]], axis=0)
+        outs.append((y, [g.export_state(s) for s in (0, S // 2, S - 1)]))
+        g.close()
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    for a, b_ in zip(outs[0][1], outs[1][1]):
+        assert bytes(a) == bytes(b_)
+    for d in range(D):
+        s_ = int(np.nonzero(idx == d)[0][0])
+        want = OracleBt(n).run(xs[d])
+        assert np.array_equal(outs[1][0][:, s_].reshape(-1).view(np.uint32), want.view(np.uint32)), d
+
+
 def test_flush_partial_macroblock(bt):
     for n in (256, 1024, 320, 480):
         g = bt.BtBatch(2, n)
