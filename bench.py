@@ -32,14 +32,16 @@ ALGO_BYTES_PER_FRAME = 15716  # frame-synchronous NS mod
 # known byte count at 32768 streams as MI355X_MICROARCH.md prescribes for access widths it does not
 # cover; see profiles/README.md ("HBM traffic of the NS kernel").  Measured once per round, not live.
 
-# Secondary lines: fabric-side bytes from the same counters (tools/traffic_sec.sh, profiles/r02_traffic_sec.txt),
-# stored per unit of work, not measured in the run.  BT: 2 x 10.0948 KB FETCH_SIZE + 20.000 KB WRITE_SIZE per
-# macroblock (8-byte lanes: the guide's factor 2 on reads; 1.005 x the algorithmic 40 960 B).  AEC: 33.40 KB
-# FETCH_SIZE and 32.98 KB WRITE_SIZE per stream and frame of 4-byte-per-lane accesses (a width the guide does not
-# calibrate; with its factor 2 on reads 1.40 x the algorithmic 71 400 B: FilterAdaptation reads the far history and
-# the filter a second time, from the Infinity Cache).
-BT_TRAFFIC_BYTES_PER_MACROBLOCK = (2 * 10.0948 + 20.0) * 1024
-AEC_TRAFFIC_BYTES_PER_FRAME = (2 * 33.4001 + 32.9825) * 1024
+# Secondary lines: fabric-side bytes from the same counters (tools/traffic_sec.sh, profiles/r04_traffic_sec.txt),
+# stored per unit of work, not measured in the run.  BT-1024: 2 x 10.0943 KB FETCH_SIZE + 20.000 KB WRITE_SIZE per
+# macroblock (8-byte lanes: the guide's factor 2 on reads; 1.005 x the algorithmic 40 960 B); BT-256: 2 x 2.6127 KB +
+# 5.000 KB per macroblock (1.02 x the algorithmic 10 240 B).  AEC (hand-off build): 28.51 KB FETCH_SIZE and 31.86 KB
+# WRITE_SIZE per stream and frame of 4-byte-per-lane accesses (a width the guide does not calibrate; with its factor
+# 2 on reads 1.27 x the algorithmic 71 400 B: FilterAdaptation reads the far history and the filter a second time,
+# from the Infinity Cache).
+BT_TRAFFIC_BYTES_PER_MACROBLOCK = (2 * 10.0943 + 20.0) * 1024
+BT256_TRAFFIC_BYTES_PER_MACROBLOCK = (2 * 2.6127 + 5.0) * 1024
+AEC_TRAFFIC_BYTES_PER_FRAME = (2 * 28.5106 + 31.8561) * 1024
 
 # ns_frame1_kernel<false> (the benched kernel, round 3: profiles/r03_ns_traffic.txt): FETCH_SIZE 3.8648 /
 # WRITE_SIZE 7.2188 KB per stream and launch at 4096 streams against 3.8233 / 7.2188 KB at 32768 streams, where
@@ -216,8 +218,8 @@ def bench_bt(args):
                    "samples_per_s": S * world * g.macro / launch_s,
                    "parallelism": "stream-sharded x%d, no collectives" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": BT_TRAFFIC_BYTES_PER_MACROBLOCK * S if n == 1024 else None,
-                     "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), per step of all stream-channels; not measured in this run",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": (BT_TRAFFIC_BYTES_PER_MACROBLOCK if n == 1024 else BT256_TRAFFIC_BYTES_PER_MACROBLOCK) * S,
+                     "traffic_source": "stored constant: PMC passes kept under profiles/r04_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), per step of all stream-channels; not measured in this run",
                      "kernel": ("bt_macroblock8_kernel<false, %s>" if n == 1024 else "bt_macroblock8_kernel<true, %s> (four stream-channels per workgroup)") % ("true" if bt_flow else "false"),
                      "launch_chains": 1 if bt_flow else 2 if S >= 2048 else 1,
                      "macroblock_steps_per_launch": min(steps, 64) if bt_flow else 1,
@@ -363,7 +365,7 @@ def bench_aec(args):
                    "parallelism": "stream-sharded x%d, no collectives" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None if ext else AEC_TRAFFIC_BYTES_PER_FRAME * S,
-                     "traffic_source": "stored constant: PMC passes kept under profiles/r02_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE; 4-byte-per-lane accesses, a width MI355X_MICROARCH.md does not calibrate), per frame step of all streams; not measured in this run",
+                     "traffic_source": "stored constant: PMC passes kept under profiles/r04_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE; 4-byte-per-lane accesses, a width MI355X_MICROARCH.md does not calibrate), per frame step of all streams; not measured in this run",
                      "kernel": ("aec_process_flow_kernel" if flow else "aec_process_kernel") + " (the far-end work of the frame inside it)",
                      "launch_chains": 1 if flow else 2 if S >= 2048 and dmode == "off" else 1,
                      "frame_steps_per_launch": min(steps, 64) if flow else 1,
