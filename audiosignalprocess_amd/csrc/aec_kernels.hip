@@ -37,6 +37,12 @@ namespace {
 
 // Per-bin loops: trip 0 puts bin q on lane q, trip 1 is bin 64 computed by every lane (uniform
 // values, identical stores), so both trips are straight-line code whose loads overlap.
+#ifndef AEC_CARRY
+#define AEC_CARRY 1  // a block's filter update also accumulates the next block's FilterFar (0: every block loads its own)
+#endif
+#if AEC_CARRY && !AEC_FILTERFAR_FIRST
+#error "AEC_CARRY needs AEC_FILTERFAR_FIRST (the other order recomputes FilterFar in every block)"
+#endif
 #ifndef AEC_TRIPS
 #define AEC_TRIPS 2  // (1: timing probe only -- bin 64 is then not computed and the results are wrong)
 #endif
@@ -749,7 +755,11 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
                                               int nlp_mode, float mu, float error_threshold,
                                               int lane, const double* __restrict__ exp2_global,
                                               int num_high, float* __restrict__ met,
-                                              unsigned long long* stamps, float* __restrict__ spec_out) {
+                                              unsigned long long* stamps, float* __restrict__ spec_out,
+                                              bool carry_in, const float* __restrict__ next_slot, int next_xf_pos) {
+  // carry_in: the echo estimate's spectrum of this block is already in the YFR / YFI rows (the previous block of
+  // this call accumulated it during its filter update); next_slot != nullptr: this block does the same for the
+  // next one, whose far spectrum sits in next_slot and whose xfBufBlockPos is next_xf_pos.
   // diagnostic phase stamps (never enabled by the product entry points)
 #define AEC_STAMP(k) \
   if (stamps != nullptr) stamps[k] = __builtin_amdgcn_s_memtime();
@@ -842,6 +852,75 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   // (the 32 partitions of the extended filter do not fit in registers: their FilterFar loads row by row)
   constexpr int kFarRegs = kExtended ? 1 : kNumPart, kFarUnroll = kExtended ? 8 : kNumPart;
   float xr[kFarRegs], xi[kFarRegs], wr[kFarRegs], wi[kFarRegs];
+  float p_xpow, p_dpow, p_dmin, p_dinit, p_outbuf;
+  // rows of the power / noise-floor update and the overlap-add tail: in flight during the first FFT
+#define AEC_LOAD_POWER_ROWS()                  \
+  p_xpow = sld(sb, ROWO(R_XPOW), lane);        \
+  p_dpow = sld(sb, ROWO(R_DPOW), lane);        \
+  p_dmin = sld(sb, ROWO(R_DMINPOW), lane);     \
+  p_dinit = sld(sb, ROWO(R_DINITMINPOW), lane); \
+  p_outbuf = sld(sb, kOffOutBuf, lane);        \
+  wave_fence();
+  // the far spectra of this block (aec_core.c:1137, 888-891)
+#define AEC_FAR_SPECTRA()                                                                      \
+  BINS_2TRIPS {                                                                                \
+    XFR[bin] = t_ == 0 ? fs_lane[0] : fs_64[0];                                                \
+    XFI[bin] = t_ == 0 ? fs_lane[1] : fs_64[1];                                                \
+    const float xwr = t_ == 0 ? fs_lane[2] : fs_64[2], xwi = t_ == 0 ? fs_lane[3] : fs_64[3];  \
+    XWR[bin] = xwr;                                                                            \
+    XWI[bin] = xwi;                                                                            \
+    ROW_ST((R_XFW + 2 * op.xfw_head), xwr);                                                    \
+    ROW_ST((R_XFW + 2 * op.xfw_head + 1), xwi);                                                \
+  }                                                                                            \
+  wave_fence();
+#if AEC_FILTERFAR_FIRST
+  if (carry_in) {  // the echo estimate's spectrum waits in YFR / YFI (the previous block's filter update left it)
+    AEC_LOAD_POWER_ROWS()
+    AEC_FAR_SPECTRA()
+  } else {
+#pragma unroll
+    for (int i = 0; i < kFarRegs; ++i) {
+      int px = i + op.xf_pos;
+      if (px >= kNumPart) px -= kNumPart;
+      if (i > 0) {
+        xr[i] = sld(sb, ROWO((R_XF_RE + px)), lane);
+        xi[i] = sld(sb, ROWO((R_XF_IM + px)), lane);
+      }
+      wr[i] = sld(sb, ROWO((R_WF_RE + i)), lane);
+      wi[i] = sld(sb, ROWO((R_WF_IM + i)), lane);
+    }
+    AEC_LOAD_POWER_ROWS()
+    xr[0] = fs_lane[0];
+    xi[0] = fs_lane[1];
+    AEC_FAR_SPECTRA()
+    // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
+    BINS_2TRIPS {
+      float yr = 0.f, yi = 0.f;
+#pragma unroll kFarUnroll
+      for (int i = 0; i < kNumPart; ++i) {
+        int px = i + op.xf_pos;
+        if (px >= kNumPart) px -= kNumPart;
+        float ar, ai, br, bi;
+        if constexpr (kExtended) {
+          ar = i == 0 ? XFR[bin] : ROW_LD((R_XF_RE + px));
+          ai = i == 0 ? XFI[bin] : ROW_LD((R_XF_IM + px));
+          br = ROW_LD((R_WF_RE + i));
+          bi = ROW_LD((R_WF_IM + i));
+        } else {
+          ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
+          ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
+          br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
+          bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
+        }
+        yr += ar * br - ai * bi;
+        yi += ar * bi + ai * br;
+      }
+      YFR[bin] = yr;
+      YFI[bin] = yi;
+    }
+    wave_fence();
+  }
+#else
 #pragma unroll
   for (int i = 0; i < kFarRegs; ++i) {
     int px = i + op.xf_pos;
@@ -853,55 +932,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     wr[i] = sld(sb, ROWO((R_WF_RE + i)), lane);
     wi[i] = sld(sb, ROWO((R_WF_IM + i)), lane);
   }
-
-  // rows of the power / noise-floor update and the overlap-add tail: in flight during the first FFT
-  const float p_xpow = sld(sb, ROWO(R_XPOW), lane), p_dpow = sld(sb, ROWO(R_DPOW), lane);
-  const float p_dmin = sld(sb, ROWO(R_DMINPOW), lane), p_dinit = sld(sb, ROWO(R_DINITMINPOW), lane);
-  const float p_outbuf = sld(sb, kOffOutBuf, lane);
-  wave_fence();
-
-#if AEC_FILTERFAR_FIRST
-  // the far spectra of this block (aec_core.c:1137, 888-891)
-  xr[0] = fs_lane[0];
-  xi[0] = fs_lane[1];
-  BINS_2TRIPS {
-    XFR[bin] = t_ == 0 ? fs_lane[0] : fs_64[0];
-    XFI[bin] = t_ == 0 ? fs_lane[1] : fs_64[1];
-    const float xwr = t_ == 0 ? fs_lane[2] : fs_64[2], xwi = t_ == 0 ? fs_lane[3] : fs_64[3];
-    XWR[bin] = xwr;
-    XWI[bin] = xwi;
-    ROW_ST((R_XFW + 2 * op.xfw_head), xwr);
-    ROW_ST((R_XFW + 2 * op.xfw_head + 1), xwi);
-  }
-  wave_fence();
-  // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
-  BINS_2TRIPS {
-    float yr = 0.f, yi = 0.f;
-#pragma unroll kFarUnroll
-    for (int i = 0; i < kNumPart; ++i) {
-      int px = i + op.xf_pos;
-      if (px >= kNumPart) px -= kNumPart;
-      float ar, ai, br, bi;
-      if constexpr (kExtended) {
-        ar = i == 0 ? XFR[bin] : ROW_LD((R_XF_RE + px));
-        ai = i == 0 ? XFI[bin] : ROW_LD((R_XF_IM + px));
-        br = ROW_LD((R_WF_RE + i));
-        bi = ROW_LD((R_WF_IM + i));
-      } else {
-        ar = t_ == 0 ? xr[i] : (i == 0 ? XFR[64] : c64[R_XF_RE + px]);
-        ai = t_ == 0 ? xi[i] : (i == 0 ? XFI[64] : c64[R_XF_IM + px]);
-        br = t_ == 0 ? wr[i] : c64[R_WF_RE + i];
-        bi = t_ == 0 ? wi[i] : c64[R_WF_IM + i];
-      }
-      yr += ar * br - ai * bi;
-      yi += ar * bi + ai * br;
-    }
-    YFR[bin] = yr;
-    YFI[bin] = yi;
-  }
-  wave_fence();
-
-
+  AEC_LOAD_POWER_ROWS()
 #endif
   AEC_STAMP(1)
   // ---- near fft (aec_core.c:1140-1141)
@@ -933,19 +964,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   wave_fence();
 
 #if !AEC_FILTERFAR_FIRST
-  // the far spectra of this block (aec_core.c:1137, 888-891)
   xr[0] = fs_lane[0];
   xi[0] = fs_lane[1];
-  BINS_2TRIPS {
-    XFR[bin] = t_ == 0 ? fs_lane[0] : fs_64[0];
-    XFI[bin] = t_ == 0 ? fs_lane[1] : fs_64[1];
-    const float xwr = t_ == 0 ? fs_lane[2] : fs_64[2], xwi = t_ == 0 ? fs_lane[3] : fs_64[3];
-    XWR[bin] = xwr;
-    XWI[bin] = xwi;
-    ROW_ST((R_XFW + 2 * op.xfw_head), xwr);
-    ROW_ST((R_XFW + 2 * op.xfw_head + 1), xwi);
-  }
-  wave_fence();
+  AEC_FAR_SPECTRA()
   // ---- FilterFar (aec_core.c:147-169): partitions in order, per bin
   BINS_2TRIPS {
     float yr = 0.f, yi = 0.f;
@@ -1107,6 +1128,22 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     gw[buf][2 * k + 1] = sld(sb, ROWO((R_WF_IM + i_)), lane);                       \
   }
   AEC_LOAD_GROUP(0, 0)
+  // The next block's FilterFar (aec_core.c:147-169) rides along: its partition i multiplies the far spectrum this
+  // block holds as partition i - 1 (the history moves by one block; partition 0 = the next block's own spectrum)
+  // with the filter partition i as this update leaves it -- both in registers here, in the reference's partition
+  // order.  The sums wait in the YFR / YFI rows, and the next block skips its 46 row loads.
+  const bool carry_out = next_slot != nullptr;
+  float cy_r = 0.f, cy_i = 0.f, nx_r = 0.f, nx_i = 0.f;
+  if (carry_out) {
+    if constexpr (FLOW) {
+      const StateBufT<kSc1> nb = state_buf<kSc1>(next_slot, kFarSlotDwords);
+      nx_r = sld(nb, 0, lane);
+      nx_i = sld(nb, kRow, lane);
+    } else {
+      nx_r = next_slot[lane];
+      nx_i = next_slot[kRow + lane];
+    }
+  }
 #pragma unroll
   for (int g = 0; g < kNumPart / 4; ++g) {
     const int cb = g & 1;
@@ -1144,10 +1181,42 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       if (lane == 0) c64[R_WF_RE + i] += v.y;
       sst(sb, ROWO((R_WF_RE + i)), lane, wr_new);
       sst(sb, ROWO((R_WF_IM + i)), lane, wi_new);
+      if (carry_out) {
+        cy_r += nx_r * wr_new - nx_i * wi_new;
+        cy_i += nx_r * wi_new + nx_i * wr_new;
+      }
+      nx_r = gx[cb][2 * k];
+      nx_i = gx[cb][2 * k + 1];
     }
     wave_fence();
   }
 #undef AEC_LOAD_GROUP
+  if (carry_out) {
+    float nx64_r, nx64_i;
+    if constexpr (FLOW) {
+      const StateBufT<kSc1> nb = state_buf<kSc1>(next_slot, kFarSlotDwords);
+      nx64_r = sld(nb, 64, 0);
+      nx64_i = sld(nb, kRow + 64, 0);
+    } else {
+      nx64_r = next_slot[64];
+      nx64_i = next_slot[kRow + 64];
+    }
+    float yr = 0.f, yi = 0.f;  // bin 64: the column copy holds this block's spectrum and the updated filter
+#pragma unroll kFarUnroll
+    for (int i = 0; i < kNumPart; ++i) {
+      int px = i + next_xf_pos;
+      if (px >= kNumPart) px -= kNumPart;
+      const float ar = i == 0 ? nx64_r : c64[R_XF_RE + px], ai = i == 0 ? nx64_i : c64[R_XF_IM + px];
+      const float br = c64[R_WF_RE + i], bi = c64[R_WF_IM + i];
+      yr += ar * br - ai * bi;
+      yi += ar * bi + ai * br;
+    }
+    YFR[lane] = cy_r;
+    YFI[lane] = cy_i;
+    YFR[64] = yr;
+    YFI[64] = yi;
+    wave_fence();
+  }
 
   AEC_STAMP(8)
   // =================================================== NonLinearProcessing (aec_core.c:852-1082)
@@ -1451,6 +1520,8 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     if (64 * (k + 1) <= kC64Lds || 64 * k + lane < kC64Lds) sst(sb, kOffC64 + 64 * k, lane, c64[64 * k + lane]);
   AEC_STAMP(15)
 #undef AEC_STAMP
+#undef AEC_LOAD_POWER_ROWS
+#undef AEC_FAR_SPECTRA
 #undef ROW_LD
 #undef ROWO
 #undef ROW_ST
@@ -1483,6 +1554,10 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
   int blk = 0;  // blocks of this launch so far
+  bool carried = false;  // the coming block finds its echo estimate's spectrum in LDS
+  // (not with the high band, whose comfort noise borrows the YFR / YFI rows; not in the delay-agnostic mode, where
+  // the next block's far slot is the estimator's to choose)
+  [[maybe_unused]] const bool carry_ok = FLOW || (ops.num_high == 0 && !ops.agnostic);
   for (int s = 0; s < ops.nsub; ++s) {
     const auto& sf = ops.sub[s];
     // near samples of this sub-frame are read into registers first: `out` may alias `nearend`
@@ -1508,6 +1583,24 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     for (int k = 0; k < sf.nblocks; ++k) {
       const auto& op = sf.blk[k];
+      // the block after this one, when this call holds one: its echo estimate is accumulated during this block's
+      // filter update (process_block, carry_out)
+      const float* next_slot = nullptr;
+      int next_xf = 0;
+#if AEC_CARRY
+      if (carry_ok) {
+        int nslot = -1;
+        if (k + 1 < sf.nblocks) {
+          nslot = sf.blk[k + 1].far_slot;
+          next_xf = sf.blk[k + 1].xf_pos;
+        } else if (s + 1 < ops.nsub && ops.sub[s + 1].nblocks > 0) {
+          nslot = ops.sub[s + 1].blk[0].far_slot;
+          next_xf = ops.sub[s + 1].blk[0].xf_pos;
+        }
+        if (nslot >= 0 && next_xf == (op.xf_pos == 0 ? NP - 1 : op.xf_pos - 1))
+          next_slot = far_ring + ((size_t)nslot * num_streams + stream) * kFarSlotDwords;
+      }
+#endif
       // the far slot: the batch's (lock-step), or in the delay-agnostic mode the stream's own (aec_delay_kernel)
       const int far_slot = (!FLOW && ops.agnostic) ? __builtin_amdgcn_readfirstlane(dblocks[stream].slot[blk & 1]) : op.far_slot;
       const float* slot = far_ring + ((size_t)far_slot * num_streams + stream) * kFarSlotDwords;
@@ -1516,7 +1609,8 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
       process_block<kMetrics, NP, FLOW>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
                     FLOW ? 0 : ops.num_high, met,
                     (stamps != nullptr && stream == 0 && s == 0 && k == 0) ? stamps : nullptr,  // wave-uniform; every lane stores the same scalar time
-                    spec_out);
+                    spec_out, carried, next_slot, next_xf);
+      carried = next_slot != nullptr;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
