@@ -35,7 +35,9 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const DelayBlock* dblocks = nullptr);
 hipError_t launch_aec_process_flow(float* state, float* far_ring, const AecTables* T, int num_streams, int nrOfSamples,
                                    const AecFlowStep* descs, int steps, unsigned* seq, unsigned* abort_w, unsigned want,
-                                   int num_part, hipStream_t s);
+                                   int num_part, hipStream_t s, DelayBlock* est, unsigned* bits);
+hipError_t launch_aec_delay_bits(DelayBlock* blocks, const unsigned* bits, int num_streams, int npending, int logging,
+                                 hipStream_t s);
 hipError_t launch_aec_farend_v(float* state, float* far_ring, const AecTables* T, const float* farend, int num_streams,
                                const FarOps* vfar, int nrOfSamples, int num_part, hipStream_t s);
 hipError_t launch_aec_process_v(float* state, float* far_ring, const AecTables* T, const float* nearend, float* out,
@@ -288,6 +290,8 @@ struct AspAecBatch : AecCtl {
   unsigned* flow_abort = nullptr;            // 16 B: word 0 != 0 after a wait timed out
   unsigned flow_count = 0;
   bool flow_unchecked = false;
+  unsigned* flow_bits = nullptr;             // delay logging: [S][kFlowBitsBlocks][2] binary spectra of the recorded steps' blocks
+  int flow_blocks = 0;                       // blocks of the recording so far (their spectra wait for aec_delay_bits_kernel)
   // Per-stream control (AspAecBatch_ProcessV / _InitStream): one control plane per stream on the host, the launch
   // descriptors of a call recorded per stream and read by the kernels from device memory
   std::vector<AecCtl> per;                   // empty while the batch runs in lock-step
@@ -358,6 +362,7 @@ int estimate_skew(const int* rawSkew, int size, int deviceSampleRateHz, float* s
 
 namespace {
 constexpr int kAecFlowMaxSteps = 64, kAecFlowSlots = 4;
+static_assert(kFlowBitsBlocks >= 4 * kAecFlowMaxSteps, "a step has at most four blocks");
 
 bool aec_flow_default() {
   const char* e = getenv("ASP_AEC_FLOW");
@@ -368,10 +373,12 @@ bool aec_flow_default() {
 bool aec_flow_applies(const AspAecBatch* b, int steps) {
   const bool on = b->flow < 0 ? aec_flow_default() : b->flow != 0;
   if (!b->per.empty()) return false;  // per-stream control: one far-end and one Process launch per call
-  return on && steps >= 2 && !b->sim && b->num_high == 0 && !b->metricsMode && !b->delay_logging &&
+  return on && steps >= 2 && !b->sim && b->num_high == 0 && !b->metricsMode &&
          b->reported_delay_enabled && !b->skewMode && b->debug_stamps == nullptr;
 }
 int aec_flow_resources(AspAecBatch* b) {
+  if (b->delay_logging && b->flow_bits == nullptr)
+    AEC_TRY(hipMalloc((void**)&b->flow_bits, (size_t)b->S * kFlowBitsBlocks * 2 * sizeof(unsigned)));
   if (b->flow_seq) return 0;
   AEC_TRY(hipMalloc((void**)&b->flow_seq, (size_t)b->S * sizeof(unsigned)));
   AEC_TRY(hipMalloc((void**)&b->flow_abort, 16));
@@ -393,8 +400,14 @@ int aec_flow_flush(AspAecBatch* b) {
   const int n = b->flow_n;
   b->flow_n = 0;
   AEC_TRY(hipMemcpyAsync(d, h, sizeof(AecFlowStep) * n, hipMemcpyHostToDevice, b->stream));
+  const int blocks = b->flow_blocks;  // > 0: delay logging is on
+  b->flow_blocks = 0;
   AEC_TRY(launch_aec_process_flow(b->state, b->far_ring, b->tables, b->S, b->flow_nr, d, n, b->flow_seq, b->flow_abort,
-                                  b->flow_count, b->num_part, b->stream));
+                                  b->flow_count, b->num_part, b->stream, blocks > 0 ? b->dblocks : nullptr,
+                                  blocks > 0 ? b->flow_bits : nullptr));
+  // the estimator's share of these steps (aec_core.c:1191-1203): one launch for all their blocks, from the binary
+  // spectra the process kernel left
+  if (blocks > 0) AEC_TRY(launch_aec_delay_bits(b->dblocks, b->flow_bits, b->S, blocks, 1, b->stream));
   AEC_TRY(hipEventRecord(b->flow_ev[slot], b->stream));
   b->flow_count += (unsigned)n;
   b->flow_unchecked = true;
@@ -417,6 +430,11 @@ int aec_flow_record(AspAecBatch* b, const float* near_dev, float* out_dev, int n
   st.farend = far_src;
   st.nearend = near_dev;
   st.out = out_dev;
+  st.spec_base = -1;
+  if (b->delay_logging) {
+    st.spec_base = b->flow_blocks;
+    for (int j = 0; j < ops.nsub; ++j) b->flow_blocks += ops.sub[j].nblocks;  // <= 4 per step, kFlowBitsBlocks = 4 * kAecFlowMaxSteps
+  }
   if (b->flow_n == kAecFlowMaxSteps) return aec_flow_flush(b);
   return 0;
 }
@@ -889,7 +907,7 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
   if (b->reported_delay_enabled) {
     AEC_TRY(batch_launch_process(b, near_dev, out_dev, n, ops, far_src, fops, b->cur_near_high, b->cur_out_high, met,
                                  b->debug_stamps));
-    if (b->delay_logging) {  // the estimator takes the blocks of this call (aec_core.c:1191-1203)
+    if (b->delay_logging && !b->flow_rec) {  // the estimator takes the blocks of this call (aec_core.c:1191-1203; hand-off build: aec_flow_flush)
       DelayOps d;
       memset(&d, 0, sizeof d);
       for (int j = 0; j < ops.nsub; ++j) d.npending += ops.sub[j].nblocks;
@@ -1354,6 +1372,7 @@ int AspAecBatch_Free(AspAecBatch* b) {
   if (b->vfar_dev) (void)hipFree(b->vfar_dev);
   if (b->vev) (void)hipEventDestroy(b->vev);
   if (b->flow_seq) (void)hipFree(b->flow_seq);
+  if (b->flow_bits) (void)hipFree(b->flow_bits);
   if (b->flow_abort) (void)hipFree(b->flow_abort);
   if (b->flow_dev) (void)hipFree(b->flow_dev);
   if (b->flow_host) (void)hipHostFree(b->flow_host);
@@ -1752,6 +1771,7 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
         b->flow_rec = false;
         if (err == 0) err = aec_flow_flush(b);
         b->flow_n = 0;
+        b->flow_blocks = 0;
       }
       if (err == 0) {
         e = hipMemcpyAsync(out + per * f0, dout, per * nf * sizeof(float), hipMemcpyDeviceToHost, b->stream);
@@ -1778,6 +1798,7 @@ int AspAecBatch_Run(AspAecBatch* b, const float* farend, const float* nearend, f
     if (err != 0) {
       b->flow_rec = false;
       b->flow_n = 0;
+      b->flow_blocks = 0;
       return err;
     }
     rc_all |= rc;
@@ -1833,6 +1854,7 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
     b->flow_rec = false;
     if (err == 0) err = aec_flow_flush(b);
     b->flow_n = 0;
+    b->flow_blocks = 0;
   }
   if (dual) {
     b->dual = false;

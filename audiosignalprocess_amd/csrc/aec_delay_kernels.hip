@@ -20,6 +20,7 @@
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include "aec_binspec.h"
 #include "aec_layout.h"
 
 using namespace aspaec;
@@ -28,7 +29,6 @@ namespace {
 
 constexpr int kHist = ASP_AEC_DELAY_HISTORY;        // 125
 constexpr int kNearHist = ASP_AEC_DELAY_HISTORY + 1;  // max_lookahead = kHistorySizeBlocks (aec_core.c:1363-1366)
-constexpr int kBandFirst = 12, kBandLast = 43;        // delay_estimator_wrapper.c:20-23
 constexpr int kMaxBitCountsQ9 = 32 << 9;              // delay_estimator.h:17
 
 __device__ __forceinline__ void wave_fence() {
@@ -103,23 +103,6 @@ struct Scalars {  // the wave-uniform part of AspAecDelayState
   float delay_quality_threshold;
 };
 
-// BinarySpectrumFloat (delay_estimator_wrapper.c:96-124): lane = band; the threshold of band `lane` in `thr`
-__device__ __forceinline__ unsigned binary_spectrum(float spec, float& thr, int& initialized, int lane) {
-  const bool band = lane >= kBandFirst && lane <= kBandLast;
-  const float kScale = 1 / 64.0;
-  if (!initialized) {
-    const bool pos = band && spec > 0.0f;
-    if (pos) thr = spec / 2;
-    if (__ballot(pos) != 0) initialized = 1;
-  }
-  bool bit = false;
-  if (band) {
-    thr += (spec - thr) * kScale;  // MeanEstimatorFloat, :43-48
-    bit = spec > thr;
-  }
-  return (unsigned)((__ballot(bit) >> kBandFirst) & 0xffffffffull);
-}
-
 __device__ __forceinline__ void mean_fix(int new_value, int factor, int& mean_value) {  // delay_estimator.c:672-684
   int diff = new_value - mean_value;
   if (diff < 0) {
@@ -130,10 +113,9 @@ __device__ __forceinline__ void mean_fix(int new_value, int factor, int& mean_va
   mean_value += diff;
 }
 
-// one block: AddFarSpectrum + DelayEstimatorProcessFloat; returns last_delay
-__device__ __forceinline__ int estimator_block(AspAecDelayState* __restrict__ g, unsigned* __restrict__ wl,
-                                               Scalars& sc, float far_pow, float near_pow, float& thr_far,
-                                               float& thr_near, int lane) {
+// one block from its two binary spectra: WebRtc_AddBinaryFarSpectrum + WebRtc_ProcessBinarySpectrum; returns last_delay
+__device__ __forceinline__ int estimator_block_bits(AspAecDelayState* __restrict__ g, unsigned* __restrict__ wl,
+                                                    Scalars& sc, unsigned bfar, unsigned bnear, int lane) {
   unsigned* far_hist = wl + kLFarHist;
   int* far_bits = reinterpret_cast<int*>(wl + kLFarBits);
   unsigned* near_hist = wl + kLNearHist;
@@ -142,7 +124,6 @@ __device__ __forceinline__ int estimator_block(AspAecDelayState* __restrict__ g,
   const int i0 = lane, i1 = lane + 64;
   const bool has1 = i1 < kHist;
   // ---- far end (aec_core.c:1194-1195)
-  const unsigned bfar = binary_spectrum(sqrtf(far_pow), thr_far, sc.far_init, lane);
   {
     const unsigned h0 = i0 > 0 ? far_hist[i0 - 1] : bfar, h1 = far_hist[i1 - 1];
     const int c0 = i0 > 0 ? far_bits[i0 - 1] : __popc(bfar), c1 = far_bits[i1 - 1];
@@ -155,7 +136,6 @@ __device__ __forceinline__ int estimator_block(AspAecDelayState* __restrict__ g,
     }
   }
   // ---- near end (:1196-1197): shift the near history, pull out the delayed spectrum
-  unsigned bnear = binary_spectrum(sqrtf(near_pow), thr_near, sc.near_init, lane);
   {
     const unsigned n0 = i0 > 0 ? near_hist[i0 - 1] : bnear, n1 = near_hist[i1 - 1];
     wave_fence();
@@ -267,6 +247,15 @@ __device__ __forceinline__ int estimator_block(AspAecDelayState* __restrict__ g,
   return sc.last_delay;
 }
 
+// one block: AddFarSpectrum + DelayEstimatorProcessFloat; returns last_delay
+__device__ __forceinline__ int estimator_block(AspAecDelayState* __restrict__ g, unsigned* __restrict__ wl,
+                                               Scalars& sc, float far_pow, float near_pow, float& thr_far,
+                                               float& thr_near, int lane) {
+  const unsigned bfar = binary_spectrum(sqrtf(far_pow), thr_far, sc.far_init, lane);
+  const unsigned bnear = binary_spectrum(sqrtf(near_pow), thr_near, sc.near_init, lane);
+  return estimator_block_bits(g, wl, sc, bfar, bnear, lane);
+}
+
 // WebRtc_SoftResetDelayEstimator + ...Farend (delay_estimator.c:500-511, 309-339) by `delay_shift` partitions
 __device__ __forceinline__ void soft_reset(unsigned* __restrict__ wl, Scalars& sc, int delay_shift, int lane) {
   sc.lookahead -= delay_shift;
@@ -296,17 +285,9 @@ __device__ __forceinline__ void soft_reset(unsigned* __restrict__ wl, Scalars& s
   wave_fence();
 }
 
-__global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__ blocks, const float* __restrict__ spectra,
-                                                        int num_streams, DelayOps ops) {
-  __shared__ unsigned lds[4 * kLdsWave];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int stream = blockIdx.x * 4 + wave;
-  if (stream >= num_streams) return;
-  unsigned* wl = lds + wave * kLdsWave;
-  DelayBlock* blk = blocks + stream;
-  AspAecDelayState* g = &blk->s;
-  // ---- the histories into LDS, the scalars into registers
+// the histories into LDS, the scalars into registers
+__device__ __forceinline__ void load_estimator(const AspAecDelayState* __restrict__ g, unsigned* __restrict__ wl, Scalars& sc,
+                                               int lane) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int i = lane + 64 * t;
@@ -316,7 +297,6 @@ __global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__
     wl[kLMean + i] = i < kHist + 1 ? (unsigned)g->mean_bit_counts[i] : 0u;
     wl[kLHistogram + i] = i < kHist + 1 ? __float_as_uint(g->histogram[i]) : 0u;
   }
-  Scalars sc;
   sc.far_init = g->far_spectrum_initialized;
   sc.near_init = g->near_spectrum_initialized;
   sc.minimum_probability = g->minimum_probability;
@@ -332,6 +312,58 @@ __global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__
   sc.delay_correction_count = g->delay_correction_count;
   sc.shift_offset = g->shift_offset;
   sc.delay_quality_threshold = g->delay_quality_threshold;
+}
+
+// back to HBM.  kSpectra: with the mean spectra' initialised flags (the hand-off build of the process kernel keeps
+// those and the mean spectra themselves: aec_kernels.hip, flow_binary_spectra)
+template <bool kSpectra>
+__device__ __forceinline__ void store_estimator(AspAecDelayState* __restrict__ g, const unsigned* __restrict__ wl,
+                                                const Scalars& sc, int lane) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = lane + 64 * t;
+    if (i < kHist) {
+      g->binary_far_history[i] = wl[kLFarHist + i];
+      g->far_bit_counts[i] = (int)wl[kLFarBits + i];
+    }
+    if (i < kNearHist) g->binary_near_history[i] = wl[kLNearHist + i];
+    if (i < kHist + 1) {
+      g->mean_bit_counts[i] = (int)wl[kLMean + i];
+      g->histogram[i] = __uint_as_float(wl[kLHistogram + i]);
+    }
+  }
+  if (lane == 0) {
+    if (kSpectra) {
+      g->far_spectrum_initialized = sc.far_init;
+      g->near_spectrum_initialized = sc.near_init;
+    }
+    g->minimum_probability = sc.minimum_probability;
+    g->last_delay_probability = sc.last_delay_probability;
+    g->last_delay = sc.last_delay;
+    g->last_candidate_delay = sc.last_candidate_delay;
+    g->compare_delay = sc.compare_delay;
+    g->candidate_hits = sc.candidate_hits;
+    g->last_delay_histogram = sc.last_delay_histogram;
+    g->lookahead = sc.lookahead;
+    g->previous_delay = sc.previous_delay;
+    g->delay_correction_count = sc.delay_correction_count;
+    g->shift_offset = sc.shift_offset;
+    g->delay_quality_threshold = sc.delay_quality_threshold;
+  }
+}
+
+__global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__ blocks, const float* __restrict__ spectra,
+                                                        int num_streams, DelayOps ops) {
+  __shared__ unsigned lds[4 * kLdsWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  unsigned* wl = lds + wave * kLdsWave;
+  DelayBlock* blk = blocks + stream;
+  AspAecDelayState* g = &blk->s;
+  Scalars sc;
+  load_estimator(g, wl, sc, lane);
   float thr_far = lane < 65 ? g->mean_far_spectrum[lane] : 0.f;
   float thr_near = lane < 65 ? g->mean_near_spectrum[lane] : 0.f;
   wave_fence();
@@ -419,39 +451,36 @@ __global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__
 
   // ---- back to HBM
   wave_fence();
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int i = lane + 64 * t;
-    if (i < kHist) {
-      g->binary_far_history[i] = wl[kLFarHist + i];
-      g->far_bit_counts[i] = (int)wl[kLFarBits + i];
-    }
-    if (i < kNearHist) g->binary_near_history[i] = wl[kLNearHist + i];
-    if (i < kHist + 1) {
-      g->mean_bit_counts[i] = (int)wl[kLMean + i];
-      g->histogram[i] = __uint_as_float(wl[kLHistogram + i]);
-    }
-  }
+  store_estimator<true>(g, wl, sc, lane);
   if (lane < 65) {
     g->mean_far_spectrum[lane] = thr_far;
     g->mean_near_spectrum[lane] = thr_near;
   }
-  if (lane == 0) {
-    g->far_spectrum_initialized = sc.far_init;
-    g->near_spectrum_initialized = sc.near_init;
-    g->minimum_probability = sc.minimum_probability;
-    g->last_delay_probability = sc.last_delay_probability;
-    g->last_delay = sc.last_delay;
-    g->last_candidate_delay = sc.last_candidate_delay;
-    g->compare_delay = sc.compare_delay;
-    g->candidate_hits = sc.candidate_hits;
-    g->last_delay_histogram = sc.last_delay_histogram;
-    g->lookahead = sc.lookahead;
-    g->previous_delay = sc.previous_delay;
-    g->delay_correction_count = sc.delay_correction_count;
-    g->shift_offset = sc.shift_offset;
-    g->delay_quality_threshold = sc.delay_quality_threshold;
+}
+
+// The estimator's share of a hand-off launch (aec_kernels.hip, aec_process_flow_kernel): `npending` blocks per stream
+// whose binary spectra the process kernel left in `bits` ([stream][kFlowBitsBlocks][far, near]), in block order.
+__global__ __launch_bounds__(256) void aec_delay_bits_kernel(DelayBlock* __restrict__ blocks, const unsigned* __restrict__ bits,
+                                                             int num_streams, int npending, int logging) {
+  __shared__ unsigned lds[4 * kLdsWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = blockIdx.x * 4 + wave;
+  if (stream >= num_streams) return;
+  unsigned* wl = lds + wave * kLdsWave;
+  AspAecDelayState* g = &blocks[stream].s;
+  Scalars sc;
+  load_estimator(g, wl, sc, lane);
+  wave_fence();
+  const unsigned* w = bits + (size_t)stream * kFlowBitsBlocks * 2;
+  for (int k = 0; k < npending; ++k) {
+    const unsigned bfar = __builtin_amdgcn_readfirstlane(w[2 * k]), bnear = __builtin_amdgcn_readfirstlane(w[2 * k + 1]);
+    const int delay_estimate = estimator_block_bits(g, wl, sc, bfar, bnear, lane);
+    if (logging && delay_estimate >= 0 && lane == 0) g->delay_histogram[delay_estimate]++;
+    wave_fence();
   }
+  wave_fence();
+  store_estimator<false>(g, wl, sc, lane);
 }
 
 // WebRtcAec_ResampleLinear for every stream (aec_resampler.c:74-123; echo_cancellation.c:304-313, skew compensation):
@@ -497,6 +526,13 @@ hipError_t launch_aec_resample(float* rs_buffer, const float* farend, float* out
 hipError_t launch_aec_delay(DelayBlock* blocks, const float* spectra, int num_streams, const DelayOps& ops,
                             hipStream_t s) {
   hipLaunchKernelGGL(aec_delay_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, blocks, spectra, num_streams, ops);
+  return hipGetLastError();
+}
+
+hipError_t launch_aec_delay_bits(DelayBlock* blocks, const unsigned* bits, int num_streams, int npending, int logging,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(aec_delay_bits_kernel, dim3((num_streams + 3) / 4), dim3(256), 0, s, blocks, bits, num_streams, npending,
+                     logging);
   return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include "aec_binspec.h"
 #include "aec_layout.h"
 #include "ns_device.h"  // lean fp64 pow / sincos shared with the NS kernels
 #include "pk_f32.h"     // complex arithmetic as packed f32
@@ -433,6 +434,8 @@ struct AecFlowArgs {
   unsigned* seq;             // [num_streams]: hand-off steps stream s has completed
   unsigned* abort_w;         // != 0: a wait timed out (1 + stream)
   unsigned want;             // blockIdx.y == 0 is step `want` of every stream
+  DelayBlock* est;           // delay logging: the streams' estimator blocks (their mean spectra are kept here) and the
+  unsigned* bits;            // launch's binary spectra [stream][kFlowBitsBlocks][far, near]; nullptr: off
 };
 typedef __attribute__((address_space(1))) unsigned gu32;
 __device__ __forceinline__ bool flow_wait(const AecFlowArgs& fa, unsigned want, int stream, int lane) {
@@ -473,6 +476,32 @@ __device__ __forceinline__ void unpack_tile_buf(float* wl, int f, const StateBuf
 
 // ------------------------------------------------------------------ far end
 // The far-end work of one WebRtcAec_BufferFarend call for this wave's stream.
+// Delay logging in the hand-off build (aec_core.c:1191-1203): the block's two binary spectra are formed here, where
+// |X|^2 and |D|^2 of bins 0..63 are in registers (bands 12..43 are all the estimator looks at), against the mean
+// spectra in the stream's estimator block; the rest of the estimator runs once per launch (aec_delay_bits_kernel).
+// The mean spectra pass from one step's wave to the next like the state block: sc1 accesses.
+__device__ __forceinline__ void flow_binary_spectra(const DelayBlock* est, unsigned* bits_out, float far_pow, float near_pow,
+                                                    int lane) {
+  constexpr int oFar = __builtin_offsetof(AspAecDelayState, mean_far_spectrum) / 4;
+  constexpr int oNear = __builtin_offsetof(AspAecDelayState, mean_near_spectrum) / 4;
+  constexpr int oFarInit = __builtin_offsetof(AspAecDelayState, far_spectrum_initialized) / 4;
+  constexpr int oNearInit = __builtin_offsetof(AspAecDelayState, near_spectrum_initialized) / 4;
+  const StateBufT<kSc1> eb = state_buf<kSc1>(reinterpret_cast<const float*>(&est->s), (int)(sizeof(AspAecDelayState) / 4));
+  float thr_far = sld(eb, oFar, lane), thr_near = sld(eb, oNear, lane);
+  int far_init = __builtin_amdgcn_readfirstlane(__float_as_int(sld(eb, oFarInit, 0)));
+  int near_init = __builtin_amdgcn_readfirstlane(__float_as_int(sld(eb, oNearInit, 0)));
+  const unsigned bfar = binary_spectrum(sqrtf(far_pow), thr_far, far_init, lane);
+  const unsigned bnear = binary_spectrum(sqrtf(near_pow), thr_near, near_init, lane);
+  sst(eb, oFar, lane, thr_far);
+  sst(eb, oNear, lane, thr_near);
+  if (lane == 0) {
+    sst(eb, oFarInit, 0, __int_as_float(far_init));
+    sst(eb, oNearInit, 0, __int_as_float(near_init));
+    bits_out[0] = bfar;  // read by a later launch
+    bits_out[1] = bnear;
+  }
+}
+
 template <bool FLOW = false, class OPS = FarOps>
 __device__ __forceinline__ void farend_work(float* __restrict__ st, float* __restrict__ far_ring,
                                             float* __restrict__ wl, const SharedTables& T,
@@ -756,7 +785,8 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
                                               int lane, const double* __restrict__ exp2_global,
                                               int num_high, float* __restrict__ met,
                                               unsigned long long* stamps, float* __restrict__ spec_out,
-                                              bool carry_in, const float* __restrict__ next_slot, int next_xf_pos) {
+                                              bool carry_in, const float* __restrict__ next_slot, int next_xf_pos,
+                                              const DelayBlock* est = nullptr) {
   // carry_in: the echo estimate's spectrum of this block is already in the YFR / YFI rows (the previous block of
   // this call accumulated it during its filter update); next_slot != nullptr: this block does the same for the
   // next one, whose far spectrum sits in next_slot and whose xfBufBlockPos is next_xf_pos.
@@ -1007,7 +1037,10 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     const float near_spectrum = DFR[bin] * DFR[bin] + DFI[bin] * DFI[bin];
     const float xp = 0.9f * (t_ == 0 ? p_xpow : c64[R_XPOW]) + 0.1f * kNumPart * far_spectrum;
     const float dp = 0.9f * (t_ == 0 ? p_dpow : c64[R_DPOW]) + 0.1f * near_spectrum;
-    if (spec_out != nullptr) {  // delay estimation on: |X|^2 and |D|^2 of the block for aec_delay_kernel (aec_core.c:1154-1155, 1191-1203)
+    if constexpr (FLOW) {  // delay logging: spec_out = this block's two words of binary spectra
+      if (spec_out != nullptr && t_ == 0)
+        flow_binary_spectra(est, reinterpret_cast<unsigned*>(spec_out), far_spectrum, near_spectrum, lane);
+    } else if (spec_out != nullptr) {  // delay estimation on: |X|^2 and |D|^2 of the block for aec_delay_kernel (aec_core.c:1154-1155, 1191-1203)
       spec_out[bin] = far_spectrum;
       spec_out[kRow + bin] = near_spectrum;
     }
@@ -1604,12 +1637,13 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
       // the far slot: the batch's (lock-step), or in the delay-agnostic mode the stream's own (aec_delay_kernel)
       const int far_slot = (!FLOW && ops.agnostic) ? __builtin_amdgcn_readfirstlane(dblocks[stream].slot[blk & 1]) : op.far_slot;
       const float* slot = far_ring + ((size_t)far_slot * num_streams + stream) * kFarSlotDwords;
-      float* spec_out = (!FLOW && ops.spectra) ? spectra + ((size_t)stream * kSpecBlocks + (blk & (kSpecBlocks - 1))) * kSpecDwords : nullptr;
+      float* spec_out = FLOW ? (spectra != nullptr ? spectra + 2 * blk : nullptr)  // hand-off build: `spectra` = this step's binary-spectra words
+                             : ops.spectra ? spectra + ((size_t)stream * kSpecBlocks + (blk & (kSpecBlocks - 1))) * kSpecDwords : nullptr;
       ++blk;
       process_block<kMetrics, NP, FLOW>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
                     FLOW ? 0 : ops.num_high, met,
                     (stamps != nullptr && stream == 0 && s == 0 && k == 0) ? stamps : nullptr,  // wave-uniform; every lane stores the same scalar time
-                    spec_out, carried, next_slot, next_xf);
+                    spec_out, carried, next_slot, next_xf, FLOW && dblocks != nullptr ? dblocks + stream : nullptr);
       carried = next_slot != nullptr;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -1686,8 +1720,11 @@ __global__ __launch_bounds__(256, NP == kNumPartNormal ? AEC_WAVES : 3) void aec
   const float* nin = fs->nearend + (size_t)stream * nrOfSamples;
   float* o = fs->out + (size_t)stream * nrOfSamples;
   if (!flow_wait(fa, want, stream, lane)) return;
+  const int spec_base = fs->spec_base;
+  float* bits = (fa.bits != nullptr && spec_base >= 0)
+                    ? reinterpret_cast<float*>(fa.bits + ((size_t)stream * kFlowBitsBlocks + spec_base) * 2) : nullptr;
   process_call<false, NP, true>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, fs->ops,
-                                fs->farend, fs->fops, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                fs->farend, fs->fops, nullptr, nullptr, nullptr, nullptr, bits, fa.est);
   // publish: every store of this wave drained first
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_store((gu32*)(fa.seq + stream), want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1820,11 +1857,11 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
 // of every stream; `descs` [steps] in device memory.
 hipError_t launch_aec_process_flow(float* state, float* far_ring, const AecTables* T, int num_streams, int nrOfSamples,
                                    const AecFlowStep* descs, int steps, unsigned* seq, unsigned* abort_w, unsigned want,
-                                   int num_part, hipStream_t s) {
+                                   int num_part, hipStream_t s, DelayBlock* est, unsigned* bits) {
   if (num_part != kNumPartNormal && num_part != kNumPartMax) return hipErrorInvalidValue;
   const int gx = ((num_streams + 3) / 4 + 7) / 8 * 8;  // a multiple of 8: a stream's consecutive steps on one XCD's in-order share
   const dim3 grid(gx, steps);
-  const AecFlowArgs fa = {descs, seq, abort_w, want};
+  const AecFlowArgs fa = {descs, seq, abort_w, want, est, bits};
   if (num_part == kNumPartNormal)
     hipLaunchKernelGGL((aec_process_flow_kernel<kNumPartNormal>), grid, dim3(256), 0, s, state, far_ring, T, num_streams,
                        nrOfSamples, fa);

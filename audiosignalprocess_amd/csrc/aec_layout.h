@@ -135,7 +135,7 @@ struct ProcOps {
 struct AecFlowStep {
   ProcOps ops;
   FarOps fops;
-  int32_t pad;
+  int32_t spec_base;     // delay logging: index of this step's first block in the launch's binary-spectra scratch (-1: off)
   const float* farend;   // nullptr: no far-end work in this step
   const float* nearend;
   float* out;
@@ -166,6 +166,7 @@ static_assert(sizeof(DelayBlock) % 16 == 0, "delay blocks stay 16-byte aligned")
 constexpr int kResamplingDelay = 1, kResamplerBufferSize = 4 * kFrameLen, kSkewEstimateFrames = 400;
 
 constexpr int kSpecBlocks = 4;             // power spectra of up to 4 blocks wait for the estimator
+constexpr int kFlowBitsBlocks = 256;       // hand-off build: binary far / near spectra of up to 64 steps x 4 blocks wait for the estimator
 constexpr int kSpecDwords = 2 * kRow;      // per block: |X|^2 then |D|^2, 65 bins each (aec_core.c:1148-1155)
 constexpr int kMaxFarEvents = 8;
 

@@ -300,7 +300,7 @@ def bench_split(args):
 
 def aec_flow_active(ext, dmode, steps):
     """Does AspAecBatch_TimedSteps run the hand-off build?  (aec_api.hip, aec_flow_applies)"""
-    return os.environ.get("ASP_AEC_FLOW", "1")[:1] != "0" and dmode == "off" and steps >= 2
+    return os.environ.get("ASP_AEC_FLOW", "1")[:1] != "0" and dmode in ("off", "logging") and steps >= 2
 
 
 def bench_aec(args):
@@ -328,7 +328,7 @@ def bench_aec(args):
     if ext:     # WebRtcAec_enable_delay_correction: the 32-partition extended filter
         g.enable_delay_correction(1)
     dmode = getattr(args, "aec_delay", "off")
-    if dmode != "off":      # delay logging (one estimator launch per frame) / the delay-agnostic mode (per sub-frame)
+    if dmode != "off":      # delay logging (hand-off build: one estimator launch per process launch; else one per frame) / the delay-agnostic mode (per sub-frame)
         assert g.set_config(1, delay_logging=1) == 0
         if dmode == "agnostic":
             g.enable_reported_delay(0)
