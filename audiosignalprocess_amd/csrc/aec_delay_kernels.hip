@@ -13,9 +13,12 @@
 //     a full far buffer drops its oldest partition).
 //
 // One wave64 per stream, four per workgroup.  The process kernel leaves |X|^2 and |D|^2 of each block in a
-// scratch ([stream][block][2][kRow]); this kernel runs after it.  Lane q owns entries q and q + 64 of the
-// 125 / 126-entry histories, which sit in LDS while the wave works; every lane carries the estimator's scalars
-// (wave-uniform) and lane 0 writes them back.  Integer and float operations are the reference's, in its order.
+// scratch ([stream][block][2][kRow]) -- or, in its hand-off build, the block's two binary spectra (two words) -- and
+// this kernel runs after it.  Lane q owns entries q and q + 64 of the 125 / 126-entry arrays, in registers while
+// the wave works: the histories move up by one entry per block with a DPP wave shift, entries named by a
+// wave-uniform index (the lookahead, the compared delay, the candidate) are read with v_readlane, the best / worst
+// candidates are DPP reductions; the estimator's scalars live in SGPRs and lane 0 writes them back.  No LDS, no
+// barriers.  Integer and float operations are the reference's, in its order.
 //
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
@@ -35,23 +38,6 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    const int o = __shfl_xor(v, m, 64);
-    v = o < v ? o : v;
-  }
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    const int o = __shfl_xor(v, m, 64);
-    v = o > v ? o : v;
-  }
-  return v;
 }
 
 // ring_buffer.c position logic on the stream's far buffer (250 partitions)
@@ -91,10 +77,17 @@ __device__ __forceinline__ void fp_write_one(FarPos& r) {  // WebRtc_WriteBuffer
   r.write += m;
 }
 
-// per-wave LDS: five 128-entry arrays
-constexpr int kLFarHist = 0, kLFarBits = 128, kLNearHist = 256, kLMean = 384, kLHistogram = 512, kLdsWave = 640;
+// ---- the estimator's arrays in registers: lane q holds entries q and q + 64 of each 125 / 126-entry array
+struct Hist {
+  unsigned fh0, fh1;  // binary_far_history   (125)
+  int fb0, fb1;       // far_bit_counts       (125)
+  unsigned nh0, nh1;  // binary_near_history  (126)
+  int m0, m1;         // mean_bit_counts      (126)
+  float h0, h1;       // histogram            (126)
+  int bc0, bc1;       // bit_counts           (125): the last block's
+};
 
-struct Scalars {  // the wave-uniform part of AspAecDelayState
+struct Scalars {  // the wave-uniform part of AspAecDelayState (in SGPRs: every load goes through v_readfirstlane)
   int far_init, near_init;
   int minimum_probability, last_delay_probability, last_delay, last_candidate_delay, compare_delay, candidate_hits;
   float last_delay_histogram;
@@ -102,6 +95,55 @@ struct Scalars {  // the wave-uniform part of AspAecDelayState
   int previous_delay, delay_correction_count, shift_offset;
   float delay_quality_threshold;
 };
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// lane i takes lane i - 1's value (lane 0: not used by the callers)
+#ifndef AEC_DELAY_DPP_SHIFT
+#define AEC_DELAY_DPP_SHIFT 1  // v_mov_b32_dpp wave_shr:1 (0: ds_bpermute)
+#endif
+__device__ __forceinline__ int shr1(int v, int lane) {
+#if AEC_DELAY_DPP_SHIFT
+  (void)lane;
+  return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
+#else
+  return __builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, v);
+#endif
+}
+// entry idx (wave-uniform, 0..127) of an array held as (v0, v1)
+__device__ __forceinline__ int pick(int v0, int v1, int idx) {
+  const int a = __builtin_amdgcn_readlane(v0, idx & 63), b = __builtin_amdgcn_readlane(v1, idx & 63);
+  return idx < 64 ? a : b;
+}
+__device__ __forceinline__ float pickf(float v0, float v1, int idx) {
+  return __int_as_float(pick(__float_as_int(v0), __float_as_int(v1), idx));
+}
+// reductions over the wave: four DPP steps inside each row of 16, then the four rows through SGPRs
+#define ASP_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, false)
+__device__ __forceinline__ int wave_min_i(int v) {
+  int o;
+  o = ASP_DPP(v, 0xB1); v = o < v ? o : v;   // quad_perm [1, 0, 3, 2]
+  o = ASP_DPP(v, 0x4E); v = o < v ? o : v;   // quad_perm [2, 3, 0, 1]
+  o = ASP_DPP(v, 0x141); v = o < v ? o : v;  // row_half_mirror
+  o = ASP_DPP(v, 0x140); v = o < v ? o : v;  // row_mirror
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  const int ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+  int o;
+  o = ASP_DPP(v, 0xB1); v = o > v ? o : v;
+  o = ASP_DPP(v, 0x4E); v = o > v ? o : v;
+  o = ASP_DPP(v, 0x141); v = o > v ? o : v;
+  o = ASP_DPP(v, 0x140); v = o > v ? o : v;
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  const int ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+#undef ASP_DPP
 
 __device__ __forceinline__ void mean_fix(int new_value, int factor, int& mean_value) {  // delay_estimator.c:672-684
   int diff = new_value - mean_value;
@@ -114,54 +156,40 @@ __device__ __forceinline__ void mean_fix(int new_value, int factor, int& mean_va
 }
 
 // one block from its two binary spectra: WebRtc_AddBinaryFarSpectrum + WebRtc_ProcessBinarySpectrum; returns last_delay
-__device__ __forceinline__ int estimator_block_bits(AspAecDelayState* __restrict__ g, unsigned* __restrict__ wl,
-                                                    Scalars& sc, unsigned bfar, unsigned bnear, int lane) {
-  unsigned* far_hist = wl + kLFarHist;
-  int* far_bits = reinterpret_cast<int*>(wl + kLFarBits);
-  unsigned* near_hist = wl + kLNearHist;
-  int* mean_bc = reinterpret_cast<int*>(wl + kLMean);
-  float* histogram = reinterpret_cast<float*>(wl + kLHistogram);
+__device__ __forceinline__ int estimator_block_bits(Hist& H, Scalars& sc, unsigned bfar, unsigned bnear_new, int lane) {
   const int i0 = lane, i1 = lane + 64;
   const bool has1 = i1 < kHist;
-  // ---- far end (aec_core.c:1194-1195)
+  // ---- far end (aec_core.c:1194-1195; delay_estimator.c:356-369): the histories move up by one entry
   {
-    const unsigned h0 = i0 > 0 ? far_hist[i0 - 1] : bfar, h1 = far_hist[i1 - 1];
-    const int c0 = i0 > 0 ? far_bits[i0 - 1] : __popc(bfar), c1 = far_bits[i1 - 1];
-    wave_fence();
-    far_hist[i0] = h0;
-    far_bits[i0] = c0;
-    if (has1) {
-      far_hist[i1] = h1;
-      far_bits[i1] = c1;
-    }
+    const int top_h = __builtin_amdgcn_readlane((int)H.fh0, 63), top_c = __builtin_amdgcn_readlane(H.fb0, 63);
+    const int s0 = shr1((int)H.fh0, lane), s1 = shr1((int)H.fh1, lane), c0 = shr1(H.fb0, lane), c1 = shr1(H.fb1, lane);
+    H.fh0 = lane == 0 ? bfar : (unsigned)s0;
+    H.fb0 = lane == 0 ? __popc(bfar) : c0;
+    H.fh1 = lane == 0 ? (unsigned)top_h : (unsigned)s1;
+    H.fb1 = lane == 0 ? top_c : c1;
   }
   // ---- near end (:1196-1197): shift the near history, pull out the delayed spectrum
   {
-    const unsigned n0 = i0 > 0 ? near_hist[i0 - 1] : bnear, n1 = near_hist[i1 - 1];
-    wave_fence();
-    near_hist[i0] = n0;
-    if (i1 < kNearHist) near_hist[i1] = n1;
+    const int top = __builtin_amdgcn_readlane((int)H.nh0, 63);
+    const int s0 = shr1((int)H.nh0, lane), s1 = shr1((int)H.nh1, lane);
+    H.nh0 = lane == 0 ? bnear_new : (unsigned)s0;
+    H.nh1 = lane == 0 ? (unsigned)top : (unsigned)s1;
   }
-  wave_fence();
-  bnear = near_hist[sc.lookahead];
+  const unsigned bnear = (unsigned)pick((int)H.nh0, (int)H.nh1, sc.lookahead);
   // bit counts and their smoothed version (delay_estimator.c:541-560)
-  int m0, m1 = kMaxBitCountsQ9;
+  int m1 = kMaxBitCountsQ9;
   {
-    const int bc0 = __popc(bnear ^ far_hist[i0]);
-    g->bit_counts[i0] = bc0;
-    m0 = mean_bc[i0];
-    const int fb0 = far_bits[i0];
-    if (fb0 > 0) mean_fix(bc0 << 9, 13 - ((3 * fb0) >> 4), m0);
-    mean_bc[i0] = m0;
+    const int bc0 = __popc(bnear ^ H.fh0);
+    H.bc0 = bc0;
+    if (H.fb0 > 0) mean_fix(bc0 << 9, 13 - ((3 * H.fb0) >> 4), H.m0);
     if (has1) {
-      const int bc1 = __popc(bnear ^ far_hist[i1]);
-      g->bit_counts[i1] = bc1;
-      m1 = mean_bc[i1];
-      const int fb1 = far_bits[i1];
-      if (fb1 > 0) mean_fix(bc1 << 9, 13 - ((3 * fb1) >> 4), m1);
-      mean_bc[i1] = m1;
+      const int bc1 = __popc(bnear ^ H.fh1);
+      H.bc1 = bc1;
+      if (H.fb1 > 0) mean_fix(bc1 << 9, 13 - ((3 * H.fb1) >> 4), H.m1);
+      m1 = H.m1;
     }
   }
+  const int m0 = H.m0;
   // best (first minimum below 32 in Q9) and worst candidates (:564-574): value * 128 + index orders by value, then index
   int key = kMaxBitCountsQ9 * 128 + 127;
   if (m0 < kMaxBitCountsQ9) key = m0 * 128 + i0;
@@ -181,7 +209,6 @@ __device__ __forceinline__ int estimator_block_bits(AspAecDelayState* __restrict
   sc.last_delay_probability++;
   int valid_candidate = (valley_depth > 1024) && ((value_best_candidate < sc.minimum_probability) ||
                                                   (value_best_candidate < sc.last_delay_probability));
-  wave_fence();
   if (candidate_delay >= 0) {  // (-1 needs every smoothed count at 32: not reachable from the initial 20)
     // ---- UpdateRobustValidationStatistics (:90-146)
     const float kQ14Scaling = 1.f / (1 << 14);
@@ -194,12 +221,12 @@ __device__ __forceinline__ int estimator_block_bits(AspAecDelayState* __restrict
     }
     sc.candidate_hits++;
     if (sc.candidate_hits < max_hits_for_slow_change)
-      decrease_in_last_set = (mean_bc[sc.compare_delay] - value_best_candidate) * kQ14Scaling;
+      decrease_in_last_set = (pick(H.m0, H.m1, sc.compare_delay) - value_best_candidate) * kQ14Scaling;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int i = t == 0 ? i0 : i1;
       if (i < kHist) {
-        float h = histogram[i];
+        float h = t == 0 ? H.h0 : H.h1;
         if (i == candidate_delay) {
           h += valley;
           if (h > 3000.f) h = 3000.f;
@@ -208,13 +235,16 @@ __device__ __forceinline__ int estimator_block_bits(AspAecDelayState* __restrict
         const int is_in_candidate_set = (i >= candidate_delay - 2) && (i <= candidate_delay + 1);
         h -= decrease_in_last_set * is_in_last_set + valley * (!is_in_last_set && !is_in_candidate_set);
         if (h < 0) h = 0;
-        histogram[i] = h;
+        if (t == 0) {
+          H.h0 = h;
+        } else {
+          H.h1 = h;
+        }
       }
     }
-    wave_fence();
     // ---- HistogramBasedValidation (:173-214) and RobustValidation (:236-258)
     float fraction = 1.f;
-    float histogram_threshold = histogram[sc.compare_delay];
+    float histogram_threshold = pickf(H.h0, H.h1, sc.compare_delay);
     const int delay_difference = candidate_delay - sc.last_delay;
     if (delay_difference > sc.allowed_offset) {
       fraction = 1.f - 0.05f * (delay_difference - sc.allowed_offset);
@@ -225,7 +255,7 @@ __device__ __forceinline__ int estimator_block_bits(AspAecDelayState* __restrict
     }
     histogram_threshold *= fraction;
     histogram_threshold = (histogram_threshold > 1.5f ? histogram_threshold : 1.5f);
-    const float h_cand = histogram[candidate_delay];
+    const float h_cand = pickf(H.h0, H.h1, candidate_delay);
     const int is_histogram_valid = (h_cand >= histogram_threshold) && (sc.candidate_hits > 10);
     int is_robust = (sc.last_delay < 0) && (valid_candidate || is_histogram_valid);
     is_robust |= valid_candidate && is_histogram_valid;
@@ -234,10 +264,11 @@ __device__ __forceinline__ int estimator_block_bits(AspAecDelayState* __restrict
     if (valid_candidate) {  // :619-641
       if (candidate_delay != sc.last_delay) {
         sc.last_delay_histogram = (h_cand > 250.f ? 250.f : h_cand);
-        const float h_cmp = histogram[sc.compare_delay];
-        wave_fence();
-        if (h_cand < h_cmp && lane == 0) histogram[sc.compare_delay] = h_cand;
-        wave_fence();
+        const float h_cmp = pickf(H.h0, H.h1, sc.compare_delay);
+        if (h_cand < h_cmp) {
+          if (i0 == sc.compare_delay) H.h0 = h_cand;
+          if (i1 == sc.compare_delay) H.h1 = h_cand;
+        }
       }
       sc.last_delay = candidate_delay;
       if (value_best_candidate < sc.last_delay_probability) sc.last_delay_probability = value_best_candidate;
@@ -248,89 +279,90 @@ __device__ __forceinline__ int estimator_block_bits(AspAecDelayState* __restrict
 }
 
 // one block: AddFarSpectrum + DelayEstimatorProcessFloat; returns last_delay
-__device__ __forceinline__ int estimator_block(AspAecDelayState* __restrict__ g, unsigned* __restrict__ wl,
-                                               Scalars& sc, float far_pow, float near_pow, float& thr_far,
+__device__ __forceinline__ int estimator_block(Hist& H, Scalars& sc, float far_pow, float near_pow, float& thr_far,
                                                float& thr_near, int lane) {
   const unsigned bfar = binary_spectrum(sqrtf(far_pow), thr_far, sc.far_init, lane);
   const unsigned bnear = binary_spectrum(sqrtf(near_pow), thr_near, sc.near_init, lane);
-  return estimator_block_bits(g, wl, sc, bfar, bnear, lane);
+  return estimator_block_bits(H, sc, bfar, bnear, lane);
 }
 
 // WebRtc_SoftResetDelayEstimator + ...Farend (delay_estimator.c:500-511, 309-339) by `delay_shift` partitions
-__device__ __forceinline__ void soft_reset(unsigned* __restrict__ wl, Scalars& sc, int delay_shift, int lane) {
+__device__ __forceinline__ void soft_reset(Hist& H, Scalars& sc, int delay_shift, int lane) {
   sc.lookahead -= delay_shift;
   if (sc.lookahead < 0) sc.lookahead = 0;
   if (sc.lookahead > kNearHist - 1) sc.lookahead = kNearHist - 1;
   if (delay_shift == 0) return;
-  unsigned* far_hist = wl + kLFarHist;
-  unsigned* far_bits = wl + kLFarBits;
   // entry i takes entry i - delay_shift (zero outside the history)
-  unsigned h[2], c[2];
+  unsigned h[2];
+  int c[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int i = lane + 64 * t, src = i - delay_shift;
     const bool ok = i < kHist && src >= 0 && src < kHist;
-    h[t] = ok ? far_hist[src] : 0u;
-    c[t] = ok ? far_bits[src] : 0u;
+    const int addr = (src & 63) << 2;
+    const int ha = __builtin_amdgcn_ds_bpermute(addr, (int)H.fh0), hb = __builtin_amdgcn_ds_bpermute(addr, (int)H.fh1);
+    const int ca = __builtin_amdgcn_ds_bpermute(addr, H.fb0), cb = __builtin_amdgcn_ds_bpermute(addr, H.fb1);
+    h[t] = ok ? (unsigned)(src < 64 ? ha : hb) : 0u;
+    c[t] = ok ? (src < 64 ? ca : cb) : 0;
   }
-  wave_fence();
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int i = lane + 64 * t;
-    if (i < kHist) {
-      far_hist[i] = h[t];
-      far_bits[i] = c[t];
-    }
-  }
-  wave_fence();
+  H.fh0 = h[0];
+  H.fh1 = h[1];
+  H.fb0 = c[0];
+  H.fb1 = c[1];
 }
 
-// the histories into LDS, the scalars into registers
-__device__ __forceinline__ void load_estimator(const AspAecDelayState* __restrict__ g, unsigned* __restrict__ wl, Scalars& sc,
-                                               int lane) {
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int i = lane + 64 * t;
-    wl[kLFarHist + i] = i < kHist ? g->binary_far_history[i] : 0u;
-    wl[kLFarBits + i] = i < kHist ? (unsigned)g->far_bit_counts[i] : 0u;
-    wl[kLNearHist + i] = i < kNearHist ? g->binary_near_history[i] : 0u;
-    wl[kLMean + i] = i < kHist + 1 ? (unsigned)g->mean_bit_counts[i] : 0u;
-    wl[kLHistogram + i] = i < kHist + 1 ? __float_as_uint(g->histogram[i]) : 0u;
-  }
-  sc.far_init = g->far_spectrum_initialized;
-  sc.near_init = g->near_spectrum_initialized;
-  sc.minimum_probability = g->minimum_probability;
-  sc.last_delay_probability = g->last_delay_probability;
-  sc.last_delay = g->last_delay;
-  sc.last_candidate_delay = g->last_candidate_delay;
-  sc.compare_delay = g->compare_delay;
-  sc.candidate_hits = g->candidate_hits;
-  sc.last_delay_histogram = g->last_delay_histogram;
-  sc.lookahead = g->lookahead;
-  sc.allowed_offset = g->allowed_offset;
-  sc.previous_delay = g->previous_delay;
-  sc.delay_correction_count = g->delay_correction_count;
-  sc.shift_offset = g->shift_offset;
-  sc.delay_quality_threshold = g->delay_quality_threshold;
+// the arrays and the scalars into registers
+__device__ __forceinline__ void load_estimator(const AspAecDelayState* __restrict__ g, Hist& H, Scalars& sc, int lane) {
+  const int i0 = lane, i1 = lane + 64;
+  H.fh0 = g->binary_far_history[i0];
+  H.fb0 = g->far_bit_counts[i0];
+  H.nh0 = g->binary_near_history[i0];
+  H.m0 = g->mean_bit_counts[i0];
+  H.h0 = g->histogram[i0];
+  H.bc0 = g->bit_counts[i0];
+  H.fh1 = i1 < kHist ? g->binary_far_history[i1] : 0u;
+  H.fb1 = i1 < kHist ? g->far_bit_counts[i1] : 0;
+  H.bc1 = i1 < kHist ? g->bit_counts[i1] : 0;
+  H.nh1 = i1 < kNearHist ? g->binary_near_history[i1] : 0u;
+  H.m1 = i1 < kHist + 1 ? g->mean_bit_counts[i1] : 0;
+  H.h1 = i1 < kHist + 1 ? g->histogram[i1] : 0.f;
+  sc.far_init = uni(g->far_spectrum_initialized);
+  sc.near_init = uni(g->near_spectrum_initialized);
+  sc.minimum_probability = uni(g->minimum_probability);
+  sc.last_delay_probability = uni(g->last_delay_probability);
+  sc.last_delay = uni(g->last_delay);
+  sc.last_candidate_delay = uni(g->last_candidate_delay);
+  sc.compare_delay = uni(g->compare_delay);
+  sc.candidate_hits = uni(g->candidate_hits);
+  sc.last_delay_histogram = unif(g->last_delay_histogram);
+  sc.lookahead = uni(g->lookahead);
+  sc.allowed_offset = uni(g->allowed_offset);
+  sc.previous_delay = uni(g->previous_delay);
+  sc.delay_correction_count = uni(g->delay_correction_count);
+  sc.shift_offset = uni(g->shift_offset);
+  sc.delay_quality_threshold = unif(g->delay_quality_threshold);
 }
 
-// back to HBM.  kSpectra: with the mean spectra' initialised flags (the hand-off build of the process kernel keeps
+// back to HBM.  kSpectra: with the mean spectra's initialised flags (the hand-off build of the process kernel keeps
 // those and the mean spectra themselves: aec_kernels.hip, flow_binary_spectra)
 template <bool kSpectra>
-__device__ __forceinline__ void store_estimator(AspAecDelayState* __restrict__ g, const unsigned* __restrict__ wl,
-                                                const Scalars& sc, int lane) {
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int i = lane + 64 * t;
-    if (i < kHist) {
-      g->binary_far_history[i] = wl[kLFarHist + i];
-      g->far_bit_counts[i] = (int)wl[kLFarBits + i];
-    }
-    if (i < kNearHist) g->binary_near_history[i] = wl[kLNearHist + i];
-    if (i < kHist + 1) {
-      g->mean_bit_counts[i] = (int)wl[kLMean + i];
-      g->histogram[i] = __uint_as_float(wl[kLHistogram + i]);
-    }
+__device__ __forceinline__ void store_estimator(AspAecDelayState* __restrict__ g, const Hist& H, const Scalars& sc, int lane) {
+  const int i0 = lane, i1 = lane + 64;
+  g->binary_far_history[i0] = H.fh0;
+  g->far_bit_counts[i0] = H.fb0;
+  g->binary_near_history[i0] = H.nh0;
+  g->mean_bit_counts[i0] = H.m0;
+  g->histogram[i0] = H.h0;
+  g->bit_counts[i0] = H.bc0;
+  if (i1 < kHist) {
+    g->binary_far_history[i1] = H.fh1;
+    g->far_bit_counts[i1] = H.fb1;
+    g->bit_counts[i1] = H.bc1;
+  }
+  if (i1 < kNearHist) g->binary_near_history[i1] = H.nh1;
+  if (i1 < kHist + 1) {
+    g->mean_bit_counts[i1] = H.m1;
+    g->histogram[i1] = H.h1;
   }
   if (lane == 0) {
     if (kSpectra) {
@@ -354,27 +386,24 @@ __device__ __forceinline__ void store_estimator(AspAecDelayState* __restrict__ g
 
 __global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__ blocks, const float* __restrict__ spectra,
                                                         int num_streams, DelayOps ops) {
-  __shared__ unsigned lds[4 * kLdsWave];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int stream = blockIdx.x * 4 + wave;
   if (stream >= num_streams) return;
-  unsigned* wl = lds + wave * kLdsWave;
   DelayBlock* blk = blocks + stream;
   AspAecDelayState* g = &blk->s;
+  Hist H;
   Scalars sc;
-  load_estimator(g, wl, sc, lane);
-  float thr_far = lane < 65 ? g->mean_far_spectrum[lane] : 0.f;
-  float thr_near = lane < 65 ? g->mean_near_spectrum[lane] : 0.f;
-  wave_fence();
+  load_estimator(g, H, sc, lane);
+  float thr_far = g->mean_far_spectrum[lane];
+  float thr_near = g->mean_near_spectrum[lane];
 
   // ---- the blocks the process kernel left behind (aec_core.c:1191-1203)
   const float* sp = spectra + (size_t)stream * kSpecBlocks * kSpecDwords;
   for (int k = 0; k < ops.npending; ++k) {
     const float far_pow = sp[k * kSpecDwords + lane], near_pow = sp[k * kSpecDwords + kRow + lane];
-    const int delay_estimate = estimator_block(g, wl, sc, far_pow, near_pow, thr_far, thr_near, lane);
+    const int delay_estimate = estimator_block(H, sc, far_pow, near_pow, thr_far, thr_near, lane);
     if (ops.logging && delay_estimate >= 0 && lane == 0) g->delay_histogram[delay_estimate]++;
-    wave_fence();
   }
 
   // ---- agnostic mode: the stream's far buffer for the coming sub-frame
@@ -387,10 +416,10 @@ __global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__
       fp.wrap = ops.h_far_wrap;
       sd = ops.h_system_delay;
     } else {
-      fp.read = g->far_read;
-      fp.write = g->far_write;
-      fp.wrap = g->far_wrap;
-      sd = g->system_delay;
+      fp.read = uni(g->far_read);
+      fp.write = uni(g->far_write);
+      fp.wrap = uni(g->far_wrap);
+      sd = uni(g->system_delay);
     }
     for (int e = 0; e < ops.nevents; ++e) {  // WebRtcAec_BufferFarend since the last step (echo_cancellation.c:316-336)
       sd += ops.ev_samples[e];
@@ -404,8 +433,7 @@ __global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__
     if (sd < kFrameLen) sd -= fp_move_read(fp, -(ops.mult + 1)) * kPartLen;  // 1) aec_core.c:1696-1700
     {
       // SignalBasedDelayCorrection (aec_core.c:797-850)
-      const float* histogram = reinterpret_cast<const float*>(wl + kLHistogram);
-      const float quality = histogram[sc.compare_delay] / 3000.f;  // WebRtc_binary_last_delay_quality, robust validation on
+      const float quality = pickf(H.h0, H.h1, sc.compare_delay) / 3000.f;  // WebRtc_binary_last_delay_quality, robust validation on
       int delay_correction = 0;
       const int last_delay = sc.last_delay;
       if ((last_delay >= 0) && (last_delay != sc.previous_delay) && (quality > sc.delay_quality_threshold)) {
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__
         sc.delay_quality_threshold = (delay_quality > sc.delay_quality_threshold ? delay_quality : sc.delay_quality_threshold);
       }
       const int moved_elements = fp_move_read(fp, delay_correction);  // 2 b) aec_core.c:1719-1730
-      soft_reset(wl, sc, moved_elements, lane);
+      soft_reset(H, sc, moved_elements, lane);
       if (fp_avail_read(fp) < (ops.mult + 1)) sd -= fp_move_read(fp, -(ops.mult + 1)) * kPartLen;  // :1747-1750
     }
     for (int k = 0; k < ops.nblocks; ++k) {  // WebRtc_ReadBuffer(far_buf) of each block to come (aec_core.c:1140-1141)
@@ -450,37 +478,30 @@ __global__ __launch_bounds__(256) void aec_delay_kernel(DelayBlock* __restrict__
   }
 
   // ---- back to HBM
-  wave_fence();
-  store_estimator<true>(g, wl, sc, lane);
-  if (lane < 65) {
-    g->mean_far_spectrum[lane] = thr_far;
-    g->mean_near_spectrum[lane] = thr_near;
-  }
+  store_estimator<true>(g, H, sc, lane);
+  g->mean_far_spectrum[lane] = thr_far;
+  g->mean_near_spectrum[lane] = thr_near;
 }
 
 // The estimator's share of a hand-off launch (aec_kernels.hip, aec_process_flow_kernel): `npending` blocks per stream
 // whose binary spectra the process kernel left in `bits` ([stream][kFlowBitsBlocks][far, near]), in block order.
 __global__ __launch_bounds__(256) void aec_delay_bits_kernel(DelayBlock* __restrict__ blocks, const unsigned* __restrict__ bits,
                                                              int num_streams, int npending, int logging) {
-  __shared__ unsigned lds[4 * kLdsWave];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int stream = blockIdx.x * 4 + wave;
   if (stream >= num_streams) return;
-  unsigned* wl = lds + wave * kLdsWave;
   AspAecDelayState* g = &blocks[stream].s;
+  Hist H;
   Scalars sc;
-  load_estimator(g, wl, sc, lane);
-  wave_fence();
+  load_estimator(g, H, sc, lane);
   const unsigned* w = bits + (size_t)stream * kFlowBitsBlocks * 2;
   for (int k = 0; k < npending; ++k) {
     const unsigned bfar = __builtin_amdgcn_readfirstlane(w[2 * k]), bnear = __builtin_amdgcn_readfirstlane(w[2 * k + 1]);
-    const int delay_estimate = estimator_block_bits(g, wl, sc, bfar, bnear, lane);
+    const int delay_estimate = estimator_block_bits(H, sc, bfar, bnear, lane);
     if (logging && delay_estimate >= 0 && lane == 0) g->delay_histogram[delay_estimate]++;
-    wave_fence();
   }
-  wave_fence();
-  store_estimator<false>(g, wl, sc, lane);
+  store_estimator<false>(g, H, sc, lane);
 }
 
 // WebRtcAec_ResampleLinear for every stream (aec_resampler.c:74-123; echo_cancellation.c:304-313, skew compensation):

@@ -480,23 +480,29 @@ __device__ __forceinline__ void unpack_tile_buf(float* wl, int f, const StateBuf
 // |X|^2 and |D|^2 of bins 0..63 are in registers (bands 12..43 are all the estimator looks at), against the mean
 // spectra in the stream's estimator block; the rest of the estimator runs once per launch (aec_delay_bits_kernel).
 // The mean spectra pass from one step's wave to the next like the state block: sc1 accesses.
+struct EstOffsets {
+  static constexpr int oFar = __builtin_offsetof(AspAecDelayState, mean_far_spectrum) / 4;
+  static constexpr int oNear = __builtin_offsetof(AspAecDelayState, mean_near_spectrum) / 4;
+  static constexpr int oFarInit = __builtin_offsetof(AspAecDelayState, far_spectrum_initialized) / 4;
+  static constexpr int oNearInit = __builtin_offsetof(AspAecDelayState, near_spectrum_initialized) / 4;
+};
+__device__ __forceinline__ StateBufT<kSc1> est_buf(const DelayBlock* est) {
+  return state_buf<kSc1>(reinterpret_cast<const float*>(&est->s), (int)(sizeof(AspAecDelayState) / 4));
+}
+// thr_far / thr_near: the lane's band means; the flags as float bits (all read at the top of the block, parked in LDS)
 __device__ __forceinline__ void flow_binary_spectra(const DelayBlock* est, unsigned* bits_out, float far_pow, float near_pow,
+                                                    float thr_far, float thr_near, float far_init_f, float near_init_f,
                                                     int lane) {
-  constexpr int oFar = __builtin_offsetof(AspAecDelayState, mean_far_spectrum) / 4;
-  constexpr int oNear = __builtin_offsetof(AspAecDelayState, mean_near_spectrum) / 4;
-  constexpr int oFarInit = __builtin_offsetof(AspAecDelayState, far_spectrum_initialized) / 4;
-  constexpr int oNearInit = __builtin_offsetof(AspAecDelayState, near_spectrum_initialized) / 4;
-  const StateBufT<kSc1> eb = state_buf<kSc1>(reinterpret_cast<const float*>(&est->s), (int)(sizeof(AspAecDelayState) / 4));
-  float thr_far = sld(eb, oFar, lane), thr_near = sld(eb, oNear, lane);
-  int far_init = __builtin_amdgcn_readfirstlane(__float_as_int(sld(eb, oFarInit, 0)));
-  int near_init = __builtin_amdgcn_readfirstlane(__float_as_int(sld(eb, oNearInit, 0)));
+  const StateBufT<kSc1> eb = est_buf(est);
+  int far_init = __builtin_amdgcn_readfirstlane(__float_as_int(far_init_f));
+  int near_init = __builtin_amdgcn_readfirstlane(__float_as_int(near_init_f));
   const unsigned bfar = binary_spectrum(sqrtf(far_pow), thr_far, far_init, lane);
   const unsigned bnear = binary_spectrum(sqrtf(near_pow), thr_near, near_init, lane);
-  sst(eb, oFar, lane, thr_far);
-  sst(eb, oNear, lane, thr_near);
+  sst(eb, EstOffsets::oFar, lane, thr_far);
+  sst(eb, EstOffsets::oNear, lane, thr_near);
   if (lane == 0) {
-    sst(eb, oFarInit, 0, __int_as_float(far_init));
-    sst(eb, oNearInit, 0, __int_as_float(near_init));
+    sst(eb, EstOffsets::oFarInit, 0, __int_as_float(far_init));
+    sst(eb, EstOffsets::oNearInit, 0, __int_as_float(near_init));
     bits_out[0] = bfar;  // read by a later launch
     bits_out[1] = bnear;
   }
@@ -848,6 +854,18 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
       c64[r] = (v);                          \
     }                                        \
   } while (0)
+  // delay logging in the hand-off build: the band means of the binary spectra, asked for first and parked in the
+  // (still dead) error-spectrum rows with the first LDS writes below, so that the power phase finds them in LDS
+  [[maybe_unused]] float est_tf = 0.f, est_tn = 0.f, est_fi = 0.f, est_ni = 0.f;
+  if constexpr (FLOW) {
+    if (spec_out != nullptr) {
+      const StateBufT<kSc1> eb = est_buf(est);
+      est_tf = sld(eb, EstOffsets::oFar, lane);
+      est_tn = sld(eb, EstOffsets::oNear, lane);
+      est_fi = sld(eb, EstOffsets::oFarInit, 0);
+      est_ni = sld(eb, EstOffsets::oNearInit, 0);
+    }
+  }
   // loads return in order: the few the first FFT round waits for go first
   float c64_in[kC64Chunks];
 #pragma unroll
@@ -872,6 +890,14 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   dbuf[lane] = sld(sb, kOffDBuf, lane);
   dbuf[64 + lane] = ne;
   ebuf[lane] = sld(sb, kOffEBuf, lane);
+  if constexpr (FLOW) {
+    if (spec_out != nullptr) {
+      EFR[lane] = est_tf;
+      EFI[lane] = est_tn;
+      misc[6] = est_fi;
+      misc[7] = est_ni;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kC64Chunks; ++k)
     if (64 * (k + 1) <= kC64Lds || 64 * k + lane < kC64Lds) c64[64 * k + lane] = c64_in[k];
@@ -1039,7 +1065,8 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     const float dp = 0.9f * (t_ == 0 ? p_dpow : c64[R_DPOW]) + 0.1f * near_spectrum;
     if constexpr (FLOW) {  // delay logging: spec_out = this block's two words of binary spectra
       if (spec_out != nullptr && t_ == 0)
-        flow_binary_spectra(est, reinterpret_cast<unsigned*>(spec_out), far_spectrum, near_spectrum, lane);
+        flow_binary_spectra(est, reinterpret_cast<unsigned*>(spec_out), far_spectrum, near_spectrum, EFR[lane], EFI[lane],
+                            misc[6], misc[7], lane);
     } else if (spec_out != nullptr) {  // delay estimation on: |X|^2 and |D|^2 of the block for aec_delay_kernel (aec_core.c:1154-1155, 1191-1203)
       spec_out[bin] = far_spectrum;
       spec_out[kRow + bin] = near_spectrum;

@@ -291,7 +291,9 @@ int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in);
 int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* out);
 int AspAecBatch_Synchronize(AspAecBatch* b);
 /* Hand-off build of the multi-frame entry points (Run, TimedSteps) in the plain configuration (one band, reported
- * delays, no delay logging / skew compensation / metrics): the Process launches of up to 64 consecutive frames go
+ * delays, no skew compensation / metrics; with or without delay logging -- with it the process kernel forms each
+ * block's binary far / near spectra and the rest of the estimator runs once per launch over all its blocks): the
+ * Process launches of up to 64 consecutive frames go
  * into ONE launch (grid y = frame step, its descriptors in device memory), and a per-stream step counter in device
  * memory orders step k + 1 of a stream behind its own step k (every access to the stream's state and far-ring
  * slots write-through / L1-bypassing), so consecutive steps overlap on the chip instead of meeting at a launch
