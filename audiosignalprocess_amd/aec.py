@@ -48,6 +48,7 @@ def _lib():
             "AspAecBatch_TimedSteps": [vp, vp, vp, vp, ip, ip, ip, C.POINTER(C.c_float)],
             "AspAec_rdft128_batch": [vp, vp, ip, ip, ip],
             "AspAec_host_table": [ip, vp, ip],
+            "AspAec_delay_estimator_batch": [vp, ip, vp, vp, ip, ip],
         }
         for name, args in sig.items():
             if os.environ.get("ASP_AMD_LIB") and not hasattr(lib, name):
@@ -245,6 +246,21 @@ def rdft128(rows, isgn, device=0):
     _check(lib.AspAec_rdft128_batch(rows.ctypes.data, out.ctypes.data, isgn, rows.size // 128, device),
            "AspAec_rdft128_batch")
     return out
+
+
+def delay_estimator_batch(states, binary_far, binary_near, device=0):
+    """`len(states)` binary delay estimators (AspAecDelayState, updated in place), each over its own row of
+    binary far / near spectra ([count][nblocks] uint32), on the GPU (include/asp_aec.h)."""
+    from ._abi import AspAecDelayState
+    lib = _lib()
+    far = np.ascontiguousarray(binary_far, np.uint32)
+    near = np.ascontiguousarray(binary_near, np.uint32)
+    assert far.shape == near.shape and far.shape[0] == len(states)
+    arr = (AspAecDelayState * len(states))(*states)
+    _check(lib.AspAec_delay_estimator_batch(C.byref(arr), len(states), far.ctypes.data, near.ctypes.data, far.shape[1],
+                                            device), "AspAec_delay_estimator_batch")
+    for i in range(len(states)):
+        C.memmove(C.byref(states[i]), C.byref(arr[i]), C.sizeof(AspAecDelayState))
 
 
 def host_table(which, n):

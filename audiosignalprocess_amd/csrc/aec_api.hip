@@ -2236,6 +2236,45 @@ int AspAec_rdft128_batch(const float* src, float* dst, int isgn, int count, int 
   return ASP_OK;
 }
 
+int AspAec_delay_estimator_batch(AspAecDelayState* states, int count, const uint32_t* binary_far, const uint32_t* binary_near,
+                                 int nblocks, int device) {
+  AspDeviceScope dev_scope_;
+  if (!states || !binary_far || !binary_near || count <= 0 || nblocks < 0)
+    return aec_fail(ASP_ERR_PARAM, "delay_estimator_batch: bad argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return aec_fail(ASP_ERR_NO_DEVICE, "no HIP device: the echo canceller has no CPU fallback");
+  AEC_TRY(hipSetDevice(device));
+  std::vector<DelayBlock> blocks((size_t)count);
+  for (int i = 0; i < count; ++i) {
+    memset(&blocks[i], 0, sizeof(DelayBlock));
+    blocks[i].s = states[i];
+  }
+  std::vector<unsigned> words((size_t)count * kFlowBitsBlocks * 2);
+  DelayBlock* d_blocks = nullptr;
+  unsigned* d_bits = nullptr;
+  hipError_t e = hipMalloc((void**)&d_blocks, blocks.size() * sizeof(DelayBlock));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_bits, words.size() * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemcpy(d_blocks, blocks.data(), blocks.size() * sizeof(DelayBlock), hipMemcpyHostToDevice);
+  for (int k0 = 0; k0 < nblocks && e == hipSuccess; k0 += kFlowBitsBlocks) {  // as many launches as hand-off launches would carry
+    const int nb = nblocks - k0 < kFlowBitsBlocks ? nblocks - k0 : kFlowBitsBlocks;
+    for (int i = 0; i < count; ++i)
+      for (int k = 0; k < nb; ++k) {
+        words[((size_t)i * kFlowBitsBlocks + k) * 2] = binary_far[(size_t)i * nblocks + k0 + k];
+        words[((size_t)i * kFlowBitsBlocks + k) * 2 + 1] = binary_near[(size_t)i * nblocks + k0 + k];
+      }
+    e = hipMemcpy(d_bits, words.data(), words.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_aec_delay_bits(d_blocks, d_bits, count, nb, 1, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(blocks.data(), d_blocks, blocks.size() * sizeof(DelayBlock), hipMemcpyDeviceToHost);
+  if (d_blocks) (void)hipFree(d_blocks);
+  if (d_bits) (void)hipFree(d_bits);
+  if (e != hipSuccess) return aec_fail(ASP_ERR_HIP, "delay_estimator_batch", e);
+  for (int i = 0; i < count; ++i) states[i] = blocks[i].s;
+  return ASP_OK;
+}
+
 int AspAec_host_table(int which, float* out, int capacity) {
   AspDeviceScope dev_scope_;
   AecTables T;

@@ -308,6 +308,13 @@ int AspAecBatch_TimedSteps(AspAecBatch* b, const float* farend, const float* nea
 /* aec_rdft_forward_128 / aec_rdft_inverse_128 (aec_rdft.c:539-556) on `count` rows of 128
  * floats, in place semantics (src -> dst), host pointers.  Parity-test seam. */
 int AspAec_rdft128_batch(const float* src, float* dst, int isgn, int count, int device);
+/* The binary delay estimator on its own (WebRtc_AddBinaryFarSpectrum + WebRtc_ProcessBinarySpectrum with the robust
+ * validation, utility/delay_estimator.c:356-369, 513-644; the logging histogram counts each block's estimate,
+ * aec_core.c:1199-1202): `count` independent estimators, each fed its own `nblocks` binary far / near spectra
+ * ([count][nblocks], in block order), states in and out through host memory.  Parity-test seam of the kernel the
+ * hand-off build runs (utility/delay_estimator_unittest.cc:424-570 restated in tests/test_delay_estimator.py). */
+int AspAec_delay_estimator_batch(AspAecDelayState* states, int count, const uint32_t* binary_far, const uint32_t* binary_near,
+                                 int nblocks, int device);
 /* Host-built constant tables (parity tests compare them with the oracle's and the reference's):
  * which: 0 rdft_w[64], 1 rdft_wk3ri_first[16], 2 rdft_wk3ri_second[16], 3 sqrtHanning[65],
  * 4 weightCurve[65], 5 overDriveCurve[65].  Returns the number of floats written. */

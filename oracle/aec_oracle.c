@@ -600,12 +600,15 @@ static uint32_t de_binary_spectrum(const float* spectrum, float* threshold, int3
   return out;
 }
 
-static void de_add_far(AspAecDelayState* d, const float* far_spectrum) { /* dw:231-255, de:356-369 */
-  const uint32_t b = de_binary_spectrum(far_spectrum, d->mean_far_spectrum, &d->far_spectrum_initialized);
+static void de_add_binary_far(AspAecDelayState* d, uint32_t b) { /* WebRtc_AddBinaryFarSpectrum, de:356-369 */
   memmove(&d->binary_far_history[1], &d->binary_far_history[0], (DE_HIST - 1) * sizeof(uint32_t));
   d->binary_far_history[0] = b;
   memmove(&d->far_bit_counts[1], &d->far_bit_counts[0], (DE_HIST - 1) * sizeof(int32_t));
   d->far_bit_counts[0] = de_bitcount(b);
+}
+
+static void de_add_far(AspAecDelayState* d, const float* far_spectrum) { /* WebRtc_AddFarSpectrumFloat, dw:231-255 */
+  de_add_binary_far(d, de_binary_spectrum(far_spectrum, d->mean_far_spectrum, &d->far_spectrum_initialized));
 }
 
 static void de_update_robust(AspAecDelayState* d, int candidate_delay, int32_t valley_depth_q14,
@@ -647,8 +650,7 @@ static int de_histogram_valid(const AspAecDelayState* d, int candidate_delay) { 
   return (d->histogram[candidate_delay] >= histogram_threshold) && (d->candidate_hits > 10);
 }
 
-static int de_process(AspAecDelayState* d, const float* near_spectrum) { /* dw:446-469, de:513-644 */
-  uint32_t binary_near = de_binary_spectrum(near_spectrum, d->mean_near_spectrum, &d->near_spectrum_initialized);
+static int de_process_binary(AspAecDelayState* d, uint32_t binary_near) { /* WebRtc_ProcessBinarySpectrum, de:513-644 */
   int i, candidate_delay = -1, valid_candidate;
   int32_t value_best_candidate = kMaxBitCountsQ9, value_worst_candidate = 0, valley_depth;
   memmove(&d->binary_near_history[1], &d->binary_near_history[0], (DE_NEAR - 1) * sizeof(uint32_t));
@@ -699,6 +701,10 @@ static int de_process(AspAecDelayState* d, const float* near_spectrum) { /* dw:4
     d->compare_delay = d->last_delay;
   }
   return d->last_delay;
+}
+
+static int de_process(AspAecDelayState* d, const float* near_spectrum) { /* WebRtc_DelayEstimatorProcessFloat, dw:446-469 */
+  return de_process_binary(d, de_binary_spectrum(near_spectrum, d->mean_near_spectrum, &d->near_spectrum_initialized));
 }
 
 static float de_quality(const AspAecDelayState* d) { return d->histogram[d->compare_delay] / 3000.f; } /* de:655-658 */
@@ -778,6 +784,18 @@ static void init_core(AspAecOracle* o, int sampFreq) { /* WebRtcAec_InitAec, cor
 
 /* WebRtcAec_enable_delay_correction / _delay_correction_enabled, core:1876-1885 (reached through
  * WebRtcAec_aec_core(handle)). */
+/* The estimator on its own (the seam utility/delay_estimator_unittest.cc tests): robust validation on, history 125. */
+void asp_de_oracle_init(AspAecDelayState* d, int lookahead, int allowed_offset) {
+  d->lookahead = lookahead;
+  d->allowed_offset = allowed_offset;
+  de_init(d);
+}
+void asp_de_oracle_add_binary_far(AspAecDelayState* d, uint32_t binary_far) { de_add_binary_far(d, binary_far); }
+int asp_de_oracle_process_binary(AspAecDelayState* d, uint32_t binary_near) { return de_process_binary(d, binary_near); }
+void asp_de_oracle_add_far(AspAecDelayState* d, const float* far_spectrum) { de_add_far(d, far_spectrum); }
+int asp_de_oracle_process(AspAecDelayState* d, const float* near_spectrum) { return de_process(d, near_spectrum); }
+float asp_de_oracle_quality(const AspAecDelayState* d) { return de_quality(d); }
+
 void asp_aec_oracle_enable_delay_correction(AspAecOracle* o, int enable) {
   o->extended_filter_enabled = enable;
   o->num_partitions = enable ? NPART_MAX : NPART_NORMAL;

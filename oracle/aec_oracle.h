@@ -31,6 +31,14 @@ void asp_aec_oracle_enable_reported_delay(AspAecOracle* o, int enable);  /* core
 int asp_aec_oracle_reported_delay_enabled(const AspAecOracle* o);
 int asp_aec_oracle_get_delay_metrics(AspAecOracle* o, int* median, int* std); /* ec:550-571, core:1780-1836 */
 void asp_aec_oracle_export_delay(const AspAecOracle* o, AspAecDelayState* d);
+/* the delay estimator on its own (utility/delay_estimator.c, delay_estimator_wrapper.c; robust validation on,
+ * 125 blocks of history): the seam utility/delay_estimator_unittest.cc tests */
+void asp_de_oracle_init(AspAecDelayState* d, int lookahead, int allowed_offset);
+void asp_de_oracle_add_binary_far(AspAecDelayState* d, uint32_t binary_far);  /* WebRtc_AddBinaryFarSpectrum */
+int asp_de_oracle_process_binary(AspAecDelayState* d, uint32_t binary_near);  /* WebRtc_ProcessBinarySpectrum */
+void asp_de_oracle_add_far(AspAecDelayState* d, const float* far_spectrum);   /* WebRtc_AddFarSpectrumFloat */
+int asp_de_oracle_process(AspAecDelayState* d, const float* near_spectrum);   /* WebRtc_DelayEstimatorProcessFloat */
+float asp_de_oracle_quality(const AspAecDelayState* d);                       /* WebRtc_last_delay_quality */
 void asp_aec_oracle_export_skew(const AspAecOracle* o, float* position, float* skew, int* resample, int* index);
 int asp_aec_oracle_buffer_farend(AspAecOracle* o, const float* farend, int nrOfSamples);
 int asp_aec_oracle_process(AspAecOracle* o, const float* nearend, float* out, int nrOfSamples,
