@@ -52,7 +52,7 @@ def build_library(force=False, verbose=False):
     """Compile csrc/*.hip into lib/libasp_amd.so; returns its path."""
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    hdrs = [os.path.join(CSRC, "ns_layout.h"), os.path.join(CSRC, "ns_device.h"), os.path.join(CSRC, "ns_pair_fft.h"), os.path.join(CSRC, "bt_layout.h"), os.path.join(CSRC, "pk_f32.h"), os.path.join(CSRC, "bt_sure.h"), os.path.join(CSRC, "aec_layout.h"), os.path.join(CSRC, "aec_binspec.h"), os.path.join(CSRC, "sinc_layout.h"), os.path.join(CSRC, "device_scope.h"),
+    hdrs = [os.path.join(CSRC, "ns_layout.h"), os.path.join(CSRC, "ns_device.h"), os.path.join(CSRC, "ns_pair_fft.h"), os.path.join(CSRC, "bt_layout.h"), os.path.join(CSRC, "pk_f32.h"), os.path.join(CSRC, "bt_sure.h"), os.path.join(CSRC, "aec_layout.h"), os.path.join(CSRC, "aec_binspec.h"), os.path.join(CSRC, "aec_estimator.h"), os.path.join(CSRC, "sinc_layout.h"), os.path.join(CSRC, "device_scope.h"),
                    os.path.join(ROOT, "include", "asp_ns.h"), os.path.join(ROOT, "include", "asp_bt.h"), os.path.join(ROOT, "include", "asp_aec.h"), os.path.join(ROOT, "include", "asp_split.h"), os.path.join(ROOT, "include", "asp_resample.h")]
     objs = []
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]

@@ -22,8 +22,7 @@
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
-#include "aec_binspec.h"
-#include "aec_layout.h"
+#include "aec_estimator.h"
 #include "ns_device.h"  // lean fp64 pow / sincos shared with the NS kernels
 #include "pk_f32.h"     // complex arithmetic as packed f32
 
@@ -783,7 +782,9 @@ __device__ __forceinline__ float set_lane(float row, int bits) {
 }
 
 // NP = 12 partitions, or 32: the extended filter (aec_core_internal.h:23-25, WebRtcAec_enable_delay_correction)
-template <bool kMetrics, int NP, bool FLOW = false, class BLOCKOP = BlockOp>
+// BITS: the block's two binary spectra are formed here (delay logging in the hand-off build; the fused delay-agnostic
+// form), spec_out = where its two words go
+template <bool kMetrics, int NP, bool FLOW = false, bool BITS = FLOW, class BLOCKOP = BlockOp>
 __device__ __forceinline__ void process_block(float* __restrict__ st, float* __restrict__ wl,
                                               const float* __restrict__ far_slot,
                                               const SharedTables& T, const BLOCKOP& op, int mult,
@@ -857,7 +858,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   // delay logging in the hand-off build: the band means of the binary spectra, asked for first and parked in the
   // (still dead) error-spectrum rows with the first LDS writes below, so that the power phase finds them in LDS
   [[maybe_unused]] float est_tf = 0.f, est_tn = 0.f, est_fi = 0.f, est_ni = 0.f;
-  if constexpr (FLOW) {
+  if constexpr (BITS) {
     if (spec_out != nullptr) {
       const StateBufT<kSc1> eb = est_buf(est);
       est_tf = sld(eb, EstOffsets::oFar, lane);
@@ -890,7 +891,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   dbuf[lane] = sld(sb, kOffDBuf, lane);
   dbuf[64 + lane] = ne;
   ebuf[lane] = sld(sb, kOffEBuf, lane);
-  if constexpr (FLOW) {
+  if constexpr (BITS) {
     if (spec_out != nullptr) {
       EFR[lane] = est_tf;
       EFI[lane] = est_tn;
@@ -1063,7 +1064,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
     const float near_spectrum = DFR[bin] * DFR[bin] + DFI[bin] * DFI[bin];
     const float xp = 0.9f * (t_ == 0 ? p_xpow : c64[R_XPOW]) + 0.1f * kNumPart * far_spectrum;
     const float dp = 0.9f * (t_ == 0 ? p_dpow : c64[R_DPOW]) + 0.1f * near_spectrum;
-    if constexpr (FLOW) {  // delay logging: spec_out = this block's two words of binary spectra
+    if constexpr (BITS) {  // delay logging: spec_out = this block's two words of binary spectra
       if (spec_out != nullptr && t_ == 0)
         flow_binary_spectra(est, reinterpret_cast<unsigned*>(spec_out), far_spectrum, near_spectrum, EFR[lane], EFI[lane],
                             misc[6], misc[7], lane);
@@ -1594,7 +1595,9 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 // One WebRtcAec_Process call of one stream (running phase), after the far-end work that precedes it: per
 // 80-sample sub-frame append the near samples, run the scheduled blocks, emit 80 output samples.  OPS / FOPS:
 // the call's descriptors, in the kernel's arguments (plain build) or in device memory (hand-off build).
-template <bool kMetrics, int NP, bool FLOW, class OPS, class FOPS>
+// AGN: the delay-agnostic mode inside the call (agn != nullptr): per sub-frame the stream's own far-buffer control
+// step, which picks the far slots of its blocks, then the blocks, then the estimator's share of them.
+template <bool kMetrics, int NP, bool FLOW, class OPS, class FOPS, bool AGN = false>
 __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_ring, float* __restrict__ wl,
                                              const SharedTables& T, const AecTables* __restrict__ G,
                                              const float* __restrict__ nin, float* __restrict__ o, int num_streams,
@@ -1602,7 +1605,7 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
                                              const float* __restrict__ farend, const FOPS& fops,
                                              const float* near_high, float* out_high, float* met,
                                              unsigned long long* __restrict__ stamps, float* spectra,
-                                             const DelayBlock* dblocks) {
+                                             const DelayBlock* dblocks, const AgnOps* agn = nullptr) {
   constexpr int kAux = FLOW ? kSc1 : 0;
   constexpr int kDwords = AecRows(NP).state_dwords;
   [[maybe_unused]] const StateBufT<kAux> sb = state_buf<kAux>(st, kDwords);
@@ -1617,7 +1620,7 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
   bool carried = false;  // the coming block finds its echo estimate's spectrum in LDS
   // (not with the high band, whose comfort noise borrows the YFR / YFI rows; not in the delay-agnostic mode, where
   // the next block's far slot is the estimator's to choose)
-  [[maybe_unused]] const bool carry_ok = FLOW || (ops.num_high == 0 && !ops.agnostic);
+  [[maybe_unused]] const bool carry_ok = !AGN && (FLOW || (ops.num_high == 0 && !ops.agnostic));
   for (int s = 0; s < ops.nsub; ++s) {
     const auto& sf = ops.sub[s];
     // near samples of this sub-frame are read into registers first: `out` may alias `nearend`
@@ -1641,6 +1644,16 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    [[maybe_unused]] int agn_slot0 = 0, agn_slot1 = 0;
+    [[maybe_unused]] float* agn_bits = wl + kLdsMisc + 12;  // the sub-frame's binary spectra: 2 x 2 words behind the NLP's scratch
+    if constexpr (AGN) {
+      DelayBlock* eb = const_cast<DelayBlock*>(dblocks) + stream;
+      aspaec_est::Hist H;
+      aspaec_est::Scalars sc;
+      aspaec_est::load_estimator(&eb->s, H, sc, lane);
+      aspaec_est::control_step(eb, H, sc, agn->sub[s], lane, agn_slot0, agn_slot1);
+      aspaec_est::store_estimator<false>(&eb->s, H, sc, lane);
+    }
     for (int k = 0; k < sf.nblocks; ++k) {
       const auto& op = sf.blk[k];
       // the block after this one, when this call holds one: its echo estimate is accumulated during this block's
@@ -1662,19 +1675,36 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
       }
 #endif
       // the far slot: the batch's (lock-step), or in the delay-agnostic mode the stream's own (aec_delay_kernel)
-      const int far_slot = (!FLOW && ops.agnostic) ? __builtin_amdgcn_readfirstlane(dblocks[stream].slot[blk & 1]) : op.far_slot;
+      const int far_slot = AGN ? (k == 0 ? agn_slot0 : agn_slot1)
+                               : (!FLOW && ops.agnostic) ? __builtin_amdgcn_readfirstlane(dblocks[stream].slot[blk & 1]) : op.far_slot;
       const float* slot = far_ring + ((size_t)far_slot * num_streams + stream) * kFarSlotDwords;
-      float* spec_out = FLOW ? (spectra != nullptr ? spectra + 2 * blk : nullptr)  // hand-off build: `spectra` = this step's binary-spectra words
+      float* spec_out = AGN ? (agn->logging ? agn_bits + 2 * k : nullptr)
+                        : FLOW ? (spectra != nullptr ? spectra + 2 * blk : nullptr)  // hand-off build: `spectra` = this step's binary-spectra words
                              : ops.spectra ? spectra + ((size_t)stream * kSpecBlocks + (blk & (kSpecBlocks - 1))) * kSpecDwords : nullptr;
       ++blk;
-      process_block<kMetrics, NP, FLOW>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
+      process_block<kMetrics, NP, FLOW, FLOW || AGN>(st, wl, slot, T, op, ops.mult, ops.nlp_mode, ops.mu, ops.error_threshold, lane, G->exp2_64,
                     FLOW ? 0 : ops.num_high, met,
                     (stamps != nullptr && stream == 0 && s == 0 && k == 0) ? stamps : nullptr,  // wave-uniform; every lane stores the same scalar time
-                    spec_out, carried, next_slot, next_xf, FLOW && dblocks != nullptr ? dblocks + stream : nullptr);
+                    spec_out, carried, next_slot, next_xf, (FLOW || AGN) && dblocks != nullptr ? dblocks + stream : nullptr);
       carried = next_slot != nullptr;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if constexpr (AGN) {
+      if (agn->logging && sf.nblocks > 0) {  // the estimator's share of this sub-frame's blocks (aec_core.c:1191-1203)
+        DelayBlock* eb = const_cast<DelayBlock*>(dblocks) + stream;
+        aspaec_est::Hist H;
+        aspaec_est::Scalars sc;
+        aspaec_est::load_estimator(&eb->s, H, sc, lane);
+        for (int k = 0; k < sf.nblocks; ++k) {
+          const unsigned bfar = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(agn_bits[2 * k]));
+          const unsigned bnear = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(agn_bits[2 * k + 1]));
+          const int delay_estimate = aspaec_est::estimator_block_bits(H, sc, bfar, bnear, lane);
+          if (delay_estimate >= 0 && lane == 0) eb->s.delay_histogram[delay_estimate]++;
+        }
+        aspaec_est::store_estimator<false>(&eb->s, H, sc, lane);
+      }
     }
     if constexpr (FLOW) {
       o[80 * s + lane] = sld(sb, kOffOutFr, ring_idx(sf.out_rpos, lane, kFrBufLen));
@@ -1722,6 +1752,30 @@ __global__ __launch_bounds__(256, kMetrics ? 2 : NP == kNumPartNormal ? AEC_WAVE
   float* met = kMetrics ? metrics + (size_t)stream * kMetDwords : nullptr;
   process_call<kMetrics, NP, false>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, ops, farend, fops,
                                     near_high, out_high, met, stamps, spectra, dblocks);
+}
+
+// The delay-agnostic mode in one launch per call (one band, no metrics): the control steps and the estimator run in
+// the stream's own wave (process_call<AGN>), so a call is not cut into a launch per sub-frame with estimator / control
+// launches between them.
+template <int NP>
+__global__ __launch_bounds__(256, NP == kNumPartNormal ? AEC_WAVES : 3) void aec_process_agn_kernel(
+    int stream0, int stream_end, float* __restrict__ state, float* far_ring, const AecTables* __restrict__ G,
+    const float* __restrict__ nearend, float* __restrict__ out, int num_streams, int nrOfSamples, ProcOps ops,
+    const float* __restrict__ farend, FarOps fops, DelayBlock* dblocks, AgnOps agn) {
+  __shared__ SharedTables T;
+  constexpr int kWaveLds = lds_wave(NP, false);
+  __shared__ float lds[4 * kWaveLds];
+  stage_tables(T, G);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = stream0 + blockIdx.x * 4 + wave;
+  if (stream >= stream_end) return;
+  float* wl = lds + wave * kWaveLds;
+  float* st = state + (size_t)stream * AecRows(NP).state_dwords;
+  const float* nin = nearend + (size_t)stream * nrOfSamples;
+  float* o = out + (size_t)stream * nrOfSamples;
+  process_call<false, NP, false, ProcOps, FarOps, true>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, ops,
+                                                        farend, fops, nullptr, nullptr, nullptr, nullptr, nullptr, dblocks, &agn);
 }
 
 // The hand-off build: grid (groups of four streams, frame steps); see AecFlowArgs.  One band, no metrics, no
@@ -1877,6 +1931,22 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
     if (metrics != nullptr) ASP_AEC_LAUNCH(true, kNumPartMax); else ASP_AEC_LAUNCH(false, kNumPartMax);
   }
 #undef ASP_AEC_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t launch_aec_process_agn(float* state, float* far_ring, const AecTables* T, const float* nearend, float* out,
+                                  int num_streams, int nrOfSamples, const ProcOps& ops, const float* farend, const FarOps& fops,
+                                  DelayBlock* dblocks, const AgnOps& agn, hipStream_t s, int stream0, int stream_end,
+                                  int num_part) {
+  if (num_part != kNumPartNormal && num_part != kNumPartMax) return hipErrorInvalidValue;
+  if (stream_end < 0) stream_end = num_streams;
+  const dim3 grid((stream_end - stream0 + 3) / 4);
+  if (num_part == kNumPartNormal)
+    hipLaunchKernelGGL((aec_process_agn_kernel<kNumPartNormal>), grid, dim3(256), 0, s, stream0, stream_end, state, far_ring, T,
+                       nearend, out, num_streams, nrOfSamples, ops, farend, fops, dblocks, agn);
+  else
+    hipLaunchKernelGGL((aec_process_agn_kernel<kNumPartMax>), grid, dim3(256), 0, s, stream0, stream_end, state, far_ring, T,
+                       nearend, out, num_streams, nrOfSamples, ops, farend, fops, dblocks, agn);
   return hipGetLastError();
 }
 

@@ -182,4 +182,13 @@ struct DelayOps {
   int32_t ev_samples[kMaxFarEvents], ev_parts[kMaxFarEvents];
 };
 
+// The delay-agnostic mode fused into the Process launch (aec_kernels.hip, aec_process_agn_kernel): the control step
+// of each 80-sample sub-frame, run by the stream's own wave before the sub-frame's blocks, and the estimator's share
+// of those blocks right after them.
+struct AgnOps {
+  int32_t logging;   // delay_logging_enabled: the estimator runs (aec_core.c:1191-1203)
+  int32_t pad;
+  DelayOps sub[2];   // control = 1, nblocks, and for the call's first sub-frame the far-end calls to replay / the sync values
+};
+
 }  // namespace aspaec

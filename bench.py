@@ -33,15 +33,16 @@ ALGO_BYTES_PER_FRAME = 15716  # frame-synchronous NS mod
 # cover; see profiles/README.md ("HBM traffic of the NS kernel").  Measured once per round, not live.
 
 # Secondary lines: fabric-side bytes from the same counters (tools/traffic_sec.sh, profiles/r04_traffic_sec.txt),
-# stored per unit of work, not measured in the run.  BT-1024: 2 x 10.0943 KB FETCH_SIZE + 20.000 KB WRITE_SIZE per
-# macroblock (8-byte lanes: the guide's factor 2 on reads; 1.005 x the algorithmic 40 960 B); BT-256: 2 x 2.6127 KB +
-# 5.000 KB per macroblock (1.02 x the algorithmic 10 240 B).  AEC (hand-off build): 28.51 KB FETCH_SIZE and 31.86 KB
-# WRITE_SIZE per stream and frame of 4-byte-per-lane accesses (a width the guide does not calibrate; with its factor
-# 2 on reads 1.27 x the algorithmic 71 400 B: FilterAdaptation reads the far history and the filter a second time,
-# from the Infinity Cache).
-BT_TRAFFIC_BYTES_PER_MACROBLOCK = (2 * 10.0943 + 20.0) * 1024
-BT256_TRAFFIC_BYTES_PER_MACROBLOCK = (2 * 2.6127 + 5.0) * 1024
-AEC_TRAFFIC_BYTES_PER_FRAME = (2 * 28.5106 + 31.8561) * 1024
+# stored per unit of work, not measured in the run (hand-off builds, as benched).  BT-1024: 2 x 10.060 KB FETCH_SIZE +
+# 18.075 KB WRITE_SIZE per macroblock (8-byte lanes: the guide's factor 2 on reads; the input tail is written once per
+# launch, not per macroblock: 0.93 x the algorithmic 40 960 B); BT-256: 2 x 2.395 KB + 4.519 KB per macroblock.  AEC:
+# 26.01 KB FETCH_SIZE and 37.63 KB WRITE_SIZE per stream and frame (the frame's far-end work included) of
+# 4-byte-per-lane accesses (a width the guide does not calibrate; with its factor 2 on reads 1.29 x the algorithmic
+# 71 400 B: FilterAdaptation reads the far history and the filter a second time in a call's first block, from the
+# Infinity Cache).
+BT_TRAFFIC_BYTES_PER_MACROBLOCK = (2 * 10.0597 + 18.0747) * 1024
+BT256_TRAFFIC_BYTES_PER_MACROBLOCK = (2 * 2.3950 + 4.5187) * 1024
+AEC_TRAFFIC_BYTES_PER_FRAME = (2 * 26.0074 + 37.6261) * 1024
 
 # ns_frame1_kernel<false> (the benched kernel, round 3: profiles/r03_ns_traffic.txt): FETCH_SIZE 3.8648 /
 # WRITE_SIZE 7.2188 KB per stream and launch at 4096 streams against 3.8233 / 7.2188 KB at 32768 streams, where
