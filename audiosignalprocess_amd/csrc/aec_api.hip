@@ -36,6 +36,10 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
 hipError_t launch_aec_process_flow(float* state, float* far_ring, const AecTables* T, int num_streams, int nrOfSamples,
                                    const AecFlowStep* descs, int steps, unsigned* seq, unsigned* abort_w, unsigned want,
                                    int num_part, hipStream_t s, DelayBlock* est, unsigned* bits);
+hipError_t launch_aec_process_agn(float* state, float* far_ring, const AecTables* T, const float* nearend, float* out,
+                                  int num_streams, int nrOfSamples, const ProcOps& ops, const float* farend, const FarOps& fops,
+                                  DelayBlock* dblocks, const AgnOps& agn, hipStream_t s, int stream0, int stream_end,
+                                  int num_part);
 hipError_t launch_aec_delay_bits(DelayBlock* blocks, const unsigned* bits, int num_streams, int npending, int logging,
                                  hipStream_t s);
 hipError_t launch_aec_farend_v(float* state, float* far_ring, const AecTables* T, const float* farend, int num_streams,
@@ -852,6 +856,16 @@ void est_buf_delay_normal(AspAecBatch* b) {  // echo_cancellation.c:816-867
   }
 }
 
+// The delay-agnostic mode in one launch per call (aec_process_agn_kernel): one band, no echo metrics, the whole batch on
+// one control plane.  ASP_AEC_AGN_FUSED=0 keeps the launch-per-sub-frame form (the A / B switch).
+bool agn_fused(const AspAecBatch* b) {
+  static const int env = [] {
+    const char* e = getenv("ASP_AEC_AGN_FUSED");
+    return e ? atoi(e) : 1;
+  }();
+  return env != 0 && !b->sim && !b->vrec && !b->flow_rec && b->num_high == 0 && !b->metricsMode && b->debug_stamps == nullptr;
+}
+
 // WebRtcAec_ProcessFrames control plane (aec_core.c:1647-1778) -> one launch.
 // `knownDelay`: the delay ProcessNormal / ProcessExtended hand over (echo_cancellation.c:735-741, 803-812)
 int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n, int knownDelay) {
@@ -921,6 +935,45 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
   // ---- delay-agnostic mode: per 80-sample sub-frame the per-stream control step (with the estimator's share of the
   // previous sub-frame's blocks), then the blocks themselves with the far slots that step chose
   ops.agnostic = 1;
+  if (agn_fused(b)) {
+    // one launch per call: every stream's wave runs its own control steps and the estimator between its blocks
+    // (aec_kernels.hip, process_call<AGN>)
+    AgnOps agn;
+    memset(&agn, 0, sizeof agn);
+    agn.logging = b->delay_logging;
+    for (int j = 0; j < ops.nsub; ++j) {
+      DelayOps& d = agn.sub[j];
+      d.control = 1;
+      d.mult = b->mult;
+      d.num_part = b->num_part;
+      d.nblocks = ops.sub[j].nblocks;
+      if (!b->agn_synced) {  // the first sub-frame after Init: every stream starts from the batch's values
+        d.sync = 1;
+        d.h_far_read = far_at_entry.read;
+        d.h_far_write = far_at_entry.write;
+        d.h_far_wrap = far_at_entry.wrap;
+        d.h_system_delay = system_delay_at_entry;
+        b->agn_synced = true;
+        b->nevents = 0;
+      } else if (j == 0) {
+        d.nevents = b->nevents;
+        memcpy(d.ev_samples, b->ev_samples, sizeof d.ev_samples);
+        memcpy(d.ev_parts, b->ev_parts, sizeof d.ev_parts);
+        b->nevents = 0;
+      }
+    }
+    if (!b->dual)
+      AEC_TRY(launch_aec_process_agn(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
+                                     b->dblocks, agn, b->stream, 0, -1, b->num_part));
+    else {
+      const int half = ((b->S / 2 + 3) / 4) * 4;
+      AEC_TRY(launch_aec_process_agn(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
+                                     b->dblocks, agn, b->stream, 0, half, b->num_part));
+      AEC_TRY(launch_aec_process_agn(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
+                                     b->dblocks, agn, b->side, half, b->S, b->num_part));
+    }
+    return 0;
+  }
   int prev_blocks = 0;
   for (int j = 0; j < ops.nsub; ++j) {
     DelayOps d;
