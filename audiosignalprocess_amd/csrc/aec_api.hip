@@ -35,7 +35,7 @@ hipError_t launch_aec_process(float* state, float* far_ring, const AecTables* T,
                               const DelayBlock* dblocks = nullptr);
 hipError_t launch_aec_process_flow(float* state, float* far_ring, const AecTables* T, int num_streams, int nrOfSamples,
                                    const AecFlowStep* descs, int steps, unsigned* seq, unsigned* abort_w, unsigned want,
-                                   int num_part, hipStream_t s, DelayBlock* est, unsigned* bits);
+                                   int num_part, hipStream_t s, DelayBlock* est, unsigned* bits, bool agn);
 hipError_t launch_aec_process_agn(float* state, float* far_ring, const AecTables* T, const float* nearend, float* out,
                                   int num_streams, int nrOfSamples, const ProcOps& ops, const float* farend, const FarOps& fops,
                                   DelayBlock* dblocks, const AgnOps& agn, hipStream_t s, int stream0, int stream_end,
@@ -287,8 +287,9 @@ struct AspAecBatch : AecCtl {
   bool flow_rec = false;
   int flow_n = 0, flow_nr = 0;               // descriptors recorded so far; samples per call of the recording
   int flow_slot = 0;                         // ring of descriptor arrays: host (pinned) and device copies
-  AecFlowStep* flow_host = nullptr;          // [kAecFlowSlots][kAecFlowMaxSteps]
-  AecFlowStep* flow_dev = nullptr;
+  unsigned char* flow_host = nullptr;        // [kAecFlowSlots][kAecFlowMaxSteps] AecFlowStep, or AecFlowStepAgn in the delay-agnostic mode
+  unsigned char* flow_dev = nullptr;
+  bool flow_agn = false;                     // the recording's element type
   hipEvent_t flow_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // slot i's launch has consumed its descriptors
   unsigned* flow_seq = nullptr;              // [S] completed hand-off steps per stream (== flow_count between calls)
   unsigned* flow_abort = nullptr;            // 16 B: word 0 != 0 after a wait timed out
@@ -367,18 +368,29 @@ int estimate_skew(const int* rawSkew, int size, int deviceSampleRateHz, float* s
 namespace {
 constexpr int kAecFlowMaxSteps = 64, kAecFlowSlots = 4;
 static_assert(kFlowBitsBlocks >= 4 * kAecFlowMaxSteps, "a step has at most four blocks");
+constexpr size_t kAecFlowElem = sizeof(AecFlowStepAgn);  // a slot holds kAecFlowMaxSteps elements of either type
 
 bool aec_flow_default() {
   const char* e = getenv("ASP_AEC_FLOW");
   return !(e && e[0] == '0');
 }
-// The hand-off build serves the plain configuration: one band, reported delays, no delay logging, no skew
-// compensation, no metrics (the optional modes add launches of their own between the Process launches).
+// The delay-agnostic mode in one launch per call (aec_process_agn_kernel): one band, no echo metrics, the whole batch on
+// one control plane.  ASP_AEC_AGN_FUSED=0 keeps the launch-per-sub-frame form (the A / B switch).
+bool agn_fused(const AspAecBatch* b) {
+  static const int env = [] {
+    const char* e = getenv("ASP_AEC_AGN_FUSED");
+    return e ? atoi(e) : 1;
+  }();
+  return env != 0 && !b->sim && !b->vrec && b->num_high == 0 && !b->metricsMode && b->debug_stamps == nullptr;
+}
+
+// The hand-off build serves one band without skew compensation and echo metrics: the plain configuration, delay
+// logging (the estimator's launch follows each process launch) and the fused delay-agnostic mode.
 bool aec_flow_applies(const AspAecBatch* b, int steps) {
   const bool on = b->flow < 0 ? aec_flow_default() : b->flow != 0;
   if (!b->per.empty()) return false;  // per-stream control: one far-end and one Process launch per call
   return on && steps >= 2 && !b->sim && b->num_high == 0 && !b->metricsMode &&
-         b->reported_delay_enabled && !b->skewMode && b->debug_stamps == nullptr;
+         (b->reported_delay_enabled || agn_fused(b)) && !b->skewMode && b->debug_stamps == nullptr;
 }
 int aec_flow_resources(AspAecBatch* b) {
   if (b->delay_logging && b->flow_bits == nullptr)
@@ -388,8 +400,8 @@ int aec_flow_resources(AspAecBatch* b) {
   AEC_TRY(hipMalloc((void**)&b->flow_abort, 16));
   AEC_TRY(hipMemsetAsync(b->flow_seq, 0, (size_t)b->S * sizeof(unsigned), b->stream));
   AEC_TRY(hipMemsetAsync(b->flow_abort, 0, 16, b->stream));
-  AEC_TRY(hipHostMalloc((void**)&b->flow_host, sizeof(AecFlowStep) * kAecFlowSlots * kAecFlowMaxSteps, hipHostMallocDefault));
-  AEC_TRY(hipMalloc((void**)&b->flow_dev, sizeof(AecFlowStep) * kAecFlowSlots * kAecFlowMaxSteps));
+  AEC_TRY(hipHostMalloc((void**)&b->flow_host, kAecFlowElem * kAecFlowSlots * kAecFlowMaxSteps, hipHostMallocDefault));
+  AEC_TRY(hipMalloc((void**)&b->flow_dev, kAecFlowElem * kAecFlowSlots * kAecFlowMaxSteps));
   for (int i = 0; i < kAecFlowSlots; ++i) AEC_TRY(hipEventCreateWithFlags(&b->flow_ev[i], hipEventDisableTiming));
   b->flow_count = 0;
   b->flow_slot = 0;
@@ -399,16 +411,17 @@ int aec_flow_resources(AspAecBatch* b) {
 int aec_flow_flush(AspAecBatch* b) {
   if (b->flow_n == 0) return 0;
   const int slot = b->flow_slot;
-  AecFlowStep* h = b->flow_host + (size_t)slot * kAecFlowMaxSteps;
-  AecFlowStep* d = b->flow_dev + (size_t)slot * kAecFlowMaxSteps;
+  unsigned char* h = b->flow_host + (size_t)slot * kAecFlowMaxSteps * kAecFlowElem;
+  unsigned char* d = b->flow_dev + (size_t)slot * kAecFlowMaxSteps * kAecFlowElem;
   const int n = b->flow_n;
   b->flow_n = 0;
-  AEC_TRY(hipMemcpyAsync(d, h, sizeof(AecFlowStep) * n, hipMemcpyHostToDevice, b->stream));
+  const bool agn = b->flow_agn;
+  AEC_TRY(hipMemcpyAsync(d, h, (agn ? sizeof(AecFlowStepAgn) : sizeof(AecFlowStep)) * n, hipMemcpyHostToDevice, b->stream));
   const int blocks = b->flow_blocks;  // > 0: delay logging is on
   b->flow_blocks = 0;
-  AEC_TRY(launch_aec_process_flow(b->state, b->far_ring, b->tables, b->S, b->flow_nr, d, n, b->flow_seq, b->flow_abort,
-                                  b->flow_count, b->num_part, b->stream, blocks > 0 ? b->dblocks : nullptr,
-                                  blocks > 0 ? b->flow_bits : nullptr));
+  AEC_TRY(launch_aec_process_flow(b->state, b->far_ring, b->tables, b->S, b->flow_nr, reinterpret_cast<const AecFlowStep*>(d), n,
+                                  b->flow_seq, b->flow_abort, b->flow_count, b->num_part, b->stream,
+                                  (agn || blocks > 0) ? b->dblocks : nullptr, blocks > 0 ? b->flow_bits : nullptr, agn));
   // the estimator's share of these steps (aec_core.c:1191-1203): one launch for all their blocks, from the binary
   // spectra the process kernel left
   if (blocks > 0) AEC_TRY(launch_aec_delay_bits(b->dblocks, b->flow_bits, b->S, blocks, 1, b->stream));
@@ -421,13 +434,18 @@ int aec_flow_flush(AspAecBatch* b) {
   return 0;
 }
 int aec_flow_record(AspAecBatch* b, const float* near_dev, float* out_dev, int n, const ProcOps& ops, const float* far_src,
-                    const FarOps& fops) {
-  if (b->flow_n > 0 && b->flow_nr != n) {  // a launch carries calls of one length
+                    const FarOps& fops, const AgnOps* agn = nullptr) {
+  if (b->flow_n > 0 && (b->flow_nr != n || b->flow_agn != (agn != nullptr))) {  // a launch carries calls of one length and one kind
     const int rc = aec_flow_flush(b);
     if (rc != 0) return rc;
   }
   b->flow_nr = n;
-  AecFlowStep& st = b->flow_host[(size_t)b->flow_slot * kAecFlowMaxSteps + b->flow_n++];
+  b->flow_agn = agn != nullptr;
+  unsigned char* slot_base = b->flow_host + (size_t)b->flow_slot * kAecFlowMaxSteps * kAecFlowElem;
+  const int idx = b->flow_n++;
+  AecFlowStepAgn* sa = agn ? reinterpret_cast<AecFlowStepAgn*>(slot_base) + idx : nullptr;
+  AecFlowStep& st = agn ? sa->step : reinterpret_cast<AecFlowStep*>(slot_base)[idx];
+  if (agn) sa->agn = *agn;
   memset(&st, 0, sizeof st);
   st.ops = ops;
   st.fops = fops;
@@ -435,7 +453,7 @@ int aec_flow_record(AspAecBatch* b, const float* near_dev, float* out_dev, int n
   st.nearend = near_dev;
   st.out = out_dev;
   st.spec_base = -1;
-  if (b->delay_logging) {
+  if (b->delay_logging && agn == nullptr) {  // (the delay-agnostic mode runs the estimator in the process wave)
     st.spec_base = b->flow_blocks;
     for (int j = 0; j < ops.nsub; ++j) b->flow_blocks += ops.sub[j].nblocks;  // <= 4 per step, kFlowBitsBlocks = 4 * kAecFlowMaxSteps
   }
@@ -856,16 +874,6 @@ void est_buf_delay_normal(AspAecBatch* b) {  // echo_cancellation.c:816-867
   }
 }
 
-// The delay-agnostic mode in one launch per call (aec_process_agn_kernel): one band, no echo metrics, the whole batch on
-// one control plane.  ASP_AEC_AGN_FUSED=0 keeps the launch-per-sub-frame form (the A / B switch).
-bool agn_fused(const AspAecBatch* b) {
-  static const int env = [] {
-    const char* e = getenv("ASP_AEC_AGN_FUSED");
-    return e ? atoi(e) : 1;
-  }();
-  return env != 0 && !b->sim && !b->vrec && !b->flow_rec && b->num_high == 0 && !b->metricsMode && b->debug_stamps == nullptr;
-}
-
 // WebRtcAec_ProcessFrames control plane (aec_core.c:1647-1778) -> one launch.
 // `knownDelay`: the delay ProcessNormal / ProcessExtended hand over (echo_cancellation.c:735-741, 803-812)
 int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev, int n, int knownDelay) {
@@ -962,6 +970,7 @@ int process_frames_device(AspAecBatch* b, const float* near_dev, float* out_dev,
         b->nevents = 0;
       }
     }
+    if (b->flow_rec) return aec_flow_record(b, near_dev, out_dev, n, ops, far_src, fops, &agn);
     if (!b->dual)
       AEC_TRY(launch_aec_process_agn(b->state, b->far_ring, b->tables, near_dev, out_dev, b->S, n, ops, far_src, fops,
                                      b->dblocks, agn, b->stream, 0, -1, b->num_part));

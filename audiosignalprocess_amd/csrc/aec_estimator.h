@@ -287,76 +287,92 @@ __device__ __forceinline__ void soft_reset(Hist& H, Scalars& sc, int delay_shift
   H.fb1 = c[1];
 }
 
+// SC1: the hand-off build -- a stream's estimator block passes from one frame step's wave to the next without a
+// launch boundary, so every access bypasses the L1 / writes through (agent scope), like the state block
+template <bool SC1, class T>
+__device__ __forceinline__ T est_ld(const T* p) {
+  typedef __attribute__((address_space(1))) T gT;
+  if constexpr (SC1) return __hip_atomic_load((const gT*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool SC1, class T, class V>
+__device__ __forceinline__ void est_st(T* p, V v) {
+  typedef __attribute__((address_space(1))) T gT;
+  if constexpr (SC1) __hip_atomic_store((gT*)p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = (T)v;
+}
+
 // the arrays and the scalars into registers
+template <bool SC1 = false>
 __device__ __forceinline__ void load_estimator(const AspAecDelayState* __restrict__ g, Hist& H, Scalars& sc, int lane) {
   const int i0 = lane, i1 = lane + 64;
-  H.fh0 = g->binary_far_history[i0];
-  H.fb0 = g->far_bit_counts[i0];
-  H.nh0 = g->binary_near_history[i0];
-  H.m0 = g->mean_bit_counts[i0];
-  H.h0 = g->histogram[i0];
-  H.bc0 = g->bit_counts[i0];
-  H.fh1 = i1 < kHist ? g->binary_far_history[i1] : 0u;
-  H.fb1 = i1 < kHist ? g->far_bit_counts[i1] : 0;
-  H.bc1 = i1 < kHist ? g->bit_counts[i1] : 0;
-  H.nh1 = i1 < kNearHist ? g->binary_near_history[i1] : 0u;
-  H.m1 = i1 < kHist + 1 ? g->mean_bit_counts[i1] : 0;
-  H.h1 = i1 < kHist + 1 ? g->histogram[i1] : 0.f;
-  sc.far_init = uni(g->far_spectrum_initialized);
-  sc.near_init = uni(g->near_spectrum_initialized);
-  sc.minimum_probability = uni(g->minimum_probability);
-  sc.last_delay_probability = uni(g->last_delay_probability);
-  sc.last_delay = uni(g->last_delay);
-  sc.last_candidate_delay = uni(g->last_candidate_delay);
-  sc.compare_delay = uni(g->compare_delay);
-  sc.candidate_hits = uni(g->candidate_hits);
-  sc.last_delay_histogram = unif(g->last_delay_histogram);
-  sc.lookahead = uni(g->lookahead);
-  sc.allowed_offset = uni(g->allowed_offset);
-  sc.previous_delay = uni(g->previous_delay);
-  sc.delay_correction_count = uni(g->delay_correction_count);
-  sc.shift_offset = uni(g->shift_offset);
-  sc.delay_quality_threshold = unif(g->delay_quality_threshold);
+  H.fh0 = est_ld<SC1>(&g->binary_far_history[i0]);
+  H.fb0 = est_ld<SC1>(&g->far_bit_counts[i0]);
+  H.nh0 = est_ld<SC1>(&g->binary_near_history[i0]);
+  H.m0 = est_ld<SC1>(&g->mean_bit_counts[i0]);
+  H.h0 = est_ld<SC1>(&g->histogram[i0]);
+  H.bc0 = est_ld<SC1>(&g->bit_counts[i0]);
+  H.fh1 = i1 < kHist ? est_ld<SC1>(&g->binary_far_history[i1]) : 0u;
+  H.fb1 = i1 < kHist ? est_ld<SC1>(&g->far_bit_counts[i1]) : 0;
+  H.bc1 = i1 < kHist ? est_ld<SC1>(&g->bit_counts[i1]) : 0;
+  H.nh1 = i1 < kNearHist ? est_ld<SC1>(&g->binary_near_history[i1]) : 0u;
+  H.m1 = i1 < kHist + 1 ? est_ld<SC1>(&g->mean_bit_counts[i1]) : 0;
+  H.h1 = i1 < kHist + 1 ? est_ld<SC1>(&g->histogram[i1]) : 0.f;
+  sc.far_init = uni(est_ld<SC1>(&g->far_spectrum_initialized));
+  sc.near_init = uni(est_ld<SC1>(&g->near_spectrum_initialized));
+  sc.minimum_probability = uni(est_ld<SC1>(&g->minimum_probability));
+  sc.last_delay_probability = uni(est_ld<SC1>(&g->last_delay_probability));
+  sc.last_delay = uni(est_ld<SC1>(&g->last_delay));
+  sc.last_candidate_delay = uni(est_ld<SC1>(&g->last_candidate_delay));
+  sc.compare_delay = uni(est_ld<SC1>(&g->compare_delay));
+  sc.candidate_hits = uni(est_ld<SC1>(&g->candidate_hits));
+  sc.last_delay_histogram = unif(est_ld<SC1>(&g->last_delay_histogram));
+  sc.lookahead = uni(est_ld<SC1>(&g->lookahead));
+  sc.allowed_offset = uni(est_ld<SC1>(&g->allowed_offset));
+  sc.previous_delay = uni(est_ld<SC1>(&g->previous_delay));
+  sc.delay_correction_count = uni(est_ld<SC1>(&g->delay_correction_count));
+  sc.shift_offset = uni(est_ld<SC1>(&g->shift_offset));
+  sc.delay_quality_threshold = unif(est_ld<SC1>(&g->delay_quality_threshold));
 }
 
 // back to HBM.  kSpectra: with the mean spectra's initialised flags (the hand-off build of the process kernel keeps
 // those and the mean spectra themselves: aec_kernels.hip, flow_binary_spectra)
-template <bool kSpectra>
+template <bool kSpectra, bool SC1 = false>
 __device__ __forceinline__ void store_estimator(AspAecDelayState* __restrict__ g, const Hist& H, const Scalars& sc, int lane) {
   const int i0 = lane, i1 = lane + 64;
-  g->binary_far_history[i0] = H.fh0;
-  g->far_bit_counts[i0] = H.fb0;
-  g->binary_near_history[i0] = H.nh0;
-  g->mean_bit_counts[i0] = H.m0;
-  g->histogram[i0] = H.h0;
-  g->bit_counts[i0] = H.bc0;
+  est_st<SC1>(&g->binary_far_history[i0], H.fh0);
+  est_st<SC1>(&g->far_bit_counts[i0], H.fb0);
+  est_st<SC1>(&g->binary_near_history[i0], H.nh0);
+  est_st<SC1>(&g->mean_bit_counts[i0], H.m0);
+  est_st<SC1>(&g->histogram[i0], H.h0);
+  est_st<SC1>(&g->bit_counts[i0], H.bc0);
   if (i1 < kHist) {
-    g->binary_far_history[i1] = H.fh1;
-    g->far_bit_counts[i1] = H.fb1;
-    g->bit_counts[i1] = H.bc1;
+    est_st<SC1>(&g->binary_far_history[i1], H.fh1);
+    est_st<SC1>(&g->far_bit_counts[i1], H.fb1);
+    est_st<SC1>(&g->bit_counts[i1], H.bc1);
   }
-  if (i1 < kNearHist) g->binary_near_history[i1] = H.nh1;
+  if (i1 < kNearHist) est_st<SC1>(&g->binary_near_history[i1], H.nh1);
   if (i1 < kHist + 1) {
-    g->mean_bit_counts[i1] = H.m1;
-    g->histogram[i1] = H.h1;
+    est_st<SC1>(&g->mean_bit_counts[i1], H.m1);
+    est_st<SC1>(&g->histogram[i1], H.h1);
   }
   if (lane == 0) {
     if (kSpectra) {
-      g->far_spectrum_initialized = sc.far_init;
-      g->near_spectrum_initialized = sc.near_init;
+      est_st<SC1>(&g->far_spectrum_initialized, sc.far_init);
+      est_st<SC1>(&g->near_spectrum_initialized, sc.near_init);
     }
-    g->minimum_probability = sc.minimum_probability;
-    g->last_delay_probability = sc.last_delay_probability;
-    g->last_delay = sc.last_delay;
-    g->last_candidate_delay = sc.last_candidate_delay;
-    g->compare_delay = sc.compare_delay;
-    g->candidate_hits = sc.candidate_hits;
-    g->last_delay_histogram = sc.last_delay_histogram;
-    g->lookahead = sc.lookahead;
-    g->previous_delay = sc.previous_delay;
-    g->delay_correction_count = sc.delay_correction_count;
-    g->shift_offset = sc.shift_offset;
-    g->delay_quality_threshold = sc.delay_quality_threshold;
+    est_st<SC1>(&g->minimum_probability, sc.minimum_probability);
+    est_st<SC1>(&g->last_delay_probability, sc.last_delay_probability);
+    est_st<SC1>(&g->last_delay, sc.last_delay);
+    est_st<SC1>(&g->last_candidate_delay, sc.last_candidate_delay);
+    est_st<SC1>(&g->compare_delay, sc.compare_delay);
+    est_st<SC1>(&g->candidate_hits, sc.candidate_hits);
+    est_st<SC1>(&g->last_delay_histogram, sc.last_delay_histogram);
+    est_st<SC1>(&g->lookahead, sc.lookahead);
+    est_st<SC1>(&g->previous_delay, sc.previous_delay);
+    est_st<SC1>(&g->delay_correction_count, sc.delay_correction_count);
+    est_st<SC1>(&g->shift_offset, sc.shift_offset);
+    est_st<SC1>(&g->delay_quality_threshold, sc.delay_quality_threshold);
   }
 }
 
@@ -364,7 +380,7 @@ __device__ __forceinline__ void store_estimator(AspAecDelayState* __restrict__ g
 // != 0): the WebRtcAec_BufferFarend calls since the last step replayed on the stream's own read side, the under-run
 // stuffing, SignalBasedDelayCorrection, the read-pointer move with the estimator's soft reset, and the far slots of
 // the sub-frame's blocks (also left in blk->slot for a process launch that reads them from memory).
-template <class OPS>
+template <bool SC1 = false, class OPS>
 __device__ __forceinline__ void control_step(DelayBlock* __restrict__ blk, Hist& H, Scalars& sc, const OPS& ops, int lane,
                                              int& slot0_out, int& slot1_out) {
   AspAecDelayState* g = &blk->s;
@@ -376,10 +392,10 @@ __device__ __forceinline__ void control_step(DelayBlock* __restrict__ blk, Hist&
     fp.wrap = ops.h_far_wrap;
     sd = ops.h_system_delay;
   } else {
-    fp.read = uni(g->far_read);
-    fp.write = uni(g->far_write);
-    fp.wrap = uni(g->far_wrap);
-    sd = uni(g->system_delay);
+    fp.read = uni(est_ld<SC1>(&g->far_read));
+    fp.write = uni(est_ld<SC1>(&g->far_write));
+    fp.wrap = uni(est_ld<SC1>(&g->far_wrap));
+    sd = uni(est_ld<SC1>(&g->system_delay));
   }
   for (int e = 0; e < ops.nevents; ++e) {  // WebRtcAec_BufferFarend since the last step (echo_cancellation.c:316-336)
     sd += ops.ev_samples[e];
@@ -428,12 +444,12 @@ __device__ __forceinline__ void control_step(DelayBlock* __restrict__ blk, Hist&
   sd -= kFrameLen;  // 5) aec_core.c:1758
   }
   if (lane == 0) {
-    g->far_read = fp.read;
-    g->far_write = fp.write;
-    g->far_wrap = fp.wrap;
-    g->system_delay = sd;
-    blk->slot[0] = slot0;
-    blk->slot[1] = slot1;
+    est_st<SC1>(&g->far_read, fp.read);
+    est_st<SC1>(&g->far_write, fp.write);
+    est_st<SC1>(&g->far_wrap, fp.wrap);
+    est_st<SC1>(&g->system_delay, sd);
+    est_st<SC1>(&blk->slot[0], slot0);
+    est_st<SC1>(&blk->slot[1], slot1);
   }
   slot0_out = slot0;
   slot1_out = slot1;

@@ -1597,7 +1597,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
 // the call's descriptors, in the kernel's arguments (plain build) or in device memory (hand-off build).
 // AGN: the delay-agnostic mode inside the call (agn != nullptr): per sub-frame the stream's own far-buffer control
 // step, which picks the far slots of its blocks, then the blocks, then the estimator's share of them.
-template <bool kMetrics, int NP, bool FLOW, class OPS, class FOPS, bool AGN = false>
+template <bool kMetrics, int NP, bool FLOW, bool AGN = false, class OPS, class FOPS, class AGNP = const AgnOps*>
 __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_ring, float* __restrict__ wl,
                                              const SharedTables& T, const AecTables* __restrict__ G,
                                              const float* __restrict__ nin, float* __restrict__ o, int num_streams,
@@ -1605,7 +1605,7 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
                                              const float* __restrict__ farend, const FOPS& fops,
                                              const float* near_high, float* out_high, float* met,
                                              unsigned long long* __restrict__ stamps, float* spectra,
-                                             const DelayBlock* dblocks, const AgnOps* agn = nullptr) {
+                                             const DelayBlock* dblocks, AGNP agn = nullptr) {
   constexpr int kAux = FLOW ? kSc1 : 0;
   constexpr int kDwords = AecRows(NP).state_dwords;
   [[maybe_unused]] const StateBufT<kAux> sb = state_buf<kAux>(st, kDwords);
@@ -1650,9 +1650,9 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
       DelayBlock* eb = const_cast<DelayBlock*>(dblocks) + stream;
       aspaec_est::Hist H;
       aspaec_est::Scalars sc;
-      aspaec_est::load_estimator(&eb->s, H, sc, lane);
-      aspaec_est::control_step(eb, H, sc, agn->sub[s], lane, agn_slot0, agn_slot1);
-      aspaec_est::store_estimator<false>(&eb->s, H, sc, lane);
+      aspaec_est::load_estimator<FLOW>(&eb->s, H, sc, lane);
+      aspaec_est::control_step<FLOW>(eb, H, sc, agn->sub[s], lane, agn_slot0, agn_slot1);
+      aspaec_est::store_estimator<false, FLOW>(&eb->s, H, sc, lane);
     }
     for (int k = 0; k < sf.nblocks; ++k) {
       const auto& op = sf.blk[k];
@@ -1696,14 +1696,17 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
         DelayBlock* eb = const_cast<DelayBlock*>(dblocks) + stream;
         aspaec_est::Hist H;
         aspaec_est::Scalars sc;
-        aspaec_est::load_estimator(&eb->s, H, sc, lane);
+        aspaec_est::load_estimator<FLOW>(&eb->s, H, sc, lane);
         for (int k = 0; k < sf.nblocks; ++k) {
           const unsigned bfar = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(agn_bits[2 * k]));
           const unsigned bnear = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(agn_bits[2 * k + 1]));
           const int delay_estimate = aspaec_est::estimator_block_bits(H, sc, bfar, bnear, lane);
-          if (delay_estimate >= 0 && lane == 0) eb->s.delay_histogram[delay_estimate]++;
+          if (delay_estimate >= 0 && lane == 0) {
+            int32_t* cnt = &eb->s.delay_histogram[delay_estimate];
+            aspaec_est::est_st<FLOW>(cnt, aspaec_est::est_ld<FLOW>(cnt) + 1);
+          }
         }
-        aspaec_est::store_estimator<false>(&eb->s, H, sc, lane);
+        aspaec_est::store_estimator<false, FLOW>(&eb->s, H, sc, lane);
       }
     }
     if constexpr (FLOW) {
@@ -1774,13 +1777,13 @@ __global__ __launch_bounds__(256, NP == kNumPartNormal ? AEC_WAVES : 3) void aec
   float* st = state + (size_t)stream * AecRows(NP).state_dwords;
   const float* nin = nearend + (size_t)stream * nrOfSamples;
   float* o = out + (size_t)stream * nrOfSamples;
-  process_call<false, NP, false, ProcOps, FarOps, true>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, ops,
+  process_call<false, NP, false, true>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, ops,
                                                         farend, fops, nullptr, nullptr, nullptr, nullptr, nullptr, dblocks, &agn);
 }
 
 // The hand-off build: grid (groups of four streams, frame steps); see AecFlowArgs.  One band, no metrics, no
 // delay estimation (aec_api.hip keeps the other configurations on the plain build).
-template <int NP>
+template <int NP, bool AGN = false>
 __global__ __launch_bounds__(256, NP == kNumPartNormal ? AEC_WAVES : 3) void aec_process_flow_kernel(
     float* __restrict__ state, float* far_ring, const AecTables* __restrict__ G, int num_streams, int nrOfSamples,
     AecFlowArgs fa) {
@@ -1794,7 +1797,9 @@ __global__ __launch_bounds__(256, NP == kNumPartNormal ? AEC_WAVES : 3) void aec
   if (stream >= num_streams) return;
   // the step's descriptor: read-only for the whole launch, so it may come through the scalar cache
   typedef const __attribute__((address_space(4))) AecFlowStep* StepPtr;
-  const StepPtr fs = (StepPtr)(fa.steps + blockIdx.y);
+  typedef const __attribute__((address_space(4))) AecFlowStepAgn* StepAgnPtr;
+  // (delay-agnostic mode: the array holds AecFlowStepAgn elements, the step first)
+  const StepPtr fs = AGN ? (StepPtr)(reinterpret_cast<const AecFlowStepAgn*>(fa.steps) + blockIdx.y) : (StepPtr)(fa.steps + blockIdx.y);
   const unsigned want = fa.want + blockIdx.y;
   float* wl = lds + wave * kWaveLds;
   float* st = state + (size_t)stream * AecRows(NP).state_dwords;
@@ -1804,8 +1809,16 @@ __global__ __launch_bounds__(256, NP == kNumPartNormal ? AEC_WAVES : 3) void aec
   const int spec_base = fs->spec_base;
   float* bits = (fa.bits != nullptr && spec_base >= 0)
                     ? reinterpret_cast<float*>(fa.bits + ((size_t)stream * kFlowBitsBlocks + spec_base) * 2) : nullptr;
-  process_call<false, NP, true>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, fs->ops,
-                                fs->farend, fs->fops, nullptr, nullptr, nullptr, nullptr, bits, fa.est);
+  if constexpr (AGN) {
+    typedef const __attribute__((address_space(4))) AgnOps* AgnPtr;
+    const AgnPtr agn = &((StepAgnPtr)(reinterpret_cast<const AecFlowStepAgn*>(fa.steps) + blockIdx.y))->agn;
+    process_call<false, NP, true, true>(
+        st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, fs->ops, fs->farend, fs->fops, nullptr, nullptr,
+        nullptr, nullptr, nullptr, fa.est, agn);
+  } else {
+    process_call<false, NP, true>(st, far_ring, wl, T, G, nin, o, num_streams, nrOfSamples, stream, lane, fs->ops,
+                                  fs->farend, fs->fops, nullptr, nullptr, nullptr, nullptr, bits, fa.est);
+  }
   // publish: every store of this wave drained first
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_store((gu32*)(fa.seq + stream), want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1954,12 +1967,20 @@ hipError_t launch_aec_process_agn(float* state, float* far_ring, const AecTables
 // of every stream; `descs` [steps] in device memory.
 hipError_t launch_aec_process_flow(float* state, float* far_ring, const AecTables* T, int num_streams, int nrOfSamples,
                                    const AecFlowStep* descs, int steps, unsigned* seq, unsigned* abort_w, unsigned want,
-                                   int num_part, hipStream_t s, DelayBlock* est, unsigned* bits) {
+                                   int num_part, hipStream_t s, DelayBlock* est, unsigned* bits, bool agn) {
   if (num_part != kNumPartNormal && num_part != kNumPartMax) return hipErrorInvalidValue;
   const int gx = ((num_streams + 3) / 4 + 7) / 8 * 8;  // a multiple of 8: a stream's consecutive steps on one XCD's in-order share
   const dim3 grid(gx, steps);
   const AecFlowArgs fa = {descs, seq, abort_w, want, est, bits};
-  if (num_part == kNumPartNormal)
+  // agn: `descs` is an array of AecFlowStepAgn (the delay-agnostic mode: control steps and estimator in the wave)
+  if (agn) {
+    if (num_part == kNumPartNormal)
+      hipLaunchKernelGGL((aec_process_flow_kernel<kNumPartNormal, true>), grid, dim3(256), 0, s, state, far_ring, T, num_streams,
+                         nrOfSamples, fa);
+    else
+      hipLaunchKernelGGL((aec_process_flow_kernel<kNumPartMax, true>), grid, dim3(256), 0, s, state, far_ring, T, num_streams,
+                         nrOfSamples, fa);
+  } else if (num_part == kNumPartNormal)
     hipLaunchKernelGGL((aec_process_flow_kernel<kNumPartNormal>), grid, dim3(256), 0, s, state, far_ring, T, num_streams,
                        nrOfSamples, fa);
   else

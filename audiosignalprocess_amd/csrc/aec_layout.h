@@ -191,4 +191,11 @@ struct AgnOps {
   DelayOps sub[2];   // control = 1, nblocks, and for the call's first sub-frame the far-end calls to replay / the sync values
 };
 
+// A frame step of a hand-off launch in the delay-agnostic mode: the step and its sub-frames' control descriptors
+struct AecFlowStepAgn {
+  AecFlowStep step;
+  AgnOps agn;
+};
+static_assert(sizeof(AecFlowStepAgn) % 8 == 0, "steps stay 8-byte aligned in their array");
+
 }  // namespace aspaec

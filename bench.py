@@ -301,7 +301,8 @@ def bench_split(args):
 
 def aec_flow_active(ext, dmode, steps):
     """Does AspAecBatch_TimedSteps run the hand-off build?  (aec_api.hip, aec_flow_applies)"""
-    return os.environ.get("ASP_AEC_FLOW", "1")[:1] != "0" and dmode in ("off", "logging") and steps >= 2
+    fused = os.environ.get("ASP_AEC_AGN_FUSED", "1")[:1] != "0"   # aec_api.hip, agn_fused
+    return os.environ.get("ASP_AEC_FLOW", "1")[:1] != "0" and (dmode in ("off", "logging") or fused) and steps >= 2
 
 
 def bench_aec(args):

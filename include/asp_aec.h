@@ -290,9 +290,10 @@ int AspAecBatch_ExportState(AspAecBatch* b, int stream, AspAecState* out);
 int AspAecBatch_ImportState(AspAecBatch* b, int stream, const AspAecState* in);
 int AspAecBatch_GetControl(const AspAecBatch* b, AspAecControl* out);
 int AspAecBatch_Synchronize(AspAecBatch* b);
-/* Hand-off build of the multi-frame entry points (Run, TimedSteps) in the plain configuration (one band, reported
- * delays, no skew compensation / metrics; with or without delay logging -- with it the process kernel forms each
- * block's binary far / near spectra and the rest of the estimator runs once per launch over all its blocks): the
+/* Hand-off build of the multi-frame entry points (Run, TimedSteps) with one band and without skew compensation /
+ * metrics: the plain configuration; delay logging (the process kernel forms each block's binary far / near spectra and
+ * the rest of the estimator runs once per launch over all its blocks); the delay-agnostic mode (each stream's wave
+ * runs its own far-buffer control step per sub-frame and the estimator's share of its blocks): the
  * Process launches of up to 64 consecutive frames go
  * into ONE launch (grid y = frame step, its descriptors in device memory), and a per-stream step counter in device
  * memory orders step k + 1 of a stream behind its own step k (every access to the stream's state and far-ring

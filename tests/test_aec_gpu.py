@@ -948,6 +948,62 @@ def test_handoff_build_delay_logging(aec, S, ext):
     for g in batches:
         g.close()
 
+@pytest.mark.parametrize("S,ext", [(37, 0), (1030, 0), (37, 1)])
+def test_handoff_build_delay_agnostic(aec, S, ext):
+    """The delay-agnostic mode in the hand-off build: each stream's wave runs its own far-buffer control step per
+    sub-frame (SignalBasedDelayCorrection, read-pointer moves, soft reset) and the estimator's share of its blocks,
+    inside a launch of up to 64 frame steps -- against one launch per call (the same fused wave, aec_process_agn_kernel):
+    outputs, the whole state, the estimator and the far-buffer positions bit for bit; the first streams against the
+    oracle; the streams' read positions must have moved apart."""
+    from audiosignalprocess_amd.ns import DeviceBuffer
+
+    F, D = 330, 6
+    far8, near8 = _lagged_frames(D, F, [6, 0, 9, 3, 6, 12])
+    idx = (np.arange(S) * 5) % D
+    far = np.ascontiguousarray(far8[:, idx])
+    near = np.ascontiguousarray(near8[:, idx])
+    df, dn = DeviceBuffer(far.nbytes), DeviceBuffer(near.nbytes)
+    df.upload(far)
+    dn.upload(near)
+    outs, batches = [], []
+    for flow in (0, 1):
+        g = aec.AecBatch(S)
+        assert g.set_config(1, delay_logging=1) == 0
+        if ext:
+            g.enable_delay_correction(1)
+        g.enable_reported_delay(0)
+        g.set_flow(flow)
+        do = DeviceBuffer(near.nbytes)
+        for f0, f1 in ((0, 150), (150, 151), (151, F)):
+            off = f0 * S * 160 * 4
+            g.run_device(df.ptr + off, dn.ptr + off, do.ptr + off, 160, f1 - f0, 20)
+        outs.append(do)
+        batches.append(g)
+    for g in batches:
+        g.synchronize()
+    y = [o.download(near.shape) for o in outs]
+    assert np.array_equal(_bits(y[0]), _bits(y[1]))
+    reads = set()
+    for s_ in sorted(set([0, 1, 2, 3, 4, 5, S // 2, S - 1])):
+        d0, d1 = batches[0].delay_state(s_), batches[1].delay_state(s_)
+        assert d1.diff(d0) == [], s_
+        reads.add(d1.far_available())
+        rep = _state_report(batches[1].export_state(s_), batches[0].export_state(s_))
+        assert all(v[0] for v in rep.values()), (s_, {f: v for f, v in rep.items() if not v[0]})
+    assert len(reads) >= 3, reads
+    for k in range(3):
+        o = OracleAec(16000)
+        assert o.set_nlp(1, delay_logging=1) == 0
+        if ext:
+            o.enable_delay_correction(1)
+        o.enable_reported_delay(0)
+        for f in range(F):
+            oo, _ = o.frame(far[f, k], near[f, k], 20)
+            assert _rel_l2(y[1][f, k], oo) <= 1e-5, (f, k)
+        assert batches[1].delay_state(k).diff(o.delay_state()) == [], k
+    for g in batches:
+        g.close()
+
 
 def test_wav_driver_end_to_end(aec, aec_golden, tmp_path):
     """drivers/test_aec_module (the reference's test_aec_module.cpp loop in C over WebRtcAec_*):
