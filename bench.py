@@ -366,9 +366,13 @@ def bench_aec(args):
                                   "; hand-off build: %d frame steps per launch" % min(steps, 64) if flow else ""),
                    "parallelism": "stream-sharded x%d, no collectives" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if ext else AEC_TRAFFIC_BYTES_PER_FRAME * S,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if (ext or dmode != "off") else AEC_TRAFFIC_BYTES_PER_FRAME * S,
                      "traffic_source": "stored constant: PMC passes kept under profiles/r04_traffic_sec.txt (2 x FETCH_SIZE + WRITE_SIZE; 4-byte-per-lane accesses, a width MI355X_MICROARCH.md does not calibrate), per frame step of all streams; not measured in this run",
-                     "kernel": ("aec_process_flow_kernel" if flow else "aec_process_kernel") + " (the far-end work of the frame inside it)",
+                     "kernel": ("aec_process_flow_kernel" if flow else
+                                "aec_process_agn_kernel" if dmode == "agnostic" and os.environ.get("ASP_AEC_AGN_FUSED", "1")[:1] != "0"
+                                else "aec_process_kernel") + " (the far-end work of the frame inside it"
+                               + (", the stream's far-buffer control steps and delay estimator too" if dmode == "agnostic" and (flow or os.environ.get("ASP_AEC_AGN_FUSED", "1")[:1] != "0") else "")
+                               + ("; aec_delay_bits_kernel once per launch" if flow and dmode == "logging" else "") + ")",
                      "launch_chains": 1 if flow else 2 if S >= 2048 and dmode == "off" else 1,
                      "frame_steps_per_launch": min(steps, 64) if flow else 1,
                      "algorithmic_bytes_per_step": algo * S, "avg_step_us": step_s * 1e6},
