@@ -1350,14 +1350,26 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   }
   wave_fence();
   const int prefBandSize = 24 / mult, minPrefBand = 4 / mult;
-  if (lane < 4) {  // the four sequential sums of the reference, one lane each
-    const float* src = lane == 0 ? T0 : lane == 1 ? XPW : lane == 2 ? COHXD : COHDE;
-    const int lo = lane < 2 ? 0 : minPrefBand, hi = lane < 2 ? 65 : prefBandSize + minPrefBand;
+  if (lane < 4) {
+    // the four sequential sums of the reference, one lane each: lanes 0, 1 all 65 bins of sd / se, lanes 2, 3 the
+    // preferred band of cohxd / cohde, read from its first bin on.  The band's length (24 / mult terms) is the part all
+    // four lanes share; the rest is lanes 0, 1 alone -- straight runs of adds, no per-term range test
+    const float* src = lane == 0 ? T0 : lane == 1 ? XPW : (lane == 2 ? COHXD : COHDE) + minPrefBand;
     float acc = 0.f;
+    if (mult == 1) {
 #pragma unroll
-    for (int j = 0; j < 65; ++j) {  // fixed trip count: the LDS reads batch, the adds stay in order
-      const float v = src[j];
-      if (j >= lo && j < hi) acc += v;
+      for (int j = 0; j < 24; ++j) acc += src[j];
+      if (lane < 2) {
+#pragma unroll
+        for (int j = 24; j < 65; ++j) acc += src[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) acc += src[j];
+      if (lane < 2) {
+#pragma unroll
+        for (int j = 12; j < 65; ++j) acc += src[j];
+      }
     }
     misc[lane] = acc;
   }
