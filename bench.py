@@ -191,7 +191,10 @@ def bench_bt(args):
     x = bt_samples(S, ring * g.macro, stream0=stream0).reshape(S, ring, g.macro).transpose(1, 0, 2)
     d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     d_out = torch.empty_like(d_in)
-    steps, warm = max(args.steps // 10, 10), max(args.warmup // 10, 4)
+    # timed region: `--steps` macroblock steps (the default 1000 = 117 ms at N = 1024).  A region costs 1-2 ms however long it
+    # is (the chip's clock ramps up after the idle gap of the barrier; both builds show it: profiles/r04_region_length.txt),
+    # so the 13 ms regions of earlier rounds (--steps / 10) read 12 % slower than the sustained rate
+    steps, warm = max(args.steps, 10), max(args.warmup // 10, 4)
     g.timed_steps(d_in.data_ptr(), d_out.data_ptr(), ring, warm)
     rank_barrier(dist)
     t0 = time.perf_counter()
@@ -334,7 +337,9 @@ def bench_aec(args):
         assert g.set_config(1, delay_logging=1) == 0
         if dmode == "agnostic":
             g.enable_reported_delay(0)
-    steps, warm = max(args.steps // 4, 10), max(args.warmup // 2, 80)   # warm-up passes the start-up phase
+    # warm-up passes the start-up phase; timed region: `--steps` frames (the default 1000 = 79 ms; the 20 ms regions of
+    # earlier rounds, --steps / 4, carry the same ~1 ms per-region cost as the BT line: profiles/r04_region_length.txt)
+    steps, warm = max(args.steps, 10), max(args.warmup // 2, 80)
     g.timed_steps(d_far.data_ptr(), d_near.data_ptr(), d_out.data_ptr(), 160, ring, warm)
     rank_barrier(dist)
     assert g.control().startup_phase == 0
