@@ -1108,7 +1108,7 @@ __device__ __forceinline__ void process_block(float* __restrict__ st, float* __r
   if (noise_init) noiseEstCtr++;
 
   AEC_STAMP(3)
-  AEC_STAMP(4)
+  // (mark 4 is taken at the call's entry, ahead of the far-end work: process_call)
   // ---- echo estimate and error (aec_core.c:1222-1238)
 #if AEC_FILTERFAR_FIRST
   const float y = y_est;
@@ -1621,6 +1621,7 @@ __device__ __forceinline__ void process_call(float* __restrict__ st, float* far_
   constexpr int kAux = FLOW ? kSc1 : 0;
   constexpr int kDwords = AecRows(NP).state_dwords;
   [[maybe_unused]] const StateBufT<kAux> sb = state_buf<kAux>(st, kDwords);
+  if (stamps != nullptr && stream == 0) stamps[4] = __builtin_amdgcn_s_memtime();  // diagnostic: the call's entry
   if (farend != nullptr) {
     // the WebRtcAec_BufferFarend call that preceded this Process call, fused into the launch
     farend_work<FLOW>(st, far_ring, wl, T, farend, num_streams, stream, fops, lane, kDwords);

@@ -23,5 +23,8 @@ for S in (4, 4096):
                                            C.c_void_p(to.data_ptr() + f * per), st)
         assert rc == 0
         t = np.array(list(st), dtype=np.int64)
+        entry = t[4]              # mark 4: the call's entry, ahead of the fused far-end work (process_call)
+        t[4] = t[3]
         d = np.diff(t)
-        print("S=%d f=%d total %d ticks:" % (S, f, t[-1] - t[0]), {n: int(v) for n, v in zip(names, d)})
+        print("S=%d f=%d first block %d ticks, far-end work + sub-frame set-up ahead of it %d ticks:" % (S, f, t[-1] - t[0], t[0] - entry),
+              {n: int(v) for n, v in zip(names, d)})
